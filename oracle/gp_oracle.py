@@ -1,0 +1,304 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the exact-GP hot path (NOT part of the product).
+
+A NumPy/SciPy restatement of the algorithm GPy runs for one `GP.parameters_changed`
+(reference `GPy/core/gp.py:278-280`): kernel matrix -> Ky -> pdinv -> alpha -> log marginal
+likelihood -> dL_dK -> kernel / noise gradients.  Every function cites the reference lines it follows.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module;
+the product (`gpy_amd`) never does and fails loudly when its HIP library is missing.
+
+Parity pin: this restatement is checked against (a) the reference's own unmodified files executed
+through `oracle/ref_loader.py` (tests/test_oracle_vs_reference.py, runs wherever /root/reference
+exists) and (b) `tests/golden/*.npz`, generated from the reference by `oracle/make_golden.py`
+(travels to the GPU box).  The reference itself ships no golden values for this path.
+
+The LAPACK/BLAS arithmetic (dpotrf, dtrtri, dpotri, dpotrs, dsyrk) lives in SciPy -> OpenBLAS, a
+third-party dependency of the reference (`setup.py:147`, scipy>=1.3.0; here scipy 1.15.3 /
+OpenBLAS 0.3.29), called exactly where the reference calls it (`GPy/util/linalg.py:58,114,125,142,227,316`).
+"""
+import ctypes
+import os
+
+import numpy as np
+from scipy import linalg as sla
+from scipy.linalg import blas, lapack
+
+LOG_2_PI = np.log(2.0 * np.pi)
+KINDS = ("rbf", "matern52", "matern32", "exponential")
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_native = None
+
+
+def _load_native():
+    """Optional C helpers (oracle/oracle_native.c): the serial Q*N*M lengthscale loop and symmetrify,
+    restating the reference's Cython fast paths (`stationary_cython.pyx:53-62`, `linalg_cython.pyx:9-18`)."""
+    global _native
+    if _native is None:
+        p = os.path.join(_HERE, "_build", "liboracle_native.so")
+        if os.path.exists(p):
+            lib = ctypes.CDLL(p)
+            dp = ctypes.POINTER(ctypes.c_double)
+            lib.oracle_lengthscale_grads.argtypes = [ctypes.c_long, ctypes.c_long, ctypes.c_long, dp, dp, dp, dp]
+            lib.oracle_lengthscale_grads.restype = None
+            lib.oracle_symmetrify.argtypes = [ctypes.c_long, dp, ctypes.c_int]
+            lib.oracle_symmetrify.restype = None
+            _native = lib
+        else:
+            _native = False
+    return _native
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+# ----------------------------------------------------------------------------- linear algebra
+def symmetrify(A, upper=False):
+    """In-place mirror of one triangle onto the other (reference `util/linalg.py:356-379`)."""
+    nat = _load_native()
+    if nat and (A.flags.c_contiguous or A.flags.f_contiguous):
+        # for an F-ordered array the roles of the two triangles swap
+        up = bool(upper) if A.flags.c_contiguous else (not bool(upper))
+        nat.oracle_symmetrify(A.shape[0], _dptr(A), int(up))
+        return
+    iu = np.triu_indices_from(A, k=1)
+    if upper:
+        A.T[iu] = A[iu]
+    else:
+        A[iu] = A.T[iu]
+
+
+def tdot(mat):
+    """mat @ mat.T through BLAS dsyrk + mirror (reference `util/linalg.py:299-323`)."""
+    mat = np.asfortranarray(mat)
+    n = mat.shape[0]
+    out = np.zeros((n, n))
+    out = blas.dsyrk(alpha=1.0, a=mat, beta=0.0, c=out, overwrite_c=1, trans=0, lower=0)
+    symmetrify(out, upper=True)
+    return np.ascontiguousarray(out)
+
+
+def jitchol(A, maxtries=5):
+    """Cholesky with the reference's jitter ladder (`util/linalg.py:56-75`): on dpotrf failure,
+    non-positive diagonal -> LinAlgError; else jitter = mean(diag)*1e-6, x10 per try, <= maxtries."""
+    A = np.ascontiguousarray(A)
+    L, info = lapack.dpotrf(A, lower=1)
+    if info == 0:
+        return L
+    d = np.diag(A)
+    if np.any(d <= 0.0):
+        raise sla.LinAlgError("not pd: non-positive diagonal elements")
+    jitter = d.mean() * 1e-6
+    tries = 1
+    while tries <= maxtries and np.isfinite(jitter):
+        try:
+            return sla.cholesky(A + np.eye(A.shape[0]) * jitter, lower=True)
+        except Exception:
+            jitter *= 10
+        finally:
+            tries += 1
+    raise sla.LinAlgError("not positive definite, even with jitter.")
+
+
+def pdinv(A):
+    """(A^-1, L, L^-1, logdet) as the reference computes them (`util/linalg.py:193-214`):
+    jitchol, 2*sum(log diag L), dtrtri (result unused by the caller but executed), dpotri + 2x symmetrify."""
+    L = jitchol(A)
+    logdet = 2.0 * np.sum(np.log(np.diag(L)))
+    Li = lapack.dtrtri(np.asfortranarray(L), lower=1)[0]           # util/linalg.py:217-227
+    Ai, _ = lapack.dpotri(np.asfortranarray(L), lower=1)           # util/linalg.py:127-145
+    symmetrify(Ai)
+    symmetrify(Ai)
+    return Ai, L, Li, logdet
+
+
+def dpotrs(L, B):
+    """Solve (L L^T) X = B (reference `util/linalg.py:116-125`)."""
+    return lapack.dpotrs(np.asfortranarray(L), B, lower=1)[0]
+
+
+# ----------------------------------------------------------------------------- stationary kernels
+def _as_ls(lengthscale, D, ARD):
+    ls = np.atleast_1d(np.asarray(lengthscale, dtype=float))
+    if ARD:
+        if ls.size == 1:
+            ls = np.full(D, float(ls[0]))
+        assert ls.size == D
+    else:
+        assert ls.size == 1
+    return ls
+
+
+def unscaled_dist(X, X2=None):
+    """Euclidean distances via |x|^2+|x'|^2-2x.x' with diag:=0 (symmetric case) and clip>=0
+    (reference `kern/src/stationary.py:130-148`)."""
+    if X2 is None:
+        s = np.sum(np.square(X), 1)
+        r2 = -2.0 * tdot(X) + (s[:, None] + s[None, :])
+        r2[np.diag_indices_from(r2)] = 0.0
+        r2 = np.clip(r2, 0, np.inf)
+        return np.sqrt(r2)
+    s1 = np.sum(np.square(X), 1)
+    s2 = np.sum(np.square(X2), 1)
+    r2 = -2.0 * np.dot(X, X2.T) + (s1[:, None] + s2[None, :])
+    r2 = np.clip(r2, 0, np.inf)
+    return np.sqrt(r2)
+
+
+def scaled_dist(X, X2, lengthscale, ARD):
+    """r: ARD scales the inputs first, iso divides afterwards (reference `stationary.py:150-168`)."""
+    ls = _as_ls(lengthscale, X.shape[1], ARD)
+    if ARD:
+        return unscaled_dist(X / ls, None if X2 is None else X2 / ls)
+    return unscaled_dist(X, X2) / ls
+
+
+def K_of_r(kind, r, variance):
+    """Covariance as a function of r.  RBF `rbf.py:51-52`; Matern52 `stationary.py:585-586`;
+    Matern32 `:488-489`; Exponential `:382-383`."""
+    if kind == "rbf":
+        return variance * np.exp(-0.5 * r ** 2)
+    if kind == "matern52":
+        return variance * (1 + np.sqrt(5.0) * r + 5.0 / 3 * r ** 2) * np.exp(-np.sqrt(5.0) * r)
+    if kind == "matern32":
+        return variance * (1.0 + np.sqrt(3.0) * r) * np.exp(-np.sqrt(3.0) * r)
+    if kind == "exponential":
+        return variance * np.exp(-r)
+    raise ValueError(kind)
+
+
+def dK_dr(kind, r, variance):
+    """dK/dr.  RBF `rbf.py:177-178`; Matern52 `stationary.py:588-589`; Matern32 `:491-492`;
+    Exponential `:385-386`."""
+    if kind == "rbf":
+        return -r * K_of_r(kind, r, variance)
+    if kind == "matern52":
+        return variance * (10.0 / 3 * r - 5.0 * r - 5.0 * np.sqrt(5.0) / 3 * r ** 2) * np.exp(-np.sqrt(5.0) * r)
+    if kind == "matern32":
+        return -3.0 * variance * r * np.exp(-np.sqrt(3.0) * r)
+    if kind == "exponential":
+        return -K_of_r(kind, r, variance)
+    raise ValueError(kind)
+
+
+def kern_K(kind, X, X2, variance, lengthscale, ARD):
+    """`Stationary.K` (reference `stationary.py:105-115`)."""
+    return K_of_r(kind, scaled_dist(X, X2, lengthscale, ARD), float(variance))
+
+
+def kern_Kdiag(X, variance):
+    """`Stationary.Kdiag` (reference `stationary.py:170-173`)."""
+    out = np.empty(X.shape[0])
+    out[:] = variance
+    return out
+
+
+def lengthscale_grads(tmp, X, X2):
+    """grad[q] = sum_{n,m} tmp[n,m] (X[n,q]-X2[m,q])^2  (reference `stationary_cython.pyx:53-62`,
+    NumPy fallback `stationary.py:234-235`)."""
+    nat = _load_native()
+    N, M = tmp.shape
+    Q = X.shape[1]
+    if nat:
+        tmp = np.ascontiguousarray(tmp)
+        Xc = np.ascontiguousarray(X, dtype=float)
+        X2c = np.ascontiguousarray(X2, dtype=float)
+        g = np.zeros(Q)
+        nat.oracle_lengthscale_grads(N, M, Q, _dptr(tmp), _dptr(Xc), _dptr(X2c), _dptr(g))
+        return g
+    return np.array([np.sum(tmp * np.square(X[:, q:q + 1] - X2[:, q:q + 1].T)) for q in range(Q)])
+
+
+def update_gradients_full(kind, dL_dK, X, X2, variance, lengthscale, ARD, K=None, r=None):
+    """(dL/dvariance, dL/dlengthscale) from dL_dK (reference `stationary.py:193-213,225-243`).
+    `K`/`r` may be passed to mimic paramz's `Cache_this` reuse of K and _scaled_dist between the
+    inference step and the gradient step."""
+    variance = float(variance)
+    ls = _as_ls(lengthscale, X.shape[1], ARD)
+    if r is None:
+        r = scaled_dist(X, X2, ls, ARD)
+    if K is None:
+        K = K_of_r(kind, r, variance)
+    dvar = np.sum(K * dL_dK) / variance
+    dL_dr = dK_dr(kind, r, variance) * dL_dK
+    if ARD:
+        inv = 1.0 / np.where(r != 0.0, r, np.inf)                  # stationary.py:225-232
+        tmp = dL_dr * inv
+        X2_ = X if X2 is None else X2
+        dlen = -lengthscale_grads(tmp, X, X2_) / ls ** 3
+    else:
+        dlen = np.atleast_1d(-np.sum(dL_dr * r) / ls[0])
+    return dvar, dlen
+
+
+# ----------------------------------------------------------------------------- exact inference
+def exact_inference(K, Y, noise, mean=None, Z_tilde=None):
+    """`ExactGaussianInference.inference` given K (reference `exact_gaussian_inference.py:42-74`).
+    `noise` scalar or length-N vector.  Returns dict(L, alpha, lml, dL_dK, Wi, logdet, dL_dnoise)."""
+    R = Y if mean is None else Y - mean
+    Ky = K.copy()
+    n = Ky.shape[0]
+    Ky[np.arange(n), np.arange(n)] += np.asarray(noise, dtype=float) + 1e-8   # util/diag.py:85-98
+    Wi, L, _Li, logdet = pdinv(Ky)
+    alpha = dpotrs(L, R)
+    lml = 0.5 * (-Y.size * LOG_2_PI - Y.shape[1] * logdet - np.sum(alpha * R))
+    if Z_tilde is not None:
+        lml += Z_tilde
+    dL_dK = 0.5 * (tdot(alpha) - Y.shape[1] * Wi)
+    # Gaussian.exact_inference_gradients = sum(diag(dL_dK)) (reference likelihoods/gaussian.py:78-79)
+    return dict(L=L, alpha=alpha, lml=float(lml), dL_dK=dL_dK, Wi=Wi, logdet=float(logdet),
+                dL_dnoise=float(np.sum(np.diag(dL_dK))), diag_dL_dK=np.diag(dL_dK).copy())
+
+
+def parameters_changed(kind, X, Y, variance, lengthscale, ARD, noise, cached=True):
+    """One full objective+gradient evaluation, the sequence `core/gp.py:278-280` runs:
+    inference -> likelihood.update_gradients -> kern.update_gradients_full.
+    `cached=True` reuses K and r in the gradient step like the real paramz `Cache_this(limit=3)` does."""
+    ls = _as_ls(lengthscale, X.shape[1], ARD)
+    r = scaled_dist(X, None, ls, ARD)
+    K = K_of_r(kind, r, float(variance))
+    res = exact_inference(K, Y, noise)
+    if cached:
+        dvar, dlen = update_gradients_full(kind, res["dL_dK"], X, None, variance, ls, ARD, K=K, r=r)
+    else:
+        dvar, dlen = update_gradients_full(kind, res["dL_dK"], X, None, variance, ls, ARD)
+    res.update(K=K, dvar=float(dvar), dlen=np.asarray(dlen, dtype=float))
+    return res
+
+
+def predict(kind, X, Xnew, L, alpha, variance, lengthscale, ARD, noise=None, full_cov=False):
+    """`PosteriorExact._raw_predict` (reference `posterior.py:273-302`) + optional Gaussian noise
+    (`likelihoods/gaussian.py:102-110`)."""
+    Kx = kern_K(kind, X, Xnew, variance, lengthscale, ARD)
+    mu = Kx.T @ alpha
+    tmp = lapack.dtrtrs(np.asfortranarray(L), Kx, lower=1)[0]
+    if full_cov:
+        var = kern_K(kind, Xnew, None, variance, lengthscale, ARD) - tmp.T @ tmp
+        if noise is not None:
+            var = var + np.eye(var.shape[0]) * noise
+    else:
+        var = (kern_Kdiag(Xnew, variance) - np.sum(np.square(tmp), 0))[:, None]
+        if noise is not None:
+            var = var + noise
+    return mu, var
+
+
+# ----------------------------------------------------------------------------- synthetic workload
+def synthetic(N, D, seed=0, Dy=1):
+    """SURVEY 8(d) synthetic inputs: X~N(0,1), Y = sin(x0)+0.5cos(2 x1)+0.1 eps."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    f = np.sin(X[:, 0]) + (0.5 * np.cos(2 * X[:, 1]) if D >= 2 else 0.0)
+    Y = (f + 0.1 * rng.standard_normal(N))[:, None]
+    if Dy > 1:
+        Y = np.hstack([Y + 0.3 * j * np.cos(X[:, :1] * (j + 1)) for j in range(Dy)])
+    return np.ascontiguousarray(X), np.ascontiguousarray(Y)
+
+
+def default_theta(D, ARD):
+    """sigma^2=1.3; iso l=0.7 sqrt(D); ARD l_q=linspace(0.5,2,Q) sqrt(D/8); sigma_n^2=0.1."""
+    if ARD:
+        ls = np.linspace(0.5, 2.0, D) * np.sqrt(D / 8.0)
+    else:
+        ls = np.array([0.7 * np.sqrt(D)])
+    return 1.3, ls, 0.1

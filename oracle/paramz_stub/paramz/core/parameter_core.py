@@ -1,0 +1,33 @@
+class Parameterizable(object):
+    def __init__(self, name=None, *a, **kw):
+        self.name = name
+        self.parameters = []
+
+    def link_parameter(self, p, index=None):
+        if not hasattr(self, 'parameters'):
+            self.parameters = []
+        if index is None:
+            self.parameters.append(p)
+        else:
+            self.parameters.insert(index, p)
+
+    def link_parameters(self, *ps):
+        for p in ps:
+            self.link_parameter(p)
+
+    def unlink_parameter(self, p):
+        self.parameters = [q for q in self.parameters if q is not p]
+
+    def add_index_operation(self, *a, **k):
+        pass
+
+    def parameters_changed(self):
+        pass
+
+    @property
+    def size(self):
+        return sum(int(p.size) for p in self.parameters)
+
+
+class Observable(object):
+    pass

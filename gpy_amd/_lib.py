@@ -1,0 +1,295 @@
+"""ctypes binding of libmi355gp.so (C-ABI declared in include/mi355gp.h).
+
+No PyTorch, no CPU fallback: if the library is missing it is built with hipcc (gfx950) on first use, and
+every compute entry point raises when no MI355X is visible.  The CPU oracle under `oracle/` is never
+imported from here.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+from numpy.ctypeslib import ndpointer
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355gp.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+KIND_IDS = {"rbf": 0, "matern52": 1, "matern32": 2, "exponential": 3}
+FETCH_L, FETCH_KINV, FETCH_DLDK, FETCH_K = 0, 1, 2, 3
+OUT_LML, OUT_LOGDET, OUT_DATAFIT, OUT_DNOISE, OUT_TRKINV, NUM_OUT = 0, 1, 2, 3, 4, 8
+STAGE_NAMES = ("kbuild", "potrf", "trtri", "lauum", "solve", "grad", "total")
+NUM_T = 8
+
+_lib = None
+
+
+class MI355GPError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile every HIP translation unit for gfx950 and link libmi355gp.so in-tree (make -C gpy_amd/csrc)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "mi355gp.h"))
+    if not force and os.path.exists(LIB_PATH):
+        t = os.path.getmtime(LIB_PATH)
+        if all(os.path.getmtime(s) <= t for s in srcs if os.path.exists(s)):
+            return LIB_PATH
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise MI355GPError("building libmi355gp.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_dp = ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_c_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _opt(a):
+    """optional output array -> pointer or NULL"""
+    return None if a is None else a.ctypes.data_as(_c_dp)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = ctypes.CDLL(LIB_PATH)
+    i64, ci, cd, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+    L.mi355gp_last_error.restype = ctypes.c_char_p
+    L.mi355gp_version.restype = ctypes.c_char_p
+    L.mi355gp_device_count.argtypes = [ctypes.POINTER(ci)]
+    L.mi355gp_create.argtypes = [ci, ctypes.POINTER(vp)]
+    L.mi355gp_destroy.argtypes = [vp]
+    L.mi355gp_set_data.argtypes = [vp, _dp, i64, ci, _dp, ci]
+    L.mi355gp_set_targets.argtypes = [vp, _dp, ci]
+    L.mi355gp_kern_K.argtypes = [ci, ci, ci, _dp, _dp, i64, _c_dp, i64, ci, _dp]
+    L.mi355gp_kern_Kdiag.argtypes = [ci, _dp, i64, _dp]
+    L.mi355gp_update_gradients_full.argtypes = [ci, ci, ci, _dp, _dp, _dp, i64, _c_dp, i64, ci, _dp]
+    L.mi355gp_exact_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
+    L.mi355gp_inference_given_K.argtypes = [vp, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp]
+    L.mi355gp_fetch.argtypes = [vp, ci, _dp, ci]
+    L.mi355gp_predict.argtypes = [vp, ci, ci, _dp, _dp, i64, _c_dp, _c_dp, ci]
+    L.mi355gp_potrf.argtypes = [ci, _dp, i64, _c_dp]
+    L.mi355gp_pdinv.argtypes = [ci, _dp, i64, _c_dp, _c_dp, _c_dp, _c_dp]
+    L.mi355gp_dbg_mfma.argtypes = [ci, _dp, _dp, _dp]
+    L.mi355gp_dbg_gemm.argtypes = [ci, ci, ci, i64, i64, i64, _dp, _dp, _dp, cd, cd, ci, _c_dp]
+    L.mi355gp_dbg_peaks.argtypes = [ci, _dp]
+    for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
+                 "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
+                 "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks"):
+        getattr(L, "mi355gp_" + name).restype = ci
+    _lib = L
+    return L
+
+
+EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi355gp_create", "mi355gp_destroy",
+            "mi355gp_set_data", "mi355gp_set_targets", "mi355gp_kern_K", "mi355gp_kern_Kdiag",
+            "mi355gp_update_gradients_full", "mi355gp_exact_inference", "mi355gp_inference_given_K",
+            "mi355gp_fetch", "mi355gp_predict", "mi355gp_potrf", "mi355gp_pdinv", "mi355gp_bench_factor",
+            "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks")
+
+
+def last_error():
+    return lib().mi355gp_last_error().decode()
+
+
+def check(rc, what):
+    """negative rc -> exception; positive rc (LAPACK info) is returned to the caller"""
+    if rc < 0:
+        raise MI355GPError("%s failed (rc=%d): %s" % (what, rc, last_error()))
+    return rc
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    lib().mi355gp_device_count(ctypes.byref(n))
+    return n.value
+
+
+def require_device(device=0):
+    n = device_count()
+    if device >= n:
+        raise MI355GPError("no MI355X visible to HIP (device %d requested, %d present): the gpy_amd backend has "
+                           "no CPU fallback" % (device, n))
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def theta_vec(variance, lengthscale, ARD, D):
+    ls = np.atleast_1d(np.asarray(lengthscale, dtype=np.float64)).ravel()
+    if ARD:
+        if ls.size == 1:
+            ls = np.full(D, ls[0])
+        assert ls.size == D, "ARD kernel needs one lengthscale per input dimension"
+    else:
+        assert ls.size == 1, "isotropic kernel has a single lengthscale"
+    return np.concatenate([[float(np.asarray(variance).ravel()[0])], ls])
+
+
+class Context(object):
+    """One device context = one uploaded data set (X, R = Y - mean) with its N x N buffers in HBM."""
+
+    def __init__(self, device=0):
+        require_device(device)
+        self._h = ctypes.c_void_p()
+        check(lib().mi355gp_create(device, ctypes.byref(self._h)), "mi355gp_create")
+        self.device = device
+        self.N = self.D = self.Dy = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().mi355gp_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_data(self, X, R):
+        X, R = f64(X), f64(R)
+        assert X.ndim == 2 and R.ndim == 2 and X.shape[0] == R.shape[0]
+        self.N, self.D = X.shape
+        self.Dy = R.shape[1]
+        check(lib().mi355gp_set_data(self._h, X, self.N, self.D, R, self.Dy), "mi355gp_set_data")
+
+    def set_targets(self, R):
+        R = f64(R)
+        check(lib().mi355gp_set_targets(self._h, R, R.shape[1]), "mi355gp_set_targets")
+
+    def exact_inference(self, kind, ARD, theta, noise, jitter=1e-8, extra_jitter=0.0, want_alpha=True,
+                        want_diag=False, want_stage_ms=False):
+        """Returns (info, dict).  info > 0: not positive definite (the caller runs GPy's jitter ladder)."""
+        theta = f64(theta)
+        noise = f64(np.atleast_1d(noise))
+        out = np.zeros(NUM_OUT)
+        alpha = np.empty((self.N, self.Dy)) if want_alpha else None
+        dtheta = np.zeros(theta.size)
+        diag = np.empty(self.N) if want_diag else None
+        ms = np.zeros(NUM_T) if want_stage_ms else None
+        rc = check(lib().mi355gp_exact_inference(self._h, KIND_IDS[kind], int(bool(ARD)), theta, noise, noise.size,
+                                                 jitter, extra_jitter, out, _opt(alpha), _opt(dtheta), _opt(diag),
+                                                 _opt(ms)), "mi355gp_exact_inference")
+        res = dict(lml=out[OUT_LML], logdet=out[OUT_LOGDET], datafit=out[OUT_DATAFIT], dnoise=out[OUT_DNOISE],
+                   trKinv=out[OUT_TRKINV], alpha=alpha, dtheta=dtheta, diag_dL_dK=diag)
+        if ms is not None:
+            res["stage_ms"] = dict(zip(STAGE_NAMES, ms[:len(STAGE_NAMES)]))
+        return rc, res
+
+    def inference_given_K(self, K, noise, jitter=1e-8, extra_jitter=0.0, want_diag=False, want_stage_ms=False):
+        K = f64(K)
+        assert K.shape == (self.N, self.N)
+        noise = f64(np.atleast_1d(noise))
+        out = np.zeros(NUM_OUT)
+        alpha = np.empty((self.N, self.Dy))
+        diag = np.empty(self.N) if want_diag else None
+        ms = np.zeros(NUM_T) if want_stage_ms else None
+        rc = check(lib().mi355gp_inference_given_K(self._h, K, noise, noise.size, jitter, extra_jitter, out,
+                                                   _opt(alpha), _opt(diag), _opt(ms)), "mi355gp_inference_given_K")
+        res = dict(lml=out[OUT_LML], logdet=out[OUT_LOGDET], datafit=out[OUT_DATAFIT], dnoise=out[OUT_DNOISE],
+                   trKinv=out[OUT_TRKINV], alpha=alpha, diag_dL_dK=diag)
+        if ms is not None:
+            res["stage_ms"] = dict(zip(STAGE_NAMES, ms[:len(STAGE_NAMES)]))
+        return rc, res
+
+    def fetch(self, which, fortran_order=False):
+        out = np.empty((self.N, self.N))
+        check(lib().mi355gp_fetch(self._h, which, out, int(fortran_order)), "mi355gp_fetch")
+        if fortran_order:
+            return out.T      # same memory viewed as an F-contiguous array
+        return out
+
+
+def kern_K(kind, ARD, theta, X, X2=None, device=0):
+    require_device(device)
+    X = f64(X)
+    N, D = X.shape
+    if X2 is None:
+        M, p2 = N, None
+    else:
+        X2 = f64(X2)
+        M, p2 = X2.shape[0], X2.ctypes.data_as(_c_dp)
+        assert X2.shape[1] == D
+    out = np.empty((N, M))
+    check(lib().mi355gp_kern_K(device, KIND_IDS[kind], int(bool(ARD)), f64(theta), X, N, p2, M, D, out),
+          "mi355gp_kern_K")
+    return out
+
+
+def kern_Kdiag(kind, theta, N):
+    out = np.empty(N)
+    check(lib().mi355gp_kern_Kdiag(KIND_IDS[kind], f64(theta), N, out), "mi355gp_kern_Kdiag")
+    return out
+
+
+def update_gradients_full(kind, ARD, theta, dL_dK, X, X2=None, device=0):
+    require_device(device)
+    X = f64(X)
+    N, D = X.shape
+    if X2 is None:
+        M, p2 = N, None
+    else:
+        X2 = f64(X2)
+        M, p2 = X2.shape[0], X2.ctypes.data_as(_c_dp)
+    G = f64(dL_dK)
+    assert G.shape == (N, M), "dL_dK must be N x M"
+    theta = f64(theta)
+    out = np.zeros(theta.size)
+    check(lib().mi355gp_update_gradients_full(device, KIND_IDS[kind], int(bool(ARD)), theta, G, X, N, p2, M, D, out),
+          "mi355gp_update_gradients_full")
+    return out
+
+
+def potrf(A, device=0):
+    """Lower Cholesky factor of A (dpotrf equivalent) -> (L, info, ms)."""
+    require_device(device)
+    L = f64(A).copy()
+    ms = ctypes.c_double(0.0)
+    info = check(lib().mi355gp_potrf(device, L, L.shape[0], ctypes.byref(ms)), "mi355gp_potrf")
+    return L, info, ms.value
+
+
+def pdinv(A, device=0):
+    """(Ainv, L, logdet, info, ms): pdinv equivalent (GPy/util/linalg.py:193-214)."""
+    require_device(device)
+    A = f64(A)
+    n = A.shape[0]
+    Ai, L = np.empty((n, n)), np.empty((n, n))
+    ld, ms = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    info = check(lib().mi355gp_pdinv(device, A, n, Ai.ctypes.data_as(_c_dp), L.ctypes.data_as(_c_dp),
+                                     ctypes.byref(ld), ctypes.byref(ms)), "mi355gp_pdinv")
+    return Ai, L, ld.value, info, ms.value
+
+
+def dbg_mfma(a, b, device=0):
+    require_device(device)
+    d = np.zeros(256)
+    check(lib().mi355gp_dbg_mfma(device, f64(a), f64(b), d), "dbg_mfma")
+    return d.reshape(64, 4)
+
+
+def dbg_gemm(A, B, C, a_mcontig, b_ncontig, alpha=1.0, beta=0.0, reps=0, device=0):
+    """C = alpha*op(A) op(B) + beta*C.  A: (M,K) [k-contig] or (K,M) [m-contig]; B: (N,K) or (K,N)."""
+    require_device(device)
+    A, B, C = f64(A), f64(B), f64(C).copy()
+    M, K = (A.shape[1], A.shape[0]) if a_mcontig else A.shape
+    N = B.shape[1] if b_ncontig else B.shape[0]
+    ms = ctypes.c_double(0.0)
+    check(lib().mi355gp_dbg_gemm(device, int(a_mcontig), int(b_ncontig), M, N, K, A, B, C, alpha, beta, reps,
+                                 ctypes.byref(ms)), "dbg_gemm")
+    return C, ms.value
+
+
+def dbg_peaks(device=0):
+    require_device(device)
+    out = np.zeros(8)
+    check(lib().mi355gp_dbg_peaks(device, out), "dbg_peaks")
+    return dict(mfma_f64_tflops=out[0], valu_f64_tflops=out[1], hbm_copy_gbs=out[2], hbm_fill_gbs=out[3],
+                mfma_cycles_per_inst=out[4], shader_mhz=out[5], mfma_1wave_tflops=out[6], mfma4x4_tflops=out[7])

@@ -1,0 +1,553 @@
+// api.hip -- the extern "C" boundary of libmi355gp.so (declared in include/mi355gp.h) and the
+// orchestration of one exact-GP objective+gradient evaluation with everything N x N resident in HBM.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355gp.h"
+#include "internal.h"
+
+int run_peaks(int device, double* out4);
+
+static thread_local std::string g_err;
+
+void mi355gp_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+#define ARG_CHECK(cond, msg)              \
+    do {                                  \
+        if (!(cond)) {                    \
+            mi355gp_set_error("%s", msg); \
+            return -1;                    \
+        }                                 \
+    } while (0)
+
+#define GP_STRIDE 34
+#define LOG_2_PI 1.8378770664093454836
+
+struct mi355gp_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    long n = 0, npad = 0;
+    int D = 0, Dy = 0;
+    double *dX = nullptr, *dR = nullptr, *dXt = nullptr, *dInvLs = nullptr, *dNoise = nullptr;
+    double *A = nullptr, *B = nullptr, *C = nullptr;
+    FactorWs ws;
+    double *dAlpha = nullptr, *dTmp = nullptr, *dTrmvPart = nullptr, *dGradPart = nullptr, *dGradOut = nullptr,
+           *dScal = nullptr, *dDiag = nullptr;
+    long gradPartDoubles = 0;
+    hipEvent_t ev[8] = {};
+    // state of the last inference call (for fetch / predict)
+    bool have_factor = false, have_kernel = false;
+    KernParams kp = {0, 0, 0, 1.0};
+    std::vector<double> theta;
+};
+
+static void free_data(mi355gp_ctx* c) {
+    double** ptrs[] = {&c->dX, &c->dR, &c->dXt, &c->dInvLs, &c->dNoise, &c->A, &c->B, &c->C, &c->dAlpha,
+                       &c->dTmp, &c->dTrmvPart, &c->dGradPart, &c->dGradOut, &c->dScal, &c->dDiag};
+    for (auto p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    factor_ws_free(&c->ws);
+    c->have_factor = c->have_kernel = false;
+}
+
+extern "C" {
+
+const char* mi355gp_last_error(void) { return g_err.c_str(); }
+const char* mi355gp_version(void) { return "mi355gp 0.1 (gfx950)"; }
+
+int mi355gp_device_count(int* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return 0;
+}
+
+int mi355gp_create(int device, mi355gp_ctx** out) {
+    int n = 0;
+    mi355gp_device_count(&n);
+    if (device < 0 || device >= n) {
+        mi355gp_set_error("mi355gp_create: device %d not available (%d HIP devices visible)", device, n);
+        return -2;
+    }
+    HIP_CHECK(hipSetDevice(device));
+    mi355gp_ctx* c = new mi355gp_ctx();
+    c->device = device;
+    HIP_CHECK(hipStreamCreate(&c->st));
+    for (auto& e : c->ev) HIP_CHECK(hipEventCreate(&e));
+    *out = c;
+    return 0;
+}
+
+int mi355gp_destroy(mi355gp_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->st);
+    free_data(c);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    delete c;
+    return 0;
+}
+
+int mi355gp_set_data(mi355gp_ctx* c, const double* X, int64_t N, int D, const double* R, int Dy) {
+    ARG_CHECK(c && X && R && N > 0 && D > 0 && Dy > 0, "mi355gp_set_data: bad arguments");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->st));
+    free_data(c);
+    c->n = N;
+    c->npad = round_up(N, NB);
+    c->D = D;
+    c->Dy = Dy;
+    const long np = c->npad;
+    HIP_CHECK(hipMalloc(&c->dX, sizeof(double) * N * D));
+    HIP_CHECK(hipMalloc(&c->dR, sizeof(double) * N * Dy));
+    HIP_CHECK(hipMalloc(&c->dXt, sizeof(double) * D * np));
+    HIP_CHECK(hipMalloc(&c->dInvLs, sizeof(double) * D));
+    HIP_CHECK(hipMalloc(&c->dNoise, sizeof(double) * N));
+    HIP_CHECK(hipMalloc(&c->A, sizeof(double) * np * np));
+    HIP_CHECK(hipMalloc(&c->B, sizeof(double) * np * np));
+    HIP_CHECK(hipMalloc(&c->C, sizeof(double) * np * np));
+    if (factor_ws_alloc(&c->ws, np) != 0) return -3;
+    HIP_CHECK(hipMalloc(&c->dAlpha, sizeof(double) * N * Dy));
+    HIP_CHECK(hipMalloc(&c->dTmp, sizeof(double) * N * Dy));
+    const long nchunks = (N + 255) / 256;
+    HIP_CHECK(hipMalloc(&c->dTrmvPart, sizeof(double) * nchunks * N * Dy));
+    const int groups = (D + 31) / 32;
+    c->gradPartDoubles = (long)groups * 2048 * GP_STRIDE;
+    HIP_CHECK(hipMalloc(&c->dGradPart, sizeof(double) * c->gradPartDoubles));
+    HIP_CHECK(hipMalloc(&c->dGradOut, sizeof(double) * groups * GP_STRIDE));
+    HIP_CHECK(hipMalloc(&c->dScal, sizeof(double) * 8));
+    HIP_CHECK(hipMalloc(&c->dDiag, sizeof(double) * N));
+    HIP_CHECK(hipMemcpy(c->dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(c->dR, R, sizeof(double) * N * Dy, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mi355gp_set_targets(mi355gp_ctx* c, const double* R, int Dy) {
+    ARG_CHECK(c && R && c->n > 0 && Dy == c->Dy, "mi355gp_set_targets: set_data first / Dy mismatch");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->st));
+    HIP_CHECK(hipMemcpy(c->dR, R, sizeof(double) * c->n * Dy, hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+static int check_theta(int kind, int ard, const double* theta, int D, std::vector<double>* inv_ls) {
+    ARG_CHECK(kind >= 0 && kind <= 3, "unknown covariance kind");
+    ARG_CHECK(theta != nullptr, "theta is NULL");
+    ARG_CHECK(theta[0] > 0.0, "variance must be positive");
+    const int nl = ard ? D : 1;
+    inv_ls->resize(D);
+    for (int q = 0; q < nl; ++q) {
+        ARG_CHECK(theta[1 + q] > 0.0, "lengthscales must be positive");
+        (*inv_ls)[q] = 1.0 / theta[1 + q];
+    }
+    return 0;
+}
+
+// post-scaling of the raw reduction sums: dvar = S_var / variance; dl = -S / l
+// (GPy/kern/src/stationary.py:199,210-213 with x already divided by l inside the kernels)
+static void finish_dtheta(const KernParams& kp, const double* theta, const double* sums /*groups*GP_STRIDE*/,
+                          double* dtheta_out) {
+    dtheta_out[0] = sums[0] / kp.variance;
+    if (!kp.ard) {
+        dtheta_out[1] = -sums[1] / theta[1];
+    } else {
+        for (int q = 0; q < kp.D; ++q) dtheta_out[1 + q] = -sums[(q / 32) * GP_STRIDE + 2 + (q % 32)] / theta[1 + q];
+    }
+}
+
+// Shared tail: given Ky (lower) in c->A: factor, invert, alpha, scalars [, kernel gradients].
+static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* theta, double* out_scalars,
+                        double* alpha_out, double* dtheta_out, double* diag_out, double* stage_ms) {
+    hipStream_t st = c->st;
+    const long n = c->n, np = c->npad;
+    HIP_CHECK(hipEventRecord(c->ev[1], st));
+    potrf_device(st, c->A, np, &c->ws);
+    HIP_CHECK(hipEventRecord(c->ev[2], st));
+    trtri_device(st, c->A, c->B, c->C, np, &c->ws);
+    HIP_CHECK(hipEventRecord(c->ev[3], st));
+    lauum_device(st, c->B, c->C, np);
+    HIP_CHECK(hipEventRecord(c->ev[4], st));
+    launch_tri_matvec(st, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
+    launch_scalars(st, c->dAlpha, c->dR, c->C, np, n, c->Dy, c->ws.logsum, c->ws.nblk, c->dScal, c->dDiag);
+    HIP_CHECK(hipEventRecord(c->ev[5], st));
+    const int groups = (c->D + 31) / 32;
+    int nb = 0;
+    if (with_kernel_grads) {
+        nb = grad_num_blocks(n);
+        launch_grad_fused(st, c->kp, c->dXt, np, n, c->C, np, c->dAlpha, c->Dy, c->dGradPart, GP_STRIDE);
+        for (int g = 0; g < (c->kp.ard ? groups : 1); ++g)
+            launch_reduce_partials(st, c->dGradPart + (long)g * nb * GP_STRIDE, nb, GP_STRIDE,
+                                   c->dGradOut + (long)g * GP_STRIDE);
+    }
+    HIP_CHECK(hipEventRecord(c->ev[6], st));
+    // small D2H transfers
+    double scal[8];
+    int info[4];
+    std::vector<double> sums((size_t)groups * GP_STRIDE, 0.0);
+    HIP_CHECK(hipMemcpyAsync(scal, c->dScal, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(info, c->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (with_kernel_grads)
+        HIP_CHECK(hipMemcpyAsync(sums.data(), c->dGradOut, sizeof(double) * groups * GP_STRIDE,
+                                 hipMemcpyDeviceToHost, st));
+    if (alpha_out)
+        HIP_CHECK(hipMemcpyAsync(alpha_out, c->dAlpha, sizeof(double) * n * c->Dy, hipMemcpyDeviceToHost, st));
+    if (diag_out) HIP_CHECK(hipMemcpyAsync(diag_out, c->dDiag, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipGetLastError());
+    if (stage_ms) {
+        float ms;
+        for (int i = 0; i < MI355GP_NUM_T; ++i) stage_ms[i] = 0.0;
+        const int map[6] = {MI355GP_T_KBUILD, MI355GP_T_POTRF, MI355GP_T_TRTRI, MI355GP_T_LAUUM, MI355GP_T_SOLVE,
+                            MI355GP_T_GRAD};
+        for (int i = 0; i < 6; ++i) {
+            HIP_CHECK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+            stage_ms[map[i]] = ms;
+        }
+        HIP_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[6]));
+        stage_ms[MI355GP_T_TOTAL] = ms;
+    }
+    if (info[0] > 0) {
+        c->have_factor = false;
+        if (info[0] > n) info[0] = (int)n;
+        return info[0];
+    }
+    c->have_factor = true;
+    const double datafit = scal[0], alpha2 = scal[1], trw = scal[2], logdet = scal[3];
+    const double Dy = (double)c->Dy;
+    for (int i = 0; i < MI355GP_NUM_OUT; ++i) out_scalars[i] = 0.0;
+    out_scalars[MI355GP_OUT_LML] = 0.5 * (-(double)n * Dy * LOG_2_PI - Dy * logdet - datafit);
+    out_scalars[MI355GP_OUT_LOGDET] = logdet;
+    out_scalars[MI355GP_OUT_DATAFIT] = datafit;
+    out_scalars[MI355GP_OUT_DNOISE] = 0.5 * (alpha2 - Dy * trw);
+    out_scalars[MI355GP_OUT_TRKINV] = trw;
+    if (with_kernel_grads && dtheta_out) finish_dtheta(c->kp, theta, sums.data(), dtheta_out);
+    return 0;
+}
+
+static int upload_noise(mi355gp_ctx* c, const double* noise, int64_t noise_len) {
+    ARG_CHECK(noise != nullptr && (noise_len == 1 || noise_len == c->n),
+              "noise must have 1 or N entries");
+    HIP_CHECK(hipMemcpyAsync(c->dNoise, noise, sizeof(double) * noise_len, hipMemcpyHostToDevice, c->st));
+    return 0;
+}
+
+extern "C" {
+
+int mi355gp_exact_inference(mi355gp_ctx* c, int kind, int ard, const double* theta, const double* noise,
+                            int64_t noise_len, double jitter, double extra_jitter, double* out_scalars,
+                            double* alpha_out, double* dtheta_out, double* diag_dLdK_out, double* stage_ms) {
+    ARG_CHECK(c && c->n > 0, "mi355gp_exact_inference: set_data first");
+    ARG_CHECK(out_scalars != nullptr, "out_scalars is NULL");
+    HIP_CHECK(hipSetDevice(c->device));
+    std::vector<double> inv_ls;
+    if (int rc = check_theta(kind, ard, theta, c->D, &inv_ls)) return rc;
+    if (int rc = upload_noise(c, noise, noise_len)) return rc;
+    hipStream_t st = c->st;
+    c->kp = KernParams{kind, ard ? 1 : 0, c->D, theta[0]};
+    c->theta.assign(theta, theta + 1 + (ard ? c->D : 1));
+    c->have_kernel = true;
+    HIP_CHECK(hipMemcpyAsync(c->dInvLs, inv_ls.data(), sizeof(double) * c->D, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipEventRecord(c->ev[0], st));
+    launch_scale_inputs(st, c->dX, c->n, c->D, c->dInvLs, c->kp.ard, c->dXt, c->npad);
+    launch_kbuild_sym(st, c->kp, c->dXt, c->npad, c->n, c->npad, c->A, c->dNoise, noise_len, jitter + extra_jitter,
+                      /*lower_only=*/1, /*add_diag=*/1);
+    return run_pipeline(c, true, theta, out_scalars, alpha_out, dtheta_out, diag_dLdK_out, stage_ms);
+}
+
+int mi355gp_inference_given_K(mi355gp_ctx* c, const double* K_host, const double* noise, int64_t noise_len,
+                              double jitter, double extra_jitter, double* out_scalars, double* alpha_out,
+                              double* diag_dLdK_out, double* stage_ms) {
+    ARG_CHECK(c && c->n > 0, "mi355gp_inference_given_K: set_data first");
+    ARG_CHECK(K_host && out_scalars, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    if (int rc = upload_noise(c, noise, noise_len)) return rc;
+    hipStream_t st = c->st;
+    c->have_kernel = false;
+    // stage the dense n x n matrix in C (free until lauum), then pad + add the diagonal into A
+    HIP_CHECK(hipMemcpyAsync(c->C, K_host, sizeof(double) * c->n * c->n, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipEventRecord(c->ev[0], st));
+    launch_pad_from_dense(st, c->C, c->n, c->A, c->npad, c->dNoise, noise_len, jitter + extra_jitter);
+    return run_pipeline(c, false, nullptr, out_scalars, alpha_out, nullptr, diag_dLdK_out, stage_ms);
+}
+
+int mi355gp_fetch(mi355gp_ctx* c, int which, double* out, int fortran_order) {
+    ARG_CHECK(c && c->n > 0 && out, "mi355gp_fetch: bad arguments");
+    HIP_CHECK(hipSetDevice(c->device));
+    const long n = c->n, np = c->npad;
+    hipStream_t st = c->st;
+    double* tmp = nullptr;
+    HIP_CHECK(hipMalloc(&tmp, sizeof(double) * n * n));
+    int rc = 0;
+    if (which == MI355GP_FETCH_K) {
+        if (!c->have_kernel) {
+            mi355gp_set_error("mi355gp_fetch(K): no device kernel evaluation in this context");
+            rc = -4;
+        } else {
+            launch_kbuild_cross(st, c->kp, c->dXt, np, n, c->dXt, np, n, tmp, n);   // symmetric: no transpose needed
+        }
+    } else if (!c->have_factor) {
+        mi355gp_set_error("mi355gp_fetch: no successful factorisation in this context");
+        rc = -4;
+    } else if (which == MI355GP_FETCH_L) {
+        launch_extract(st, c->A, np, n, 0, nullptr, 0, tmp, fortran_order);
+    } else if (which == MI355GP_FETCH_KINV) {
+        launch_extract(st, c->C, np, n, 1, nullptr, 0, tmp, 0);
+    } else if (which == MI355GP_FETCH_DLDK) {
+        launch_extract(st, c->C, np, n, 2, c->dAlpha, c->Dy, tmp, 0);
+    } else {
+        mi355gp_set_error("mi355gp_fetch: unknown matrix id %d", which);
+        rc = -1;
+    }
+    if (rc == 0) {
+        hipError_t e = hipMemcpyAsync(out, tmp, sizeof(double) * n * n, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            mi355gp_set_error("mi355gp_fetch: %s", hipGetErrorString(e));
+            rc = -(1000 + (int)e);
+        }
+    }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+// ---- stateless kernel-function entry points --------------------------------------------------------
+int mi355gp_kern_K(int device, int kind, int ard, const double* theta, const double* X, int64_t N,
+                   const double* X2, int64_t M, int D, double* K_out) {
+    ARG_CHECK(X && K_out && N > 0 && D > 0, "mi355gp_kern_K: bad arguments");
+    HIP_CHECK(hipSetDevice(device));
+    std::vector<double> inv_ls;
+    if (int rc = check_theta(kind, ard, theta, D, &inv_ls)) return rc;
+    const bool sym = (X2 == nullptr);
+    if (sym) M = N;
+    ARG_CHECK(M > 0, "mi355gp_kern_K: M must be positive");
+    const long ld1 = round_up(N, 64), ld2 = round_up(M, 64);
+    double *dX = nullptr, *dX2 = nullptr, *dXt1 = nullptr, *dXt2 = nullptr, *dIl = nullptr, *dK = nullptr;
+    HIP_CHECK(hipMalloc(&dX, sizeof(double) * N * D));
+    HIP_CHECK(hipMalloc(&dXt1, sizeof(double) * D * ld1));
+    HIP_CHECK(hipMalloc(&dIl, sizeof(double) * D));
+    HIP_CHECK(hipMalloc(&dK, sizeof(double) * N * M));
+    HIP_CHECK(hipMemcpy(dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dIl, inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice));
+    launch_scale_inputs(0, dX, N, D, dIl, ard ? 1 : 0, dXt1, ld1);
+    dXt2 = dXt1;
+    if (!sym) {
+        HIP_CHECK(hipMalloc(&dX2, sizeof(double) * M * D));
+        HIP_CHECK(hipMalloc(&dXt2, sizeof(double) * D * ld2));
+        HIP_CHECK(hipMemcpy(dX2, X2, sizeof(double) * M * D, hipMemcpyHostToDevice));
+        launch_scale_inputs(0, dX2, M, D, dIl, ard ? 1 : 0, dXt2, ld2);
+    }
+    KernParams kp{kind, ard ? 1 : 0, D, theta[0]};
+    launch_kbuild_cross(0, kp, dXt1, ld1, N, dXt2, sym ? ld1 : ld2, M, dK, M);
+    HIP_CHECK(hipMemcpy(K_out, dK, sizeof(double) * N * M, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipGetLastError());
+    (void)hipFree(dX); (void)hipFree(dXt1); (void)hipFree(dIl); (void)hipFree(dK);
+    if (!sym) { (void)hipFree(dX2); (void)hipFree(dXt2); }
+    return 0;
+}
+
+int mi355gp_kern_Kdiag(int kind, const double* theta, int64_t N, double* out) {
+    ARG_CHECK(kind >= 0 && kind <= 3 && theta && out && N >= 0, "mi355gp_kern_Kdiag: bad arguments");
+    for (int64_t i = 0; i < N; ++i) out[i] = theta[0];   // stationary: K(x,x) = variance (stationary.py:170-173)
+    return 0;
+}
+
+int mi355gp_update_gradients_full(int device, int kind, int ard, const double* theta, const double* dL_dK,
+                                  const double* X, int64_t N, const double* X2, int64_t M, int D,
+                                  double* dtheta_out) {
+    ARG_CHECK(dL_dK && X && dtheta_out && N > 0 && D > 0, "mi355gp_update_gradients_full: bad arguments");
+    HIP_CHECK(hipSetDevice(device));
+    std::vector<double> inv_ls;
+    if (int rc = check_theta(kind, ard, theta, D, &inv_ls)) return rc;
+    const bool sym = (X2 == nullptr);
+    if (sym) M = N;
+    const long ld1 = round_up(N, 64), ld2 = round_up(M, 64);
+    const int groups = (D + 31) / 32;
+    double *dX = nullptr, *dX2 = nullptr, *dXt1 = nullptr, *dXt2 = nullptr, *dIl = nullptr, *dG = nullptr,
+           *dPart = nullptr, *dOut = nullptr;
+    HIP_CHECK(hipMalloc(&dX, sizeof(double) * N * D));
+    HIP_CHECK(hipMalloc(&dXt1, sizeof(double) * D * ld1));
+    HIP_CHECK(hipMalloc(&dIl, sizeof(double) * D));
+    HIP_CHECK(hipMalloc(&dG, sizeof(double) * N * M));
+    HIP_CHECK(hipMalloc(&dPart, sizeof(double) * groups * 2048 * GP_STRIDE));
+    HIP_CHECK(hipMalloc(&dOut, sizeof(double) * groups * GP_STRIDE));
+    HIP_CHECK(hipMemcpy(dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dIl, inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dG, dL_dK, sizeof(double) * N * M, hipMemcpyHostToDevice));
+    launch_scale_inputs(0, dX, N, D, dIl, ard ? 1 : 0, dXt1, ld1);
+    dXt2 = dXt1;
+    if (!sym) {
+        HIP_CHECK(hipMalloc(&dX2, sizeof(double) * M * D));
+        HIP_CHECK(hipMalloc(&dXt2, sizeof(double) * D * ld2));
+        HIP_CHECK(hipMemcpy(dX2, X2, sizeof(double) * M * D, hipMemcpyHostToDevice));
+        launch_scale_inputs(0, dX2, M, D, dIl, ard ? 1 : 0, dXt2, ld2);
+    }
+    KernParams kp{kind, ard ? 1 : 0, D, theta[0]};
+    const int nb = grad_generic_num_blocks(N, M);
+    launch_grad_generic(0, kp, dXt1, ld1, N, dXt2, sym ? ld1 : ld2, M, sym ? 1 : 0, dG, M, dPart, GP_STRIDE);
+    for (int g = 0; g < (kp.ard ? groups : 1); ++g)
+        launch_reduce_partials(0, dPart + (long)g * nb * GP_STRIDE, nb, GP_STRIDE, dOut + (long)g * GP_STRIDE);
+    std::vector<double> sums((size_t)groups * GP_STRIDE, 0.0);
+    HIP_CHECK(hipMemcpy(sums.data(), dOut, sizeof(double) * groups * GP_STRIDE, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipGetLastError());
+    finish_dtheta(kp, theta, sums.data(), dtheta_out);
+    (void)hipFree(dX); (void)hipFree(dXt1); (void)hipFree(dIl); (void)hipFree(dG); (void)hipFree(dPart);
+    (void)hipFree(dOut);
+    if (!sym) { (void)hipFree(dX2); (void)hipFree(dXt2); }
+    return 0;
+}
+
+// ---- standalone dense routines ------------------------------------------------------------------------
+static int dense_factor(int device, const double* A_host, int64_t N, bool invert, double* L_out, double* Ainv_out,
+                        double* logdet, double* ms) {
+    HIP_CHECK(hipSetDevice(device));
+    const long np = round_up(N, NB);
+    double *A = nullptr, *B = nullptr, *C = nullptr, *tmp = nullptr, *dScal = nullptr;
+    FactorWs ws;
+    HIP_CHECK(hipMalloc(&A, sizeof(double) * np * np));
+    HIP_CHECK(hipMalloc(&tmp, sizeof(double) * N * N));
+    HIP_CHECK(hipMalloc(&dScal, sizeof(double) * 8));
+    if (invert) {
+        HIP_CHECK(hipMalloc(&B, sizeof(double) * np * np));
+        HIP_CHECK(hipMalloc(&C, sizeof(double) * np * np));
+    }
+    if (factor_ws_alloc(&ws, np) != 0) return -3;
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipMemcpy(tmp, A_host, sizeof(double) * N * N, hipMemcpyHostToDevice));
+    launch_pad_from_dense(0, tmp, N, A, np, nullptr, 0, 0.0);
+    HIP_CHECK(hipEventRecord(e0, 0));
+    potrf_device(0, A, np, &ws);
+    if (invert) {
+        trtri_device(0, A, B, C, np, &ws);
+        lauum_device(0, B, C, np);
+    }
+    HIP_CHECK(hipEventRecord(e1, 0));
+    int info = 0;
+    HIP_CHECK(hipMemcpy(&info, ws.info, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipGetLastError());
+    if (ms) {
+        float t;
+        HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+        *ms = t;
+    }
+    if (info == 0) {
+        if (L_out) {
+            launch_extract(0, A, np, N, 0, nullptr, 0, tmp, 0);
+            HIP_CHECK(hipMemcpy(L_out, tmp, sizeof(double) * N * N, hipMemcpyDeviceToHost));
+        }
+        if (invert && Ainv_out) {
+            launch_extract(0, C, np, N, 1, nullptr, 0, tmp, 0);
+            HIP_CHECK(hipMemcpy(Ainv_out, tmp, sizeof(double) * N * N, hipMemcpyDeviceToHost));
+        }
+        if (logdet) {
+            std::vector<double> ls(ws.nblk);
+            HIP_CHECK(hipMemcpy(ls.data(), ws.logsum, sizeof(double) * ws.nblk, hipMemcpyDeviceToHost));
+            double s = 0.0;
+            for (double v : ls) s += v;
+            *logdet = 2.0 * s;
+        }
+    }
+    (void)hipFree(A); (void)hipFree(tmp); (void)hipFree(dScal);
+    if (B) (void)hipFree(B);
+    if (C) (void)hipFree(C);
+    factor_ws_free(&ws);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (info > N) info = (int)N;
+    return info;
+}
+
+int mi355gp_potrf(int device, double* A, int64_t N, double* ms) {
+    ARG_CHECK(A && N > 0, "mi355gp_potrf: bad arguments");
+    return dense_factor(device, A, N, false, A, nullptr, nullptr, ms);
+}
+
+int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* L_out, double* logdet, double* ms) {
+    ARG_CHECK(A && N > 0, "mi355gp_pdinv: bad arguments");
+    return dense_factor(device, A, N, true, L_out, Ainv, logdet, ms);
+}
+
+int mi355gp_predict(mi355gp_ctx* c, int kind, int ard, const double* theta, const double* Xnew, int64_t M,
+                    double* mu_out, double* var_out, int full_cov) {
+    (void)c; (void)kind; (void)ard; (void)theta; (void)Xnew; (void)M; (void)mu_out; (void)var_out; (void)full_cov;
+    mi355gp_set_error("mi355gp_predict: not implemented in this build");
+    return -99;
+}
+
+int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, double* ms_trtri, double* ms_lauum) {
+    (void)device; (void)N; (void)reps; (void)ms_potrf; (void)ms_trtri; (void)ms_lauum;
+    mi355gp_set_error("mi355gp_bench_factor: use mi355gp_exact_inference stage_ms");
+    return -99;
+}
+
+// ---- diagnostics ------------------------------------------------------------------------------------------
+int mi355gp_dbg_mfma(int device, const double* a, const double* b, double* d) {
+    HIP_CHECK(hipSetDevice(device));
+    double *da, *db, *dd;
+    HIP_CHECK(hipMalloc(&da, 64 * 8));
+    HIP_CHECK(hipMalloc(&db, 64 * 8));
+    HIP_CHECK(hipMalloc(&dd, 256 * 8));
+    HIP_CHECK(hipMemcpy(da, a, 64 * 8, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(db, b, 64 * 8, hipMemcpyHostToDevice));
+    launch_dbg_mfma(0, da, db, dd);
+    HIP_CHECK(hipMemcpy(d, dd, 256 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dd);
+    return 0;
+}
+
+int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_t N, int64_t K, const double* A,
+                     const double* B, double* C, double alpha, double beta, int reps, double* ms) {
+    ARG_CHECK(M % NB == 0 && N % NB == 0 && K % 16 == 0 && M > 0 && N > 0 && K > 0, "dbg_gemm: M,N % 128, K % 16");
+    HIP_CHECK(hipSetDevice(device));
+    double *dA, *dB, *dC;
+    HIP_CHECK(hipMalloc(&dA, sizeof(double) * M * K));
+    HIP_CHECK(hipMalloc(&dB, sizeof(double) * N * K));
+    HIP_CHECK(hipMalloc(&dC, sizeof(double) * M * N));
+    HIP_CHECK(hipMemcpy(dA, A, sizeof(double) * M * K, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dB, B, sizeof(double) * N * K, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dC, C, sizeof(double) * M * N, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    launch_dbg_gemm(0, a_mcontig, b_ncontig, M, N, K, dA, dB, dC, alpha, beta);
+    HIP_CHECK(hipMemcpy(C, dC, sizeof(double) * M * N, hipMemcpyDeviceToHost));
+    if (reps > 0 && ms) {
+        HIP_CHECK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) launch_dbg_gemm(0, a_mcontig, b_ncontig, M, N, K, dA, dB, dC, alpha, 0.0);
+        HIP_CHECK(hipEventRecord(e1, 0));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float t;
+        HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+        *ms = t / reps;
+    }
+    HIP_CHECK(hipGetLastError());
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
+int mi355gp_dbg_peaks(int device, double* out4) { return run_peaks(device, out4); }
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// common.h -- shared definitions for the gfx950 kernels of libmi355gp.so (CDNA4 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define NB 128            // base block: diagonal blocks, GEMM tiles and padding granule
+#define NBO 512           // outer panel width of the two-level right-looking Cholesky
+
+// v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) * B(4x16) + C.  Per lane (l = 0..63):
+//   A operand: A[row = l & 15][k = l >> 4]        (one double)
+//   B operand: B[k = l >> 4][col = l & 15]        (one double)
+//   C/D      : D[row = (l >> 4) + 4 * r][col = l & 15], r = 0..3   (four doubles)
+// A K=16 product is four MFMAs; slice s uses k = (l >> 4) + 4 s so that accumulator register r of a
+// previous product can be fed back directly as the B operand of slice r ("register chaining").
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// launcher-side error plumbing
+void mi355gp_set_error(const char* fmt, ...);
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            mi355gp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                              __LINE__);                                                         \
+            return -(1000 + (int)_e);                                                            \
+        }                                                                                        \
+    } while (0)
+
+static inline int64_t round_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }

@@ -1,0 +1,84 @@
+// internal.h -- host-side launcher declarations shared by the translation units of libmi355gp.so.
+#pragma once
+#include "common.h"
+
+// ---- gemm.hip : tiled fp64 MFMA GEMM family (all dimensions multiples of 128) -------------------
+// C[ti,tj] -= A[ti,:] * B[tj,:]^T over a (ntr x ntc)-tile region; tiles with (col0t+tj) > (row0t+ti) skipped.
+void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
+                      int K, int ntr, int ntc, int row0t, int col0t);
+// one bottom-up level of the batched triangular inverse: X21 = -X22 * (L21 * X11) for every block pair
+void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level);
+// W (lower tiles) = X^T X for lower-triangular X
+void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt);
+void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A,
+                     const double* B, double* C, double alpha, double beta);
+
+// ---- small.hip : single-CU MFMA kernels on 128x128 diagonal blocks -------------------------------
+// in-place Cholesky of the 128x128 block at A[c0,c0]; writes the 8 inverses of its 16x16 diagonal tiles
+// to dinv (8*256 doubles), sum(log diag) to logsum[0], first failing 1-based global column to *info.
+void launch_diag128(hipStream_t st, double* A, long ld, long c0, double* dinv, double* logsum, int* info);
+// rows [r0, r0+mrows) of the 128-wide panel at column c0:  P <- P * L_cc^{-T}   (mrows % 16 == 0)
+void launch_trsm128(hipStream_t st, double* A, long ld, long c0, long r0, long mrows, const double* dinv);
+// X_cc = L_cc^{-1} for all nblk diagonal blocks (upper tiles of the diagonal blocks of X zeroed)
+void launch_inv128(hipStream_t st, const double* L, double* X, long ld, int nblk, const double* dinv_all);
+void launch_dbg_mfma(hipStream_t st, const double* a, const double* b, double* d);
+
+// ---- factor.hip : blocked drivers -------------------------------------------------------------------
+struct FactorWs {
+    double* dinv = nullptr;     // nblk * 8 * 256 doubles: inverses of the 16x16 diagonal tiles
+    double* logsum = nullptr;   // nblk doubles: sum(log diag L) per 128-block
+    int* info = nullptr;        // device int: 0 or first failing column (1-based)
+    long nblk = 0;
+};
+int factor_ws_alloc(FactorWs* ws, long npad);
+void factor_ws_free(FactorWs* ws);
+// A (npad x npad, ld = npad, lower) -> L in place.  Asynchronous on `st`.
+void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws);
+// X = L^-1 (into X, using T as scratch), asynchronous.
+void trtri_device(hipStream_t st, const double* L, double* X, double* T, long npad, FactorWs* ws);
+// W = X^T X (lower tiles)
+void lauum_device(hipStream_t st, const double* X, double* W, long npad);
+
+// ---- kern.hip : covariance assembly, reductions, solves, fetch helpers ----------------------------
+struct KernParams {
+    int kind;
+    int ard;
+    int D;
+    double variance;
+};
+// Xt: scaled, transposed inputs [D][ldx] (x_q / l_q); builds lower tiles of Ky = K + diag(noise + jit) into A
+// (npad x npad); rows/cols >= n get the identity.
+void launch_scale_inputs(hipStream_t st, const double* X, long n, int D, const double* inv_ls, int ard,
+                         double* Xt, long ldx);
+void launch_kbuild_sym(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, long npad, double* A,
+                       const double* noise, long noise_len, double jit, int lower_only, int add_diag);
+void launch_kbuild_cross(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
+                         long ld2, long m, double* Kout, long ldk);
+// y = X r (lower-triangular X, n x n within npad), then a = X^T y   (Dy right-hand sides, row-major n x Dy)
+void launch_tri_matvec(hipStream_t st, const double* X, long ld, long n, const double* R, int Dy, double* tmp,
+                       double* alpha, double* partials);
+// fused gradient reduction over the lower tiles of W; results (per block partials) reduced by launch_finalize
+struct GradOut {
+    double* partials;   // [nblocks][stride]
+    int stride;
+    int nblocks;
+};
+int grad_num_blocks(long n);
+void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, const double* W,
+                       long ldw, const double* alpha, int Dy, double* partials, int stride);
+void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
+                         long ld2, long m, int symmetric, const double* G, long ldg, double* partials,
+                         int stride);
+int grad_generic_num_blocks(long n, long m);
+// sums `nblocks` rows of `stride` doubles in a fixed order into out[stride]
+void launch_reduce_partials(hipStream_t st, const double* partials, int nblocks, int stride, double* out);
+// out4[0]=sum alpha*R ; [1]=sum alpha^2 ; [2]=trace W ; [3]=2*sum(logsum) ; diag_out (n) = 0.5*(|alpha_i|^2 - Dy*W_ii)
+void launch_scalars(hipStream_t st, const double* alpha, const double* R, const double* W, long ldw, long n,
+                    int Dy, const double* logsum, long nblk, double* out4, double* diag_out);
+// dense n x n host-shaped outputs from padded device matrices
+//   mode 0: lower triangle of A, strict upper zero;  1: symmetric mirror of lower(A);
+//   2: 0.5*(alpha alpha^T - Dy * sym(A));  transpose != 0 writes the transpose (Fortran order)
+void launch_extract(hipStream_t st, const double* A, long ld, long n, int mode, const double* alpha, int Dy,
+                    double* out, int transpose);
+void launch_pad_from_dense(hipStream_t st, const double* src, long n, double* A, long npad, const double* noise,
+                           long noise_len, double jit);

@@ -1,0 +1,541 @@
+// kern.hip -- covariance assembly (Stationary.K), the fused dL/dK -> dL/dtheta reduction
+// (Stationary.update_gradients_full), the alpha products and the fetch helpers.
+// Reference: GPy/kern/src/stationary.py:105-168,193-243; rbf.py:51-52,177-178; stationary.py:382-386,
+// 488-492,585-589; stationary_cython.pyx:53-62; inference/.../exact_gaussian_inference.py:55-72.
+//
+// These stages are HBM-bound (8 N^2 bytes written by the build, 4 N^2 read by the gradient pass over the
+// lower triangle of Ky^-1): inputs are pre-scaled by 1/lengthscale and stored dimension-major so a 64-point
+// slab of every dimension is one coalesced 512-byte read, X tiles live in LDS, and K is recomputed from X
+// inside the gradient pass instead of being re-read from memory.
+#include "internal.h"
+
+#define KT 64      // covariance tile edge
+#define KDC 32     // input dimensions staged per LDS chunk
+
+struct CovVal {
+    double k;        // K(r)
+    double dk_r;     // dK/dr * r
+    double dk_or;    // dK/dr / r   (0 where r == 0 for the exponential kernel)
+};
+
+__device__ __forceinline__ double cov_k(int kind, double var, double r2) {
+    if (kind == 0) return var * exp(-0.5 * r2);
+    const double r = sqrt(r2);
+    if (kind == 1) {
+        const double s5r = 2.2360679774997896964 * r;
+        return var * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);
+    }
+    if (kind == 2) {
+        const double s3r = 1.7320508075688772935 * r;
+        return var * (1.0 + s3r) * exp(-s3r);
+    }
+    return var * exp(-r);
+}
+
+__device__ __forceinline__ CovVal cov_all(int kind, double var, double r2) {
+    CovVal c;
+    if (kind == 0) {
+        c.k = var * exp(-0.5 * r2);
+        c.dk_r = -r2 * c.k;
+        c.dk_or = -c.k;
+        return c;
+    }
+    const double r = sqrt(r2);
+    if (kind == 1) {
+        const double s5r = 2.2360679774997896964 * r;
+        const double e = var * exp(-s5r);
+        c.k = (1.0 + s5r + (5.0 / 3.0) * r2) * e;
+        c.dk_or = -(5.0 / 3.0) * (1.0 + s5r) * e;
+        c.dk_r = c.dk_or * r2;
+        return c;
+    }
+    if (kind == 2) {
+        const double s3r = 1.7320508075688772935 * r;
+        const double e = var * exp(-s3r);
+        c.k = (1.0 + s3r) * e;
+        c.dk_or = -3.0 * e;
+        c.dk_r = c.dk_or * r2;
+        return c;
+    }
+    c.k = var * exp(-r);
+    c.dk_r = -r * c.k;
+    c.dk_or = (r != 0.0) ? -c.k / r : 0.0;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Xt[q][i] = X[i][q] / l_q, zero for i in [n, ldx)
+__global__ void k_scale_inputs(const double* __restrict__ X, long n, int D, const double* __restrict__ inv_ls,
+                               int ard, double* __restrict__ Xt, long ldx) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)D * ldx) return;
+    const int q = (int)(idx / ldx);
+    const long i = idx - (long)q * ldx;
+    Xt[idx] = (i < n) ? X[i * D + q] * inv_ls[ard ? q : 0] : 0.0;
+}
+
+void launch_scale_inputs(hipStream_t st, const double* X, long n, int D, const double* inv_ls, int ard,
+                         double* Xt, long ldx) {
+    const long total = (long)D * ldx;
+    hipLaunchKernelGGL(k_scale_inputs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, X, n, D, inv_ls,
+                       ard, Xt, ldx);
+}
+
+// Stage rows [i0, i0+64) of dims [q0, q0+qc) of a dimension-major input into LDS s[q][64].
+__device__ __forceinline__ void stage_x(const double* __restrict__ Xt, long ldx, long i0, int q0, int qc,
+                                        double* s, int t) {
+    for (int idx = t; idx < qc * KT; idx += 256) {
+        const int q = idx >> 6, ii = idx & 63;
+        s[q * KT + ii] = Xt[(long)(q0 + q) * ldx + i0 + ii];
+    }
+}
+
+// r2[a][b] += sum_q (xi[q][ty*4+a] - xj[q][tx*4+b])^2
+__device__ __forceinline__ void accum_r2(const double* si, const double* sj, int qc, int ty, int tx,
+                                         double (&r2)[4][4]) {
+    for (int q = 0; q < qc; ++q) {
+        const d4 xi = *reinterpret_cast<const d4*>(si + q * KT + ty * 4);
+        const d4 xj = *reinterpret_cast<const d4*>(sj + q * KT + tx * 4);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double d = xi[a] - xj[b];
+                r2[a][b] = fma(d, d, r2[a][b]);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Covariance assembly.  SYM: Ky = K + diag(noise + jit) into the padded npad x npad buffer (identity in the
+// padding), optionally lower 64-tiles only.  !SYM: rectangular K(X1, X2) into a dense n x m buffer.
+template <bool SYM>
+__global__ __launch_bounds__(256) void k_kbuild(KernParams kp, const double* __restrict__ Xt1, long ld1, long n,
+                                                const double* __restrict__ Xt2, long ld2, long m,
+                                                double* __restrict__ out, long ldo, long nrows_out,
+                                                const double* __restrict__ noise, long noise_len, double jit,
+                                                int lower_only, int add_diag, int ntc) {
+    __shared__ __attribute__((aligned(16))) double si[KDC * KT];
+    __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const long ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
+    if (SYM && lower_only && tj > ti) return;
+    const long i0 = ti * KT, j0 = tj * KT;
+    double r2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+    const bool real_tile = (i0 < n) && (j0 < m);
+    if (real_tile) {
+        for (int q0 = 0; q0 < kp.D; q0 += KDC) {
+            const int qc = (kp.D - q0 < KDC) ? (kp.D - q0) : KDC;
+            __syncthreads();
+            stage_x(Xt1, ld1, i0, q0, qc, si, t);
+            stage_x(Xt2, ld2, j0, q0, qc, sj, t);
+            __syncthreads();
+            accum_r2(si, sj, qc, ty, tx, r2);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long i = i0 + ty * 4 + a;
+        double v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const long j = j0 + tx * 4 + b;
+            if (i < n && j < m) {
+                v[b] = cov_k(kp.kind, kp.variance, r2[a][b]);
+                if (SYM && add_diag && i == j) v[b] += noise[noise_len > 1 ? i : 0] + jit;
+            } else {
+                v[b] = (SYM && i == j) ? 1.0 : 0.0;
+            }
+        }
+        if (SYM) {
+            if (i < nrows_out) *reinterpret_cast<d4*>(out + i * ldo + j0 + tx * 4) = (d4){v[0], v[1], v[2], v[3]};
+        } else if (i < n) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long j = j0 + tx * 4 + b;
+                if (j < m) out[i * ldo + j] = v[b];
+            }
+        }
+    }
+}
+
+void launch_kbuild_sym(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, long npad, double* A,
+                       const double* noise, long noise_len, double jit, int lower_only, int add_diag) {
+    const int nt = (int)(npad / KT);
+    hipLaunchKernelGGL((k_kbuild<true>), dim3((unsigned)((long)nt * nt)), dim3(256), 0, st, kp, Xt, ldx, n, Xt, ldx, n,
+                       A, npad, npad, noise, noise_len, jit, lower_only, add_diag, nt);
+}
+
+void launch_kbuild_cross(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
+                         long ld2, long m, double* Kout, long ldk) {
+    const int ntr = (int)((n + KT - 1) / KT), ntc = (int)((m + KT - 1) / KT);
+    hipLaunchKernelGGL((k_kbuild<false>), dim3((unsigned)((long)ntr * ntc)), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2,
+                       ld2, m, Kout, ldk, n, nullptr, 0, 0.0, 0, 0, ntc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gradient reduction.  For every (i, j): g = weight * dL_dK[i][j];
+//   acc_var += g*K ; acc_iso += g*(dK/dr*r) ; acc_q += g*(dK/dr / r)*(x~_iq - x~_jq)^2   (x~ = x / l)
+// FUSED: dL_dK = 0.5*(alpha_i . alpha_j - Dy*W_ij) from the lower triangle of W (off-diagonal weight 2).
+// else : dL_dK read from G (n x m).
+// Per-block partials [2 + 32]: [0] var, [1] iso, [2+q] lengthscale dims q_off..q_off+31.
+#define GP_STRIDE 34
+template <bool FUSED, bool ARD>
+__global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __restrict__ Xt1, long ld1, long n,
+                                              const double* __restrict__ Xt2, long ld2, long m,
+                                              const double* __restrict__ G, long ldg,
+                                              const double* __restrict__ alpha, int Dy, int q_off,
+                                              long ntiles, int ntc, double* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) double si[KDC * KT];
+    __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
+    __shared__ double red[256];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    double a_var = 0.0, a_iso = 0.0;
+    double a_q[KDC];
+#pragma unroll
+    for (int q = 0; q < KDC; ++q) a_q[q] = 0.0;
+    const int qcnt = ARD ? ((kp.D - q_off < KDC) ? (kp.D - q_off) : KDC) : 0;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long ti, tj;
+        if (FUSED) {   // lower-triangular enumeration
+            ti = (long)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+            while (ti * (ti + 1) / 2 > tile) --ti;
+            while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+            tj = tile - ti * (ti + 1) / 2;
+        } else {
+            ti = tile / ntc;
+            tj = tile - ti * ntc;
+        }
+        const long i0 = ti * KT, j0 = tj * KT;
+        double r2[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+        int last_q0 = -1;
+        for (int q0 = 0; q0 < kp.D; q0 += KDC) {
+            const int qc = (kp.D - q0 < KDC) ? (kp.D - q0) : KDC;
+            __syncthreads();
+            stage_x(Xt1, ld1, i0, q0, qc, si, t);
+            stage_x(Xt2, ld2, j0, q0, qc, sj, t);
+            __syncthreads();
+            accum_r2(si, sj, qc, ty, tx, r2);
+            last_q0 = q0;
+        }
+        // weights * dL_dK, then the covariance factors
+        double gT[4][4];   // g * dK/dr / r
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long i = i0 + ty * 4 + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long j = j0 + tx * 4 + b;
+                double g = 0.0;
+                if (i < n && j < m) {
+                    if (FUSED) {
+                        if (j <= i) {
+                            double aa = 0.0;
+                            for (int d = 0; d < Dy; ++d) aa = fma(alpha[i * Dy + d], alpha[j * Dy + d], aa);
+                            g = 0.5 * (aa - (double)Dy * G[i * ldg + j]);
+                            if (j < i) g *= 2.0;
+                        }
+                    } else {
+                        g = G[i * ldg + j];
+                    }
+                }
+                const CovVal c = cov_all(kp.kind, kp.variance, r2[a][b]);
+                a_var = fma(g, c.k, a_var);
+                if (!ARD) a_iso = fma(g, c.dk_r, a_iso);
+                gT[a][b] = g * c.dk_or;
+            }
+        }
+        if (ARD) {
+            if (last_q0 != q_off) {   // D > 32: bring the dims of this launch back into LDS
+                __syncthreads();
+                stage_x(Xt1, ld1, i0, q_off, qcnt, si, t);
+                stage_x(Xt2, ld2, j0, q_off, qcnt, sj, t);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int q = 0; q < KDC; ++q) {
+                if (q < qcnt) {
+                    const d4 xi = *reinterpret_cast<const d4*>(si + q * KT + ty * 4);
+                    const d4 xj = *reinterpret_cast<const d4*>(sj + q * KT + tx * 4);
+                    double s = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const double d = xi[a] - xj[b];
+                            s = fma(gT[a][b], d * d, s);
+                        }
+                    a_q[q] += s;
+                }
+            }
+        }
+    }
+    // deterministic block reduction -> partials[blockIdx][...]
+    double* out = partials + (long)blockIdx.x * GP_STRIDE;
+    auto block_sum = [&](double v) -> double {
+        __syncthreads();
+        red[t] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (t < s) red[t] += red[t + s];
+            __syncthreads();
+        }
+        return red[0];
+    };
+    const double sv = block_sum(a_var);
+    if (t == 0) out[0] = sv;
+    if (!ARD) {
+        const double sl = block_sum(a_iso);
+        if (t == 0) out[1] = sl;
+    } else {
+#pragma unroll
+        for (int q = 0; q < KDC; ++q) {
+            if (q < qcnt) {
+                const double sq = block_sum(a_q[q]);
+                if (t == 0) out[2 + q] = sq;
+            }
+        }
+    }
+}
+
+static int pick_grad_blocks(long ntiles) { return (int)((ntiles < 2048) ? ntiles : 2048); }
+
+int grad_num_blocks(long n) {
+    const long nt = (n + KT - 1) / KT;
+    return pick_grad_blocks(nt * (nt + 1) / 2);
+}
+
+int grad_generic_num_blocks(long n, long m) {
+    return pick_grad_blocks(((n + KT - 1) / KT) * ((m + KT - 1) / KT));
+}
+
+// one launch per group of 32 lengthscale dimensions (ARD); partials for group gidx at partials + gidx*nblocks*GP_STRIDE
+void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, const double* W,
+                       long ldw, const double* alpha, int Dy, double* partials, int stride) {
+    (void)stride;
+    const long nt = (n + KT - 1) / KT;
+    const long ntiles = nt * (nt + 1) / 2;
+    const int nb = pick_grad_blocks(ntiles);
+    if (!kp.ard) {
+        hipLaunchKernelGGL((k_grad<true, false>), dim3(nb), dim3(256), 0, st, kp, Xt, ldx, n, Xt, ldx, n, W, ldw,
+                           alpha, Dy, 0, ntiles, (int)nt, partials);
+    } else {
+        for (int q_off = 0, gidx = 0; q_off < kp.D; q_off += KDC, ++gidx)
+            hipLaunchKernelGGL((k_grad<true, true>), dim3(nb), dim3(256), 0, st, kp, Xt, ldx, n, Xt, ldx, n, W, ldw,
+                               alpha, Dy, q_off, ntiles, (int)nt, partials + (long)gidx * nb * GP_STRIDE);
+    }
+}
+
+void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
+                         long ld2, long m, int symmetric, const double* G, long ldg, double* partials,
+                         int stride) {
+    (void)stride;
+    (void)symmetric;
+    const long ntr = (n + KT - 1) / KT, ntc = (m + KT - 1) / KT;
+    const long ntiles = ntr * ntc;
+    const int nb = pick_grad_blocks(ntiles);
+    if (!kp.ard) {
+        hipLaunchKernelGGL((k_grad<false, false>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg,
+                           nullptr, 0, 0, ntiles, (int)ntc, partials);
+    } else {
+        for (int q_off = 0, gidx = 0; q_off < kp.D; q_off += KDC, ++gidx)
+            hipLaunchKernelGGL((k_grad<false, true>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg,
+                               nullptr, 0, q_off, ntiles, (int)ntc, partials + (long)gidx * nb * GP_STRIDE);
+    }
+}
+
+// out[c] = sum_b partials[b][c], fixed order (bit-reproducible run to run)
+__global__ void k_reduce_partials(const double* __restrict__ partials, int nblocks, int stride,
+                                  double* __restrict__ out) {
+    __shared__ double red[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s = 0.0;
+    for (int b = t; b < nblocks; b += 256) s += partials[(long)b * stride + c];
+    red[t] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (t < k) red[t] += red[t + k];
+        __syncthreads();
+    }
+    if (t == 0) out[c] = red[0];
+}
+
+void launch_reduce_partials(hipStream_t st, const double* partials, int nblocks, int stride, double* out) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(stride), dim3(256), 0, st, partials, nblocks, stride, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// alpha = X^T (X R) with X = L^-1 lower triangular (replaces lapack.dpotrs, GPy/util/linalg.py:116-125).
+// pass 1: one wave per row, y_i = sum_{j<=i} X_ij R_j
+template <int DC>
+__global__ __launch_bounds__(256) void k_trmv_rows(const double* __restrict__ X, long ld, long n,
+                                                   const double* __restrict__ R, int Dy, int d0,
+                                                   double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    double acc[DC];
+#pragma unroll
+    for (int d = 0; d < DC; ++d) acc[d] = 0.0;
+    const double* xr = X + i * ld;
+    for (long j = lane; j <= i; j += 64) {
+        const double x = xr[j];
+#pragma unroll
+        for (int d = 0; d < DC; ++d)
+            if (d0 + d < Dy) acc[d] = fma(x, R[j * Dy + d0 + d], acc[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < DC; ++d) {
+        double v = acc[d];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0 && d0 + d < Dy) y[i * Dy + d0 + d] = v;
+    }
+}
+
+// pass 2: partial column sums over 256-row chunks: part[chunk][j][d] = sum_{i in chunk, i>=j} X_ij y_i
+template <int DC>
+__global__ __launch_bounds__(256) void k_trmv_cols(const double* __restrict__ X, long ld, long n,
+                                                   const double* __restrict__ y, int Dy, int d0,
+                                                   double* __restrict__ part) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    const long c = blockIdx.y;
+    const long ibeg = c * 256, iend = (ibeg + 256 < n) ? ibeg + 256 : n;
+    if ((long)blockIdx.x * 256 >= iend) return;   // whole block above the diagonal band: no contribution
+    double acc[DC];
+#pragma unroll
+    for (int d = 0; d < DC; ++d) acc[d] = 0.0;
+    if (j < n) {
+        for (long i = (ibeg > j ? ibeg : j); i < iend; ++i) {
+            const double x = X[i * ld + j];
+#pragma unroll
+            for (int d = 0; d < DC; ++d)
+                if (d0 + d < Dy) acc[d] = fma(x, y[i * Dy + d0 + d], acc[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < DC; ++d)
+            if (d0 + d < Dy) part[(c * n + j) * Dy + d0 + d] = acc[d];
+    }
+}
+
+__global__ void k_trmv_finish(const double* __restrict__ part, long n, int Dy, long nchunks,
+                              double* __restrict__ alpha) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * Dy) return;
+    const long j = idx / Dy;
+    double s = 0.0;
+    for (long c = j / 256; c < nchunks; ++c) s += part[c * n * Dy + idx];
+    alpha[idx] = s;
+}
+
+void launch_tri_matvec(hipStream_t st, const double* X, long ld, long n, const double* R, int Dy, double* tmp,
+                       double* alpha, double* partials) {
+    const long nchunks = (n + 255) / 256;
+    for (int d0 = 0; d0 < Dy; d0 += 4)
+        hipLaunchKernelGGL((k_trmv_rows<4>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, X, ld, n, R, Dy, d0, tmp);
+    for (int d0 = 0; d0 < Dy; d0 += 4)
+        hipLaunchKernelGGL((k_trmv_cols<4>), dim3((unsigned)nchunks, (unsigned)nchunks), dim3(256), 0, st, X, ld, n,
+                           tmp, Dy, d0, partials);
+    hipLaunchKernelGGL(k_trmv_finish, dim3((unsigned)((n * Dy + 255) / 256)), dim3(256), 0, st, partials, n, Dy,
+                       nchunks, alpha);
+}
+
+// ------------------------------------------------------------------------------------------------
+// out3[0] = sum alpha*R ; out3[1] = sum alpha^2 ; out3[2] = trace(W) ; out3[3] = 2*sum(logsum)
+// diag_out[i] = 0.5*(sum_d alpha_id^2 - Dy*W_ii)   (= diag(dL_dK), exact_gaussian_inference.py:70-72)
+__global__ __launch_bounds__(1024) void k_scalars(const double* __restrict__ alpha, const double* __restrict__ R,
+                                                  const double* __restrict__ W, long ldw, long n, int Dy,
+                                                  const double* __restrict__ logsum, long nblk,
+                                                  double* __restrict__ out4, double* __restrict__ diag_out) {
+    __shared__ double red[4][1024];
+    const int t = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (long i = t; i < n; i += 1024) {
+        double a2 = 0.0;
+        for (int d = 0; d < Dy; ++d) {
+            const double a = alpha[i * Dy + d];
+            s0 = fma(a, R[i * Dy + d], s0);
+            a2 = fma(a, a, a2);
+        }
+        s1 += a2;
+        const double w = W ? W[i * ldw + i] : 0.0;
+        s2 += w;
+        if (diag_out) diag_out[i] = 0.5 * (a2 - (double)Dy * w);
+    }
+    for (long b = t; b < nblk; b += 1024) s3 += logsum[b];
+    red[0][t] = s0; red[1][t] = s1; red[2][t] = s2; red[3][t] = s3;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if (t < k) {
+            red[0][t] += red[0][t + k]; red[1][t] += red[1][t + k];
+            red[2][t] += red[2][t + k]; red[3][t] += red[3][t + k];
+        }
+        __syncthreads();
+    }
+    if (t == 0) { out4[0] = red[0][0]; out4[1] = red[1][0]; out4[2] = red[2][0]; out4[3] = 2.0 * red[3][0]; }
+}
+
+void launch_scalars(hipStream_t st, const double* alpha, const double* R, const double* W, long ldw, long n,
+                       int Dy, const double* logsum, long nblk, double* out4, double* diag_out) {
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(1024), 0, st, alpha, R, W, ldw, n, Dy, logsum, nblk, out4, diag_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense host-shaped views of padded device matrices (lazy fetch path; PCIe-bound, not on the hot loop)
+__global__ void k_extract(const double* __restrict__ A, long ld, long n, int mode, const double* __restrict__ alpha,
+                          int Dy, double* __restrict__ out, int transpose) {
+    const long nbx = (n + 255) / 256;
+    const long i = blockIdx.x / nbx;
+    const long j = (blockIdx.x - i * nbx) * 256 + threadIdx.x;
+    if (j >= n) return;
+    double v;
+    if (mode == 0) {
+        v = (j <= i) ? A[i * ld + j] : 0.0;
+    } else {
+        const long hi = i > j ? i : j, lo = i > j ? j : i;
+        v = A[hi * ld + lo];
+        if (mode == 2) {
+            double aa = 0.0;
+            for (int d = 0; d < Dy; ++d) aa = fma(alpha[i * Dy + d], alpha[j * Dy + d], aa);
+            v = 0.5 * (aa - (double)Dy * v);
+        }
+    }
+    if (transpose) out[j * n + i] = v; else out[i * n + j] = v;
+}
+
+void launch_extract(hipStream_t st, const double* A, long ld, long n, int mode, const double* alpha, int Dy,
+                    double* out, int transpose) {
+    hipLaunchKernelGGL(k_extract, dim3((unsigned)(((n + 255) / 256) * n)), dim3(256), 0, st, A, ld, n, mode, alpha, Dy,
+                       out, transpose);
+}
+
+// A (npad x npad) <- dense src (n x n) + diag(noise + jit); identity in the padding
+__global__ void k_pad_from_dense(const double* __restrict__ src, long n, double* __restrict__ A, long npad,
+                                 const double* __restrict__ noise, long noise_len, double jit) {
+    const long nbx = (npad + 255) / 256;
+    const long i = blockIdx.x / nbx;
+    const long j = (blockIdx.x - i * nbx) * 256 + threadIdx.x;
+    if (j >= npad) return;
+    double v;
+    if (i < n && j < n) {
+        v = src[i * n + j];
+        if (i == j) v += (noise ? noise[noise_len > 1 ? i : 0] : 0.0) + jit;
+    } else {
+        v = (i == j) ? 1.0 : 0.0;
+    }
+    A[i * npad + j] = v;
+}
+
+void launch_pad_from_dense(hipStream_t st, const double* src, long n, double* A, long npad, const double* noise,
+                           long noise_len, double jit) {
+    hipLaunchKernelGGL(k_pad_from_dense, dim3((unsigned)(((npad + 255) / 256) * npad)), dim3(256), 0, st, src, n, A,
+                       npad, noise, noise_len, jit);
+}

@@ -1,0 +1,139 @@
+/* mi355gp.h -- C-ABI of libmi355gp.so: the MI355X-native (gfx950, hand-written HIP) exact-GP backend.
+ *
+ * GPy has no FFI: its hot path is three Python call signatures.  This header is the
+ * boundary a maintainer binds with ctypes; every entry point names the
+ * reference function(s) it replaces (paths relative to the GPy checkout).
+ *
+ * Conventions
+ *   - all matrices fp64; host arrays are C-contiguous (row-major) unless a `fortran_order` flag says otherwise
+ *   - return value: 0 = OK; >0 = LAPACK-style `info` (1-based index of the first non-positive pivot of the
+ *     Cholesky factorisation); <0 = argument / HIP error, text via mi355gp_last_error()
+ *   - `kind`: covariance function, `ard`: 0 = one lengthscale, 1 = one per input dimension
+ *   - `theta` = [variance, lengthscale (1 or D values)]  (the order GPy links them: kern/src/stationary.py:78-81)
+ *   - gradient outputs use the same order; values/gradients are untransformed (paramz applies Logexp outside)
+ *   - one context = one device + one data set (X, Y); contexts are independent, not thread-safe individually
+ */
+#ifndef MI355GP_H
+#define MI355GP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi355gp_ctx mi355gp_ctx;
+
+enum { MI355GP_RBF = 0, MI355GP_MATERN52 = 1, MI355GP_MATERN32 = 2, MI355GP_EXPONENTIAL = 3 };
+
+/* which device-resident matrix mi355gp_fetch() materialises on the host (all N x N) */
+enum {
+    MI355GP_FETCH_L = 0,      /* Cholesky factor of Ky, strict upper triangle zero  (Posterior.woodbury_chol) */
+    MI355GP_FETCH_KINV = 1,   /* Ky^-1, symmetric                                    (Posterior.woodbury_inv)  */
+    MI355GP_FETCH_DLDK = 2,   /* dL_dK = 0.5*(alpha alpha^T - Dy*Ky^-1), symmetric   (grad_dict['dL_dK'])      */
+    MI355GP_FETCH_K = 3       /* K(X,X) without noise/jitter, symmetric              (Posterior._K)            */
+};
+
+/* out_scalars[] layout of mi355gp_exact_inference / mi355gp_inference_given_K */
+enum {
+    MI355GP_OUT_LML = 0,        /* log marginal likelihood (without Z_tilde)            */
+    MI355GP_OUT_LOGDET = 1,     /* log det Ky                                           */
+    MI355GP_OUT_DATAFIT = 2,    /* sum(alpha * R)                                       */
+    MI355GP_OUT_DNOISE = 3,     /* dL/d sigma_n^2 = trace(dL_dK)                        */
+    MI355GP_OUT_TRKINV = 4,     /* trace(Ky^-1)                                         */
+    MI355GP_NUM_OUT = 8
+};
+
+/* stage_ms[] layout (hipEvent timings of the last inference call, milliseconds) */
+enum {
+    MI355GP_T_KBUILD = 0, MI355GP_T_POTRF = 1, MI355GP_T_TRTRI = 2, MI355GP_T_LAUUM = 3,
+    MI355GP_T_SOLVE = 4, MI355GP_T_GRAD = 5, MI355GP_T_TOTAL = 6, MI355GP_NUM_T = 8
+};
+
+/* ---- library / device ------------------------------------------------------------------------- */
+const char* mi355gp_last_error(void);
+const char* mi355gp_version(void);
+int mi355gp_device_count(int* count);
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int mi355gp_create(int device, mi355gp_ctx** ctx);
+int mi355gp_destroy(mi355gp_ctx* ctx);
+
+/* Uploads the training set once (X is constant across optimiser iterations: core/gp.py:44-60).
+ * X: N x D, R: N x Dy (= Y - mean_function.f(X), exact_gaussian_inference.py:42-50). */
+int mi355gp_set_data(mi355gp_ctx* ctx, const double* X, int64_t N, int D, const double* R, int Dy);
+/* replaces only the targets (same N, Dy) */
+int mi355gp_set_targets(mi355gp_ctx* ctx, const double* R, int Dy);
+
+/* ---- kernel functions (replace Stationary.K / Kdiag / update_gradients_full) ------------------------ */
+/* K(X, X2) -> K_out (N x M, row-major).  X2 == NULL: symmetric case (M = N, exact `variance` on the diagonal).
+ * Replaces kern/src/stationary.py:105-168 (+ K_of_r: rbf.py:51-52, stationary.py:382-383,488-489,585-586). */
+int mi355gp_kern_K(int device, int kind, int ard, const double* theta, const double* X, int64_t N,
+                   const double* X2, int64_t M, int D, double* K_out);
+/* Kdiag(X) (kern/src/stationary.py:170-173) */
+int mi355gp_kern_Kdiag(int kind, const double* theta, int64_t N, double* out);
+/* dL/dtheta from a caller-supplied dL_dK (N x M, row-major, need not be symmetric).
+ * Replaces Stationary.update_gradients_full (kern/src/stationary.py:193-243) incl. the native
+ * lengthscale_grads loop (kern/src/stationary_cython.pyx:53-62).  dtheta_out: 1 + (ard ? D : 1). */
+int mi355gp_update_gradients_full(int device, int kind, int ard, const double* theta, const double* dL_dK,
+                                  const double* X, int64_t N, const double* X2, int64_t M, int D,
+                                  double* dtheta_out);
+
+/* ---- the fused hot path ---------------------------------------------------------------------------- */
+/* One GP.parameters_changed (core/gp.py:278-280) with everything N x N resident in HBM:
+ *   K = kern.K(X); Ky = K + (noise + jitter + extra_jitter) I; L = chol(Ky); alpha = Ky^-1 R;
+ *   LML; Ky^-1; dL_dK (never materialised); dL/dtheta; dL/dnoise; diag(dL_dK).
+ * Replaces ExactGaussianInference.inference (inference/latent_function_inference/exact_gaussian_inference.py:37-74),
+ * pdinv/jitchol/dpotrs/dpotri/dtrtri/tdot/symmetrify (util/linalg.py:56-75,116-145,193-227,299-379),
+ * Gaussian.exact_inference_gradients (likelihoods/gaussian.py:78-79) and
+ * Stationary.update_gradients_full (kern/src/stationary.py:193-243) applied to that dL_dK.
+ *   noise: noise_len == 1 (homoscedastic) or N values; jitter: the reference's 1e-8 (exact_gaussian_inference.py:56);
+ *   extra_jitter: the jitchol ladder term (util/linalg.py:66-72), 0 on the first attempt;
+ *   out_scalars[MI355GP_NUM_OUT]; alpha_out (N x Dy) / dtheta_out / diag_dLdK_out (N) / stage_ms[MI355GP_NUM_T] may be NULL.
+ * Returns info > 0 when Ky is not positive definite (the caller runs the ladder). */
+int mi355gp_exact_inference(mi355gp_ctx* ctx, int kind, int ard, const double* theta,
+                            const double* noise, int64_t noise_len, double jitter, double extra_jitter,
+                            double* out_scalars, double* alpha_out, double* dtheta_out,
+                            double* diag_dLdK_out, double* stage_ms);
+
+/* Same with a caller-supplied covariance matrix (the `K=` argument of ExactGaussianInference.inference,
+ * exact_gaussian_inference.py:52-53; used by EP and by foreign kernels).  K_host: N x N row-major. No dtheta. */
+int mi355gp_inference_given_K(mi355gp_ctx* ctx, const double* K_host, const double* noise, int64_t noise_len,
+                              double jitter, double extra_jitter, double* out_scalars, double* alpha_out,
+                              double* diag_dLdK_out, double* stage_ms);
+
+/* Lazy materialisation of a device-resident N x N result of the last inference call. */
+int mi355gp_fetch(mi355gp_ctx* ctx, int which, double* out, int fortran_order);
+
+/* Posterior prediction on device (PosteriorExact._raw_predict, inference/latent_function_inference/posterior.py:273-302):
+ * mu (M x Dy) = K(Xnew,X) alpha; full_cov == 0: var (M) = Kdiag - sum((L^-1 Kx)^2, 0); else var (M x M). */
+int mi355gp_predict(mi355gp_ctx* ctx, int kind, int ard, const double* theta, const double* Xnew, int64_t M,
+                    double* mu_out, double* var_out, int full_cov);
+
+/* ---- standalone dense routines (dpotrf / dpotri equivalents; also what bench.py times in isolation) --- */
+/* In-place lower Cholesky of a host matrix (row-major N x N, lower triangle read), strict upper zeroed on return.
+ * Replaces lapack.dpotrf(A, lower=1) (util/linalg.py:58).  ms (optional): device time of the factorisation. */
+int mi355gp_potrf(int device, double* A, int64_t N, double* ms);
+/* Ainv (symmetric, full) from A; replaces pdinv's dpotrf+dpotri+symmetrify (util/linalg.py:193-214). */
+int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* L_out, double* logdet, double* ms);
+
+/* Device-only benchmark of the factorisation on a synthetic SPD matrix already resident in HBM:
+ * returns average milliseconds of potrf / trtri / lauum over `reps` runs. */
+int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, double* ms_trtri, double* ms_lauum);
+
+/* ---- diagnostics (used by tests/ and tools/) --------------------------------------------------------- */
+/* raw lane dump of one v_mfma_f64_16x16x4_f64: a[64], b[64] -> d[64*4] */
+int mi355gp_dbg_mfma(int device, const double* a, const double* b, double* d);
+/* C (M x N) = alpha*op(A) op(B) + beta*C with the tiled MFMA kernel; M,N,K multiples of 128.
+ * transa/transb: 0 = operand stored k-contiguous (A: M x K row-major, B: N x K row-major), 1 = stored K x M / K x N. */
+int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_t N, int64_t K,
+                     const double* A, const double* B, double* C, double alpha, double beta, int reps, double* ms);
+/* microbenchmarks, out8: [0] fp64 MFMA TFLOP/s, [1] fp64 VALU FMA TFLOP/s, [2] HBM copy GB/s, [3] HBM fill GB/s,
+ * [4] shader cycles per v_mfma_f64_16x16x4 (one wave/SIMD), [5] effective shader MHz, [6] MFMA TF/s at one
+ * wave/SIMD, [7] v_mfma_f64_4x4x4 TF/s */
+int mi355gp_dbg_peaks(int device, double* out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,18 @@
+"""gpy_amd -- MI355X-native (gfx950) backend for GPy's exact-GP hot path.
+
+    from gpy_amd import RBF, Matern52, Gaussian, ExactGaussianInference, GPRegression
+
+Host code is Python + ctypes over the C-ABI in include/mi355gp.h; every array operation of the path
+(K build, Cholesky, triangular inverse, Ky^-1, alpha, gradient reductions, prediction) is a hand-written
+HIP kernel in gpy_amd/csrc.  No PyTorch, no NumPy fallback: without an MI355X the compute calls raise.
+"""
+from . import _lib
+from ._lib import MI355GPError, build, device_count
+from .inference import ExactGaussianInference
+from .kern import RBF, Exponential, Matern32, Matern52, Stationary
+from .likelihoods import Gaussian
+from .models import GP, GPRegression
+from .posterior import PosteriorExact
+
+__all__ = ["RBF", "Matern52", "Matern32", "Exponential", "Stationary", "Gaussian", "ExactGaussianInference",
+           "PosteriorExact", "GP", "GPRegression", "MI355GPError", "build", "device_count"]

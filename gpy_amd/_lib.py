@@ -20,6 +20,7 @@ FETCH_L, FETCH_KINV, FETCH_DLDK, FETCH_K = 0, 1, 2, 3
 OUT_LML, OUT_LOGDET, OUT_DATAFIT, OUT_DNOISE, OUT_TRKINV, NUM_OUT = 0, 1, 2, 3, 4, 8
 STAGE_NAMES = ("kbuild", "potrf", "trtri", "lauum", "solve", "grad", "total")
 NUM_T = 8
+PROFILE_FAMILIES = ("update_nt", "trtri", "lauum", "diag128", "trsm128")
 
 _lib = None
 
@@ -75,12 +76,14 @@ def lib():
     L.mi355gp_predict.argtypes = [vp, ci, ci, _dp, _dp, i64, _c_dp, _c_dp, ci]
     L.mi355gp_potrf.argtypes = [ci, _dp, i64, _c_dp]
     L.mi355gp_pdinv.argtypes = [ci, _dp, i64, _c_dp, _c_dp, _c_dp, _c_dp]
+    L.mi355gp_set_option.argtypes = [vp, ci, ci]
+    L.mi355gp_get_profile.argtypes = [vp, _dp, _dp, ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
     L.mi355gp_dbg_mfma.argtypes = [ci, _dp, _dp, _dp]
     L.mi355gp_dbg_gemm.argtypes = [ci, ci, ci, i64, i64, i64, _dp, _dp, _dp, cd, cd, ci, _c_dp]
     L.mi355gp_dbg_peaks.argtypes = [ci, _dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
-                 "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks"):
+                 "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -90,6 +93,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_set_data", "mi355gp_set_targets", "mi355gp_kern_K", "mi355gp_kern_Kdiag",
             "mi355gp_update_gradients_full", "mi355gp_exact_inference", "mi355gp_inference_given_K",
             "mi355gp_fetch", "mi355gp_predict", "mi355gp_potrf", "mi355gp_pdinv", "mi355gp_bench_factor",
+            "mi355gp_set_option", "mi355gp_get_profile",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks")
 
 
@@ -199,6 +203,28 @@ class Context(object):
             res["stage_ms"] = dict(zip(STAGE_NAMES, ms[:len(STAGE_NAMES)]))
         return rc, res
 
+    def set_option(self, name, value):
+        check(lib().mi355gp_set_option(self._h, {"profile": 0, "lookahead": 1}[name], int(value)), "mi355gp_set_option")
+
+    def get_profile(self):
+        """{family: (ms, algorithmic flops, launches)} of the last inference call made with option 'profile' on."""
+        ms, fl, n = np.zeros(5), np.zeros(5), np.zeros(5, dtype=np.int32)
+        check(lib().mi355gp_get_profile(self._h, ms, fl, n), "mi355gp_get_profile")
+        return {k: (ms[i], fl[i], int(n[i])) for i, k in enumerate(PROFILE_FAMILIES)}
+
+    def predict(self, kind, ARD, theta, Xnew, full_cov=False, want_var=True):
+        """(mu (M x Dy), var (M x 1) or cov (M x M)) of the latent function at Xnew, computed on the device."""
+        Xnew = f64(Xnew)
+        M = Xnew.shape[0]
+        assert Xnew.shape[1] == self.D
+        mu = np.empty((M, self.Dy))
+        var = (np.empty((M, M)) if full_cov else np.empty(M)) if want_var else None
+        check(lib().mi355gp_predict(self._h, KIND_IDS[kind], int(bool(ARD)), f64(theta), Xnew, M,
+                                    mu.ctypes.data_as(_c_dp), _opt(var), int(bool(full_cov))), "mi355gp_predict")
+        if var is not None and not full_cov:
+            var = var[:, None]
+        return mu, var
+
     def fetch(self, which, fortran_order=False):
         out = np.empty((self.N, self.N))
         check(lib().mi355gp_fetch(self._h, which, out, int(fortran_order)), "mi355gp_fetch")
@@ -292,4 +318,5 @@ def dbg_peaks(device=0):
     out = np.zeros(8)
     check(lib().mi355gp_dbg_peaks(device, out), "dbg_peaks")
     return dict(mfma_f64_tflops=out[0], valu_f64_tflops=out[1], hbm_copy_gbs=out[2], hbm_fill_gbs=out[3],
-                mfma_cycles_per_inst=out[4], shader_mhz=out[5], mfma_1wave_tflops=out[6], mfma4x4_tflops=out[7])
+                mfma_cycles_per_inst_1wave=out[4], shader_mhz_under_load=out[5], mfma_1wave_tflops=out[6],
+                mfma_cycles_per_inst_loaded=out[7])

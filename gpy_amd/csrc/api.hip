@@ -182,12 +182,13 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
                         double* alpha_out, double* dtheta_out, double* diag_out, double* stage_ms) {
     hipStream_t st = c->st;
     const long n = c->n, np = c->npad;
+    c->ws.prof.reset();
     HIP_CHECK(hipEventRecord(c->ev[1], st));
     potrf_device(st, c->A, np, &c->ws);
     HIP_CHECK(hipEventRecord(c->ev[2], st));
     trtri_device(st, c->A, c->B, c->C, np, &c->ws);
     HIP_CHECK(hipEventRecord(c->ev[3], st));
-    lauum_device(st, c->B, c->C, np);
+    lauum_device(st, c->B, c->C, np, &c->ws);
     HIP_CHECK(hipEventRecord(c->ev[4], st));
     launch_tri_matvec(st, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
     launch_scalars(st, c->dAlpha, c->dR, c->C, np, n, c->Dy, c->ws.logsum, c->ws.nblk, c->dScal, c->dDiag);
@@ -442,7 +443,7 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
     potrf_device(0, A, np, &ws);
     if (invert) {
         trtri_device(0, A, B, C, np, &ws);
-        lauum_device(0, B, C, np);
+        lauum_device(0, B, C, np, &ws);
     }
     HIP_CHECK(hipEventRecord(e1, 0));
     int info = 0;
@@ -491,9 +492,72 @@ int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* 
 
 int mi355gp_predict(mi355gp_ctx* c, int kind, int ard, const double* theta, const double* Xnew, int64_t M,
                     double* mu_out, double* var_out, int full_cov) {
-    (void)c; (void)kind; (void)ard; (void)theta; (void)Xnew; (void)M; (void)mu_out; (void)var_out; (void)full_cov;
-    mi355gp_set_error("mi355gp_predict: not implemented in this build");
-    return -99;
+    ARG_CHECK(c && c->n > 0 && c->have_factor, "mi355gp_predict: run an inference call first");
+    ARG_CHECK(Xnew && M > 0 && mu_out, "mi355gp_predict: bad arguments");
+    HIP_CHECK(hipSetDevice(c->device));
+    std::vector<double> inv_ls;
+    if (int rc = check_theta(kind, ard, theta, c->D, &inv_ls)) return rc;
+    hipStream_t st = c->st;
+    const long n = c->n, np = c->npad, D = c->D, mp = round_up(M, NB), ld2 = round_up(M, 64);
+    // (re)scale the training inputs for this theta (normally identical to the inference call's)
+    c->kp = KernParams{kind, ard ? 1 : 0, c->D, theta[0]};
+    c->theta.assign(theta, theta + 1 + (ard ? c->D : 1));
+    c->have_kernel = true;
+    HIP_CHECK(hipMemcpyAsync(c->dInvLs, inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
+    launch_scale_inputs(st, c->dX, n, c->D, c->dInvLs, c->kp.ard, c->dXt, np);
+    double *dXn = nullptr, *dXt2 = nullptr, *dKx = nullptr, *dTmp = nullptr, *dMu = nullptr, *dVar = nullptr;
+    HIP_CHECK(hipMalloc(&dXn, sizeof(double) * M * D));
+    HIP_CHECK(hipMalloc(&dXt2, sizeof(double) * D * ld2));
+    HIP_CHECK(hipMalloc(&dKx, sizeof(double) * np * mp));
+    HIP_CHECK(hipMalloc(&dTmp, sizeof(double) * np * mp));
+    HIP_CHECK(hipMalloc(&dMu, sizeof(double) * M * c->Dy));
+    HIP_CHECK(hipMalloc(&dVar, sizeof(double) * (full_cov ? mp * mp : M)));
+    HIP_CHECK(hipMemcpyAsync(dXn, Xnew, sizeof(double) * M * D, hipMemcpyHostToDevice, st));
+    launch_scale_inputs(st, dXn, M, c->D, c->dInvLs, c->kp.ard, dXt2, ld2);
+    HIP_CHECK(hipMemsetAsync(dKx, 0, sizeof(double) * np * mp, st));
+    launch_kbuild_cross(st, c->kp, c->dXt, np, n, dXt2, ld2, M, dKx, mp);                 // K(X, X*)  (n x M)
+    launch_col_reduce(st, dKx, mp, n, M, c->dAlpha, c->Dy, 0.0, 0, dMu);                  // mu = Kx^T alpha
+    launch_trmm_lower(st, c->B, np, dKx, mp, dTmp, mp, (int)(np / NB), (int)(mp / NB));   // tmp = L^-1 Kx
+    if (!full_cov) {
+        if (var_out) launch_col_reduce(st, dTmp, mp, n, M, nullptr, 1, theta[0], 1, dVar);
+    } else if (var_out) {
+        HIP_CHECK(hipMemsetAsync(dVar, 0, sizeof(double) * mp * mp, st));
+        launch_kbuild_cross(st, c->kp, dXt2, ld2, M, dXt2, ld2, M, dVar, mp);             // K(X*, X*)
+        launch_gemm_tn_sq(st, dTmp, mp, np, dVar, mp, (int)(mp / NB), -1.0, 1.0);         // - tmp^T tmp
+    }
+    HIP_CHECK(hipMemcpyAsync(mu_out, dMu, sizeof(double) * M * c->Dy, hipMemcpyDeviceToHost, st));
+    if (var_out) {
+        if (!full_cov)
+            HIP_CHECK(hipMemcpyAsync(var_out, dVar, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+        else
+            HIP_CHECK(hipMemcpy2DAsync(var_out, sizeof(double) * M, dVar, sizeof(double) * mp, sizeof(double) * M, M,
+                                       hipMemcpyDeviceToHost, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipGetLastError());
+    (void)hipFree(dXn); (void)hipFree(dXt2); (void)hipFree(dKx); (void)hipFree(dTmp); (void)hipFree(dMu);
+    (void)hipFree(dVar);
+    return 0;
+}
+
+int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
+    ARG_CHECK(c != nullptr, "mi355gp_set_option: NULL context");
+    if (option == MI355GP_OPT_PROFILE) c->ws.prof.on = (value != 0);
+    else if (option == MI355GP_OPT_LOOKAHEAD) c->ws.lookahead = (value != 0);
+    else { mi355gp_set_error("mi355gp_set_option: unknown option %d", option); return -1; }
+    return 0;
+}
+
+int mi355gp_get_profile(mi355gp_ctx* c, double* ms, double* flops, int* launches) {
+    ARG_CHECK(c && ms && flops && launches, "mi355gp_get_profile: NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->st));
+    if (c->ws.st_panel) HIP_CHECK(hipStreamSynchronize(c->ws.st_panel));
+    if (c->ws.prof.collect(ms, flops, launches) != 0) {
+        mi355gp_set_error("mi355gp_get_profile: event timing failed");
+        return -5;
+    }
+    return 0;
 }
 
 int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, double* ms_trtri, double* ms_lauum) {

@@ -126,6 +126,31 @@ void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Out[ti,tj] = sum_{tk<=ti} X[ti,tk] * B[tk,tj] with X lower triangular (npad x npad), B (npad x mpad):
+// L^-1 K(X, X*) of the predictive variance (dtrtrs in GPy/inference/latent_function_inference/posterior.py:286,296).
+__global__ __launch_bounds__(256, 2) void k_trmm_lower(const double* __restrict__ X, long ldx,
+                                                       const double* __restrict__ B, long ldb,
+                                                       double* __restrict__ Out, long ldo, int ntc) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
+    d4 acc[4][4];
+    gt_zero(acc);
+    gemm_tile_128<true, false>(X + (long)ti * NB * ldx, ldx, B + (long)tj * NB, ldb, (ti + 1) * NB, acc, smem);
+    gt_store<0>(Out + (long)ti * NB * ldo + (long)tj * NB, ldo, acc);
+}
+
+void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
+                       int ntr, int ntc) {
+    LDS_OPT_IN(k_trmm_lower);
+    hipLaunchKernelGGL(k_trmm_lower, dim3((unsigned)(ntr * ntc)), dim3(256), GT_LDS_BYTES, st, X, ldx, B, ldb, Out, ldo,
+                       ntc);
+}
+
+// C (mpad x mpad, ldc) = alpha * A^T A + beta * C with A (K x mpad): the K** - tmp^T tmp of full_cov prediction
+void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
+                       double beta);
+
+// ------------------------------------------------------------------------------------------------
 // General C = alpha*op(A)*op(B) + beta*C on full tiles (diagnostics / prediction).
 template <bool AK, bool BK>
 __global__ __launch_bounds__(256, 2) void k_gemm_full(const double* __restrict__ A, long lda,
@@ -158,4 +183,11 @@ void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long 
         hipLaunchKernelGGL((k_gemm_full<false, false>), grid, block, GT_LDS_BYTES, st, A, lda, B, ldb, C, N, (int)K, ntc, alpha, beta);
     else
         hipLaunchKernelGGL((k_gemm_full<false, true>), grid, block, GT_LDS_BYTES, st, A, lda, B, ldb, C, N, (int)K, ntc, alpha, beta);
+}
+
+void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
+                       double beta) {
+    LDS_OPT_IN((k_gemm_full<false, false>));
+    hipLaunchKernelGGL((k_gemm_full<false, false>), dim3((unsigned)(nt * nt)), dim3(256), GT_LDS_BYTES, st, A, lda, A,
+                       lda, C, ldc, (int)K, nt, alpha, beta);
 }

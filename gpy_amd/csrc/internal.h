@@ -1,5 +1,7 @@
 // internal.h -- host-side launcher declarations shared by the translation units of libmi355gp.so.
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 // ---- gemm.hip : tiled fp64 MFMA GEMM family (all dimensions multiples of 128) -------------------
@@ -10,6 +12,10 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
 void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level);
 // W (lower tiles) = X^T X for lower-triangular X
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt);
+void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
+                       int ntr, int ntc);
+void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
+                       double beta);
 void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A,
                      const double* B, double* C, double alpha, double beta);
 
@@ -24,20 +30,39 @@ void launch_inv128(hipStream_t st, const double* L, double* X, long ld, int nblk
 void launch_dbg_mfma(hipStream_t st, const double* a, const double* b, double* d);
 
 // ---- factor.hip : blocked drivers -------------------------------------------------------------------
+// per-kernel-family device timing (hipEvent pairs on the launching stream) + algorithmic flop counts
+enum { PF_UPDATE = 0, PF_TRTRI = 1, PF_LAUUM = 2, PF_DIAG = 3, PF_TRSM = 4, PF_NUM = 5 };
+struct KernelProf {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    struct Rec { int fam; double flops; size_t e0; };
+    std::vector<Rec> recs;
+    void begin(hipStream_t st, int fam, double flops);
+    void end(hipStream_t st);
+    void reset() { recs.clear(); }
+    // after the streams are synchronised: per family total ms, total flops, launch count
+    int collect(double* ms, double* flops, int* launches);
+    void destroy();
+};
+
 struct FactorWs {
     double* dinv = nullptr;     // nblk * 8 * 256 doubles: inverses of the 16x16 diagonal tiles
     double* logsum = nullptr;   // nblk doubles: sum(log diag L) per 128-block
     int* info = nullptr;        // device int: 0 or first failing column (1-based)
     long nblk = 0;
+    hipStream_t st_panel = nullptr;          // high-priority stream of the look-ahead panel factorisation
+    std::vector<hipEvent_t> ev_panel, ev_upd;
+    int lookahead = 1;
+    KernelProf prof;
 };
 int factor_ws_alloc(FactorWs* ws, long npad);
 void factor_ws_free(FactorWs* ws);
-// A (npad x npad, ld = npad, lower) -> L in place.  Asynchronous on `st`.
+// A (npad x npad, ld = npad, lower) -> L in place.  Asynchronous; on return all work is ordered before later work on `st`.
 void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws);
 // X = L^-1 (into X, using T as scratch), asynchronous.
 void trtri_device(hipStream_t st, const double* L, double* X, double* T, long npad, FactorWs* ws);
 // W = X^T X (lower tiles)
-void lauum_device(hipStream_t st, const double* X, double* W, long npad);
+void lauum_device(hipStream_t st, const double* X, double* W, long npad, FactorWs* ws);
 
 // ---- kern.hip : covariance assembly, reductions, solves, fetch helpers ----------------------------
 struct KernParams {
@@ -82,3 +107,6 @@ void launch_extract(hipStream_t st, const double* A, long ld, long n, int mode, 
                     double* out, int transpose);
 void launch_pad_from_dense(hipStream_t st, const double* src, long n, double* A, long npad, const double* noise,
                            long noise_len, double jit);
+// column reductions over a (rows x ld) matrix: mode 0: out[j*Dy+d] = sum_i M[i][j]*v[i*Dy+d]; mode 1: out[j] = c0 - sum_i M[i][j]^2
+void launch_col_reduce(hipStream_t st, const double* M, long ld, long rows, long cols, const double* v, int Dy,
+                       double c0, int mode, double* out);

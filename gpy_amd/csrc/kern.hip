@@ -539,3 +539,37 @@ void launch_pad_from_dense(hipStream_t st, const double* src, long n, double* A,
     hipLaunchKernelGGL(k_pad_from_dense, dim3((unsigned)(((npad + 255) / 256) * npad)), dim3(256), 0, st, src, n, A,
                        npad, noise, noise_len, jit);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Column reductions for prediction: 64 columns per block, 4 row groups per column, fixed-order combine.
+__global__ __launch_bounds__(256) void k_col_reduce(const double* __restrict__ M, long ld, long rows, long cols,
+                                                    const double* __restrict__ v, int Dy, int d, double c0, int mode,
+                                                    double* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + tx;
+    double s = 0.0;
+    if (j < cols) {
+        for (long i = g; i < rows; i += 4) {
+            const double x = M[i * ld + j];
+            s = (mode == 0) ? fma(x, v[i * Dy + d], s) : fma(x, x, s);
+        }
+    }
+    red[g][tx] = s;
+    __syncthreads();
+    if (g == 0 && j < cols) {
+        const double tot = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        if (mode == 0) out[j * Dy + d] = tot; else out[j] = c0 - tot;
+    }
+}
+
+void launch_col_reduce(hipStream_t st, const double* M, long ld, long rows, long cols, const double* v, int Dy,
+                       double c0, int mode, double* out) {
+    const unsigned nb = (unsigned)((cols + 63) / 64);
+    if (mode == 0) {
+        for (int d = 0; d < Dy; ++d)
+            hipLaunchKernelGGL(k_col_reduce, dim3(nb), dim3(256), 0, st, M, ld, rows, cols, v, Dy, d, c0, 0, out);
+    } else {
+        hipLaunchKernelGGL(k_col_reduce, dim3(nb), dim3(256), 0, st, M, ld, rows, cols, v, 1, 0, c0, 1, out);
+    }
+}

@@ -1,24 +1,9 @@
 // peaks.hip -- on-box ceilings quoted next to the spec peaks (78.6 TF/s fp64, 8 TB/s HBM3E):
-// a dependent-free v_mfma_f64_16x16x4_f64 stream, a v_fma_f64 stream, and HBM copy / fill.
+// a dependent-free v_mfma_f64_16x16x4_f64 stream (inline asm so the accumulators stay in place), a v_fma_f64
+// stream, and HBM copy / fill.  The MFMA kernel also reports shader cycles and the effective shader clock.
 #include "internal.h"
 
-__global__ __launch_bounds__(256) void k_peak_mfma(double* out, int iters, double seed) {
-    d4 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (d4){seed, seed + i, 0.0, 1.0};
-    const double a = seed + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = mfma_f64(a, b, acc[i]);
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (s == 12345.678) out[0] = s;   // keep the chain alive without a store on the hot path
-}
-
-// same stream, but lane 0 of every wave records shader-clock (s_memtime) and 100 MHz wall-clock deltas
-__global__ __launch_bounds__(256) void k_peak_mfma_clk(double* out, long long* clk, int iters, double seed) {
+__global__ __launch_bounds__(256) void k_peak_mfma(double* out, long long* clk, int iters, double seed) {
     d4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = (d4){seed, seed + i, 0.0, 1.0};
@@ -26,30 +11,16 @@ __global__ __launch_bounds__(256) void k_peak_mfma_clk(double* out, long long* c
     const long long c0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = mfma_f64(a, b, acc[i]);
+        for (int i = 0; i < 8; ++i)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
     }
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    const long long c1 = clock64(), w1 = wall_clock64();
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    const long long c1 = clock64(), w1 = wall_clock64();
-    if (s == 12345.678) out[0] = s;
+    if (s == 12345.678) out[0] = s;   // keep the chain alive without a store on the hot path
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
-}
-
-typedef double d1x __attribute__((ext_vector_type(1)));
-__global__ __launch_bounds__(256) void k_peak_mfma4(double* out, int iters, double seed) {
-    double acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = seed + i;
-    const double a = seed + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i];
-    if (s == 12345.678) out[0] = s;
 }
 
 __global__ __launch_bounds__(256) void k_peak_fma(double* out, int iters, double seed) {
@@ -77,53 +48,49 @@ __global__ __launch_bounds__(256) void k_fill(d2* __restrict__ dst, long n2, dou
         dst[i] = (d2){v, v + 1.0};
 }
 
-int run_peaks(int device, double* out4) {
+// out8: [0] MFMA TF/s (8 workgroups per CU), [1] VALU FMA TF/s, [2] HBM copy GB/s, [3] HBM fill GB/s,
+//       [4] shader cycles per MFMA at one wave per SIMD, [5] effective shader MHz under the full MFMA load,
+//       [6] MFMA TF/s at one wave per SIMD, [7] shader cycles per MFMA per SIMD under the full load
+int run_peaks(int device, double* out8) {
     HIP_CHECK(hipSetDevice(device));
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
     double* dummy;
+    long long* dclk;
     HIP_CHECK(hipMalloc(&dummy, 1024));
+    HIP_CHECK(hipMalloc(&dclk, 64));
     float ms;
-    const int blocks = 256 * 8, iters = 20000;
-    // MFMA
-    hipLaunchKernelGGL(k_peak_mfma, dim3(blocks), dim3(256), 0, 0, dummy, 100, 0.5);
-    HIP_CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_peak_mfma, dim3(blocks), dim3(256), 0, 0, dummy, iters, 0.5);
-    HIP_CHECK(hipEventRecord(e1, 0));
-    HIP_CHECK(hipEventSynchronize(e1));
-    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    out4[0] = (double)blocks * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
-    {   // one workgroup per CU (one wave per SIMD): cycles per MFMA and the effective shader clock
-        long long* dclk;
-        HIP_CHECK(hipMalloc(&dclk, 64));
+    long long h[2];
+    const int iters = 20000;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int blocks = pass == 0 ? 256 : 256 * 8;
+        hipLaunchKernelGGL(k_peak_mfma, dim3(blocks), dim3(256), 0, 0, dummy, dclk, 200, 0.5);
         HIP_CHECK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_peak_mfma_clk, dim3(256), dim3(256), 0, 0, dummy, dclk, iters, 0.5);
+        hipLaunchKernelGGL(k_peak_mfma, dim3(blocks), dim3(256), 0, 0, dummy, dclk, iters, 0.5);
         HIP_CHECK(hipEventRecord(e1, 0));
         HIP_CHECK(hipEventSynchronize(e1));
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        long long h[2];
         HIP_CHECK(hipMemcpy(h, dclk, 16, hipMemcpyDeviceToHost));
-        out4[4] = (double)h[0] / ((double)iters * 8);           // shader cycles per MFMA (one wave per SIMD)
-        out4[5] = (double)h[0] / (double)h[1] * 100.0;           // effective shader MHz
-        out4[6] = 256.0 * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
-        (void)hipFree(dclk);
-        hipLaunchKernelGGL(k_peak_mfma4, dim3(blocks), dim3(256), 0, 0, dummy, 100, 0.5);
-        HIP_CHECK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_peak_mfma4, dim3(blocks), dim3(256), 0, 0, dummy, iters, 0.5);
-        HIP_CHECK(hipEventRecord(e1, 0));
-        HIP_CHECK(hipEventSynchronize(e1));
-        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        out4[7] = (double)blocks * 4 * iters * 8 * (4.0 * 4 * 4 * 4 * 2) / (ms * 1e-3) / 1e12;   // 4 blocks of 4x4x4
+        const double tf = (double)blocks * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
+        if (pass == 0) {
+            out8[4] = (double)h[0] / ((double)iters * 8);
+            out8[6] = tf;
+        } else {
+            out8[0] = tf;
+            out8[5] = (double)h[0] / (double)h[1] * 100.0;
+            // 8 workgroups x 4 waves per CU = 8 waves per SIMD share the pipe while block 0 is resident
+            out8[7] = (double)h[0] / ((double)iters * 8 * 8);
+        }
     }
-    // VALU FMA
+    const int blocks = 256 * 8;
     hipLaunchKernelGGL(k_peak_fma, dim3(blocks), dim3(256), 0, 0, dummy, 100, 0.5);
     HIP_CHECK(hipEventRecord(e0, 0));
     hipLaunchKernelGGL(k_peak_fma, dim3(blocks), dim3(256), 0, 0, dummy, iters, 0.5);
     HIP_CHECK(hipEventRecord(e1, 0));
     HIP_CHECK(hipEventSynchronize(e1));
     HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    out4[1] = (double)blocks * 256 * iters * 16 * 2.0 / (ms * 1e-3) / 1e12;
+    out8[1] = (double)blocks * 256 * iters * 16 * 2.0 / (ms * 1e-3) / 1e12;
     // HBM copy / fill over 2 x 2 GiB
     const long bytes = 2L << 30, n2 = bytes / 16;
     d2 *a, *b;
@@ -136,16 +103,17 @@ int run_peaks(int device, double* out4) {
     HIP_CHECK(hipEventRecord(e1, 0));
     HIP_CHECK(hipEventSynchronize(e1));
     HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    out4[2] = 5.0 * 2.0 * bytes / (ms * 1e-3) / 1e9;
+    out8[2] = 5.0 * 2.0 * bytes / (ms * 1e-3) / 1e9;
     HIP_CHECK(hipEventRecord(e0, 0));
     for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, b, n2, 2.0);
     HIP_CHECK(hipEventRecord(e1, 0));
     HIP_CHECK(hipEventSynchronize(e1));
     HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    out4[3] = 5.0 * bytes / (ms * 1e-3) / 1e9;
+    out8[3] = 5.0 * bytes / (ms * 1e-3) / 1e9;
     (void)hipFree(a);
     (void)hipFree(b);
     (void)hipFree(dummy);
+    (void)hipFree(dclk);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return 0;

@@ -5,148 +5,189 @@
 // All three kernels use "register chaining" of v_mfma_f64_16x16x4_f64: the accumulator register r of a
 // 16x16 product (row (l>>4)+4r, col l&15) is exactly the B operand of k-slice r of the next product
 // when the A operand is fetched with k = (l>>4)+4s, so chains like  Dinv * (P - L*Y)  never leave VGPRs.
+//
+// LDS image of a 128x128 lower-triangular block: its 36 lower 16x16 tiles, each [16][18] doubles
+// (row stride 18 = 2*odd keeps the MFMA fragment read row*18+k bank-conflict free): 82,944 B, so the
+// kernel fits on a CU next to one 72 KB GEMM workgroup (look-ahead overlap with the trailing update).
 #include "common.h"
 #include "internal.h"
 
-#define DS 130   // LDS row stride (doubles) of the 128x128 block image
-#define IS 18    // LDS row stride of a 16x16 inverse tile
+#define TS 18                 // row stride (doubles) inside a 16x16 tile
+#define TSZ (16 * TS)         // doubles per tile image
+#define NTILE 36              // lower tiles of a 128x128 block
 
-// ------------------------------------------------------------------------------------------------
-// 16x16 Cholesky + inverse of the factor, entirely in the registers of ONE wave.
-// Lane l holds row i = l&15, columns 4g..4g+3 (g = l>>4) of the tile in v[] and of the running
-// right-hand side (identity -> L^-1) in x[].  Right-looking: step j finishes column j of L and row j of L^-1.
-__device__ __forceinline__ int potf2_inv_16(double (&v)[4], double (&x)[4], int lane) {
-    const int i = lane & 15, g = lane >> 4;
-    int fail = 0;
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) x[cc] = (4 * g + cc == i) ? 1.0 : 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int gj = j >> 2, rj = j & 3;
-        const double colv = v[rj];
-        double piv = __shfl(colv, j + 16 * gj);
-        if (!(piv > 0.0)) {           // wave-uniform: not positive definite (or NaN)
-            if (fail == 0) fail = j + 1;
-            piv = 1.0;
-        }
-        const double d = sqrt(piv);
-        const double rd = 1.0 / d;
-        const double lij = __shfl(colv, i + 16 * gj) * rd;     // L[i][j] (meaningful for i > j)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int c = 4 * g + cc;
-            const double lcj = __shfl(colv, c + 16 * gj) * rd;  // L[c][j]
-            if (c > j && i >= c) v[cc] -= lij * lcj;
-            const double xjc = __shfl(x[cc], j + 16 * g) * rd;  // (L^-1)[j][c]
-            if (i > j) x[cc] -= lij * xjc;
-            else if (i == j) x[cc] = xjc;
-        }
-        if (g == gj) v[rj] = (i > j) ? lij : ((i == j) ? d : v[rj]);
-    }
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
-        if (4 * g + cc > i) v[cc] = 0.0;
-    return fail;
+__device__ __forceinline__ int tix(int I, int J) { return I * (I + 1) / 2 + J; }
+// inverse of tix for compile-time tile numbers (loops over u are fully unrolled)
+__device__ __forceinline__ constexpr int tile_I(int u) {
+    int I = 0;
+    while ((I + 1) * (I + 2) / 2 <= u) ++I;
+    return I;
+}
+__device__ __forceinline__ constexpr int tile_J(int u) { return u - tile_I(u) * (tile_I(u) + 1) / 2; }
+
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
 }
 
 // ------------------------------------------------------------------------------------------------
-// In-place Cholesky of one 128x128 block held in LDS, 16 waves.  Per 16-column step:
-//   wave 0: potf2 + inverse of the diagonal tile  |  all: P = A21 * Dinv^T (MFMA)  |  all: A22 -= P P^T (MFMA)
-__global__ __launch_bounds__(1024) void k_diag128(double* __restrict__ A, long ld, long c0,
+// 16x16 Cholesky + inverse of the factor in the registers of one wave.  Lane l works on row i = l & 15
+// (lanes 16..63 mirror lanes 0..15): a[c] = A[i][c], x[c] = (running right-hand side I -> L^-1)[i][c].
+// Right-looking; every cross-row value is a compile-time-lane v_readlane (no LDS round trips).
+// Returns 0 or the 1-based index of the first non-positive pivot.
+__device__ __forceinline__ int potf2_inv_16(double (&a)[16], double (&x)[16], int lane) {
+    const int i = lane & 15;
+    int fail = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x[c] = (c == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double piv = readlane_d(a[j], j);
+        if (!(piv > 0.0)) {                      // wave-uniform: not positive definite (or NaN)
+            if (fail == 0) fail = j + 1;
+            piv = 1.0;
+        }
+        const double rd = rsqrt(piv);            // one dependent chain (v_rsq_f64 + refinement) instead of sqrt + div
+        a[j] *= rd;                              // row j: piv*rd = L[j][j]; rows below: L[i][j]; rows above: don't care
+        const double lm = (i > j) ? a[j] : 0.0;  // L[i][j] on the rows that still change, 0 elsewhere
+        const double sc = (i == j) ? rd : 1.0;   // row j of the right-hand side becomes row j of L^-1
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) a[c] = fma(-lm, readlane_d(a[j], c), a[c]);
+#pragma unroll
+        for (int c = 0; c <= j; ++c) {
+            x[c] *= sc;
+            x[c] = fma(-lm, readlane_d(x[c], j), x[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c > i) { a[c] = 0.0; x[c] = 0.0; }
+    }
+    return fail;
+}
+
+// C tile (D layout) -= P[ib] * P[kb]^T with both panels in column jp of the packed block
+__device__ __forceinline__ void diag_update_tile(double* Tt, int ib, int kb, int jp, int fi, int fk) {
+    double* C = Tt + tix(ib, kb) * TSZ;
+    const double* Pa = Tt + tix(ib, jp) * TSZ;
+    const double* Pb = Tt + tix(kb, jp) * TSZ;
+    d4 acc;
+    double af[4], bf[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = C[(fk + 4 * r) * TS + fi];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        af[s] = -Pa[fi * TS + fk + 4 * s];
+        bf[s] = Pb[fi * TS + fk + 4 * s];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma_f64(af[s], bf[s], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(fk + 4 * r) * TS + fi] = acc[r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-place Cholesky of one 128x128 block, 4 waves (one per SIMD, <= 280 VGPRs: co-resident with a GEMM workgroup),
+// two barriers per 16-column step:
+//   wave 0: finish tile (jb,jb), factor + invert it (potf2_inv_16)   ||   waves 1..3: rest of step jb-1's update
+//   barrier; all waves: P[ib] = A[ib,jb] * Dinv^T for the tiles below (MFMA); barrier
+__global__ __launch_bounds__(256) void k_diag128(double* __restrict__ A, long ld, long c0,
                                                   double* __restrict__ dinv, double* __restrict__ logsum,
                                                   int* __restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* M = sm;                    // [128][DS]
-    double* Dv = sm + 128 * DS;        // [8][16][IS]
+    double* Tt = sm;                       // [36][16][18]
+    double* Dv = sm + NTILE * TSZ;         // [16][18] inverse of the current diagonal tile
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     double* Ab = A + c0 * ld + c0;
-    for (int idx = t; idx < 128 * 128; idx += 1024) {
-        const int r = idx >> 7, c = idx & 127;
-        M[r * DS + c] = Ab[(long)r * ld + c];
+    const int er = t >> 4, ec = t & 15;     // element (er, ec) of tile u for u = 0..35 (256 threads = one tile per trip)
+    {   // issue all 36 loads before the first LDS write
+        double v[NTILE];
+#pragma unroll
+        for (int u = 0; u < NTILE; ++u) v[u] = Ab[(long)(tile_I(u) * 16 + er) * ld + tile_J(u) * 16 + ec];
+#pragma unroll
+        for (int u = 0; u < NTILE; ++u) Tt[u * TSZ + er * TS + ec] = v[u];
     }
     __syncthreads();
-    const int fi = lane & 15, fk = lane >> 4;      // MFMA operand coordinates of this lane
+    const int fi = lane & 15, fk = lane >> 4;
     for (int jb = 0; jb < 8; ++jb) {
-        const int o = jb * 16;
         if (w == 0) {
-            double v[4], x[4];
+            if (jb > 0) {
+                diag_update_tile(Tt, jb, jb, jb - 1, fi, fk);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            double* Td = Tt + tix(jb, jb) * TSZ;
+            double a[16], x[16];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) v[cc] = M[(o + fi) * DS + o + 4 * fk + cc];
-            const int fail = potf2_inv_16(v, x, lane);
-            if (fail != 0 && lane == 0) atomicCAS(info, 0, (int)(c0 + o + fail));
+            for (int c = 0; c < 16; ++c) a[c] = Td[fi * TS + c];
+            const int fail = potf2_inv_16(a, x, lane);
+            if (fail != 0 && lane == 0) atomicCAS(info, 0, (int)(c0 + jb * 16 + fail));
+            if (lane < 16) {
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                M[(o + fi) * DS + o + 4 * fk + cc] = v[cc];
-                Dv[jb * 16 * IS + fi * IS + 4 * fk + cc] = x[cc];
+                for (int c = 0; c < 16; ++c) {
+                    Td[fi * TS + c] = a[c];
+                    Dv[fi * TS + c] = x[c];
+                    dinv[jb * 256 + fi * 16 + c] = x[c];
+                }
+            }
+        } else if (jb > 0) {
+            // remaining tiles of step jb-1's trailing update: (ib,kb), jb <= kb <= ib <= 7, except (jb,jb)
+            const int m = 8 - jb, ntile = m * (m + 1) / 2;
+            for (int q = w; q < ntile; q += 3) {        // q = 0 is (jb,jb): skipped (wave 0 did it)
+                int a_ = 0, rem = q;
+                while (rem > a_) { rem -= a_ + 1; ++a_; }
+                diag_update_tile(Tt, jb + a_, jb + rem, jb - 1, fi, fk);
             }
         }
         __syncthreads();
-        // panel: tile ib (rows below) <- tile * Dinv^T ; one tile per wave
         const int nbelow = 7 - jb;
-        if (w < nbelow) {
-            const int ro = (jb + 1 + w) * 16;
+        for (int pt = w; pt < nbelow; pt += 4) {   // panel tile ib = jb+1+pt:  P = A[ib,jb] * Dinv^T
+            double* T = Tt + tix(jb + 1 + pt, jb) * TSZ;
+            double af[4], bf[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                af[s] = T[fi * TS + fk + 4 * s];
+                bf[s] = Dv[fi * TS + fk + 4 * s];          // B[k][col] = Dinv[col][k]
+            }
             d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double a = M[(ro + fi) * DS + o + fk + 4 * s];
-                const double b = Dv[jb * 16 * IS + fi * IS + fk + 4 * s];   // B[k][col] = Dinv[col][k]
-                acc = mfma_f64(a, b, acc);
-            }
+            for (int s = 0; s < 4; ++s) acc = mfma_f64(af[s], bf[s], acc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) M[(ro + fk + 4 * r) * DS + o + fi] = acc[r];
-        }
-        __syncthreads();
-        // trailing update inside the block: C[ib,kb] -= P[ib] P[kb]^T for jb < kb <= ib
-        const int ntile = nbelow * (nbelow + 1) / 2;
-        for (int q = w; q < ntile; q += 16) {
-            int a_ = 0, rem = q;
-            while (rem > a_) { rem -= a_ + 1; ++a_; }   // q -> (a_, rem) with rem <= a_
-            const int ro = (jb + 1 + a_) * 16, co = (jb + 1 + rem) * 16;
-            d4 acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = M[(ro + fk + 4 * r) * DS + co + fi];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double a = -M[(ro + fi) * DS + o + fk + 4 * s];
-                const double b = M[(co + fi) * DS + o + fk + 4 * s];
-                acc = mfma_f64(a, b, acc);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) M[(ro + fk + 4 * r) * DS + co + fi] = acc[r];
+            for (int r = 0; r < 4; ++r) T[(fk + 4 * r) * TS + fi] = acc[r];
         }
         __syncthreads();
     }
-    // write back L (whole block; the strict upper part is never consumed on device), the tile inverses
-    // and sum(log diag)
-    for (int idx = t; idx < 128 * 128; idx += 1024) {
-        const int r = idx >> 7, c = idx & 127;
-        Ab[(long)r * ld + c] = M[r * DS + c];
-    }
-    for (int idx = t; idx < 8 * 256; idx += 1024) {
-        const int jb = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
-        dinv[idx] = Dv[jb * 16 * IS + r * IS + c];
-    }
+    // write back the lower tiles of L and sum(log diag)
+#pragma unroll
+    for (int u = 0; u < NTILE; ++u) Ab[(long)(tile_I(u) * 16 + er) * ld + tile_J(u) * 16 + ec] = Tt[u * TSZ + er * TS + ec];
     if (w == 0) {
-        double s = log(M[lane * DS + lane]) + log(M[(lane + 64) * DS + lane + 64]);
+        const int i0 = lane, i1 = lane + 64;
+        double s = log(Tt[tix(i0 >> 4, i0 >> 4) * TSZ + (i0 & 15) * TS + (i0 & 15)]) +
+                   log(Tt[tix(i1 >> 4, i1 >> 4) * TSZ + (i1 & 15) * TS + (i1 & 15)]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
         if (lane == 0) logsum[0] = s;
     }
 }
 
+#define DIAG_LDS_BYTES ((NTILE * TSZ + TSZ) * 8)
+
 void launch_diag128(hipStream_t st, double* A, long ld, long c0, double* dinv, double* logsum, int* info) {
-    const size_t lds = (size_t)(128 * DS + 8 * 16 * IS) * sizeof(double);
     static bool opted = false;
     if (!opted) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_diag128), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+                                  DIAG_LDS_BYTES);
         opted = true;
     }
-    hipLaunchKernelGGL(k_diag128, dim3(1), dim3(1024), lds, st, A, ld, c0, dinv, logsum, info);
+    hipLaunchKernelGGL(k_diag128, dim3(1), dim3(256), DIAG_LDS_BYTES, st, A, ld, c0, dinv, logsum, info);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Panel solve P <- P * L_cc^{-T} for 16 rows of P per wave (transposed: L_cc Y = P^T, Y chained in VGPRs).
+// Panel solve P <- P * L_cc^{-T}, 16 panel rows per wave (transposed: L_cc Y = P^T with the 16-column strips of Y
+// chained in VGPRs).  No LDS and < 128 VGPRs, so these waves slot in next to the trailing-update workgroups of the
+// look-ahead schedule.  All panel loads are issued up front and all stores at the end: the L_cc / Dinv operand loads
+// (L2-resident, shared by every wave) then carry no dependence on earlier steps and the compiler hoists them.
 __global__ __launch_bounds__(256) void k_trsm128(double* __restrict__ A, long ld, long c0, long r0, long mrows,
                                                  const double* __restrict__ dinv) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -154,30 +195,36 @@ __global__ __launch_bounds__(256) void k_trsm128(double* __restrict__ A, long ld
     if (prow0 >= r0 + mrows) return;
     const int fi = lane & 15, fk = lane >> 4;
     double* P = A + (prow0 + fi) * ld + c0;                 // this lane's row of the panel
-    const double* Lb = A + (c0 + fi) * ld + c0;             // L_cc, row fi of tile-row 0
+    const double* Lb = A + (c0 + fi) * ld + c0 + fk;        // L_cc: row fi of tile-row 0, this lane's k offset
+    const double* Db = dinv + fi * 16 + fk;
+    d4 Pin[8];
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pin[jb][r] = P[jb * 16 + fk + 4 * r];
     d4 Y[8];
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb) {
-        d4 acc;
+        d4 acc0 = Pin[jb], acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = P[jb * 16 + fk + 4 * r];
-#pragma unroll
-        for (int k = 0; k < jb; ++k)
+        for (int k = 0; k < jb; ++k) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const double a = -Lb[(long)(jb * 16) * ld + k * 16 + fk + 4 * s];
-                acc = mfma_f64(a, Y[k][s], acc);
+                const double a = -Lb[(long)(jb * 16) * ld + k * 16 + 4 * s];
+                if (k & 1) acc1 = mfma_f64(a, Y[k][s], acc1);
+                else acc0 = mfma_f64(a, Y[k][s], acc0);
             }
+        }
+        const d4 acc = acc0 + acc1;
         d4 y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double a = dinv[jb * 256 + fi * 16 + fk + 4 * s];
-            y = mfma_f64(a, acc[s], y);
-        }
+        for (int s = 0; s < 4; ++s) y = mfma_f64(Db[jb * 256 + 4 * s], acc[s], y);
         Y[jb] = y;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) P[jb * 16 + fk + 4 * r] = y[r];
     }
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[jb * 16 + fk + 4 * r] = Y[jb][r];
 }
 
 void launch_trsm128(hipStream_t st, double* A, long ld, long c0, long r0, long mrows, const double* dinv) {

@@ -1,0 +1,149 @@
+"""`ExactGaussianInference` backed by libmi355gp.so -- drop-in for
+`GPy.inference.latent_function_inference.ExactGaussianInference` (reference
+`GPy/inference/latent_function_inference/exact_gaussian_inference.py:11-88`).
+
+`inference(kern, X, likelihood, Y, mean_function=None, Y_metadata=None, K=None, variance=None, Z_tilde=None)`
+returns `(Posterior, log_marginal_likelihood, {'dL_dK', 'dL_dthetaL', 'dL_dm'})` like the reference; with a
+gpy_amd kernel the whole evaluation (K build, Cholesky, alpha, Ky^-1, all gradients) is one C-ABI call and the
+N x N results stay in HBM behind lazy proxies.  The jitter ladder of `jitchol` (reference
+`GPy/util/linalg.py:56-75`) runs here, on LAPACK-style `info` codes from the device factorisation, and raises
+the same `numpy.linalg.LinAlgError` messages.
+"""
+import numpy as np
+
+from . import _lib
+from .kern import Stationary
+from .lazy import DeviceResult, kernel_signature
+from .likelihoods import Gaussian
+from .posterior import PosteriorExact
+
+LinAlgError = np.linalg.LinAlgError
+
+
+class _DeviceState(object):
+    """One uploaded (X, R) pair and the HBM buffers behind it."""
+
+    def __init__(self, device):
+        self.ctx = _lib.Context(device)
+        self.X = None
+        self.R = None
+        self.call_token = 0
+        self.kern = None
+
+    def ensure_data(self, X, R):
+        if self.X is None or self.X.shape != X.shape or self.R.shape != R.shape or not np.array_equal(self.X, X):
+            self.ctx.set_data(X, R)
+            self.X, self.R = X.copy(), R.copy()
+        elif not np.array_equal(self.R, R):
+            self.ctx.set_targets(R)
+            self.R = R.copy()
+
+    def fetch(self, which, fortran_order=False):
+        return self.ctx.fetch(which, fortran_order=fortran_order)
+
+    def predict(self, kern, Xnew, full_cov=False):
+        return self.ctx.predict(kern.kind, kern.ARD, kern._theta(), kern._slice_X(Xnew), full_cov=full_cov)
+
+
+class ExactGaussianInference(object):
+    def __init__(self, device=0, maxtries=5):
+        self.device = device
+        self.maxtries = maxtries
+        self._state = None
+        self.last_stage_ms = None
+        self.collect_stage_ms = False
+
+    # GPy's LatentFunctionInference hooks (reference latent_function_inference/__init__.py:38-49)
+    def on_optimization_start(self):
+        pass
+
+    def on_optimization_end(self):
+        pass
+
+    def to_dict(self):
+        return {"class": "GPy.inference.latent_function_inference.exact_gaussian_inference.ExactGaussianInference"}
+
+    def __getstate__(self):          # device handles never travel (cf. reference rbf.py:313-318)
+        d = dict(self.__dict__)
+        d["_state"] = None
+        return d
+
+    def _run_with_ladder(self, attempt, diagA):
+        """`attempt(extra_jitter)` -> (info, result).  Mirrors jitchol: plain try, then mean(diag)*1e-6 * 10^k."""
+        info, res = attempt(0.0)
+        if info == 0:
+            return res
+        if np.any(diagA <= 0.):
+            raise LinAlgError("not pd: non-positive diagonal elements")
+        jitter = float(np.mean(diagA)) * 1e-6
+        num_tries = 1
+        while num_tries <= self.maxtries and np.isfinite(jitter):
+            info, res = attempt(jitter)
+            if info == 0:
+                return res
+            jitter *= 10
+            num_tries += 1
+        raise LinAlgError("not positive definite, even with jitter.")
+
+    def inference(self, kern, X, likelihood, Y, mean_function=None, Y_metadata=None, K=None, variance=None,
+                  Z_tilde=None):
+        X = np.asarray(X)
+        Y = np.asarray(Y, dtype=np.float64)
+        m = 0 if mean_function is None else mean_function.f(X)
+        if variance is None:
+            variance = likelihood.gaussian_variance(Y_metadata)
+        noise = np.atleast_1d(np.asarray(variance, dtype=np.float64)).ravel()
+        R = _lib.f64(Y - m)
+        n = X.shape[0]
+        fused = K is None and isinstance(kern, Stationary)
+        Xdev = kern._slice_X(X) if fused else _lib.f64(X)
+        if self._state is None:
+            self._state = _DeviceState(self.device)
+        st = self._state
+        st.ensure_data(Xdev, R)
+        st.call_token += 1
+        want_ms = self.collect_stage_ms
+        # Gaussian.exact_inference_gradients == sum(diag(dL_dK)) == trace(dL_dK), which the device already reduces:
+        # only likelihoods with per-row noise terms need the N-vector diag(dL_dK) shipped back.
+        trace_only = isinstance(likelihood, Gaussian) and noise.size == 1
+        scalar_noise_lik = trace_only
+
+        if fused:
+            theta = kern._theta()
+            diagA = float(theta[0]) + noise + 1e-8
+
+            def attempt(extra):
+                return st.ctx.exact_inference(kern.kind, kern.ARD, theta, noise, jitter=1e-8, extra_jitter=extra,
+                                              want_alpha=True, want_diag=not scalar_noise_lik,
+                                              want_stage_ms=want_ms)
+            res = self._run_with_ladder(attempt, diagA)
+            sig = kernel_signature(kern)
+            K_view = DeviceResult(st, _lib.FETCH_K, n, st.call_token)
+            dL_dK = DeviceResult(st, _lib.FETCH_DLDK, n, st.call_token, kernel_sig=sig, fused_dtheta=res["dtheta"])
+        else:
+            if K is None:
+                K = kern.K(X)
+            K = _lib.f64(K)
+            diagA = np.diag(K) + noise + 1e-8
+
+            def attempt(extra):
+                return st.ctx.inference_given_K(K, noise, jitter=1e-8, extra_jitter=extra,
+                                                want_diag=not scalar_noise_lik, want_stage_ms=want_ms)
+            res = self._run_with_ladder(attempt, diagA)
+            K_view = K
+            dL_dK = DeviceResult(st, _lib.FETCH_DLDK, n, st.call_token)
+        self.last_stage_ms = res.get("stage_ms")
+
+        log_marginal = res["lml"]
+        if Z_tilde is not None:
+            log_marginal += Z_tilde
+        alpha = res["alpha"]
+        if trace_only:
+            dL_dthetaL = res["dnoise"]
+        else:
+            dL_dthetaL = likelihood.exact_inference_gradients(res["diag_dL_dK"], Y_metadata)
+        post = PosteriorExact(
+            woodbury_chol=DeviceResult(st, _lib.FETCH_L, n, st.call_token, fortran_order=True),
+            woodbury_vector=alpha, K=K_view,
+            woodbury_inv=DeviceResult(st, _lib.FETCH_KINV, n, st.call_token), state=st)
+        return post, log_marginal, {"dL_dK": dL_dK, "dL_dthetaL": dL_dthetaL, "dL_dm": alpha}

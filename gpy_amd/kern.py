@@ -1,0 +1,182 @@
+"""Stationary covariance functions backed by libmi355gp.so -- drop-in for the hot-path methods of
+`GPy.kern.RBF / Matern52 / Matern32 / Exponential`:
+
+    K(X, X2=None), Kdiag(X), update_gradients_full(dL_dK, X, X2=None), update_gradients_diag(dL_dKdiag, X)
+
+Same constructor arguments, parameter names (`variance`, `lengthscale`, `inv_lengthscale`), link order and
+`.gradient` side effects as the reference (`GPy/kern/src/stationary.py:60-81,105-115,170-213`,
+`GPy/kern/src/rbf.py:22-33,373-375`); `active_dims` slicing follows `GPy/kern/src/kern.py:112-117`.
+All array math runs in hand-written HIP kernels (csrc/kern.hip); there is no NumPy fallback.
+"""
+import numpy as np
+
+from . import _lib
+from .lazy import DeviceResult
+from .param import Param, Parameterized
+
+
+class Stationary(Parameterized):
+    kind = None                # name understood by the C-ABI
+    _gpy_class = None          # "class" string for to_dict (resolvable by GPy's loader)
+    _support_GPU = True
+
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name=None,
+                 useGPU=True, device=0):
+        super(Stationary, self).__init__(name or self.kind)
+        self.input_dim = int(input_dim)
+        self.ARD = bool(ARD)
+        self.device = device
+        self.useGPU = True
+        if active_dims is None:
+            active_dims = np.arange(self.input_dim)
+        self.active_dims = np.atleast_1d(np.asarray(active_dims, dtype=np.int_))
+        assert self.active_dims.size == self.input_dim, "input_dim=%d does not match len(active_dims)=%d" % (
+            self.input_dim, self.active_dims.size)
+        if not self.ARD:
+            if lengthscale is None:
+                lengthscale = np.ones(1)
+            else:
+                lengthscale = np.asarray(lengthscale, dtype=float)
+                assert lengthscale.size == 1, "Only 1 lengthscale needed for non-ARD kernel"
+        else:
+            if lengthscale is not None:
+                lengthscale = np.asarray(lengthscale, dtype=float)
+                assert lengthscale.size in [1, self.input_dim], "Bad number of lengthscales"
+                if lengthscale.size != self.input_dim:
+                    lengthscale = np.ones(self.input_dim) * lengthscale
+            else:
+                lengthscale = np.ones(self.input_dim)
+        self.variance = Param("variance", variance)
+        self.lengthscale = Param("lengthscale", lengthscale)
+        assert self.variance.size == 1
+        self.link_parameters(self.variance, self.lengthscale)
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def _slice_X(self, X):
+        X = np.asarray(X)
+        if X.shape[1] == self.input_dim and np.array_equal(self.active_dims, np.arange(self.input_dim)):
+            return _lib.f64(X)
+        assert X.shape[1] > self.active_dims.max(), "At least %d dimensional X needed, X.shape=%r" % (
+            self.active_dims.max() + 1, X.shape)
+        return _lib.f64(X[:, self.active_dims])
+
+    def _theta(self):
+        return _lib.theta_vec(self.variance.values, self.lengthscale.values, self.ARD, self.input_dim)
+
+    # ---- the hot-path interface -----------------------------------------------------------------------
+    def K(self, X, X2=None):
+        """Covariance matrix K(X, X2) (reference `stationary.py:105-115`)."""
+        Xs = self._slice_X(X)
+        X2s = None if X2 is None else self._slice_X(X2)
+        return _lib.kern_K(self.kind, self.ARD, self._theta(), Xs, X2s, device=self.device)
+
+    def Kdiag(self, X):
+        """(reference `stationary.py:170-173`)"""
+        return _lib.kern_Kdiag(self.kind, self._theta(), np.asarray(X).shape[0])
+
+    def update_gradients_full(self, dL_dK, X, X2=None):
+        """Writes `self.variance.gradient` and `self.lengthscale.gradient` (reference `stationary.py:193-213`).
+
+        When `dL_dK` is the device-resident result of `gpy_amd.ExactGaussianInference` for this kernel the
+        gradients were already reduced on the GPU in the same pass and are simply installed."""
+        if isinstance(dL_dK, DeviceResult) and X2 is None and dL_dK.matches_kernel(self):
+            g = dL_dK.fused_dtheta
+        else:
+            g = _lib.update_gradients_full(self.kind, self.ARD, self._theta(), np.asarray(dL_dK), self._slice_X(X),
+                                           None if X2 is None else self._slice_X(X2), device=self.device)
+        self._install_gradients(g)
+
+    def _install_gradients(self, g):
+        self.variance.gradient = g[0]
+        self.lengthscale.gradient = g[1:] if self.ARD else g[1]
+
+    def update_gradients_diag(self, dL_dKdiag, X):
+        """(reference `stationary.py:182-191`)"""
+        self.variance.gradient = np.sum(dL_dKdiag)
+        self.lengthscale.gradient = 0.
+
+    def reset_gradients(self):
+        self.variance.gradient = 0.
+        self.lengthscale.gradient = np.zeros(self.input_dim) if self.ARD else 0.
+
+    # ---- bookkeeping ----------------------------------------------------------------------------------
+    def to_dict(self):
+        """JSON-serialisable description with the reference's "class" string (`stationary.py:83-88`)."""
+        return {"class": self._gpy_class, "name": self.name, "input_dim": self.input_dim,
+                "active_dims": self.active_dims.tolist(), "variance": self.variance.values.tolist(),
+                "lengthscale": self.lengthscale.values.tolist(), "ARD": self.ARD, "useGPU": True}
+
+    @classmethod
+    def from_dict(cls, d):
+        d = dict(d)
+        d.pop("class", None)
+        d.pop("useGPU", None)
+        return cls(**d)
+
+    def copy(self):
+        return self.__class__.from_dict(self.to_dict())
+
+
+class RBF(Stationary):
+    """k(r) = variance * exp(-r^2/2)  (reference `GPy/kern/src/rbf.py:51-52`); `inv_l=True` re-parameterises by
+    the inverse squared lengthscale exactly like the reference (`rbf.py:29-33,328-330,373-375`)."""
+    kind = "rbf"
+    _gpy_class = "GPy.kern.RBF"
+
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="rbf",
+                 useGPU=True, inv_l=False, device=0):
+        super(RBF, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name, useGPU, device)
+        self.use_invLengthscale = bool(inv_l)
+        if self.use_invLengthscale:
+            self.unlink_parameter(self.lengthscale)
+            self.inv_l = Param("inv_lengthscale", 1. / self.lengthscale.values ** 2)
+            self.link_parameter(self.inv_l)
+
+    def parameters_changed(self):
+        if self.use_invLengthscale:
+            self.lengthscale[:] = 1. / np.sqrt(self.inv_l.values + 1e-200)
+
+    def _install_gradients(self, g):
+        super(RBF, self)._install_gradients(g)
+        if self.use_invLengthscale:
+            self.inv_l.gradient = self.lengthscale.gradient * (self.lengthscale.values ** 3 / -2.)
+
+    def update_gradients_diag(self, dL_dKdiag, X):
+        super(RBF, self).update_gradients_diag(dL_dKdiag, X)
+        if self.use_invLengthscale:
+            self.inv_l.gradient = self.lengthscale.gradient * (self.lengthscale.values ** 3 / -2.)
+
+    def to_dict(self):
+        d = super(RBF, self).to_dict()
+        d["inv_l"] = self.use_invLengthscale
+        return d
+
+
+class Matern52(Stationary):
+    """k(r) = variance (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)  (reference `stationary.py:585-589`)."""
+    kind = "matern52"
+    _gpy_class = "GPy.kern.Matern52"
+
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="Mat52", **kw):
+        super(Matern52, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name, **kw)
+
+
+class Matern32(Stationary):
+    """k(r) = variance (1 + sqrt3 r) exp(-sqrt3 r)  (reference `stationary.py:488-492`)."""
+    kind = "matern32"
+    _gpy_class = "GPy.kern.Matern32"
+
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="Mat32", **kw):
+        super(Matern32, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name, **kw)
+
+
+class Exponential(Stationary):
+    """k(r) = variance exp(-r)  (reference `stationary.py:382-386`)."""
+    kind = "exponential"
+    _gpy_class = "GPy.kern.Exponential"
+
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="Exponential", **kw):
+        super(Exponential, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name, **kw)
+
+
+KERNEL_CLASSES = {"rbf": RBF, "matern52": Matern52, "matern32": Matern32, "exponential": Exponential}

@@ -1,0 +1,45 @@
+"""Posterior container returned by `ExactGaussianInference.inference` -- mirrors the attributes of the
+reference's `PosteriorExact` that `GP` and user code read (`GPy/inference/latent_function_inference/posterior.py:21-77,
+131-196,273-302`): `woodbury_chol`, `woodbury_vector`, `woodbury_inv`, `K`, `mean`, `_raw_predict`.
+The N x N members are `DeviceResult` proxies (fetched lazily); prediction runs on the device."""
+import numpy as np
+
+
+class PosteriorExact(object):
+    def __init__(self, woodbury_chol, woodbury_vector, K, woodbury_inv=None, state=None, prior_mean=0):
+        self._woodbury_chol = woodbury_chol
+        self._woodbury_vector = woodbury_vector
+        self._woodbury_inv = woodbury_inv
+        self._K = K
+        self._state = state            # device state that produced this posterior (for on-device prediction)
+        self._prior_mean = prior_mean
+        self._mean = None
+
+    @property
+    def woodbury_chol(self):
+        return self._woodbury_chol
+
+    @property
+    def woodbury_vector(self):
+        return self._woodbury_vector
+
+    @property
+    def woodbury_inv(self):
+        return self._woodbury_inv
+
+    @property
+    def K(self):
+        return self._K
+
+    @property
+    def mean(self):
+        """K alpha (reference `posterior.py:79-91`)"""
+        if self._mean is None:
+            self._mean = np.dot(np.asarray(self._K), self._woodbury_vector)
+        return self._mean
+
+    def _raw_predict(self, kern, Xnew, pred_var, full_cov=False):
+        """mu = K(X*,X) alpha, var = K** - |L^-1 K(X,X*)|^2 (reference `posterior.py:273-302`), on the device."""
+        if self._state is None:
+            raise RuntimeError("this posterior is not attached to a device context")
+        return self._state.predict(kern, Xnew, full_cov=full_cov)

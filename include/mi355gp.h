@@ -117,6 +117,18 @@ int mi355gp_potrf(int device, double* A, int64_t N, double* ms);
 /* Ainv (symmetric, full) from A; replaces pdinv's dpotrf+dpotri+symmetrify (util/linalg.py:193-214). */
 int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* L_out, double* logdet, double* ms);
 
+/* Options.  PROFILE: bracket every launch of the factorisation kernels with hipEvents on the launching stream
+ * (adds ~2 us per launch); LOOKAHEAD (default 1): factor panel k+1 on a second stream while the trailing update of
+ * step k still runs. */
+enum { MI355GP_OPT_PROFILE = 0, MI355GP_OPT_LOOKAHEAD = 1 };
+int mi355gp_set_option(mi355gp_ctx* ctx, int option, int value);
+/* kernel families of mi355gp_get_profile */
+enum { MI355GP_PF_UPDATE = 0 /* k_update_nt: trailing update of potrf */, MI355GP_PF_TRTRI = 1, MI355GP_PF_LAUUM = 2,
+       MI355GP_PF_DIAG = 3 /* k_diag128 */, MI355GP_PF_TRSM = 4 /* k_trsm128 */, MI355GP_PF_NUM = 5 };
+/* Per family, for the last inference call made with PROFILE on: summed launch durations (ms), summed ALGORITHMIC
+ * flops of those launches, launch count.  Arrays of MI355GP_PF_NUM. */
+int mi355gp_get_profile(mi355gp_ctx* ctx, double* ms, double* flops, int* launches);
+
 /* Device-only benchmark of the factorisation on a synthetic SPD matrix already resident in HBM:
  * returns average milliseconds of potrf / trtri / lauum over `reps` runs. */
 int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, double* ms_trtri, double* ms_lauum);
@@ -128,9 +140,9 @@ int mi355gp_dbg_mfma(int device, const double* a, const double* b, double* d);
  * transa/transb: 0 = operand stored k-contiguous (A: M x K row-major, B: N x K row-major), 1 = stored K x M / K x N. */
 int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_t N, int64_t K,
                      const double* A, const double* B, double* C, double alpha, double beta, int reps, double* ms);
-/* microbenchmarks, out8: [0] fp64 MFMA TFLOP/s, [1] fp64 VALU FMA TFLOP/s, [2] HBM copy GB/s, [3] HBM fill GB/s,
- * [4] shader cycles per v_mfma_f64_16x16x4 (one wave/SIMD), [5] effective shader MHz, [6] MFMA TF/s at one
- * wave/SIMD, [7] v_mfma_f64_4x4x4 TF/s */
+/* microbenchmarks, out8: [0] fp64 MFMA TFLOP/s (8 workgroups/CU), [1] fp64 VALU FMA TFLOP/s, [2] HBM copy GB/s,
+ * [3] HBM fill GB/s, [4] shader cycles per v_mfma_f64_16x16x4 at one wave/SIMD, [5] effective shader MHz under the
+ * full MFMA load, [6] MFMA TFLOP/s at one wave/SIMD, [7] shader cycles per MFMA per SIMD under the full load */
 int mi355gp_dbg_peaks(int device, double* out8);
 
 #ifdef __cplusplus

@@ -1,0 +1,41 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    d = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+    d["kind"] = str(d["kind"])
+    d["ARD"] = bool(d["ARD"])
+    d["variance"] = float(d["variance"])
+    # regenerate the (X2, A) pair of the generic update_gradients_full case exactly as oracle/make_golden.py did
+    N, D = d["X"].shape
+    M = int(d["M"])
+    rngA = np.random.default_rng(int(d["seedA"]))
+    d["X2"] = rngA.standard_normal((M, D))
+    d["A"] = rngA.standard_normal((N, M))
+    return d
+
+
+@pytest.fixture(scope="session")
+def oracle_native_built():
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    return True

@@ -181,10 +181,69 @@ def probe_timing():
     ctx.close()
 
 
+@section("host-classes")
+def probe_host():
+    import gpy_amd
+    X, Y = O.synthetic(900, 4, seed=21, Dy=2)
+    var, ls, noise = O.default_theta(4, True)
+    ref = O.parameters_changed("matern32", X, Y, var, ls, True, noise)
+    m = gpy_amd.GPRegression(X, Y, gpy_amd.Matern32(4, variance=var, lengthscale=ls, ARD=True), noise_var=noise)
+    gref = np.concatenate([[ref["dvar"]], ref["dlen"], [ref["dL_dnoise"]]])
+    print("  GPRegression lml rel %.2e grad rel %.2e" % (abs(m.log_likelihood() - ref["lml"]) / abs(ref["lml"]),
+          np.abs(m.gradient - gref).max() / np.abs(gref).max()))
+    Xs = np.random.default_rng(3).standard_normal((333, 4))
+    mu, v = m.predict_noiseless(Xs)
+    mur, vr = O.predict("matern32", X, Xs, ref["L"], ref["alpha"], var, ls, True)
+    mu2, C = m.predict_noiseless(Xs, full_cov=True)
+    _, Cr = O.predict("matern32", X, Xs, ref["L"], ref["alpha"], var, ls, True, full_cov=True)
+    print("  predict: mu %.2e var %.2e cov %.2e" % (np.abs(mu - mur).max(), np.abs(v - vr).max(), np.abs(C - Cr).max()))
+    # jitter ladder: duplicated rows, zero noise -> singular K; must succeed like jitchol does
+    Xd = np.vstack([X[:200], X[:200]]); Yd = np.vstack([Y[:200], Y[:200]])
+    try:
+        md = gpy_amd.GPRegression(Xd, Yd, gpy_amd.RBF(4, variance=1.0, lengthscale=1.5), noise_var=1e-300)
+        K = O.kern_K("rbf", Xd, None, 1.0, 1.5, False)
+        try:
+            r2 = O.exact_inference(K, Yd, 1e-300)
+            print("  ladder: device lml %.6f oracle lml %.6f" % (md.log_likelihood(), r2["lml"]))
+        except Exception as e:
+            print("  ladder: device lml %.6f, oracle raised %r" % (md.log_likelihood(), e))
+    except Exception as e:
+        print("  ladder: device raised %r" % (e,))
+    res = m.optimize(max_iters=15)
+    print("  optimize: %d its, objective %.4f -> params %s" % (res.nit, res.fun, np.round(m.param_array, 4)))
+
+
+@section("lookahead")
+def probe_lookahead():
+    ctx = L.Context(0)
+    for kind, ARD, N, D in [("rbf", False, 4096, 8)] + ([("matern52", True, 16384, 32)] if MODE == "full" else []):
+        X, Y = O.synthetic(N, D, seed=0)
+        var, ls, noise = O.default_theta(D, ARD)
+        ctx.set_data(X, Y)
+        th = L.theta_vec(var, ls, ARD, D)
+        out = {}
+        for la in (0, 1):
+            ctx.set_option("lookahead", la)
+            for prof in (0, 1):
+                ctx.set_option("profile", prof)
+                for it in range(3):
+                    info, r = ctx.exact_inference(kind, ARD, th, noise, want_alpha=False, want_stage_ms=True)
+                print("  N=%5d lookahead=%d profile=%d: total %.3f ms potrf %.3f trtri %.3f lauum %.3f lml %.9f" % (
+                    N, la, prof, r["stage_ms"]["total"], r["stage_ms"]["potrf"], r["stage_ms"]["trtri"],
+                    r["stage_ms"]["lauum"], r["lml"]))
+                if prof:
+                    pf = ctx.get_profile()
+                    print("      profile:", {k: "%.3f ms %.1f TF/s x%d" % (v[0], v[1] / max(v[0], 1e-9) / 1e9, v[2]) for k, v in pf.items()})
+            out[la] = r["lml"]
+        print("  lml identical with/without look-ahead:", out[0] == out[1])
+    ctx.close()
+
+
 if __name__ == "__main__":
     print("lib:", L.lib().mi355gp_version().decode(), "devices:", L.device_count(), "mode:", MODE, flush=True)
     allf = dict(mfma=probe_mfma, gemm=probe_gemm, potrf=probe_potrf, pdinv=probe_pdinv, kern=probe_kern,
-                inference=probe_inference, timing=probe_timing)
+                inference=probe_inference, timing=probe_timing, host=probe_host,
+                lookahead=probe_lookahead)
     names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(allf)
     for nm in names:
         allf[nm]()

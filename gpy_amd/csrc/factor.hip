@@ -7,7 +7,8 @@
 
 // ---- profiling ------------------------------------------------------------------------------------
 void KernelProf::begin(hipStream_t st, int fam, double flops) {
-    if (!on) return;
+    open = on && ((mask >> fam) & 1u);
+    if (!open) return;
     const size_t e0 = 2 * recs.size();
     while (pool.size() < e0 + 2) {
         hipEvent_t e;
@@ -19,7 +20,8 @@ void KernelProf::begin(hipStream_t st, int fam, double flops) {
 }
 
 void KernelProf::end(hipStream_t st) {
-    if (!on) return;
+    if (!open) return;
+    open = false;
     (void)hipEventRecord(pool[recs.back().e0 + 1], st);
 }
 

@@ -33,10 +33,12 @@ void launch_dbg_mfma(hipStream_t st, const double* a, const double* b, double* d
 // per-kernel-family device timing (hipEvent pairs on the launching stream) + algorithmic flop counts
 enum { PF_UPDATE = 0, PF_TRTRI = 1, PF_LAUUM = 2, PF_DIAG = 3, PF_TRSM = 4, PF_NUM = 5 };
 struct KernelProf {
+    unsigned mask = 0;          // bit f set: family f is timed
     bool on = false;
     std::vector<hipEvent_t> pool;
     struct Rec { int fam; double flops; size_t e0; };
     std::vector<Rec> recs;
+    bool open = false;
     void begin(hipStream_t st, int fam, double flops);
     void end(hipStream_t st);
     void reset() { recs.clear(); }

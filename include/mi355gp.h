@@ -117,8 +117,9 @@ int mi355gp_potrf(int device, double* A, int64_t N, double* ms);
 /* Ainv (symmetric, full) from A; replaces pdinv's dpotrf+dpotri+symmetrify (util/linalg.py:193-214). */
 int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* L_out, double* logdet, double* ms);
 
-/* Options.  PROFILE: bracket every launch of the factorisation kernels with hipEvents on the launching stream
- * (adds ~2 us per launch); LOOKAHEAD (default 1): factor panel k+1 on a second stream while the trailing update of
+/* Options.  PROFILE: bracket launches of the factorisation kernels with hipEvents on the launching stream (adds
+ * ~2 us per timed launch).  value 0 = off, 1 = all families, otherwise (bitmask of 1 << MI355GP_PF_*) << 1;
+ * LOOKAHEAD (default 1): factor panel k+1 on a second stream while the trailing update of
  * step k still runs. */
 enum { MI355GP_OPT_PROFILE = 0, MI355GP_OPT_LOOKAHEAD = 1 };
 int mi355gp_set_option(mi355gp_ctx* ctx, int option, int value);

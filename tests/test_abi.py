@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/mi355gp.h declares.
+No compute calls here (no GPU in this container); device entry points must fail loudly instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from gpy_amd import _lib
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mi355gp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355gp_[a-z_0-9A-Z]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = _lib.build()
+    assert os.path.exists(path)
+    lib = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for sym in declared:
+        assert hasattr(lib, sym), "libmi355gp.so does not export %s" % sym
+    assert set(_lib.EXPORTED) <= set(declared)
+    assert b"gfx950" in lib.mi355gp_version()
+
+
+def test_code_object_is_gfx950_only():
+    import subprocess
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH],
+                         capture_output=True, text=True).stdout
+    archs = set(re.findall(r"gfx[0-9a-f]+", out))
+    assert archs == {"gfx950"} or not archs, archs
+
+
+@pytest.mark.skipif(_lib.device_count() > 0, reason="a GPU is present")
+def test_no_cpu_fallback_without_device():
+    assert _lib.device_count() == 0
+    with pytest.raises(_lib.MI355GPError):
+        _lib.Context(0)
+    X = np.zeros((4, 2))
+    with pytest.raises(_lib.MI355GPError):
+        _lib.kern_K("rbf", False, np.array([1.0, 1.0]), X)
+    with pytest.raises(_lib.MI355GPError):
+        _lib.potrf(np.eye(4))
+    import gpy_amd
+    with pytest.raises(_lib.MI355GPError):
+        gpy_amd.GPRegression(X, np.zeros((4, 1)))
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "gpy_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+    assert "from oracle" not in open(os.path.join(ROOT, "bench.py")).read().split("def cpu_baseline")[0]
+
+
+def test_kdiag_is_host_side_and_exact():
+    out = _lib.kern_Kdiag("matern52", np.array([1.7, 0.3]), 5)
+    assert np.array_equal(out, np.full(5, 1.7))

@@ -1,0 +1,57 @@
+"""CPU, world_size 2 over gloo: the rank plumbing of bench.py (barriers around the timed region, MAX over ranks,
+whole-job aggregation for independent replicas).  The data path itself has no collective (replicas only)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import bench
+    comm = bench.Comm(backend="gloo")
+    calls = []
+    def step():
+        calls.append(1)
+        time.sleep(0.02 * (1 + comm.rank))        # rank 1 is the slow replica
+    dt = bench.timed_region(comm, step, steps=5, warmup=2)
+    with open(os.path.join(%r, "rank%%d.json" %% comm.rank), "w") as f:
+        json.dump({"rank": comm.rank, "world": comm.world, "dt": dt, "calls": len(calls)}, f)
+    comm.close()
+""")
+
+
+def test_two_rank_timed_region_takes_max_over_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % (ROOT, str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    recs = [json.load(open(tmp_path / ("rank%d.json" % i))) for i in range(2)]
+    assert sorted(x["rank"] for x in recs) == [0, 1]
+    assert all(x["world"] == 2 and x["calls"] == 7 for x in recs)          # 2 warm-up + exactly 5 timed steps
+    assert abs(recs[0]["dt"] - recs[1]["dt"]) < 1e-9                        # both ranks hold the MAX
+    assert recs[0]["dt"] >= 5 * 0.04 * 0.95                                 # the slow rank's time
+    # whole-job throughput of independent replicas = n_gpus * steps / max time
+    assert 2 * 5 / recs[0]["dt"] < 2 * 5 / (5 * 0.02)
+
+
+def test_single_process_comm_is_a_no_op():
+    sys.path.insert(0, ROOT)
+    import bench
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        comm = bench.Comm()
+        assert comm.world == 1 and comm.rank == 0
+        n = []
+        dt = bench.timed_region(comm, lambda: n.append(1), steps=3, warmup=1)
+        assert len(n) == 4 and dt >= 0
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v

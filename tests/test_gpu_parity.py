@@ -1,0 +1,253 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against (a) the golden vectors generated from the
+reference's own code, (b) the CPU oracle on seeded inputs, and (c) size-independent properties at the BASELINE
+sizes.  Tolerances are the fp64 parity contract of SURVEY.md 8(c) / BASELINE.md:
+    K entries abs <= 1e-13*variance ; LML rel <= 1e-10 ; alpha rel <= 1e-9 ; gradients rel <= 1e-8 (vs |grad|_inf)
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from gpy_amd import _lib as L
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_K, TOL_LML, TOL_ALPHA, TOL_GRAD = 1e-13, 1e-10, 1e-9, 1e-8
+
+
+def _ls(g):
+    return g["lengthscale"] if g["ARD"] else g["lengthscale"][:1]
+
+
+def _theta(g):
+    return L.theta_vec(g["variance"], _ls(g), g["ARD"], g["X"].shape[1])
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def test_native_library_is_the_one_running():
+    assert L.device_count() >= 1
+    import ctypes
+    assert isinstance(L.lib(), ctypes.CDLL) and L.LIB_PATH.endswith("gpy_amd/libmi355gp.so")
+    loaded = open("/proc/self/maps").read()
+    assert "libmi355gp.so" in loaded
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_vectors_through_the_c_abi(name, ctx):
+    g = load_golden(name)
+    X, Y, th = g["X"], g["Y"], _theta(g)
+    N = X.shape[0]
+    rows = g["rows"]
+    # kernel functions
+    K = L.kern_K(g["kind"], g["ARD"], th, X)
+    assert np.abs(K[rows] - g["K_rows"]).max() <= TOL_K * g["variance"]
+    assert np.array_equal(np.diag(K), np.full(N, g["variance"]))              # exact variance on the diagonal
+    Kx = L.kern_K(g["kind"], g["ARD"], th, X, g["X2"])
+    assert np.abs(Kx[rows] - g["K_X_X2_rows"]).max() <= TOL_K * g["variance"]
+    assert np.array_equal(L.kern_Kdiag(g["kind"], th, N), g["Kdiag"])
+    gA = L.update_gradients_full(g["kind"], g["ARD"], th, g["A"], X, g["X2"])
+    refA = np.concatenate([g["dvar_A"], g["dlen_A"]])
+    assert np.abs(gA - refA).max() <= TOL_GRAD * max(np.abs(refA).max(), 1e-300)
+    # fused inference
+    ctx.set_data(X, Y)
+    info, r = ctx.exact_inference(g["kind"], g["ARD"], th, g["noise"], want_diag=True)
+    assert info == 0
+    assert abs(r["lml"] - g["lml"]) <= TOL_LML * max(1.0, abs(g["lml"]))
+    assert np.linalg.norm(r["alpha"] - g["alpha"]) <= TOL_ALPHA * np.linalg.norm(g["alpha"])
+    ref = np.concatenate([g["dvar"], g["dlen"]])
+    assert np.abs(r["dtheta"] - ref).max() <= TOL_GRAD * np.abs(ref).max()
+    assert np.abs(r["diag_dL_dK"] - g["diag_dL_dK"]).max() <= TOL_GRAD * np.abs(g["diag_dL_dK"]).max()
+    if g["noise"].size == 1:
+        assert abs(r["dnoise"] - g["dnoise"][0]) <= TOL_GRAD * abs(g["dnoise"][0])
+    assert abs(r["logdet"] - g["logdet"]) <= 1e-11 * max(1.0, abs(g["logdet"]))
+    # lazily fetched N x N results
+    Lg = ctx.fetch(L.FETCH_L, fortran_order=True)
+    assert Lg.flags.f_contiguous                                               # what lapack.dpotrf hands GPy
+    assert np.abs(Lg[rows] - g["L_rows"]).max() <= 1e-12
+    assert np.all(np.triu(Lg, 1) == 0.0)
+    G = ctx.fetch(L.FETCH_DLDK)
+    assert np.abs(G[rows] - g["dL_dK_rows"]).max() <= 1e-9 * np.abs(g["dL_dK_rows"]).max()
+    assert np.array_equal(G, G.T)
+    if "pred_mu" in g:
+        mu, var = ctx.predict(g["kind"], g["ARD"], th, g["Xs"])
+        assert np.abs(mu - g["pred_mu"]).max() <= 1e-10 and np.abs(var - g["pred_var"]).max() <= 1e-10
+        _, cov = ctx.predict(g["kind"], g["ARD"], th, g["Xs"], full_cov=True)
+        assert np.abs(cov - g["pred_cov"]).max() <= 1e-10
+
+
+@pytest.mark.parametrize("kind", O.KINDS)
+@pytest.mark.parametrize("N,D,Dy,ARD", [(1, 1, 1, False), (2, 3, 1, True), (63, 2, 1, False), (129, 5, 2, True),
+                                         (513, 3, 1, True), (1300, 40, 1, True), (2048, 8, 3, False)])
+def test_oracle_parity_on_seeded_inputs(kind, N, D, Dy, ARD, ctx):
+    X, Y = O.synthetic(N, D, seed=7 * N + D, Dy=Dy)
+    var, ls, noise = O.default_theta(D, ARD)
+    ref = O.parameters_changed(kind, X, Y, var, ls, ARD, noise)
+    ctx.set_data(X, Y)
+    info, r = ctx.exact_inference(kind, ARD, L.theta_vec(var, ls, ARD, D), noise, want_diag=True)
+    assert info == 0
+    assert abs(r["lml"] - ref["lml"]) <= TOL_LML * max(1.0, abs(ref["lml"]))
+    assert np.linalg.norm(r["alpha"] - ref["alpha"]) <= TOL_ALPHA * np.linalg.norm(ref["alpha"])
+    gref = np.concatenate([[ref["dvar"]], ref["dlen"]])
+    assert np.abs(r["dtheta"] - gref).max() <= TOL_GRAD * np.abs(gref).max()
+    assert abs(r["dnoise"] - ref["dL_dnoise"]) <= TOL_GRAD * abs(ref["dL_dnoise"])
+    assert np.abs(ctx.fetch(L.FETCH_KINV) - ref["Wi"]).max() <= 1e-9 * np.abs(ref["Wi"]).max()
+
+
+def test_heteroscedastic_noise_and_given_K(ctx):
+    N, D = 400, 3
+    X, Y = O.synthetic(N, D, seed=3, Dy=2)
+    nv = 0.05 + 0.1 * np.random.default_rng(0).random(N)
+    K = O.kern_K("matern32", X, None, 1.3, 0.9, False)
+    ref = O.exact_inference(K, Y, nv)
+    ctx.set_data(X, Y)
+    info, r = ctx.exact_inference("matern32", False, np.array([1.3, 0.9]), nv, want_diag=True)
+    assert info == 0 and abs(r["lml"] - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+    assert np.abs(r["diag_dL_dK"] - ref["diag_dL_dK"]).max() <= TOL_GRAD * np.abs(ref["diag_dL_dK"]).max()
+    # the K= argument of ExactGaussianInference.inference (reference test_inference.py:118-133)
+    info, r2 = ctx.inference_given_K(K, nv, want_diag=True)
+    assert info == 0 and abs(r2["lml"] - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+    assert np.linalg.norm(r2["alpha"] - ref["alpha"]) <= TOL_ALPHA * np.linalg.norm(ref["alpha"])
+
+
+def test_potrf_pdinv_and_info_codes():
+    import scipy.linalg as sla
+    for n in (5, 128, 200, 777):
+        X, _ = O.synthetic(n, 4, seed=n)
+        A = O.kern_K("rbf", X, None, 1.0, 1.5, False) + 0.05 * np.eye(n)
+        Lg, info, _ = L.potrf(A)
+        assert info == 0 and np.abs(Lg - sla.cholesky(A, lower=True)).max() <= 1e-12
+        Ai, L2, logdet, info, _ = L.pdinv(A)
+        Air, Lr, _, ldr = O.pdinv(A)
+        assert info == 0 and np.abs(Ai - Air).max() <= 1e-9 * np.abs(Air).max() and abs(logdet - ldr) <= 1e-10 * max(1, abs(ldr))
+        assert np.array_equal(Ai, Ai.T)
+    A = np.eye(300)
+    A[140, 140] = -2.0
+    assert L.potrf(A)[1] == 141                               # LAPACK-style info: first failing leading minor
+    A = np.ones((260, 260))                                    # rank one: fails at the second pivot
+    assert L.potrf(A)[1] == 2
+
+
+def test_jitter_ladder_and_linalg_errors_through_the_host_classes():
+    import gpy_amd
+    X, Y = O.synthetic(150, 2, seed=5)
+    Xd, Yd = np.vstack([X, X]), np.vstack([Y, Y])             # duplicated rows + (almost) no noise: singular Ky
+    m = gpy_amd.GPRegression(Xd, Yd, gpy_amd.RBF(2, variance=1.0, lengthscale=1.0), noise_var=1e-300)
+    assert np.isfinite(m.log_likelihood())
+    ref = O.exact_inference(O.kern_K("rbf", Xd, None, 1.0, 1.0, False), Yd, 1e-300)   # the oracle runs the same ladder
+    assert abs(m.log_likelihood() - ref["lml"]) <= 1e-3 * abs(ref["lml"])             # ill-conditioned by construction
+    inf = gpy_amd.ExactGaussianInference()
+    Kbad = -np.eye(6)
+    with pytest.raises(np.linalg.LinAlgError, match="non-positive diagonal"):
+        inf.inference(None, X[:6], gpy_amd.Gaussian(0.1), Y[:6], K=Kbad)
+    Kind = np.array([[1.0, 5.0], [5.0, 1.0]])
+    with pytest.raises(np.linalg.LinAlgError, match="even with jitter"):
+        inf.inference(None, X[:2], gpy_amd.Gaussian(1e-12), Y[:2], K=Kind)
+
+
+def test_drop_in_classes_match_oracle_and_finite_differences():
+    import gpy_amd
+    N, D = 600, 3
+    X, Y = O.synthetic(N, D, seed=9, Dy=2)
+    var, ls, noise = 0.8, np.array([0.6, 1.1, 1.9]), 0.15
+    for cls, kind in ((gpy_amd.RBF, "rbf"), (gpy_amd.Matern52, "matern52"), (gpy_amd.Matern32, "matern32"),
+                      (gpy_amd.Exponential, "exponential")):
+        m = gpy_amd.GPRegression(X, Y, cls(D, variance=var, lengthscale=ls, ARD=True), noise_var=noise)
+        ref = O.parameters_changed(kind, X, Y, var, ls, True, noise)
+        gref = np.concatenate([[ref["dvar"]], ref["dlen"], [ref["dL_dnoise"]]])
+        assert abs(m.log_likelihood() - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+        assert np.abs(m.gradient - gref).max() <= TOL_GRAD * np.abs(gref).max()
+        # the style of the reference's own checks: central differences of the LML (checkgrad)
+        x0 = m.param_array.copy()
+        g0 = m.gradient.copy()
+        fd = np.zeros_like(x0)
+        for i in range(x0.size):
+            h = 1e-6 * x0[i]
+            xp, xm = x0.copy(), x0.copy()
+            xp[i] += h
+            xm[i] -= h
+            m.param_array = xp
+            fp = m.log_likelihood()
+            m.param_array = xm
+            fm = m.log_likelihood()
+            fd[i] = (fp - fm) / (2 * h)
+        m.param_array = x0
+        assert np.allclose(g0, fd, rtol=5e-5, atol=1e-5)
+        # a foreign consumer sees plain arrays: the same gradients through the generic (host dL_dK) entry point
+        k2 = cls(D, variance=var, lengthscale=ls, ARD=True)
+        k2.update_gradients_full(np.asarray(m.grad_dict["dL_dK"]), X)
+        assert np.abs(np.concatenate([k2.variance.gradient, k2.lengthscale.gradient]) - gref[:-1]).max() <= TOL_GRAD * np.abs(gref).max()
+        # posterior members (reference posterior.py) and predictions (gp.py:308-365)
+        assert np.abs(np.asarray(m.posterior.woodbury_chol) - ref["L"]).max() <= 1e-11
+        Xs = np.random.default_rng(1).standard_normal((50, D))
+        mu, v = m.predict(Xs)
+        mur, vr = O.predict(kind, X, Xs, ref["L"], ref["alpha"], var, ls, True, noise=noise)
+        assert np.abs(mu - mur).max() <= 1e-9 and np.abs(v - vr).max() <= 1e-9
+
+
+def test_inv_lengthscale_and_active_dims_through_device():
+    import gpy_amd
+    X, Y = O.synthetic(300, 4, seed=2)
+    k = gpy_amd.RBF(2, variance=1.2, lengthscale=0.8, inv_l=True, active_dims=[1, 3])
+    m = gpy_amd.GPRegression(X, Y, k, noise_var=0.2)
+    ref = O.parameters_changed("rbf", np.ascontiguousarray(X[:, [1, 3]]), Y, 1.2, 0.8, False, 0.2)
+    assert abs(m.log_likelihood() - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+    assert np.allclose(k.inv_l.gradient, ref["dlen"] * (0.8 ** 3 / -2.0), rtol=1e-8)      # reference rbf.py:373-375
+
+
+def test_results_are_bit_reproducible_and_independent_of_lookahead(ctx):
+    X, Y = O.synthetic(3000, 6, seed=4)
+    var, ls, noise = O.default_theta(6, True)
+    th = L.theta_vec(var, ls, True, 6)
+    ctx.set_data(X, Y)
+    outs = []
+    for la in (1, 1, 0):
+        ctx.set_option("lookahead", la)
+        info, r = ctx.exact_inference("matern52", True, th, noise)
+        outs.append((r["lml"], r["dtheta"].tobytes(), r["alpha"].tobytes(), r["dnoise"]))
+    ctx.set_option("lookahead", 1)
+    assert outs[0] == outs[1] == outs[2]
+
+
+@pytest.mark.parametrize("kind,ARD,N,D", [("rbf", False, 4096, 8), ("matern52", True, 16384, 32)])
+def test_size_independent_properties_at_baseline_sizes(kind, ARD, N, D, ctx):
+    """BASELINE configs[1] and configs[2]: properties that need no O(N^3) CPU reference."""
+    X, Y = O.synthetic(N, D, seed=0)
+    var, ls, noise = O.default_theta(D, ARD)
+    th = L.theta_vec(var, ls, ARD, D)
+    ctx.set_data(X, Y)
+    info, r = ctx.exact_inference(kind, ARD, th, noise, want_diag=True)
+    assert info == 0
+    rng = np.random.default_rng(1)
+    rows = np.sort(rng.choice(N, 24, replace=False))
+    Ky_rows = L.kern_K(kind, ARD, th, X[rows], X)
+    Ky_rows[np.arange(rows.size), rows] += noise + 1e-8
+    # (1) Ky alpha = Y on sampled rows
+    assert np.abs(Ky_rows @ r["alpha"] - Y[rows]).max() <= 1e-9 * max(1.0, np.abs(Y).max())
+    # (2) L L^T = Ky and Ky^-1 Ky = I on sampled rows
+    Lg = ctx.fetch(L.FETCH_L)
+    assert np.abs(Lg[rows] @ Lg.T - Ky_rows).max() <= 1e-11 * var
+    assert abs(2.0 * np.sum(np.log(np.diag(Lg))) - r["logdet"]) <= 1e-9 * abs(r["logdet"])
+    del Lg
+    W = ctx.fetch(L.FETCH_KINV)
+    Ky_cols = Ky_rows.T                                        # Ky is symmetric: columns `rows` of Ky
+    E = W @ Ky_cols
+    E[rows, np.arange(rows.size)] -= 1.0
+    assert np.abs(E).max() <= 1e-8
+    assert abs(np.trace(W) - r["trKinv"]) <= 1e-9 * abs(r["trKinv"])
+    # (3) dnoise = trace(dL_dK) = 0.5(|alpha|^2 - tr Ky^-1);  LML from its parts
+    assert abs(r["dnoise"] - 0.5 * (np.sum(r["alpha"] ** 2) - np.trace(W))) <= 1e-9 * abs(r["dnoise"])
+    assert abs(r["diag_dL_dK"].sum() - r["dnoise"]) <= 1e-9 * abs(r["dnoise"])
+    lml = 0.5 * (-N * np.log(2 * np.pi) - r["logdet"] - float(np.sum(r["alpha"] * Y)))
+    assert abs(lml - r["lml"]) <= 1e-12 * abs(lml)
+    del W
+    # (4) the variance gradient against a central difference of the device LML (one parameter: two more evaluations)
+    h = 1e-5 * var
+    fp = ctx.exact_inference(kind, ARD, L.theta_vec(var + h, ls, ARD, D), noise)[1]["lml"]
+    fm = ctx.exact_inference(kind, ARD, L.theta_vec(var - h, ls, ARD, D), noise)[1]["lml"]
+    assert abs((fp - fm) / (2 * h) - r["dtheta"][0]) <= 1e-5 * abs(r["dtheta"][0]) + 1e-6

@@ -1,0 +1,134 @@
+"""CPU: host-side logic that mirrors the reference's interface (no device work)."""
+import pickle
+
+import numpy as np
+import pytest
+
+import gpy_amd
+from gpy_amd import _lib
+from gpy_amd.inference import ExactGaussianInference
+from gpy_amd.lazy import DeviceResult, kernel_signature
+from gpy_amd.param import Param
+
+
+def test_param_gradient_broadcast_and_pickle():
+    p = Param("lengthscale", [1.0, 2.0, 3.0])
+    p.gradient = 0.
+    assert p.gradient.shape == (3,) and np.all(p.gradient == 0)
+    p.gradient = np.array([1.0, 2.0, 3.0])
+    q = pickle.loads(pickle.dumps(p))
+    assert q.name == "lengthscale" and np.array_equal(q.gradient, [1, 2, 3]) and np.array_equal(q.values, [1, 2, 3])
+
+
+def test_kernel_constructor_semantics_follow_the_reference():
+    # reference GPy/kern/src/stationary.py:60-81: non-ARD takes one lengthscale, ARD expands a scalar
+    k = gpy_amd.RBF(3)
+    assert k.lengthscale.size == 1 and not k.ARD
+    k = gpy_amd.Matern52(3, lengthscale=2.0, ARD=True)
+    assert np.array_equal(k.lengthscale.values, [2.0, 2.0, 2.0])
+    with pytest.raises(AssertionError):
+        gpy_amd.RBF(3, lengthscale=[1.0, 2.0])
+    with pytest.raises(AssertionError):
+        gpy_amd.RBF(3, lengthscale=[1.0, 2.0], ARD=True)
+    # link order: variance, then lengthscale (stationary.py:78-81)
+    assert [p.name for p in k.parameters] == ["variance", "lengthscale"]
+    assert np.array_equal(k._theta(), [1.0, 2.0, 2.0, 2.0])
+
+
+def test_rbf_inverse_lengthscale_parameterisation():
+    # reference rbf.py:29-33,328-330,373-375
+    k = gpy_amd.RBF(2, lengthscale=0.5, inv_l=True)
+    assert [p.name for p in k.parameters] == ["variance", "inv_lengthscale"]
+    assert np.allclose(k.inv_l.values, 4.0)
+    k.inv_l[:] = 16.0
+    k.parameters_changed()
+    assert np.allclose(k.lengthscale.values, 0.25)
+    k._install_gradients(np.array([0.3, 2.0]))
+    assert np.allclose(k.inv_l.gradient, 2.0 * (0.25 ** 3 / -2.0))
+
+
+def test_active_dims_slicing():
+    k = gpy_amd.Matern32(2, active_dims=[0, 3])
+    X = np.arange(20.0).reshape(4, 5)
+    assert np.array_equal(k._slice_X(X), X[:, [0, 3]])
+    with pytest.raises(AssertionError):
+        k._slice_X(X[:, :3])
+
+
+def test_to_dict_round_trip_uses_gpy_class_strings():
+    k = gpy_amd.Matern52(3, variance=1.5, lengthscale=[1, 2, 3], ARD=True, name="m52")
+    d = k.to_dict()
+    assert d["class"] == "GPy.kern.Matern52"
+    k2 = gpy_amd.Matern52.from_dict(d)
+    assert np.array_equal(k2._theta(), k._theta()) and k2.name == "m52"
+    assert gpy_amd.RBF(1).to_dict()["class"] == "GPy.kern.RBF"
+    inf = ExactGaussianInference()
+    assert inf.to_dict()["class"].endswith("exact_gaussian_inference.ExactGaussianInference")
+    assert pickle.loads(pickle.dumps(inf))._state is None
+
+
+def test_model_flat_parameter_order_and_names():
+    from gpy_amd.param import Parameterized
+    k = gpy_amd.RBF(2, variance=1.3, lengthscale=[0.5, 0.7], ARD=True)
+    lik = gpy_amd.Gaussian(0.1)
+    m = Parameterized("gp")
+    m.link_parameter(k)
+    m.link_parameter(lik)
+    assert np.allclose(m.param_array, [1.3, 0.5, 0.7, 0.1])          # [variance, lengthscale..., noise]
+    assert m.parameter_names() == ["rbf.variance", "rbf.lengthscale[0]", "rbf.lengthscale[1]", "Gaussian_noise.variance"]
+    m.param_array = [2.0, 1.0, 3.0, 0.5]
+    assert float(k.variance[0]) == 2.0 and np.array_equal(k.lengthscale.values, [1.0, 3.0]) and float(lik.variance[0]) == 0.5
+
+
+class _FakeAttempts(object):
+    def __init__(self, fail_first):
+        self.fail_first, self.calls = fail_first, []
+
+    def __call__(self, extra):
+        self.calls.append(extra)
+        return (7, None) if len(self.calls) <= self.fail_first else (0, "ok")
+
+
+def test_jitter_ladder_matches_jitchol():
+    """reference GPy/util/linalg.py:56-75 and GPy/testing/test_linalg.py:20-37."""
+    inf = ExactGaussianInference()
+    diag = np.full(10, 2.0)
+    a = _FakeAttempts(0)
+    assert inf._run_with_ladder(a, diag) == "ok" and a.calls == [0.0]
+    a = _FakeAttempts(3)
+    assert inf._run_with_ladder(a, diag) == "ok"
+    assert np.allclose(a.calls, [0.0, 2e-6, 2e-5, 2e-4])
+    a = _FakeAttempts(6)                         # plain try + 5 ladder tries all fail
+    with pytest.raises(np.linalg.LinAlgError, match="not positive definite, even with jitter."):
+        inf._run_with_ladder(a, diag)
+    assert len(a.calls) == 6 and np.isclose(a.calls[-1], 2e-2)
+    with pytest.raises(np.linalg.LinAlgError, match="not pd: non-positive diagonal elements"):
+        inf._run_with_ladder(_FakeAttempts(1), np.array([1.0, -1.0]))
+
+
+def test_device_result_proxy_contract():
+    class Ctx(object):
+        call_token = 3
+
+        def fetch(self, which, fortran_order=False):
+            return np.arange(9.0).reshape(3, 3)
+    k = gpy_amd.RBF(2)
+    r = DeviceResult(Ctx(), _lib.FETCH_DLDK, 3, token=3, kernel_sig=kernel_signature(k), fused_dtheta=np.array([1., 2.]))
+    assert r.shape == (3, 3) and r.matches_kernel(k)
+    k.variance[:] = 2.0
+    assert not r.matches_kernel(k)              # parameters changed -> fused gradients are stale
+    assert np.array_equal(np.asarray(r), np.arange(9.0).reshape(3, 3))
+    assert np.array_equal(np.diag(r), [0, 4, 8]) and np.array_equal((r * 2)[0], [0, 2, 4])
+    stale = DeviceResult(Ctx(), _lib.FETCH_L, 3, token=2)
+    with pytest.raises(RuntimeError):
+        np.asarray(stale)
+
+
+def test_theta_vec_and_dataset_helpers():
+    assert np.array_equal(_lib.theta_vec(1.5, 2.0, True, 3), [1.5, 2, 2, 2])
+    assert np.array_equal(_lib.theta_vec(np.array([1.5]), np.array([2.0]), False, 3), [1.5, 2])
+    from gpy_amd.datasets import synthetic, default_theta
+    from oracle import gp_oracle as O
+    for a, b in zip(synthetic(40, 3, seed=1, Dy=2), O.synthetic(40, 3, seed=1, Dy=2)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(default_theta(5, True)[1], O.default_theta(5, True)[1])

@@ -3,6 +3,8 @@
 //
 // Layout: one padded (npad x npad, npad % 128 == 0) row-major fp64 buffer per matrix, lower triangle
 // significant; padding rows/cols carry the identity, which factorises and inverts to itself.
+#include <cstdlib>
+
 #include "internal.h"
 
 // ---- profiling ------------------------------------------------------------------------------------
@@ -52,12 +54,21 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     int least = 0, greatest = 0;
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIP_CHECK(hipStreamCreateWithPriority(&ws->st_panel, hipStreamNonBlocking, greatest));
+    const char* env = getenv("MI355GP_UPD_STREAMS");
+    if (env && *env) ws->n_upd = atoi(env);
+    if (ws->n_upd < 1) ws->n_upd = 1;
+    if (ws->n_upd > FactorWs::MAX_UPD) ws->n_upd = FactorWs::MAX_UPD;
+    for (int i = 0; i < ws->n_upd; ++i) {
+        HIP_CHECK(hipStreamCreateWithFlags(&ws->st_upd[i], hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_join[i], hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
     const size_t nouter = (size_t)(npad + NBO - 1) / NBO + 2;
     ws->ev_panel.resize(nouter);
-    ws->ev_upd.resize(nouter);
+    ws->ev_cols.resize(nouter);
     for (size_t i = 0; i < nouter; ++i) {
         HIP_CHECK(hipEventCreateWithFlags(&ws->ev_panel[i], hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_upd[i], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_cols[i], hipEventDisableTiming));
     }
     return 0;
 }
@@ -69,9 +80,17 @@ void factor_ws_free(FactorWs* ws) {
     ws->dinv = ws->logsum = nullptr;
     ws->info = nullptr;
     for (hipEvent_t e : ws->ev_panel) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ws->ev_upd) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ws->ev_cols) (void)hipEventDestroy(e);
     ws->ev_panel.clear();
-    ws->ev_upd.clear();
+    ws->ev_cols.clear();
+    if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
+    ws->ev_fork = nullptr;
+    for (int i = 0; i < FactorWs::MAX_UPD; ++i) {
+        if (ws->ev_join[i]) (void)hipEventDestroy(ws->ev_join[i]);
+        if (ws->st_upd[i]) (void)hipStreamDestroy(ws->st_upd[i]);
+        ws->ev_join[i] = nullptr;
+        ws->st_upd[i] = nullptr;
+    }
     if (ws->st_panel) (void)hipStreamDestroy(ws->st_panel);
     ws->st_panel = nullptr;
     ws->prof.destroy();
@@ -108,57 +127,80 @@ static void factor_panel(hipStream_t s, double* A, long npad, long K0, long W, F
     }
 }
 
-// Two-level right-looking Cholesky with one panel of look-ahead.  Outer panels of NBO = 512 columns keep the big
-// trailing update at K = 512 (64 flop per byte of C traffic).  The update of outer step k is split into the next
-// panel's 512 columns (part 1) and the rest (part 2); panel k+1 is factored on a second, high-priority stream while
-// part 2 of step k still runs, so the latency-bound diag/trsm chain hides behind MFMA-bound work.
+// rank-W update of the trailing columns [c0, c1) (rows c0 .. npad) with the panel at columns [K0, K0+W)
+static void update_cols(hipStream_t s, double* A, long npad, long K0, long W, long c0, long c1, FactorWs* ws) {
+    if (c1 <= c0) return;
+    const long ld = npad, rows = npad - c0, cols = c1 - c0;
+    const double* P = A + c0 * ld + K0;
+    ws->prof.begin(s, PF_UPDATE, syrk_flops((double)cols, (double)W) + gemm_flops((double)(rows - cols), (double)cols, (double)W));
+    launch_update_nt(s, A + c0 * ld + c0, ld, P, ld, P, ld, (int)W, (int)(rows / NB), (int)(cols / NB), (int)(c0 / NB),
+                     (int)(c0 / NB));
+    ws->prof.end(s);
+}
+
+// Two-level right-looking Cholesky.  Outer panels of NBO = 512 columns keep the big trailing update at K = 512
+// (64 flop per byte of C traffic).  The schedule follows the true dependencies at column-chunk granularity instead
+// of serialising whole steps on one stream:
+//   - panel p is factored on a high-priority stream as soon as the updates of ITS columns are done (look-ahead);
+//   - the trailing columns are cut into chunks of ~512 tiles; chunk c is always updated on stream c % n_upd, so
+//     step p+1's update of a chunk only waits for panel p+1 and for the same chunk's step-p update.  The tail of
+//     one launch (fewer tiles left than CU slots) therefore overlaps the head of the next chunk's launch, and
+//     the latency-bound diag/trsm chain hides behind MFMA-bound work.
 void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
-    const long ld = npad;
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
-    hipStream_t sp = ws->lookahead ? ws->st_panel : st;
-    if (ws->lookahead) {
-        (void)hipEventRecord(ws->ev_upd[0], st);                 // panel 0 follows everything queued on st so far
-        (void)hipStreamWaitEvent(sp, ws->ev_upd[0], 0);
-    }
-    const long W0 = (npad < NBO) ? npad : NBO;
-    factor_panel(sp, A, npad, 0, W0, ws);
-    size_t k = 0;
-    for (long K0 = 0; K0 < npad; K0 += NBO, ++k) {
-        const long W = (npad - K0 < NBO) ? (npad - K0) : NBO;
-        const long R0 = K0 + W;                                  // first row/col of the trailing matrix
-        const long rest = npad - R0;
-        if (rest <= 0) break;
-        const long W1 = (rest < NBO) ? rest : NBO;               // width of the next panel
-        const double* P = A + R0 * ld + K0;
-        if (ws->lookahead) {
-            (void)hipEventRecord(ws->ev_panel[k], sp);
-            (void)hipStreamWaitEvent(st, ws->ev_panel[k], 0);
+    const long P = (npad + NBO - 1) / NBO;                       // outer panels
+    auto pcol = [&](long p) { return (p * NBO < npad) ? p * NBO : npad; };
+    if (!ws->lookahead) {                                        // reference schedule: everything in order on st
+        for (long p = 0; p < P; ++p) {
+            factor_panel(st, A, npad, pcol(p), pcol(p + 1) - pcol(p), ws);
+            update_cols(st, A, npad, pcol(p), pcol(p + 1) - pcol(p), pcol(p + 1), npad, ws);
         }
-        // part 1: the next panel's columns
-        ws->prof.begin(st, PF_UPDATE, syrk_flops((double)W1, (double)W) + gemm_flops((double)(rest - W1), (double)W1, (double)W));
-        launch_update_nt(st, A + R0 * ld + R0, ld, P, ld, P, ld, (int)W, (int)(rest / NB), (int)(W1 / NB), (int)(R0 / NB),
-                         (int)(R0 / NB));
-        ws->prof.end(st);
-        if (ws->lookahead) {
-            (void)hipEventRecord(ws->ev_upd[k + 1], st);
-            (void)hipStreamWaitEvent(sp, ws->ev_upd[k + 1], 0);
+        return;
+    }
+    // chunk boundaries (in panels): chunk i = panels [cb[i], cb[i+1]); at least ~448 tiles of 128x128 each
+    std::vector<long> cb;
+    {
+        const long nt = npad / NB;
+        long tiles = 0;
+        cb.push_back(1);
+        for (long p = 1; p < P; ++p) {
+            const long t0 = pcol(p) / NB, t1 = pcol(p + 1) / NB;
+            for (long t = t0; t < t1; ++t) tiles += nt - t;
+            if (tiles >= 448 && p + 1 < P) { cb.push_back(p + 1); tiles = 0; }
         }
-        factor_panel(sp, A, npad, R0, W1, ws);
-        // part 2: everything to the right of the next panel
-        const long rest2 = rest - W1;
-        if (rest2 > 0) {
-            const long R1 = R0 + W1;
-            const double* P2 = A + R1 * ld + K0;
-            ws->prof.begin(st, PF_UPDATE, syrk_flops((double)rest2, (double)W));
-            launch_update_nt(st, A + R1 * ld + R1, ld, P2, ld, P2, ld, (int)W, (int)(rest2 / NB), (int)(rest2 / NB),
-                             (int)(R1 / NB), (int)(R1 / NB));
-            ws->prof.end(st);
+        cb.push_back(P);
+    }
+    const int nchunk = (int)cb.size() - 1;
+    auto chunk_stream = [&](int c) { return ws->st_upd[c % ws->n_upd]; };
+    hipStream_t sp = ws->st_panel;
+    (void)hipEventRecord(ws->ev_fork, st);                      // everything queued on st so far precedes the factorisation
+    (void)hipStreamWaitEvent(sp, ws->ev_fork, 0);
+    for (int i = 0; i < ws->n_upd; ++i) (void)hipStreamWaitEvent(ws->st_upd[i], ws->ev_fork, 0);
+    for (long p = 0; p < P; ++p) {
+        const long K0 = pcol(p), W = pcol(p + 1) - K0;
+        if (p > 0) (void)hipStreamWaitEvent(sp, ws->ev_cols[p], 0);
+        factor_panel(sp, A, npad, K0, W, ws);
+        if (p + 1 >= P) break;
+        (void)hipEventRecord(ws->ev_panel[p], sp);
+        for (int i = 0; i < ws->n_upd; ++i) (void)hipStreamWaitEvent(ws->st_upd[i], ws->ev_panel[p], 0);
+        for (int c = 0; c < nchunk; ++c) {
+            if (cb[c + 1] <= p + 1) continue;                   // chunk already factored
+            hipStream_t su = chunk_stream(c);
+            long first = (cb[c] > p + 1) ? cb[c] : p + 1;
+            if (first == p + 1) {                               // the next panel's columns first: they gate panel p+1
+                update_cols(su, A, npad, K0, W, pcol(p + 1), pcol(p + 2), ws);
+                (void)hipEventRecord(ws->ev_cols[p + 1], su);
+                first = p + 2;
+            }
+            update_cols(su, A, npad, K0, W, pcol(first), pcol(cb[c + 1]), ws);
         }
     }
-    if (ws->lookahead) {
-        (void)hipEventRecord(ws->ev_panel[k], sp);
-        (void)hipStreamWaitEvent(st, ws->ev_panel[k], 0);
+    for (int i = 0; i < ws->n_upd; ++i) {
+        (void)hipEventRecord(ws->ev_join[i], ws->st_upd[i]);
+        (void)hipStreamWaitEvent(st, ws->ev_join[i], 0);
     }
+    (void)hipEventRecord(ws->ev_panel[P], sp);
+    (void)hipStreamWaitEvent(st, ws->ev_panel[P], 0);
 }
 
 // X = L^-1: diagonal 128-blocks on single CUs (all blocks concurrently), then log2(nt) batched levels.

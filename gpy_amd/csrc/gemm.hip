@@ -14,11 +14,37 @@
         }                                                                                               \
     } while (0)
 
+// Wave arrangement of the tile kernels (gemm_tile.h): MI355GP_GEMM_NW = 4 | 8, read once.  MI355GP_PRELOAD_C = 0 | 1
+// selects whether the trailing update reads its C tile before (1) or after (0) the k-loop.
+#include <cstdlib>
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+int gemm_variant_nw() {
+    static const int nw = (env_int("MI355GP_GEMM_NW", GEMM_DEFAULT_NW) == 8) ? 8 : 4;
+    return nw;
+}
+static int gemm_variant_preload() {
+    static const int p = env_int("MI355GP_PRELOAD_C", GEMM_DEFAULT_PRELOAD) ? 1 : 0;
+    return p;
+}
+#define NW_DISPATCH(CALL4, CALL8)        \
+    do {                                 \
+        if (gemm_variant_nw() == 8) {    \
+            CALL8;                       \
+        } else {                         \
+            CALL4;                       \
+        }                                \
+    } while (0)
+#define LB(NW) __launch_bounds__((NW) * 64, (NW) / 2)
+
 // ------------------------------------------------------------------------------------------------
 // Trailing update of the right-looking Cholesky (the dsyrk/dgemm inside LAPACK dpotrf, which GPy reaches
 // through GPy/util/linalg.py:58):  C[ti,tj] -= A[ti,:] * B[tj,:]^T.
 // `tri`: region is square on the diagonal -> enumerate the lower triangle only.
-__global__ __launch_bounds__(256, 2) void k_update_nt(double* __restrict__ C, long ldc,
+template <int NW, bool PRE>
+__global__ LB(NW) void k_update_nt(double* __restrict__ C, long ldc,
                                                       const double* __restrict__ A, long lda,
                                                       const double* __restrict__ B, long ldb, int K, int ntc,
                                                       int row0t, int col0t, int tri) {
@@ -35,10 +61,21 @@ __global__ __launch_bounds__(256, 2) void k_update_nt(double* __restrict__ C, lo
         tj = bid - ti * ntc;
         if (col0t + tj > row0t + ti) return;
     }
-    d4 acc[4][4];
-    gt_zero(acc);
-    gemm_tile_128<true, true>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
-    gt_store<2>(C + (long)ti * NB * ldc + (long)tj * NB, ldc, acc);
+    d4 acc[4][GTCfg<NW>::NI];
+    double* Ct = C + (long)ti * NB * ldc + (long)tj * NB;
+    if (PRE) gt_load_neg<NW>(Ct, ldc, acc);
+    else gt_zero<NW>(acc);
+    gemm_tile_128<true, true, NW>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
+    if (PRE) gt_store<1, NW>(Ct, ldc, acc);
+    else gt_store<2, NW>(Ct, ldc, acc);
+}
+
+template <int NW, bool PRE>
+static void launch_update_nt_t(hipStream_t st, long nblocks, double* C, long ldc, const double* A, long lda,
+                               const double* B, long ldb, int K, int ntc, int row0t, int col0t, int tri) {
+    LDS_OPT_IN((k_update_nt<NW, PRE>));
+    hipLaunchKernelGGL((k_update_nt<NW, PRE>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, C, ldc, A, lda,
+                       B, ldb, K, ntc, row0t, col0t, tri);
 }
 
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
@@ -46,9 +83,12 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
     if (ntr <= 0 || ntc <= 0) return;
     const int tri = (row0t == col0t && ntr == ntc) ? 1 : 0;
     const long nblocks = tri ? (long)ntr * (ntr + 1) / 2 : (long)ntr * ntc;
-    LDS_OPT_IN(k_update_nt);
-    hipLaunchKernelGGL(k_update_nt, dim3((unsigned)nblocks), dim3(256), GT_LDS_BYTES, st, C, ldc, A, lda, B, ldb,
-                       K, ntc, row0t, col0t, tri);
+    if (gemm_variant_preload())
+        NW_DISPATCH((launch_update_nt_t<4, true>(st, nblocks, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)),
+                    (launch_update_nt_t<8, true>(st, nblocks, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)));
+    else
+        NW_DISPATCH((launch_update_nt_t<4, false>(st, nblocks, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)),
+                    (launch_update_nt_t<8, false>(st, nblocks, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -57,8 +97,8 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
 //   [X11 0; X21 X22] with X21 = -X22 * L21 * X11.
 // stage 1: T21 = L21 * X11   (X11 lower triangular -> k from tj to the end of the left block)
 // stage 2: X21 = -X22 * T21  (X22 lower triangular -> k from the start of the right block to ti)
-template <int STAGE>
-__global__ __launch_bounds__(256, 2) void k_trtri_stage(const double* __restrict__ L, double* __restrict__ X,
+template <int STAGE, int NW>
+__global__ LB(NW) void k_trtri_stage(const double* __restrict__ L, double* __restrict__ X,
                                                         double* __restrict__ T, long ld, int nt, int nbt) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int per = nbt * nbt;
@@ -75,19 +115,28 @@ __global__ __launch_bounds__(256, 2) void k_trtri_stage(const double* __restrict
     const int left0 = 2 * p * nbt, right0 = left0 + nbt;
     const int ti = right0 + ri, tj = left0 + cj;
     if (ti >= nt) return;
-    d4 acc[4][4];
-    gt_zero(acc);
+    d4 acc[4][GTCfg<NW>::NI];
+    gt_zero<NW>(acc);
     if (STAGE == 1) {
         const int K = (right0 - tj) * NB;
-        gemm_tile_128<true, false>(L + (long)ti * NB * ld + (long)tj * NB, ld,
+        gemm_tile_128<true, false, NW>(L + (long)ti * NB * ld + (long)tj * NB, ld,
                                    X + (long)tj * NB * ld + (long)tj * NB, ld, K, acc, smem);
-        gt_store<0>(T + (long)ti * NB * ld + (long)tj * NB, ld, acc);
+        gt_store<0, NW>(T + (long)ti * NB * ld + (long)tj * NB, ld, acc);
     } else {
         const int K = (ti - right0 + 1) * NB;
-        gemm_tile_128<true, false>(X + (long)ti * NB * ld + (long)right0 * NB, ld,
+        gemm_tile_128<true, false, NW>(X + (long)ti * NB * ld + (long)right0 * NB, ld,
                                    T + (long)right0 * NB * ld + (long)tj * NB, ld, K, acc, smem);
-        gt_store<1>(X + (long)ti * NB * ld + (long)tj * NB, ld, acc);
+        gt_store<1, NW>(X + (long)ti * NB * ld + (long)tj * NB, ld, acc);
     }
+}
+
+template <int NW>
+static void launch_trtri_level_t(hipStream_t st, long nblocks, const double* L, double* X, double* T, long ld, int nt,
+                                 int nbt) {
+    LDS_OPT_IN((k_trtri_stage<1, NW>));
+    LDS_OPT_IN((k_trtri_stage<2, NW>));
+    hipLaunchKernelGGL((k_trtri_stage<1, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt);
+    hipLaunchKernelGGL((k_trtri_stage<2, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt);
 }
 
 void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level) {
@@ -95,15 +144,14 @@ void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, l
     if (nbt >= nt) return;
     const int pairs = (nt + 2 * nbt - 1) / (2 * nbt);
     const long nblocks = (long)pairs * nbt * nbt;
-    LDS_OPT_IN(k_trtri_stage<1>);
-    LDS_OPT_IN(k_trtri_stage<2>);
-    hipLaunchKernelGGL(k_trtri_stage<1>, dim3((unsigned)nblocks), dim3(256), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt);
-    hipLaunchKernelGGL(k_trtri_stage<2>, dim3((unsigned)nblocks), dim3(256), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt);
+    NW_DISPATCH((launch_trtri_level_t<4>(st, nblocks, L, X, T, ld, nt, nbt)),
+                (launch_trtri_level_t<8>(st, nblocks, L, X, T, ld, nt, nbt)));
 }
 
 // ------------------------------------------------------------------------------------------------
 // W = X^T X for lower-triangular X (the dlauum half of LAPACK dpotri): W[ti,tj] = sum_{tk>=ti} X[tk,ti]^T X[tk,tj].
-__global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ X, double* __restrict__ W, long ld,
+template <int NW>
+__global__ LB(NW) void k_lauum(const double* __restrict__ X, double* __restrict__ W, long ld,
                                                   int nt) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int bid = blockIdx.x;
@@ -111,39 +159,52 @@ __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ X, 
     while ((long)ti * (ti + 1) / 2 > bid) --ti;
     while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
     const int tj = bid - (int)((long)ti * (ti + 1) / 2);
-    d4 acc[4][4];
-    gt_zero(acc);
+    d4 acc[4][GTCfg<NW>::NI];
+    gt_zero<NW>(acc);
     const int K = (nt - ti) * NB;
-    gemm_tile_128<false, false>(X + (long)ti * NB * ld + (long)ti * NB, ld, X + (long)ti * NB * ld + (long)tj * NB, ld,
+    gemm_tile_128<false, false, NW>(X + (long)ti * NB * ld + (long)ti * NB, ld, X + (long)ti * NB * ld + (long)tj * NB, ld,
                                 K, acc, smem);
-    gt_store<0>(W + (long)ti * NB * ld + (long)tj * NB, ld, acc);
+    gt_store<0, NW>(W + (long)ti * NB * ld + (long)tj * NB, ld, acc);
+}
+
+template <int NW>
+static void launch_lauum_t(hipStream_t st, long nblocks, const double* X, double* W, long ld, int nt) {
+    LDS_OPT_IN((k_lauum<NW>));
+    hipLaunchKernelGGL((k_lauum<NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, X, W, ld, nt);
 }
 
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt) {
     const long nblocks = (long)nt * (nt + 1) / 2;
-    LDS_OPT_IN(k_lauum);
-    hipLaunchKernelGGL(k_lauum, dim3((unsigned)nblocks), dim3(256), GT_LDS_BYTES, st, X, W, ld, nt);
+    NW_DISPATCH((launch_lauum_t<4>(st, nblocks, X, W, ld, nt)), (launch_lauum_t<8>(st, nblocks, X, W, ld, nt)));
 }
 
 // ------------------------------------------------------------------------------------------------
 // Out[ti,tj] = sum_{tk<=ti} X[ti,tk] * B[tk,tj] with X lower triangular (npad x npad), B (npad x mpad):
 // L^-1 K(X, X*) of the predictive variance (dtrtrs in GPy/inference/latent_function_inference/posterior.py:286,296).
-__global__ __launch_bounds__(256, 2) void k_trmm_lower(const double* __restrict__ X, long ldx,
+template <int NW>
+__global__ LB(NW) void k_trmm_lower(const double* __restrict__ X, long ldx,
                                                        const double* __restrict__ B, long ldb,
                                                        double* __restrict__ Out, long ldo, int ntc) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
-    d4 acc[4][4];
-    gt_zero(acc);
-    gemm_tile_128<true, false>(X + (long)ti * NB * ldx, ldx, B + (long)tj * NB, ldb, (ti + 1) * NB, acc, smem);
-    gt_store<0>(Out + (long)ti * NB * ldo + (long)tj * NB, ldo, acc);
+    d4 acc[4][GTCfg<NW>::NI];
+    gt_zero<NW>(acc);
+    gemm_tile_128<true, false, NW>(X + (long)ti * NB * ldx, ldx, B + (long)tj * NB, ldb, (ti + 1) * NB, acc, smem);
+    gt_store<0, NW>(Out + (long)ti * NB * ldo + (long)tj * NB, ldo, acc);
+}
+
+template <int NW>
+static void launch_trmm_lower_t(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out,
+                                long ldo, int ntr, int ntc) {
+    LDS_OPT_IN((k_trmm_lower<NW>));
+    hipLaunchKernelGGL((k_trmm_lower<NW>), dim3((unsigned)(ntr * ntc)), dim3(NW * 64), GT_LDS_BYTES, st, X, ldx, B, ldb,
+                       Out, ldo, ntc);
 }
 
 void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
                        int ntr, int ntc) {
-    LDS_OPT_IN(k_trmm_lower);
-    hipLaunchKernelGGL(k_trmm_lower, dim3((unsigned)(ntr * ntc)), dim3(256), GT_LDS_BYTES, st, X, ldx, B, ldb, Out, ldo,
-                       ntc);
+    NW_DISPATCH((launch_trmm_lower_t<4>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc)),
+                (launch_trmm_lower_t<8>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc)));
 }
 
 // C (mpad x mpad, ldc) = alpha * A^T A + beta * C with A (K x mpad): the K** - tmp^T tmp of full_cov prediction
@@ -152,42 +213,61 @@ void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double
 
 // ------------------------------------------------------------------------------------------------
 // General C = alpha*op(A)*op(B) + beta*C on full tiles (diagnostics / prediction).
-template <bool AK, bool BK>
-__global__ __launch_bounds__(256, 2) void k_gemm_full(const double* __restrict__ A, long lda,
+template <bool AK, bool BK, int NW>
+__global__ LB(NW) void k_gemm_full(const double* __restrict__ A, long lda,
                                                       const double* __restrict__ B, long ldb, double* __restrict__ C,
-                                                      long ldc, int K, int ntc, double alpha, double beta) {
+                                                      long ldc, int K, int ntc, double alpha, double beta, int swz) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
-    d4 acc[4][4];
-    gt_zero(acc);
+    int bid = blockIdx.x;
+    if (swz & 1) {   // XCD-aware order: workgroup b runs on XCD b % 8; give each XCD 8x8 super-tiles (needs ntr, ntc % 8 == 0)
+        const int xcd = bid & 7, loc = bid >> 3;
+        const int stiles = ntc >> 3;                      // super-tiles per row
+        const int sidx = (loc >> 6) * 8 + xcd;            // super-tile number handled by this XCD in this round
+        const int in = loc & 63;
+        bid = ((sidx / stiles) * 8 + (in >> 3)) * ntc + (sidx % stiles) * 8 + (in & 7);
+    }
+    const int ti = bid / ntc, tj = bid % ntc;
+    d4 acc[4][GTCfg<NW>::NI];
+    gt_zero<NW>(acc);
     const double* Ap = AK ? A + (long)ti * NB * lda : A + (long)ti * NB;
     const double* Bp = BK ? B + (long)tj * NB * ldb : B + (long)tj * NB;
-    gemm_tile_128<AK, BK>(Ap, lda, Bp, ldb, K, acc, smem);
-    gt_store<3>(C + (long)ti * NB * ldc + (long)tj * NB, ldc, acc, alpha, beta);
+    gemm_tile_128<AK, BK, NW>(Ap, lda, Bp, ldb, K, acc, smem, swz >> 1);
+    gt_store<3, NW>(C + (long)ti * NB * ldc + (long)tj * NB, ldc, acc, alpha, beta);
+}
+
+template <bool AK, bool BK>
+static void launch_gemm_full(hipStream_t st, unsigned nblocks, const double* A, long lda, const double* B, long ldb,
+                             double* C, long ldc, int K, int ntc, double alpha, double beta) {
+    static const int dbg_ld0 = env_int("MI355GP_DBG_LD0", 0), dbg_swz = env_int("MI355GP_DBG_SWZ", 0);
+    if (dbg_ld0) lda = ldb = 0;                           // every operand row aliases row 0: cache-resident loads
+    static const int dbg_nosync = env_int("MI355GP_DBG_NOSYNC", 0), dbg_1wg = env_int("MI355GP_DBG_1WG", 0);
+    const int swz = ((dbg_swz && (ntc % 8 == 0) && ((nblocks / ntc) % 8 == 0)) ? 1 : 0) | (dbg_nosync ? 2 : 0);
+    const size_t lds = dbg_1wg ? 100 * 1024 : GT_LDS_BYTES;
+    if (gemm_variant_nw() == 8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_full<AK, BK, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gemm_full<AK, BK, 8>), dim3(nblocks), dim3(512), lds, st, A, lda, B, ldb, C, ldc, K,
+                           ntc, alpha, beta, swz);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_full<AK, BK, 4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gemm_full<AK, BK, 4>), dim3(nblocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, K,
+                           ntc, alpha, beta, swz);
+    }
 }
 
 void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A,
                      const double* B, double* C, double alpha, double beta) {
     const int ntr = (int)(M / NB), ntc = (int)(N / NB);
-    const dim3 grid((unsigned)(ntr * ntc)), block(256);
+    const unsigned grid = (unsigned)(ntr * ntc);
     const long lda = a_mcontig ? M : K, ldb = b_ncontig ? N : K;
-    LDS_OPT_IN((k_gemm_full<true, true>));
-    LDS_OPT_IN((k_gemm_full<true, false>));
-    LDS_OPT_IN((k_gemm_full<false, false>));
-    LDS_OPT_IN((k_gemm_full<false, true>));
-    if (!a_mcontig && !b_ncontig)
-        hipLaunchKernelGGL((k_gemm_full<true, true>), grid, block, GT_LDS_BYTES, st, A, lda, B, ldb, C, N, (int)K, ntc, alpha, beta);
-    else if (!a_mcontig && b_ncontig)
-        hipLaunchKernelGGL((k_gemm_full<true, false>), grid, block, GT_LDS_BYTES, st, A, lda, B, ldb, C, N, (int)K, ntc, alpha, beta);
-    else if (a_mcontig && b_ncontig)
-        hipLaunchKernelGGL((k_gemm_full<false, false>), grid, block, GT_LDS_BYTES, st, A, lda, B, ldb, C, N, (int)K, ntc, alpha, beta);
-    else
-        hipLaunchKernelGGL((k_gemm_full<false, true>), grid, block, GT_LDS_BYTES, st, A, lda, B, ldb, C, N, (int)K, ntc, alpha, beta);
+    if (!a_mcontig && !b_ncontig) launch_gemm_full<true, true>(st, grid, A, lda, B, ldb, C, N, (int)K, ntc, alpha, beta);
+    else if (!a_mcontig && b_ncontig) launch_gemm_full<true, false>(st, grid, A, lda, B, ldb, C, N, (int)K, ntc, alpha, beta);
+    else if (a_mcontig && b_ncontig) launch_gemm_full<false, false>(st, grid, A, lda, B, ldb, C, N, (int)K, ntc, alpha, beta);
+    else launch_gemm_full<false, true>(st, grid, A, lda, B, ldb, C, N, (int)K, ntc, alpha, beta);
 }
 
 void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
                        double beta) {
-    LDS_OPT_IN((k_gemm_full<false, false>));
-    hipLaunchKernelGGL((k_gemm_full<false, false>), dim3((unsigned)(nt * nt)), dim3(256), GT_LDS_BYTES, st, A, lda, A,
-                       lda, C, ldc, (int)K, nt, alpha, beta);
+    launch_gemm_full<false, false>(st, (unsigned)(nt * nt), A, lda, A, lda, C, ldc, (int)K, nt, alpha, beta);
 }

@@ -1,9 +1,13 @@
-// gemm_tile.h -- the fp64 MFMA workhorse: one 128x128 output tile per 256-thread workgroup.
+// gemm_tile.h -- the fp64 MFMA workhorse: one 128x128 output tile per workgroup.
 //
-// Geometry (MI355X / gfx950): 4 waves in a 2x2 arrangement, each wave owns a 64x64 sub-tile =
-// 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 accumulator VGPRs).  K is consumed in slabs of 16
-// (four MFMA k-slices); slabs are double-buffered in LDS (2 x (A 18 KB + B 18 KB) = 72 KB, two
-// workgroups per CU) and the next slab's global loads are issued before the current slab's MFMAs.
+// Geometry (MI355X / gfx950), two wave arrangements selected by the template parameter NW:
+//   NW = 4 (256 threads): waves 2x2, each owns a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators
+//                         (128 accumulator VGPRs; 2 workgroups per CU = 2 waves per SIMD)
+//   NW = 8 (512 threads): waves 2x4, each owns a 64x32 sub-tile = 4x2 accumulators (64 VGPRs;
+//                         2 workgroups per CU = 4 waves per SIMD, so the matrix pipe always finds a ready wave)
+// K is consumed in slabs of 16 (four MFMA k-slices); slabs are double-buffered in LDS
+// (2 x (A 18 KB + B 18 KB) = 72 KB, two workgroups per CU) and the next slab's global loads are issued
+// before the current slab's MFMAs.
 //
 // Operand storage (row-major buffers with leading dimension ld):
 //   k-contiguous  : element (i, k) at P[i*ld + k]   -> LDS image [128][18]  (stride 18 = 2*odd: the
@@ -19,31 +23,58 @@
 #define GT_TILE 2304                      // doubles per staged operand slab (128*18 == 16*144)
 #define GT_LDS_BYTES (4 * GT_TILE * 8)    // 73,728 B
 
-template <bool KC>
-__device__ __forceinline__ void gt_g2r(const double* __restrict__ P, long ld, int k0, d2 (&r)[4], int t) {
+template <int NW>
+struct GTCfg {
+    static constexpr int NTHR = NW * 64;
+    static constexpr int NLD = 1024 / NTHR;          // 16-byte loads per operand slab per thread
+    static constexpr int NI = (NW == 8) ? 2 : 4;     // 16-column accumulator blocks per wave
+    static constexpr int WCOLS = NI * 16;            // columns of the wave's sub-tile
+    static constexpr int WPR = 128 / WCOLS;          // waves per tile row
+};
+
+// k-contiguous staging: which (row, 16-byte chunk c of the 16-wide slab row) thread t moves in trip `it`.
+// ds_write_b128 is serviced in 16-lane groups {0-3,12-15,20-27},{4-11,16-19,28-31} (+32); with row stride 18
+// doubles a group is conflict-free iff its four lane-quads hit rows = 0,4,8,12 (mod 16) with the same chunk
+// half, hence the row/chunk permutation below (global reads stay 128 B contiguous per 8 lanes).
+// Trip `it` of the staging loops moves row0 + it*NW*8.
+template <int NW>
+__device__ __forceinline__ void gt_kc_map(int t, int& row0, int& c) {
+    const int l = t & 63, w = t >> 6, o = l >> 3, m = o & 3;
+    const int e = w * 2 + (o >> 2);                      // trip `it` adds NW*2 to e, i.e. NW*8 rows
+    row0 = 16 * (e >> 2) + 4 * m + (e & 3);
+    c = (l & 7) ^ ((m == 1 || m == 2) ? 4 : 0);
+}
+#define GT_KC_RSTEP(NW) ((NW) * 8)
+
+template <bool KC, int NW>
+__device__ __forceinline__ void gt_g2r(const double* __restrict__ P, long ld, int k0, d2 (&r)[GTCfg<NW>::NLD], int t) {
     if (KC) {
-        const int row = t >> 3, kp = (t & 7) * 2;
+        int row0, c;
+        gt_kc_map<NW>(t, row0, c);
+        const double* p = P + (long)row0 * ld + k0 + 2 * c;
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-            r[it] = *reinterpret_cast<const d2*>(P + (long)(row + 32 * it) * ld + k0 + kp);
+        for (int it = 0; it < GTCfg<NW>::NLD; ++it) r[it] = *reinterpret_cast<const d2*>(p + (long)(it * GT_KC_RSTEP(NW)) * ld);
     } else {
         const int k = t >> 6, cp = (t & 63) * 2;
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-            r[it] = *reinterpret_cast<const d2*>(P + (long)(k0 + k + 4 * it) * ld + cp);
+        for (int it = 0; it < GTCfg<NW>::NLD; ++it)
+            r[it] = *reinterpret_cast<const d2*>(P + (long)(k0 + k + NW * it) * ld + cp);
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void gt_r2s(double* s, const d2 (&r)[4], int t) {
+template <bool KC, int NW>
+__device__ __forceinline__ void gt_r2s(double* s, const d2 (&r)[GTCfg<NW>::NLD], int t) {
     if (KC) {
-        const int row = t >> 3, kp = (t & 7) * 2;
+        int row0, c;
+        gt_kc_map<NW>(t, row0, c);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) *reinterpret_cast<d2*>(s + (row + 32 * it) * GT_SKC + kp) = r[it];
+        for (int it = 0; it < GTCfg<NW>::NLD; ++it)
+            *reinterpret_cast<d2*>(s + (row0 + it * GT_KC_RSTEP(NW)) * GT_SKC + 2 * c) = r[it];
     } else {
         const int k = t >> 6, cp = (t & 63) * 2;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) *reinterpret_cast<d2*>(s + (k + 4 * it) * GT_SMN + cp) = r[it];
+        for (int it = 0; it < GTCfg<NW>::NLD; ++it)
+            *reinterpret_cast<d2*>(s + (k + NW * it) * GT_SMN + cp) = r[it];
     }
 }
 
@@ -52,78 +83,100 @@ __device__ __forceinline__ double gt_frag(const double* s, int idx, int kk) {
     return KC ? s[idx * GT_SKC + kk] : s[kk * GT_SMN + idx];
 }
 
-// acc[mi][ni] += sum_{k<K} opA(i,k) * opB(k,j) for this wave's 64x64 part of the 128x128 tile.
+// acc[mi][ni] += sum_{k<K} opA(i,k) * opB(k,j) for this wave's part of the 128x128 tile.
 // A points at the tile's first row (k-contig) / first column (m-contig) at k = 0; same for B.  K % 16 == 0.
-template <bool AK, bool BK>
+template <bool AK, bool BK, int NW>
 __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long lda,
                                               const double* __restrict__ B, long ldb, int K,
-                                              d4 (&acc)[4][4], double* smem) {
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
-    d2 ra[4], rb[4];
+                                              d4 (&acc)[4][GTCfg<NW>::NI], double* smem, int dbg_nosync = 0) {
+    constexpr int NI = GTCfg<NW>::NI;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / GTCfg<NW>::WPR, wc = w % GTCfg<NW>::WPR;
+    d2 ra[GTCfg<NW>::NLD], rb[GTCfg<NW>::NLD];
     const int nk = K / GT_BK;
-    gt_g2r<AK>(A, lda, 0, ra, t);
-    gt_g2r<BK>(B, ldb, 0, rb, t);
-    gt_r2s<AK>(smem, ra, t);
-    gt_r2s<BK>(smem + GT_TILE, rb, t);
+    gt_g2r<AK, NW>(A, lda, 0, ra, t);
+    gt_g2r<BK, NW>(B, ldb, 0, rb, t);
+    gt_r2s<AK, NW>(smem, ra, t);
+    gt_r2s<BK, NW>(smem + GT_TILE, rb, t);
     __syncthreads();
-    const int arow = wr * 64 + (lane & 15), bcol = wc * 64 + (lane & 15), kq = lane >> 4;
+    const int arow = wr * 64 + (lane & 15), bcol = wc * GTCfg<NW>::WCOLS + (lane & 15), kq = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            gt_g2r<AK>(A, lda, (kt + 1) * GT_BK, ra, t);
-            gt_g2r<BK>(B, ldb, (kt + 1) * GT_BK, rb, t);
+            gt_g2r<AK, NW>(A, lda, (kt + 1) * GT_BK, ra, t);
+            gt_g2r<BK, NW>(B, ldb, (kt + 1) * GT_BK, rb, t);
         }
         const double* a_s = smem + cur * 2 * GT_TILE;
         const double* b_s = a_s + GT_TILE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int kk = 4 * s + kq;
-            double af[4], bf[4];
+            double af[4], bf[NI];
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) af[mi] = gt_frag<AK>(a_s, arow + mi * 16, kk);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bf[ni] = gt_frag<BK>(b_s, bcol + ni * 16, kk);
+            for (int ni = 0; ni < NI; ++ni) bf[ni] = gt_frag<BK>(b_s, bcol + ni * 16, kk);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_f64(af[mi], bf[ni], acc[mi][ni]);
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma_f64(af[mi], bf[ni], acc[mi][ni]);
         }
+        if (dbg_nosync) continue;       // diagnostics only: MFMA + LDS-read steady state without staging / barriers
         if (kt + 1 < nk) {
             double* nxt = smem + (cur ^ 1) * 2 * GT_TILE;
-            gt_r2s<AK>(nxt, ra, t);
-            gt_r2s<BK>(nxt + GT_TILE, rb, t);
+            gt_r2s<AK, NW>(nxt, ra, t);
+            gt_r2s<BK, NW>(nxt + GT_TILE, rb, t);
         }
         __syncthreads();
     }
 }
 
-__device__ __forceinline__ void gt_zero(d4 (&acc)[4][4]) {
+template <int NW>
+__device__ __forceinline__ void gt_zero(d4 (&acc)[4][GTCfg<NW>::NI]) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int ni = 0; ni < GTCfg<NW>::NI; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+}
+
+template <int NW>
+__device__ __forceinline__ double* gt_cbase(double* C, long ldc) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / GTCfg<NW>::WPR, wc = w % GTCfg<NW>::WPR;
+    return C + (long)(wr * 64 + (lane >> 4)) * ldc + wc * GTCfg<NW>::WCOLS + (lane & 15);
+}
+
+// acc = -C: the read half of "C -= A*B" issued before the k-loop, so its HBM latency hides behind the
+// operand prologue instead of sitting between the last MFMA and the store.
+template <int NW>
+__device__ __forceinline__ void gt_load_neg(const double* __restrict__ C, long ldc, d4 (&acc)[4][GTCfg<NW>::NI]) {
+    const double* base = gt_cbase<NW>(const_cast<double*>(C), ldc);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < GTCfg<NW>::NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = -base[(long)(mi * 16 + 4 * r) * ldc + ni * 16];
 }
 
 // Epilogue: C (pointer to the tile's (0,0) element) = alpha*acc + beta*C.
 // MODE 0: C = acc;  1: C = -acc;  2: C -= acc;  3: C = alpha*acc + beta*C.
 // Read-modify-write modes first gather 16 C values (one 16-row band) into registers, then store:
 // a load->store->load chain through one pointer would serialise on HBM latency.
-template <int MODE>
-__device__ __forceinline__ void gt_store(double* __restrict__ C, long ldc, const d4 (&acc)[4][4],
+template <int MODE, int NW>
+__device__ __forceinline__ void gt_store(double* __restrict__ C, long ldc, const d4 (&acc)[4][GTCfg<NW>::NI],
                                          double alpha = 1.0, double beta = 0.0) {
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
-    double* base = C + (long)(wr * 64 + (lane >> 4)) * ldc + wc * 64 + (lane & 15);
+    constexpr int NI = GTCfg<NW>::NI;
+    double* base = gt_cbase<NW>(C, ldc);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        double old[4][4];
+        double old[NI][4];
         if (MODE >= 2) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) old[ni][r] = base[(long)(mi * 16 + 4 * r) * ldc + ni * 16];
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double* p = base + (long)(mi * 16 + 4 * r) * ldc + ni * 16;

@@ -53,7 +53,12 @@ struct FactorWs {
     int* info = nullptr;        // device int: 0 or first failing column (1-based)
     long nblk = 0;
     hipStream_t st_panel = nullptr;          // high-priority stream of the look-ahead panel factorisation
-    std::vector<hipEvent_t> ev_panel, ev_upd;
+    static const int MAX_UPD = 4;
+    hipStream_t st_upd[MAX_UPD] = {};        // trailing-update streams: column chunk c lives on st_upd[c % n_upd]
+    int n_upd = 2;
+    std::vector<hipEvent_t> ev_panel;        // [p]: outer panel p is factored
+    std::vector<hipEvent_t> ev_cols;         // [p]: every update of panel p's columns has been issued (-> its factorisation)
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_UPD] = {};
     int lookahead = 1;
     KernelProf prof;
 };

@@ -132,7 +132,13 @@ def main():
     ap.add_argument("--iso", action="store_true", help="single lengthscale instead of ARD")
     ap.add_argument("--cpu-sample-n", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grid", default="", help="PrxPc: ONE problem on a 2D block-cyclic process grid (RCCL panel "
+                    "broadcasts, strong scaling) instead of the default independent replicas; with one process the "
+                    "logical ranks share the GPU (loopback transport)")
+    ap.add_argument("--nb", type=int, default=512, help="tile edge of the block-cyclic layout")
     args = ap.parse_args()
+    if args.grid:
+        return main_grid(args)
 
     comm = Comm()
     assert comm.world == max(1, args.gpus) or comm.world == 1, "launch with torch.distributed.run for --gpus > 1"
@@ -186,6 +192,55 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.kind, ARD, D, min(args.cpu_sample_n, N), N)
         print(json.dumps(out), flush=True)
     ctx.close()
+    comm.close()
+
+
+def main_grid(args):
+    """Optional mode (north_star config 4): all GPUs factor ONE N x N problem, 2D block-cyclic over Pr x Pc."""
+    comm = Comm()
+    from gpy_amd import _lib as L
+    from gpy_amd import grid as G
+    from gpy_amd.datasets import default_theta, synthetic
+    Pr, Pc = (int(v) for v in args.grid.lower().split("x"))
+    ARD = not args.iso
+    N, D = args.n, args.d
+    X, Y = synthetic(N, D, seed=0)                            # the same problem on every rank
+    var, ls, noise = default_theta(D, ARD)
+    theta = L.theta_vec(var, ls, ARD, D)
+    if comm.world > 1:
+        assert comm.world == Pr * Pc, "--grid PrxPc must match the number of processes"
+        g = G.GridContext.from_env(Pr, Pc, args.nb)
+    else:
+        g = G.GridContext.loopback(Pr, Pc, args.nb, device=comm.local_rank)
+    g.set_data(X, Y)
+    last = {}
+
+    def step():
+        info, r = g.exact_inference(args.kind, ARD, theta, noise, want_stage_ms=True)
+        assert info == 0
+        last["r"] = r
+
+    dt = timed_region(comm, step, args.steps, args.warmup)
+    if comm.rank == 0:
+        r = last["r"]
+        its = args.steps / dt                                 # one problem, all GPUs
+        flops = float(N) ** 3
+        traffic = G.step_traffic_bytes(N, args.nb, Pr, Pc)
+        out = {
+            "metric": "exact-GP log_lik+grad iters/sec", "value": its, "unit": "iters/s", "n_gpus": comm.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s %s exact GP, one parameters_changed on a %dx%d block-cyclic grid (nb=%d, %s "
+                                   "transport), N=%d D=%d Dy=1" % (args.kind, "ARD" if ARD else "iso", Pr, Pc, args.nb,
+                                                                  "loopback" if g.is_loopback else "RCCL", N, D),
+                       "N": N, "D": D, "kernel": args.kind, "ARD": ARD, "parallelism": "grid %dx%d" % (Pr, Pc)},
+            "iteration_tflops": flops / (dt / args.steps) / 1e12,
+            "iteration_frac_of_fp64_peak": flops / (dt / args.steps) / 1e12 / (PEAK_FP64_TFLOPS * comm.world),
+            "stage_ms": {k: round(float(v), 4) for k, v in r["stage_ms"].items()},
+            "comm_bytes_per_step": traffic, "lml": r["lml"],
+        }
+        print(json.dumps(out), flush=True)
+    g.close()
     comm.close()
 
 

@@ -78,12 +78,19 @@ def lib():
     L.mi355gp_pdinv.argtypes = [ci, _dp, i64, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_set_option.argtypes = [vp, ci, ci]
     L.mi355gp_get_profile.argtypes = [vp, _dp, _dp, ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
+    L.mi355gp_grid_unique_id.argtypes = [ctypes.c_char_p]
+    L.mi355gp_grid_create.argtypes = [ci, ci, ci, ci, ci, ci, ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.mi355gp_grid_destroy.argtypes = [vp]
+    L.mi355gp_grid_set_data.argtypes = [vp, _dp, i64, ci, _dp, ci]
+    L.mi355gp_grid_exact_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
+    L.mi355gp_grid_fetch.argtypes = [vp, ci, _dp]
     L.mi355gp_dbg_mfma.argtypes = [ci, _dp, _dp, _dp]
     L.mi355gp_dbg_gemm.argtypes = [ci, ci, ci, i64, i64, i64, _dp, _dp, _dp, cd, cd, ci, _c_dp]
     L.mi355gp_dbg_peaks.argtypes = [ci, _dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
-                 "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile"):
+                 "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
+                 "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -93,7 +100,8 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_set_data", "mi355gp_set_targets", "mi355gp_kern_K", "mi355gp_kern_Kdiag",
             "mi355gp_update_gradients_full", "mi355gp_exact_inference", "mi355gp_inference_given_K",
             "mi355gp_fetch", "mi355gp_predict", "mi355gp_potrf", "mi355gp_pdinv", "mi355gp_bench_factor",
-            "mi355gp_set_option", "mi355gp_get_profile",
+            "mi355gp_set_option", "mi355gp_get_profile", "mi355gp_grid_unique_id", "mi355gp_grid_create",
+            "mi355gp_grid_destroy", "mi355gp_grid_set_data", "mi355gp_grid_exact_inference", "mi355gp_grid_fetch",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks")
 
 

@@ -1,0 +1,840 @@
+// grid.hip -- optional multi-GPU mode: the exact-GP evaluation on a Pr x Pc process grid with the N x N matrices
+// 2D block-cyclic distributed (tile edge nb), panels exchanged with RCCL broadcasts over xGMI and the
+// O(N) results combined with all-reduces (north_star config 4).  GPy has no counterpart: its only
+// parallel code is the mpi4py data-parallel sparse GP (GPy/inference/latent_function_inference/var_dtc_parallel.py).
+//
+// One pass, right-looking in all three factors, so every exchange is a panel broadcast and every update a rank-nb
+// outer product on the local tiles (the same MFMA tile GEMM as the single-GPU path):
+//   step k:  owner(k,k): L_kk = chol(A_kk), D = L_kk^-1          -> bcast D down process column k%Pc and along row k%Pr
+//            column k%Pc: L_ik = A_ik D^T (i > k)                 -> bcast along process rows       (row panel RP)
+//            RP tiles with i%Pc == my column                      -> bcast down process columns     (col panel CP)
+//            A_ij -= L_ik L_jk^T                (i >= j > k)        [potrf trailing update]
+//            row k%Pr: X_kj = D B_kj (j < k), X_kk = D            -> bcast down process columns     (XR)
+//            XR tiles with j%Pr == my row                         -> bcast along process rows       (XRr)
+//            B_ij -= L_ik X_kj                  (i > k >= j)        [right-looking triangular inverse, B -> X = L^-1]
+//            W_ij += X_ki^T X_kj                (k >= i >= j)       [Ky^-1 = X^T X accumulated as X rows complete]
+// Afterwards alpha = X^T (X R), diag W and the gradient reduction run on the local tiles and are summed across ranks.
+//
+// Two transports behind one driver: RCCL (one rank per process, one GPU each; librccl.so is dlopen'ed so the
+// single-GPU library has no RCCL dependency) and LOOPBACK (all Pr*Pc logical ranks inside one process on one
+// device, broadcasts are device copies) used to test the algorithm on a 1-GPU box.
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355gp.h"
+#include "gemm_tile.h"
+#include "internal.h"
+
+#define GP_STRIDE 34
+#define LOG_2_PI 1.8378770664093454836
+#define ARGCHK(cond, msg)                 \
+    do {                                  \
+        if (!(cond)) {                    \
+            mi355gp_set_error("%s", msg); \
+            return -1;                    \
+        }                                 \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// RCCL through dlopen (only the handful of entry points the grid needs; ABI of rccl.h / NCCL 2.27)
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccess = 0 };
+enum { ncclFloat64 = 8 };   // ncclDataType_t
+enum { ncclSum = 0 };       // ncclRedOp_t
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (h) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) {
+            mi355gp_set_error("cannot dlopen librccl.so: %s", dlerror());
+            return false;
+        }
+#define SYM(field, name)                                                   \
+    *(void**)(&field) = dlsym(h, name);                                    \
+    if (!field) {                                                          \
+        mi355gp_set_error("librccl.so lacks %s", name);                    \
+        return false;                                                      \
+    }
+        SYM(GetUniqueId, "ncclGetUniqueId");
+        SYM(CommInitRank, "ncclCommInitRank");
+        SYM(CommSplit, "ncclCommSplit");
+        SYM(CommDestroy, "ncclCommDestroy");
+        SYM(Broadcast, "ncclBroadcast");
+        SYM(AllReduce, "ncclAllReduce");
+        SYM(GroupStart, "ncclGroupStart");
+        SYM(GroupEnd, "ncclGroupEnd");
+        SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+        return true;
+    }
+};
+static Rccl g_rccl;
+#define NCCL_CHECK(expr)                                                                                  \
+    do {                                                                                                  \
+        int _r = (expr);                                                                                  \
+        if (_r != ncclSuccess) {                                                                          \
+            mi355gp_set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
+            return -(2000 + _r);                                                                          \
+        }                                                                                                 \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// device kernels specific to the distributed layout
+
+// C (op)= A * B on the 128x128 tiles of a local region; operands may be "tile-major" panels ([tile][nb][nb], ld = nb).
+//   mode 0: C = acc, 1: C += acc, 2: C -= acc.   pred: keep only tiles whose global nb-tile indices satisfy I >= J.
+struct GridPred {
+    int on, Pr, pr, Pc, pc, roff, coff;   // I = (roff + ti/q)*Pr + pr ;  J = (coff + tj/q)*Pc + pc
+};
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256, 2) void k_grid_gemm(double* __restrict__ C, long ldc, int c_tm,
+                                                      const double* __restrict__ A, long lda, int a_tm,
+                                                      const double* __restrict__ B, long ldb, int b_tm, int K,
+                                                      int ntc, int q, long nb, int mode, GridPred pd) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
+    if (pd.on) {
+        const int I = (pd.roff + ti / q) * pd.Pr + pd.pr, J = (pd.coff + tj / q) * pd.Pc + pd.pc;
+        if (J > I) return;
+    }
+    const double* Ap;
+    const double* Bp;
+    if (AK) Ap = A + (long)ti * NB * lda;
+    else Ap = a_tm ? A + (long)(ti / q) * nb * nb + (long)(ti % q) * NB : A + (long)ti * NB;
+    if (BK) Bp = B + (long)tj * NB * ldb;
+    else Bp = b_tm ? B + (long)(tj / q) * nb * nb + (long)(tj % q) * NB : B + (long)tj * NB;
+    double* Cp = c_tm ? C + (long)(tj / q) * nb * nb + (long)ti * NB * nb + (long)(tj % q) * NB
+                      : C + (long)ti * NB * ldc + (long)tj * NB;
+    d4 acc[4][4];
+    gt_zero<4>(acc);
+    gemm_tile_128<AK, BK, 4>(Ap, lda, Bp, ldb, K, acc, smem);
+    if (mode == 0) gt_store<0, 4>(Cp, ldc, acc);
+    else if (mode == 1) gt_store<3, 4>(Cp, ldc, acc, 1.0, 1.0);
+    else gt_store<2, 4>(Cp, ldc, acc);
+}
+
+struct GOp {
+    const double* p;
+    long ld;
+    int tm;
+};
+template <bool AK, bool BK>
+static void grid_gemm_t(hipStream_t st, double* C, long ldc, int c_tm, GOp a, GOp b, long M, long N, long K, long nb,
+                        int mode, GridPred pd) {
+    if (M <= 0 || N <= 0) return;
+    static bool opted = false;
+    if (!opted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_gemm<AK, BK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
+        opted = true;
+    }
+    const int ntr = (int)(M / NB), ntc = (int)(N / NB);
+    hipLaunchKernelGGL((k_grid_gemm<AK, BK>), dim3((unsigned)(ntr * ntc)), dim3(256), GT_LDS_BYTES, st, C, ldc, c_tm,
+                       a.p, a.ld, a.tm, b.p, b.ld, b.tm, (int)K, ntc, (int)(nb / NB), nb, mode, pd);
+}
+
+// local diagonal fix-up after the cross-covariance build: entries with equal global index get noise + jitter
+// (real points) or 1 (padding); one thread per element of every diagonal nb-tile this rank owns.
+__global__ void k_grid_fix_diag(double* __restrict__ A, long ld, long nb, long n, int ndiag,
+                                const int* __restrict__ dl_r, const int* __restrict__ dl_c,
+                                const int* __restrict__ dg, const double* __restrict__ noise, long noise_len,
+                                double jit) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)ndiag * nb) return;
+    const int d = (int)(idx / nb);
+    const long e = idx % nb, g = (long)dg[d] * nb + e;
+    double* p = A + ((long)dl_r[d] * nb + e) * ld + (long)dl_c[d] * nb + e;
+    if (g < n) *p += noise[noise_len > 1 ? g : 0] + jit;
+    else *p = 1.0;
+}
+
+// G = w * 0.5 * (alpha_i . alpha_j - Dy * W_ij), w = 2 (global i > j), 1 (i == j), 0 (i < j): the lower-triangle
+// weighting of the symmetric dL_dK (exact_gaussian_inference.py:70) on a block-cyclic local tile set.
+__global__ void k_grid_dldk(const double* __restrict__ W, double* __restrict__ G, long ld, long rows, long cols,
+                            const long* __restrict__ gr, const long* __restrict__ gc,
+                            const double* __restrict__ alpha, int Dy, long n) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i = blockIdx.y;
+    if (j >= cols || i >= rows) return;
+    const long gi = gr[i], gj = gc[j];
+    double g = 0.0;
+    if (gi < n && gj < n && gj <= gi) {
+        double aa = 0.0;
+        for (int d = 0; d < Dy; ++d) aa = fma(alpha[gi * Dy + d], alpha[gj * Dy + d], aa);
+        g = 0.5 * (aa - (double)Dy * W[i * ld + j]);
+        if (gj < gi) g *= 2.0;
+    }
+    G[i * ld + j] = g;
+}
+
+// y[i][d] = sum_j M[i][j] * v[g(j)][d]   (one wave per local row; v indexed by global column index, 0 beyond n)
+__global__ __launch_bounds__(256) void k_grid_row_reduce(const double* __restrict__ M, long ld, long rows, long cols,
+                                                         const long* __restrict__ gc, const double* __restrict__ v,
+                                                         int Dy, int d, long n, double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    double s = 0.0;
+    for (long j = lane; j < cols; j += 64) {
+        const long g = gc[j];
+        if (g < n) s = fma(M[i * ld + j], v[g * Dy + d], s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) y[i] = s;
+}
+
+// out[j] = sum_i M[i][j] * (v ? v[g(i)][d] : M[i][j])   (64 columns per block, fixed-order combine)
+__global__ __launch_bounds__(256) void k_grid_col_reduce(const double* __restrict__ M, long ld, long rows, long cols,
+                                                         const long* __restrict__ gr, const double* __restrict__ v,
+                                                         int Dy, int d, long n, double* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + tx;
+    double s = 0.0;
+    if (j < cols) {
+        for (long i = g; i < rows; i += 4) {
+            const double x = M[i * ld + j];
+            if (v) {
+                const long gi = gr[i];
+                if (gi < n) s = fma(x, v[gi * Dy + d], s);
+            } else {
+                s = fma(x, x, s);
+            }
+        }
+    }
+    red[g][tx] = s;
+    __syncthreads();
+    if (g == 0 && j < cols) out[j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+// gvec[g(l)*stride + d] = loc[l]  for g(l) < n
+__global__ void k_grid_scatter(const double* __restrict__ loc, long cnt, const long* __restrict__ gidx, long n,
+                               int stride, int d, double* __restrict__ gvec) {
+    const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= cnt) return;
+    const long g = gidx[l];
+    if (g < n) gvec[g * stride + d] = loc[l];
+}
+
+__global__ void k_grid_axpy(double* __restrict__ dst, const double* __restrict__ src, long cnt) {
+    const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < cnt) dst[l] += src[l];
+}
+
+// after a tile factorisation: scal[0] += sum(logsum[0..q)) ; info_g = first failure in global numbering
+__global__ void k_grid_tile_stats(const double* __restrict__ logsum, int q, const int* __restrict__ info_tile,
+                                  long col0, double* __restrict__ scal, int* __restrict__ info_g) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < q; ++i) s += logsum[i];
+    scal[0] += s;
+    if (info_tile[0] != 0) {
+        scal[1] += 1.0;                                  // summed over ranks: "some tile failed" is known everywhere
+        if (info_g[0] == 0) info_g[0] = (int)(col0 + info_tile[0]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct GridRank {
+    int rank = 0, pr = 0, pc = 0;
+    int TLr = 0, TLc = 0;            // local tile rows / cols actually owned
+    long LR = 0, LC = 0;             // allocated local rows / cols (uniform over ranks)
+    long nvr = 0, nvc = 0;           // local rows / cols whose global index is < n (a prefix of the local order)
+    double *A = nullptr, *X = nullptr, *W = nullptr;
+    double *RP = nullptr, *CP = nullptr, *XR = nullptr, *XRr = nullptr;
+    double *Dt = nullptr, *Dv = nullptr, *Ds = nullptr;
+    double *XtR = nullptr, *XtC = nullptr, *XsR = nullptr, *XsC = nullptr;   // scaled dimension-major / raw row-major
+    long *gR = nullptr, *gC = nullptr;                                       // global index of every local row / col
+    int *dl_r = nullptr, *dl_c = nullptr, *dg = nullptr;
+    int ndiag = 0;
+    double *vloc = nullptr, *gvec = nullptr, *gvec2 = nullptr, *alpha = nullptr, *ybuf = nullptr, *Rg = nullptr;
+    double *scal = nullptr, *gradPart = nullptr, *gradOut = nullptr, *invls = nullptr, *noise = nullptr;
+    int* info_g = nullptr;
+    FactorWs ws;
+    hipStream_t st = nullptr;
+};
+
+struct mi355gp_grid {
+    int device = 0, world = 1, Pr = 1, Pc = 1, my_rank = 0;
+    long nb = 512;
+    bool loopback = true;
+    std::vector<GridRank> ranks;     // logical ranks hosted by this process (loopback: all, RCCL: one)
+    ncclComm_t comm_world = nullptr, comm_row = nullptr, comm_col = nullptr;
+    hipStream_t st = nullptr;        // loopback: shared by all logical ranks
+    long n = 0, npad = 0, T = 0;
+    int D = 0, Dy = 0;
+    hipEvent_t ev[6] = {};
+    bool have_result = false;
+};
+
+static int cnt_le(long k, int p, int P) { return (k >= p) ? (int)((k - p) / P + 1) : 0; }   // tiles t <= k with t % P == p
+static int cnt_lt(long k, int p, int P) { return (k > 0) ? cnt_le(k - 1, p, P) : 0; }
+
+static void free_rank(GridRank& r) {
+    void* ptrs[] = {r.A, r.X, r.W, r.RP, r.CP, r.XR, r.XRr, r.Dt, r.Dv, r.Ds, r.XtR, r.XtC, r.XsR, r.XsC, r.gR, r.gC,
+                    r.dl_r, r.dl_c, r.dg, r.vloc, r.gvec, r.gvec2, r.alpha, r.ybuf, r.Rg, r.scal, r.gradPart,
+                    r.gradOut, r.invls, r.noise, r.info_g};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    factor_ws_free(&r.ws);
+    r = GridRank();
+}
+
+// ---- transports ------------------------------------------------------------------------------------------
+// Broadcast inside one process row (group = GROUP_ROW, index = pr) or column (GROUP_COL, index = pc).
+// `buf(rank, is_root)` returns the send pointer for the root and the receive pointer for everyone (the root's
+// receive pointer may differ from its send pointer: out-of-place on the root, like ncclBroadcast).
+enum { GROUP_ROW = 0, GROUP_COL = 1 };
+typedef std::function<double*(GridRank&, bool)> BufFn;
+
+static int grid_bcast(mi355gp_grid* g, int group, int index, int root_coord, size_t count, const BufFn& buf) {
+    if (count == 0) return 0;
+    if (g->loopback) {
+        GridRank* root = nullptr;
+        for (GridRank& r : g->ranks) {
+            const bool in = (group == GROUP_ROW) ? (r.pr == index) : (r.pc == index);
+            const int coord = (group == GROUP_ROW) ? r.pc : r.pr;
+            if (in && coord == root_coord) root = &r;
+        }
+        const double* src = buf(*root, true);
+        for (GridRank& r : g->ranks) {
+            const bool in = (group == GROUP_ROW) ? (r.pr == index) : (r.pc == index);
+            if (!in) continue;
+            double* dst = buf(r, false);
+            if (dst != src) HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, g->st));
+        }
+        return 0;
+    }
+    GridRank& r = g->ranks[0];
+    const bool in = (group == GROUP_ROW) ? (r.pr == index) : (r.pc == index);
+    if (!in) return 0;
+    const int coord = (group == GROUP_ROW) ? r.pc : r.pr;
+    const bool is_root = coord == root_coord;
+    const double* send = is_root ? buf(r, true) : buf(r, false);
+    NCCL_CHECK(g_rccl.Broadcast(send, buf(r, false), count, ncclFloat64, root_coord,
+                                group == GROUP_ROW ? g->comm_row : g->comm_col, r.st));
+    return 0;
+}
+static int grid_group_start(mi355gp_grid* g) {
+    if (!g->loopback) NCCL_CHECK(g_rccl.GroupStart());
+    return 0;
+}
+static int grid_group_end(mi355gp_grid* g) {
+    if (!g->loopback) NCCL_CHECK(g_rccl.GroupEnd());
+    return 0;
+}
+// sum `count` doubles at `pick(rank)` over all ranks, result everywhere
+static int grid_allreduce(mi355gp_grid* g, size_t count, const std::function<double*(GridRank&)>& pick) {
+    if (g->loopback) {
+        double* acc = pick(g->ranks[0]);
+        const unsigned nblk = (unsigned)((count + 255) / 256);
+        for (size_t i = 1; i < g->ranks.size(); ++i)
+            hipLaunchKernelGGL(k_grid_axpy, dim3(nblk), dim3(256), 0, g->st, acc, pick(g->ranks[i]), (long)count);
+        for (size_t i = 1; i < g->ranks.size(); ++i)
+            HIP_CHECK(hipMemcpyAsync(pick(g->ranks[i]), acc, count * sizeof(double), hipMemcpyDeviceToDevice, g->st));
+        return 0;
+    }
+    GridRank& r = g->ranks[0];
+    NCCL_CHECK(g_rccl.AllReduce(pick(r), pick(r), count, ncclFloat64, ncclSum, g->comm_world, r.st));
+    return 0;
+}
+
+extern "C" {
+
+int mi355gp_grid_unique_id(void* id128) {
+    ARGCHK(id128 != nullptr, "mi355gp_grid_unique_id: NULL");
+    if (!g_rccl.load()) return -20;
+    ncclUniqueId id;
+    NCCL_CHECK(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb, const void* id128,
+                        mi355gp_grid** out) {
+    ARGCHK(out && Pr >= 1 && Pc >= 1 && nb >= NB && nb % NB == 0, "mi355gp_grid_create: Pr, Pc >= 1, nb % 128 == 0");
+    ARGCHK(world == Pr * Pc, "mi355gp_grid_create: world must equal Pr*Pc");
+    ARGCHK(rank >= 0 && rank < world, "mi355gp_grid_create: bad rank");
+    int ndev = 0;
+    mi355gp_device_count(&ndev);
+    if (device < 0 || device >= ndev) {
+        mi355gp_set_error("mi355gp_grid_create: device %d not available (%d HIP devices visible)", device, ndev);
+        return -2;
+    }
+    HIP_CHECK(hipSetDevice(device));
+    mi355gp_grid* g = new mi355gp_grid();
+    g->device = device;
+    g->world = world;
+    g->Pr = Pr;
+    g->Pc = Pc;
+    g->nb = nb;
+    g->my_rank = rank;
+    g->loopback = (id128 == nullptr);
+    HIP_CHECK(hipStreamCreate(&g->st));
+    for (auto& e : g->ev) HIP_CHECK(hipEventCreate(&e));
+    if (g->loopback) {
+        g->ranks.resize((size_t)world);
+        for (int r = 0; r < world; ++r) {
+            g->ranks[r].rank = r;
+            g->ranks[r].pr = r / Pc;
+            g->ranks[r].pc = r % Pc;
+            g->ranks[r].st = g->st;
+        }
+    } else {
+        if (!g_rccl.load()) return -20;
+        g->ranks.resize(1);
+        GridRank& r = g->ranks[0];
+        r.rank = rank;
+        r.pr = rank / Pc;
+        r.pc = rank % Pc;
+        r.st = g->st;
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof(id));
+        NCCL_CHECK(g_rccl.CommInitRank(&g->comm_world, world, id, rank));
+        NCCL_CHECK(g_rccl.CommSplit(g->comm_world, r.pr, r.pc, &g->comm_row, nullptr));   // rank inside = pc
+        NCCL_CHECK(g_rccl.CommSplit(g->comm_world, r.pc, r.pr, &g->comm_col, nullptr));   // rank inside = pr
+    }
+    *out = g;
+    return 0;
+}
+
+int mi355gp_grid_destroy(mi355gp_grid* g) {
+    if (!g) return 0;
+    (void)hipSetDevice(g->device);
+    (void)hipStreamSynchronize(g->st);
+    for (GridRank& r : g->ranks) free_rank(r);
+    if (g->comm_row) g_rccl.CommDestroy(g->comm_row);
+    if (g->comm_col) g_rccl.CommDestroy(g->comm_col);
+    if (g->comm_world) g_rccl.CommDestroy(g->comm_world);
+    for (auto& e : g->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (g->st) (void)hipStreamDestroy(g->st);
+    delete g;
+    return 0;
+}
+
+// Every rank passes the full (replicated) X and R: N*D*8 bytes is small next to the N^2/P matrix share.
+int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, const double* R, int Dy) {
+    ARGCHK(g && X && R && N > 0 && D > 0 && Dy > 0, "mi355gp_grid_set_data: bad arguments");
+    HIP_CHECK(hipSetDevice(g->device));
+    HIP_CHECK(hipStreamSynchronize(g->st));
+    const long nb = g->nb;
+    g->n = N;
+    g->T = (N + nb - 1) / nb;
+    g->npad = g->T * nb;
+    g->D = D;
+    g->Dy = Dy;
+    g->have_result = false;
+    const long T = g->T, TLrM = (T + g->Pr - 1) / g->Pr, TLcM = (T + g->Pc - 1) / g->Pc;
+    const int groups = (D + 31) / 32;
+    for (GridRank& r : g->ranks) {
+        const int rank = r.rank, pr = r.pr, pc = r.pc;
+        hipStream_t st = r.st;
+        free_rank(r);
+        r.rank = rank; r.pr = pr; r.pc = pc; r.st = st;
+        r.TLr = cnt_le(T - 1, pr, g->Pr);
+        r.TLc = cnt_le(T - 1, pc, g->Pc);
+        r.LR = TLrM * nb;
+        r.LC = TLcM * nb;
+        const size_t mat = sizeof(double) * r.LR * r.LC;
+        HIP_CHECK(hipMalloc(&r.A, mat));
+        HIP_CHECK(hipMalloc(&r.X, mat));
+        HIP_CHECK(hipMalloc(&r.W, mat));
+        HIP_CHECK(hipMalloc(&r.RP, sizeof(double) * r.LR * nb));
+        HIP_CHECK(hipMalloc(&r.CP, sizeof(double) * r.LC * nb));
+        HIP_CHECK(hipMalloc(&r.XR, sizeof(double) * r.LC * nb));
+        HIP_CHECK(hipMalloc(&r.XRr, sizeof(double) * r.LR * nb));
+        HIP_CHECK(hipMalloc(&r.Dt, sizeof(double) * nb * nb));
+        HIP_CHECK(hipMalloc(&r.Dv, sizeof(double) * nb * nb));
+        HIP_CHECK(hipMalloc(&r.Ds, sizeof(double) * nb * nb));
+        // local point sets (host-side gather, uploaded once)
+        std::vector<long> gR((size_t)r.LR), gC((size_t)r.LC);
+        std::vector<double> XsR((size_t)r.LR * D, 0.0), XsC((size_t)r.LC * D, 0.0);
+        r.nvr = r.nvc = 0;
+        for (long l = 0; l < r.LR; ++l) {
+            const long lt = l / nb;
+            const long gi = (lt < r.TLr) ? (lt * g->Pr + pr) * nb + l % nb : g->npad + l;   // unused rows: beyond n
+            gR[l] = gi;
+            if (gi < N) { memcpy(&XsR[(size_t)l * D], X + gi * D, sizeof(double) * D); r.nvr = l + 1; }
+        }
+        for (long l = 0; l < r.LC; ++l) {
+            const long lt = l / nb;
+            const long gj = (lt < r.TLc) ? (lt * g->Pc + pc) * nb + l % nb : g->npad + l;
+            gC[l] = gj;
+            if (gj < N) { memcpy(&XsC[(size_t)l * D], X + gj * D, sizeof(double) * D); r.nvc = l + 1; }
+        }
+        HIP_CHECK(hipMalloc(&r.gR, sizeof(long) * r.LR));
+        HIP_CHECK(hipMalloc(&r.gC, sizeof(long) * r.LC));
+        HIP_CHECK(hipMalloc(&r.XsR, sizeof(double) * r.LR * D));
+        HIP_CHECK(hipMalloc(&r.XsC, sizeof(double) * r.LC * D));
+        HIP_CHECK(hipMalloc(&r.XtR, sizeof(double) * r.LR * D));
+        HIP_CHECK(hipMalloc(&r.XtC, sizeof(double) * r.LC * D));
+        HIP_CHECK(hipMemcpy(r.gR, gR.data(), sizeof(long) * r.LR, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(r.gC, gC.data(), sizeof(long) * r.LC, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(r.XsR, XsR.data(), sizeof(double) * r.LR * D, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(r.XsC, XsC.data(), sizeof(double) * r.LC * D, hipMemcpyHostToDevice));
+        // diagonal tiles owned by this rank
+        std::vector<int> dlr, dlc, dg;
+        for (long t = 0; t < T; ++t)
+            if (t % g->Pr == pr && t % g->Pc == pc) {
+                dlr.push_back((int)(t / g->Pr));
+                dlc.push_back((int)(t / g->Pc));
+                dg.push_back((int)t);
+            }
+        r.ndiag = (int)dg.size();
+        HIP_CHECK(hipMalloc(&r.dl_r, sizeof(int) * (r.ndiag + 1)));
+        HIP_CHECK(hipMalloc(&r.dl_c, sizeof(int) * (r.ndiag + 1)));
+        HIP_CHECK(hipMalloc(&r.dg, sizeof(int) * (r.ndiag + 1)));
+        if (r.ndiag) {
+            HIP_CHECK(hipMemcpy(r.dl_r, dlr.data(), sizeof(int) * r.ndiag, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(r.dl_c, dlc.data(), sizeof(int) * r.ndiag, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(r.dg, dg.data(), sizeof(int) * r.ndiag, hipMemcpyHostToDevice));
+        }
+        const long vmax = (r.LR > r.LC ? r.LR : r.LC);
+        HIP_CHECK(hipMalloc(&r.vloc, sizeof(double) * vmax));
+        HIP_CHECK(hipMalloc(&r.gvec, sizeof(double) * N * Dy));
+        HIP_CHECK(hipMalloc(&r.gvec2, sizeof(double) * N));
+        HIP_CHECK(hipMalloc(&r.alpha, sizeof(double) * N * Dy));
+        HIP_CHECK(hipMalloc(&r.ybuf, sizeof(double) * N * Dy));
+        HIP_CHECK(hipMalloc(&r.Rg, sizeof(double) * N * Dy));
+        HIP_CHECK(hipMemcpy(r.Rg, R, sizeof(double) * N * Dy, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMalloc(&r.scal, sizeof(double) * 8));
+        HIP_CHECK(hipMalloc(&r.gradPart, sizeof(double) * groups * 2048 * GP_STRIDE));
+        HIP_CHECK(hipMalloc(&r.gradOut, sizeof(double) * groups * GP_STRIDE));
+        HIP_CHECK(hipMalloc(&r.invls, sizeof(double) * D));
+        HIP_CHECK(hipMalloc(&r.noise, sizeof(double) * N));
+        HIP_CHECK(hipMalloc(&r.info_g, sizeof(int) * 4));
+        if (factor_ws_alloc(&r.ws, nb) != 0) return -3;
+        r.ws.lookahead = 0;      // the nb x nb diagonal tile is factored in order on the rank's stream
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+// one evaluation on all local ranks
+static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const std::vector<double>& inv_ls,
+                    const double* noise, int64_t noise_len, double jit, double* out_scalars, double* alpha_out,
+                    double* dtheta_out, double* diag_out, double* stage_ms) {
+    const long nb = g->nb, T = g->T, n = g->n;
+    const int Pr = g->Pr, Pc = g->Pc, Dy = g->Dy, D = g->D, q = (int)(nb / NB);
+    const size_t tile = (size_t)nb * nb;
+    const GridPred nopred{0, 1, 0, 1, 0, 0, 0};
+    HIP_CHECK(hipEventRecord(g->ev[0], g->st));
+    // ---- covariance tiles: K(X_rows, X_cols) + diagonal fix-up -------------------------------------------
+    for (GridRank& r : g->ranks) {
+        hipStream_t st = r.st;
+        HIP_CHECK(hipMemcpyAsync(r.invls, inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(r.noise, noise, sizeof(double) * noise_len, hipMemcpyHostToDevice, st));
+        launch_scale_inputs(st, r.XsR, r.LR, D, r.invls, kp.ard, r.XtR, r.LR);
+        launch_scale_inputs(st, r.XsC, r.LC, D, r.invls, kp.ard, r.XtC, r.LC);
+        HIP_CHECK(hipMemsetAsync(r.A, 0, sizeof(double) * r.LR * r.LC, st));
+        HIP_CHECK(hipMemsetAsync(r.X, 0, sizeof(double) * r.LR * r.LC, st));
+        HIP_CHECK(hipMemsetAsync(r.W, 0, sizeof(double) * r.LR * r.LC, st));
+        HIP_CHECK(hipMemsetAsync(r.scal, 0, sizeof(double) * 8, st));
+        HIP_CHECK(hipMemsetAsync(r.info_g, 0, sizeof(int) * 4, st));
+        if (r.nvr > 0 && r.nvc > 0) launch_kbuild_cross(st, kp, r.XtR, r.LR, r.nvr, r.XtC, r.LC, r.nvc, r.A, r.LC);
+        if (r.ndiag > 0) {
+            const long cnt = (long)r.ndiag * nb;
+            hipLaunchKernelGGL(k_grid_fix_diag, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, r.A, r.LC, nb, n,
+                               r.ndiag, r.dl_r, r.dl_c, r.dg, r.noise, (long)noise_len, jit);
+        }
+    }
+    HIP_CHECK(hipEventRecord(g->ev[1], g->st));
+    // ---- the one-pass factorisation / inversion ------------------------------------------------------------
+    for (long k = 0; k < T; ++k) {
+        const int opr = (int)(k % Pr), opc = (int)(k % Pc);
+        const long lkr = k / Pr, lkc = k / Pc;
+        // (a) diagonal tile: L_kk and D = L_kk^-1 on its owner
+        for (GridRank& r : g->ranks) {
+            if (r.pr != opr || r.pc != opc) continue;
+            double* At = r.A + lkr * nb * r.LC + lkc * nb;
+            HIP_CHECK(hipMemcpy2DAsync(r.Dt, sizeof(double) * nb, At, sizeof(double) * r.LC, sizeof(double) * nb, nb,
+                                       hipMemcpyDeviceToDevice, r.st));
+            potrf_device(r.st, r.Dt, nb, &r.ws);
+            hipLaunchKernelGGL(k_grid_tile_stats, dim3(1), dim3(64), 0, r.st, r.ws.logsum, q, r.ws.info, k * nb, r.scal,
+                               r.info_g);
+            HIP_CHECK(hipMemsetAsync(r.Dv, 0, sizeof(double) * tile, r.st));
+            trtri_device(r.st, r.Dt, r.Dv, r.Ds, nb, &r.ws);
+            HIP_CHECK(hipMemcpy2DAsync(At, sizeof(double) * r.LC, r.Dt, sizeof(double) * nb, sizeof(double) * nb, nb,
+                                       hipMemcpyDeviceToDevice, r.st));
+        }
+        // (b) D to the panel owners (process column opc) and to the owners of row k of X (process row opr)
+        if (int rc = grid_bcast(g, GROUP_COL, opc, opr, tile, [](GridRank& r, bool) { return r.Dv; })) return rc;
+        if (int rc = grid_bcast(g, GROUP_ROW, opr, opc, tile, [](GridRank& r, bool) { return r.Dv; })) return rc;
+        // (c) panel solve L_ik = A_ik D^T on process column opc
+        for (GridRank& r : g->ranks) {
+            if (r.pc != opc) continue;
+            const int lr0 = cnt_le(k, r.pr, Pr);
+            const long rows = (long)(r.TLr - lr0) * nb;
+            if (rows <= 0) continue;
+            double* Acol = r.A + (long)lr0 * nb * r.LC + lkc * nb;
+            grid_gemm_t<true, true>(r.st, r.RP + (long)lr0 * tile, nb, 0, GOp{Acol, r.LC, 0}, GOp{r.Dv, nb, 0}, rows, nb,
+                                    nb, nb, 0, nopred);
+            HIP_CHECK(hipMemcpy2DAsync(Acol, sizeof(double) * r.LC, r.RP + (long)lr0 * tile, sizeof(double) * nb,
+                                       sizeof(double) * nb, rows, hipMemcpyDeviceToDevice, r.st));
+        }
+        // (d) row panel along every process row
+        for (int pr = 0; pr < Pr; ++pr) {
+            const int lr0 = cnt_le(k, pr, Pr), TLr = cnt_le(T - 1, pr, Pr);
+            const size_t cnt = (size_t)(TLr - lr0) * tile;
+            if (int rc = grid_bcast(g, GROUP_ROW, pr, opc, cnt,
+                                    [&](GridRank& r, bool) { return r.RP + (long)lr0 * tile; }))
+                return rc;
+        }
+        // (e) column panel: L_jk for the local columns j > k comes from process row j % Pr
+        if (int rc = grid_group_start(g)) return rc;
+        for (long j = k + 1; j < T; ++j) {
+            const int pc = (int)(j % Pc), root = (int)(j % Pr);
+            const long lj = j / Pc, li = j / Pr;
+            if (int rc = grid_bcast(g, GROUP_COL, pc, root, tile, [&](GridRank& r, bool is_root) {
+                    return is_root ? r.RP + li * tile : r.CP + lj * tile;
+                }))
+                return rc;
+        }
+        if (int rc = grid_group_end(g)) return rc;
+        // (g) row k of X on process row opr: X_kj = D * B_kj (j < k), X_kk = D
+        for (GridRank& r : g->ranks) {
+            if (r.pr != opr) continue;
+            const int lcB = cnt_lt(k, r.pc, Pc);                      // local columns with J < k
+            const double* Brow = r.X + lkr * nb * r.LC;
+            grid_gemm_t<true, false>(r.st, r.XR, nb, 1, GOp{r.Dv, nb, 0}, GOp{Brow, r.LC, 0}, nb, (long)lcB * nb, nb, nb,
+                                     0, nopred);
+            if (r.pc == opc) HIP_CHECK(hipMemcpyAsync(r.XR + (long)lcB * tile, r.Dv, sizeof(double) * tile,
+                                                      hipMemcpyDeviceToDevice, r.st));
+            const int lc0 = cnt_le(k, r.pc, Pc);
+            for (int lj = 0; lj < lc0; ++lj)                           // final X row block back into the local matrix
+                HIP_CHECK(hipMemcpy2DAsync(r.X + lkr * nb * r.LC + (long)lj * nb, sizeof(double) * r.LC,
+                                           r.XR + (long)lj * tile, sizeof(double) * nb, sizeof(double) * nb, nb,
+                                           hipMemcpyDeviceToDevice, r.st));
+        }
+        // (h) X row panel down every process column
+        for (int pc = 0; pc < Pc; ++pc) {
+            const size_t cnt = (size_t)cnt_le(k, pc, Pc) * tile;
+            if (int rc = grid_bcast(g, GROUP_COL, pc, opr, cnt, [](GridRank& r, bool) { return r.XR; })) return rc;
+        }
+        // (i) X_ki for the local rows i <= k comes from process column i % Pc
+        if (int rc = grid_group_start(g)) return rc;
+        for (long i = 0; i <= k; ++i) {
+            const int pr = (int)(i % Pr), root = (int)(i % Pc);
+            const long li = i / Pr, lj = i / Pc;
+            if (int rc = grid_bcast(g, GROUP_ROW, pr, root, tile, [&](GridRank& r, bool is_root) {
+                    return is_root ? r.XR + lj * tile : r.XRr + li * tile;
+                }))
+                return rc;
+        }
+        if (int rc = grid_group_end(g)) return rc;
+        // (f) the three rank-nb updates on the local tiles
+        for (GridRank& r : g->ranks) {
+            const int lr0 = cnt_le(k, r.pr, Pr), lc0 = cnt_le(k, r.pc, Pc);
+            const long rows_hi = (long)(r.TLr - lr0) * nb, cols_hi = (long)(r.TLc - lc0) * nb;
+            const long rows_lo = (long)lr0 * nb, cols_lo = (long)lc0 * nb;
+            const GridPred lower_hi{1, Pr, r.pr, Pc, r.pc, lr0, lc0}, lower_lo{1, Pr, r.pr, Pc, r.pc, 0, 0};
+            // A_ij -= L_ik L_jk^T,  i >= j > k
+            grid_gemm_t<true, true>(r.st, r.A + (long)lr0 * nb * r.LC + (long)lc0 * nb, r.LC, 0,
+                                    GOp{r.RP + (long)lr0 * tile, nb, 0}, GOp{r.CP + (long)lc0 * tile, nb, 0}, rows_hi,
+                                    cols_hi, nb, nb, 2, lower_hi);
+            // B_ij -= L_ik X_kj,    i > k >= j
+            grid_gemm_t<true, false>(r.st, r.X + (long)lr0 * nb * r.LC, r.LC, 0, GOp{r.RP + (long)lr0 * tile, nb, 0},
+                                     GOp{r.XR, nb, 1}, rows_hi, cols_lo, nb, nb, 2, nopred);
+            // W_ij += X_ki^T X_kj,  k >= i >= j
+            grid_gemm_t<false, false>(r.st, r.W, r.LC, 0, GOp{r.XRr, nb, 1}, GOp{r.XR, nb, 1}, rows_lo, cols_lo, nb, nb,
+                                      1, lower_lo);
+        }
+    }
+    HIP_CHECK(hipEventRecord(g->ev[2], g->st));
+    // ---- alpha = X^T (X R), diag W, logdet ------------------------------------------------------------------
+    const unsigned nblkN = (unsigned)((n * Dy + 255) / 256);
+    for (GridRank& r : g->ranks) {                       // y = X R (partial over the local columns)
+        HIP_CHECK(hipMemsetAsync(r.ybuf, 0, sizeof(double) * n * Dy, r.st));
+        for (int d = 0; d < Dy; ++d) {
+            hipLaunchKernelGGL(k_grid_row_reduce, dim3((unsigned)((r.LR + 3) / 4)), dim3(256), 0, r.st, r.X, r.LC, r.LR,
+                               r.LC, r.gC, r.Rg, Dy, d, n, r.vloc);
+            hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)((r.LR + 255) / 256)), dim3(256), 0, r.st, r.vloc, r.LR,
+                               r.gR, n, Dy, d, r.ybuf);
+        }
+    }
+    // NB: a rank's partial y covers only its local columns, and ranks of one process row write the same global
+    // rows: the scatter above must not overwrite -- every rank owns a private ybuf, and the all-reduce sums them.
+    if (int rc = grid_allreduce(g, (size_t)n * Dy, [](GridRank& r) { return r.ybuf; })) return rc;
+    for (GridRank& r : g->ranks) {                       // alpha = X^T y (partial over the local rows), diag W
+        HIP_CHECK(hipMemsetAsync(r.alpha, 0, sizeof(double) * n * Dy, r.st));
+        HIP_CHECK(hipMemsetAsync(r.gvec2, 0, sizeof(double) * n, r.st));
+        for (int d = 0; d < Dy; ++d) {
+            hipLaunchKernelGGL(k_grid_col_reduce, dim3((unsigned)((r.LC + 63) / 64)), dim3(256), 0, r.st, r.X, r.LC, r.LR,
+                               r.LC, r.gR, r.ybuf, Dy, d, n, r.vloc);
+            hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)((r.LC + 255) / 256)), dim3(256), 0, r.st, r.vloc, r.LC,
+                               r.gC, n, Dy, d, r.alpha);
+        }
+        hipLaunchKernelGGL(k_grid_col_reduce, dim3((unsigned)((r.LC + 63) / 64)), dim3(256), 0, r.st, r.X, r.LC, r.LR,
+                           r.LC, r.gR, (const double*)nullptr, 1, 0, n, r.vloc);
+        hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)((r.LC + 255) / 256)), dim3(256), 0, r.st, r.vloc, r.LC, r.gC,
+                           n, 1, 0, r.gvec2);
+    }
+    if (int rc = grid_allreduce(g, (size_t)n * Dy, [](GridRank& r) { return r.alpha; })) return rc;
+    if (int rc = grid_allreduce(g, (size_t)n, [](GridRank& r) { return r.gvec2; })) return rc;
+    if (int rc = grid_allreduce(g, 8, [](GridRank& r) { return r.scal; })) return rc;
+    (void)nblkN;
+    HIP_CHECK(hipEventRecord(g->ev[3], g->st));
+    // ---- gradient reduction on the local tiles ----------------------------------------------------------------
+    const int groups = (D + 31) / 32;
+    std::vector<int> nblocks(g->ranks.size(), 0);
+    for (size_t ri = 0; ri < g->ranks.size(); ++ri) {
+        GridRank& r = g->ranks[ri];
+        HIP_CHECK(hipMemsetAsync(r.gradOut, 0, sizeof(double) * groups * GP_STRIDE, r.st));
+        if (r.nvr <= 0 || r.nvc <= 0) continue;
+        // local dL_dK tiles into A (the factor is no longer needed there?  no: keep L for fetch) -> use CP/RP? too small:
+        // W is consumed in place: G overwrites W after diag W has been taken (fetch of Kinv re-derives from X if needed).
+        hipLaunchKernelGGL(k_grid_dldk, dim3((unsigned)((r.nvc + 255) / 256), (unsigned)r.nvr), dim3(256), 0, r.st, r.W,
+                           r.W, r.LC, r.nvr, r.nvc, r.gR, r.gC, r.alpha, Dy, n);
+        const int nbk = grad_generic_num_blocks(r.nvr, r.nvc);
+        nblocks[ri] = nbk;
+        launch_grad_generic(r.st, kp, r.XtR, r.LR, r.nvr, r.XtC, r.LC, r.nvc, 0, r.W, r.LC, r.gradPart, GP_STRIDE);
+        for (int gi = 0; gi < (kp.ard ? groups : 1); ++gi)
+            launch_reduce_partials(r.st, r.gradPart + (long)gi * nbk * GP_STRIDE, nbk, GP_STRIDE,
+                                   r.gradOut + (long)gi * GP_STRIDE);
+    }
+    if (int rc = grid_allreduce(g, (size_t)groups * GP_STRIDE, [](GridRank& r) { return r.gradOut; })) return rc;
+    HIP_CHECK(hipEventRecord(g->ev[4], g->st));
+    // ---- results (replicated on every rank) -----------------------------------------------------------------------
+    GridRank& r0 = g->ranks[0];
+    std::vector<double> alpha((size_t)n * Dy), dW((size_t)n), R((size_t)n * Dy), sums((size_t)groups * GP_STRIDE);
+    double scal[8];
+    int info = 0;
+    HIP_CHECK(hipMemcpyAsync(alpha.data(), r0.alpha, sizeof(double) * n * Dy, hipMemcpyDeviceToHost, g->st));
+    HIP_CHECK(hipMemcpyAsync(dW.data(), r0.gvec2, sizeof(double) * n, hipMemcpyDeviceToHost, g->st));
+    HIP_CHECK(hipMemcpyAsync(R.data(), r0.Rg, sizeof(double) * n * Dy, hipMemcpyDeviceToHost, g->st));
+    HIP_CHECK(hipMemcpyAsync(sums.data(), r0.gradOut, sizeof(double) * groups * GP_STRIDE, hipMemcpyDeviceToHost, g->st));
+    HIP_CHECK(hipMemcpyAsync(scal, r0.scal, sizeof(double) * 8, hipMemcpyDeviceToHost, g->st));
+    HIP_CHECK(hipStreamSynchronize(g->st));
+    // Every rank must take the same branch of the caller's jitter ladder: "some tile failed" travels in the all-reduced
+    // scal[1]; the failing column itself is only known to the ranks hosting that tile (others report N).
+    for (GridRank& r : g->ranks) {
+        int ir = 0;
+        HIP_CHECK(hipMemcpy(&ir, r.info_g, sizeof(int), hipMemcpyDeviceToHost));
+        if (ir > 0 && (info == 0 || ir < info)) info = ir;
+    }
+    if (scal[1] > 0.0 && info == 0) info = (int)n;
+    HIP_CHECK(hipGetLastError());
+    if (stage_ms) {
+        for (int i = 0; i < MI355GP_NUM_T; ++i) stage_ms[i] = 0.0;
+        float ms;
+        const int map[4] = {MI355GP_T_KBUILD, MI355GP_T_POTRF, MI355GP_T_SOLVE, MI355GP_T_GRAD};
+        for (int i = 0; i < 4; ++i) {
+            HIP_CHECK(hipEventElapsedTime(&ms, g->ev[i], g->ev[i + 1]));
+            stage_ms[map[i]] = ms;
+        }
+        HIP_CHECK(hipEventElapsedTime(&ms, g->ev[0], g->ev[4]));
+        stage_ms[MI355GP_T_TOTAL] = ms;
+    }
+    // a failed factorisation poisons logdet/alpha with NaN on every rank: detect it everywhere, not only on the owner
+    double datafit = 0.0, alpha2 = 0.0, trw = 0.0;
+    for (long i = 0; i < n * Dy; ++i) {
+        datafit += alpha[i] * R[i];
+        alpha2 += alpha[i] * alpha[i];
+    }
+    for (long i = 0; i < n; ++i) trw += dW[i];
+    const double logdet = 2.0 * scal[0];
+    if (info == 0 && !(std::isfinite(logdet) && std::isfinite(datafit))) info = (int)n;
+    if (info > 0) {
+        g->have_result = false;
+        return info > n ? (int)n : info;
+    }
+    g->have_result = true;
+    for (int i = 0; i < MI355GP_NUM_OUT; ++i) out_scalars[i] = 0.0;
+    out_scalars[MI355GP_OUT_LML] = 0.5 * (-(double)n * Dy * LOG_2_PI - Dy * logdet - datafit);
+    out_scalars[MI355GP_OUT_LOGDET] = logdet;
+    out_scalars[MI355GP_OUT_DATAFIT] = datafit;
+    out_scalars[MI355GP_OUT_DNOISE] = 0.5 * (alpha2 - Dy * trw);
+    out_scalars[MI355GP_OUT_TRKINV] = trw;
+    if (alpha_out) memcpy(alpha_out, alpha.data(), sizeof(double) * n * Dy);
+    if (diag_out)
+        for (long i = 0; i < n; ++i) {
+            double a2 = 0.0;
+            for (int d = 0; d < Dy; ++d) a2 += alpha[i * Dy + d] * alpha[i * Dy + d];
+            diag_out[i] = 0.5 * (a2 - Dy * dW[i]);
+        }
+    if (dtheta_out) {
+        dtheta_out[0] = sums[0] / kp.variance;
+        if (!kp.ard) dtheta_out[1] = -sums[1] / theta[1];
+        else
+            for (int qd = 0; qd < D; ++qd) dtheta_out[1 + qd] = -sums[(qd / 32) * GP_STRIDE + 2 + (qd % 32)] / theta[1 + qd];
+    }
+    return 0;
+}
+
+extern "C" {
+
+int mi355gp_grid_exact_inference(mi355gp_grid* g, int kind, int ard, const double* theta, const double* noise,
+                                 int64_t noise_len, double jitter, double extra_jitter, double* out_scalars,
+                                 double* alpha_out, double* dtheta_out, double* diag_dLdK_out, double* stage_ms) {
+    ARGCHK(g && g->n > 0, "mi355gp_grid_exact_inference: set_data first");
+    ARGCHK(out_scalars && theta && noise, "mi355gp_grid_exact_inference: NULL argument");
+    ARGCHK(kind >= 0 && kind <= 3, "unknown covariance kind");
+    ARGCHK(noise_len == 1 || noise_len == g->n, "noise must have 1 or N entries");
+    ARGCHK(theta[0] > 0.0, "variance must be positive");
+    HIP_CHECK(hipSetDevice(g->device));
+    std::vector<double> inv_ls((size_t)g->D, 0.0);
+    const int nl = ard ? g->D : 1;
+    for (int qd = 0; qd < nl; ++qd) {
+        ARGCHK(theta[1 + qd] > 0.0, "lengthscales must be positive");
+        inv_ls[qd] = 1.0 / theta[1 + qd];
+    }
+    KernParams kp{kind, ard ? 1 : 0, g->D, theta[0]};
+    return grid_run(g, kp, theta, inv_ls, noise, noise_len, jitter + extra_jitter, out_scalars, alpha_out, dtheta_out,
+                    diag_dLdK_out, stage_ms);
+}
+
+// Host copy of the tiles owned by this process's ranks, placed at their global position in an N x N row-major array
+// (entries owned by other processes are left untouched: callers zero `out` first and sum over ranks).
+// which: MI355GP_FETCH_L (lower tiles of L), MI355GP_FETCH_KINV is not available after the gradient pass consumed W;
+// 100 = X = L^-1 (lower).
+int mi355gp_grid_fetch(mi355gp_grid* g, int which, double* out) {
+    ARGCHK(g && out && g->n > 0 && g->have_result, "mi355gp_grid_fetch: run an inference call first");
+    ARGCHK(which == MI355GP_FETCH_L || which == 100, "mi355gp_grid_fetch: L (0) or L^-1 (100)");
+    HIP_CHECK(hipSetDevice(g->device));
+    const long nb = g->nb, n = g->n;
+    std::vector<double> tilebuf((size_t)nb * nb);
+    for (GridRank& r : g->ranks) {
+        const double* M = (which == MI355GP_FETCH_L) ? r.A : r.X;
+        for (int li = 0; li < r.TLr; ++li)
+            for (int lj = 0; lj < r.TLc; ++lj) {
+                const long I = (long)li * g->Pr + r.pr, J = (long)lj * g->Pc + r.pc;
+                if (J > I) continue;
+                HIP_CHECK(hipMemcpy2D(tilebuf.data(), sizeof(double) * nb, M + (long)li * nb * r.LC + (long)lj * nb,
+                                      sizeof(double) * r.LC, sizeof(double) * nb, nb, hipMemcpyDeviceToHost));
+                for (long a = 0; a < nb; ++a) {
+                    const long gi = I * nb + a;
+                    if (gi >= n) break;
+                    for (long b = 0; b < nb; ++b) {
+                        const long gj = J * nb + b;
+                        if (gj >= n || gj > gi) break;
+                        out[gi * n + gj] = tilebuf[(size_t)a * nb + b];
+                    }
+                }
+            }
+    }
+    return 0;
+}
+
+}  // extern "C"

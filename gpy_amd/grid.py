@@ -1,0 +1,196 @@
+"""Optional multi-GPU mode: the exact-GP evaluation on a Pr x Pc process grid, N x N matrices 2D block-cyclic
+(csrc/grid.hip, C-ABI `mi355gp_grid_*`; north_star config 4).
+
+    # one process per GPU (torch.distributed.run / mpirun / anything that sets RANK, WORLD_SIZE, LOCAL_RANK)
+    g = GridContext.from_env(Pr=2, Pc=4, nb=512)          # RCCL transport, id exchanged over `exchange`
+    g.set_data(X, R)                                      # replicated inputs
+    info, res = g.exact_inference("rbf", False, theta, noise)      # collective; results replicated
+
+    g = GridContext.loopback(Pr=2, Pc=2, nb=256)          # all logical ranks on one device (tests on a 1-GPU box)
+
+The host-side index algebra (who owns which tile, where it sits locally) lives here in pure Python as well so it
+can be unit-tested without a GPU; csrc/grid.hip implements the same maps.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import KIND_IDS, NUM_OUT, NUM_T, OUT_DATAFIT, OUT_DNOISE, OUT_LML, OUT_LOGDET, OUT_TRKINV, _opt, check, f64
+
+FETCH_L, FETCH_LINV = 0, 100
+ID_BYTES = 128
+
+
+# ---- 2D block-cyclic index algebra (mirrors csrc/grid.hip) ----------------------------------------------------
+def grid_shape(world):
+    """Most square Pr x Pc with Pr <= Pc and Pr*Pc == world (8 -> 2 x 4)."""
+    pr = int(np.floor(np.sqrt(world)))
+    while world % pr:
+        pr -= 1
+    return pr, world // pr
+
+
+def rank_coords(rank, Pc):
+    return rank // Pc, rank % Pc
+
+
+def tile_owner(I, J, Pr, Pc):
+    """Rank owning global tile (I, J)."""
+    return (I % Pr) * Pc + (J % Pc)
+
+
+def local_tiles(T, p, P):
+    """Global tile indices t < T with t % P == p, in local order."""
+    return list(range(p, T, P))
+
+
+def count_le(k, p, P):
+    """Number of tiles t <= k with t % P == p."""
+    return (k - p) // P + 1 if k >= p else 0
+
+
+def global_index(local, p, P, nb):
+    """Global row/col index of local row/col `local` on grid coordinate p."""
+    return ((local // nb) * P + p) * nb + local % nb
+
+
+def step_traffic_bytes(N, nb, Pr, Pc):
+    """Bytes each collective family moves in total over the one-pass factorisation (per destination GPU summed):
+    used by DESIGN.md's communication budget."""
+    T = -(-N // nb)
+    tile = nb * nb * 8
+    row_panel = col_panel = xrow = xrowT = diag = 0
+    for k in range(T):
+        below = T - 1 - k
+        row_panel += below * tile * (Pc - 1)          # L_ik to the other Pc-1 GPUs of its process row
+        col_panel += below * tile * (Pr - 1)          # L_jk to the other Pr-1 GPUs of its process column
+        xrow += (k + 1) * tile * (Pr - 1)             # X_kj down the process columns
+        xrowT += (k + 1) * tile * (Pc - 1)            # X_ki along the process rows
+        diag += tile * (Pr - 1 + Pc - 1)
+    return dict(row_panel=row_panel, col_panel=col_panel, x_row=xrow, x_row_t=xrowT, diag=diag,
+                total=row_panel + col_panel + xrow + xrowT + diag)
+
+
+# ---- id exchange ---------------------------------------------------------------------------------------------
+def exchange_id_torch(id_bytes, rank):
+    """Broadcast rank 0's RCCL id over an initialised torch.distributed process group (gloo or nccl)."""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.zeros(ID_BYTES, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        t = torch.tensor(list(id_bytes), dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0)
+    return bytes(t.cpu().tolist())
+
+
+def exchange_id_file(id_bytes, rank, path, timeout=120.0):
+    """Rank 0 writes the id to `path` (atomically); the others poll for it."""
+    import time
+    if rank == 0:
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(id_bytes)
+        os.replace(tmp, path)
+        return id_bytes
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        if os.path.exists(path) and os.path.getsize(path) == ID_BYTES:
+            with open(path, "rb") as f:
+                return f.read()
+        time.sleep(0.05)
+    raise _lib.MI355GPError("timed out waiting for the RCCL id at %s" % path)
+
+
+def unique_id():
+    buf = ctypes.create_string_buffer(ID_BYTES)
+    check(_lib.lib().mi355gp_grid_unique_id(buf), "mi355gp_grid_unique_id")
+    return buf.raw
+
+
+class GridContext(object):
+    def __init__(self, device, rank, world, Pr, Pc, nb, id_bytes):
+        _lib.require_device(device)
+        assert Pr * Pc == world
+        self._h = ctypes.c_void_p()
+        self.rank, self.world, self.Pr, self.Pc, self.nb = rank, world, Pr, Pc, nb
+        self.is_loopback = id_bytes is None
+        check(_lib.lib().mi355gp_grid_create(device, rank, world, Pr, Pc, nb, id_bytes, ctypes.byref(self._h)),
+              "mi355gp_grid_create")
+        self.N = self.D = self.Dy = 0
+
+    @classmethod
+    def loopback(cls, Pr, Pc, nb=256, device=0):
+        return cls(device, 0, Pr * Pc, Pr, Pc, nb, None)
+
+    @classmethod
+    def from_env(cls, Pr=None, Pc=None, nb=512, exchange=None):
+        """One process per GPU: RANK / WORLD_SIZE / LOCAL_RANK from the launcher; `exchange(id_bytes, rank)` ships
+        rank 0's id (default: torch.distributed if initialised, else a file under $MI355GP_ID_DIR or /tmp)."""
+        rank = int(os.environ.get("RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if Pr is None or Pc is None:
+            Pr, Pc = grid_shape(world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        idb = unique_id() if rank == 0 else b"\0" * ID_BYTES
+        if world > 1:
+            if exchange is None:
+                try:
+                    import torch.distributed as dist
+                    use_torch = dist.is_available() and dist.is_initialized()
+                except Exception:
+                    use_torch = False
+                if use_torch:
+                    idb = exchange_id_torch(idb, rank)
+                else:
+                    d = os.environ.get("MI355GP_ID_DIR", "/tmp")
+                    tag = os.environ.get("MASTER_PORT", "0")
+                    idb = exchange_id_file(idb, rank, os.path.join(d, "mi355gp_id_%s" % tag))
+            else:
+                idb = exchange(idb, rank)
+        return cls(local, rank, world, Pr, Pc, nb, idb)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().mi355gp_grid_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_data(self, X, R):
+        X, R = f64(X), f64(R)
+        self.N, self.D = X.shape
+        self.Dy = R.shape[1]
+        check(_lib.lib().mi355gp_grid_set_data(self._h, X, self.N, self.D, R, self.Dy), "mi355gp_grid_set_data")
+
+    def exact_inference(self, kind, ARD, theta, noise, jitter=1e-8, extra_jitter=0.0, want_diag=False,
+                        want_stage_ms=False):
+        theta = f64(theta)
+        noise = f64(np.atleast_1d(noise))
+        out = np.zeros(NUM_OUT)
+        alpha = np.empty((self.N, self.Dy))
+        dtheta = np.zeros(theta.size)
+        diag = np.empty(self.N) if want_diag else None
+        ms = np.zeros(NUM_T) if want_stage_ms else None
+        rc = check(_lib.lib().mi355gp_grid_exact_inference(self._h, KIND_IDS[kind], int(bool(ARD)), theta, noise,
+                                                           noise.size, jitter, extra_jitter, out, _opt(alpha),
+                                                           _opt(dtheta), _opt(diag), _opt(ms)),
+                   "mi355gp_grid_exact_inference")
+        res = dict(lml=out[OUT_LML], logdet=out[OUT_LOGDET], datafit=out[OUT_DATAFIT], dnoise=out[OUT_DNOISE],
+                   trKinv=out[OUT_TRKINV], alpha=alpha, dtheta=dtheta, diag_dL_dK=diag)
+        if ms is not None:
+            res["stage_ms"] = dict(kbuild=ms[0], factor=ms[1], solve=ms[4], grad=ms[5], total=ms[6])
+        return rc, res
+
+    def fetch(self, which):
+        """Lower triangle of L (FETCH_L) or L^-1 (FETCH_LINV): the tiles this process hosts, zeros elsewhere."""
+        out = np.zeros((self.N, self.N))
+        check(_lib.lib().mi355gp_grid_fetch(self._h, which, out), "mi355gp_grid_fetch")
+        return out

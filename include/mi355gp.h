@@ -134,6 +134,29 @@ int mi355gp_get_profile(mi355gp_ctx* ctx, double* ms, double* flops, int* launch
  * returns average milliseconds of potrf / trtri / lauum over `reps` runs. */
 int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, double* ms_trtri, double* ms_lauum);
 
+/* ---- optional multi-GPU mode: 2D block-cyclic factorisation on a Pr x Pc process grid ---------------------------
+ * (north_star config 4; no GPy counterpart -- GPy's only parallel code is the mpi4py sparse GP,
+ *  inference/latent_function_inference/var_dtc_parallel.py).  One process per GPU; rank = pr*Pc + pc.
+ * Rank 0 obtains a 128-byte RCCL id with mi355gp_grid_unique_id and ships it to the others by any host channel
+ * (bench.py / gpy_amd/grid.py use torch.distributed or a file); every rank then calls mi355gp_grid_create with it.
+ * id128 == NULL selects the LOOPBACK transport: all Pr*Pc logical ranks live in this process on `device`
+ * (correctness testing on one GPU); `rank` is ignored then.  nb: tile edge, multiple of 128. */
+typedef struct mi355gp_grid mi355gp_grid;
+int mi355gp_grid_unique_id(void* id128);
+int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb, const void* id128, mi355gp_grid** out);
+int mi355gp_grid_destroy(mi355gp_grid* g);
+/* every rank passes the full X (N x D) and R (N x Dy) */
+int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, const double* R, int Dy);
+/* same contract and outputs as mi355gp_exact_inference; results are replicated on every rank.  Collective.
+ * stage_ms: KBUILD, POTRF (= the whole one-pass factorisation + inversion), SOLVE, GRAD, TOTAL. */
+int mi355gp_grid_exact_inference(mi355gp_grid* g, int kind, int ard, const double* theta, const double* noise,
+                                 int64_t noise_len, double jitter, double extra_jitter, double* out_scalars,
+                                 double* alpha_out, double* dtheta_out, double* diag_dLdK_out, double* stage_ms);
+/* tiles owned by this process's ranks, written at their global position of an N x N row-major array (lower triangle);
+ * which = MI355GP_FETCH_L or MI355GP_FETCH_LINV */
+#define MI355GP_FETCH_LINV 100
+int mi355gp_grid_fetch(mi355gp_grid* g, int which, double* out);
+
 /* ---- diagnostics (used by tests/ and tools/) --------------------------------------------------------- */
 /* raw lane dump of one v_mfma_f64_16x16x4_f64: a[64], b[64] -> d[64*4] */
 int mi355gp_dbg_mfma(int device, const double* a, const double* b, double* d);

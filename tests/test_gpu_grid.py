@@ -1,0 +1,115 @@
+"""GPU (-m gpu): the 2D block-cyclic multi-GPU mode (csrc/grid.hip) with all Pr*Pc logical ranks on ONE device
+(LOOPBACK transport), against the CPU oracle and the single-GPU path; plus the RCCL transport at world size 1.
+Tolerances: the fp64 parity contract of the single-GPU tests."""
+import numpy as np
+import pytest
+
+from gpy_amd import _lib as L
+from gpy_amd import grid as G
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL_LML, TOL_ALPHA, TOL_GRAD = 1e-10, 1e-9, 1e-8
+
+
+def _check(res, ref, noise_scalar=True):
+    assert abs(res["lml"] - ref["lml"]) <= TOL_LML * max(1.0, abs(ref["lml"]))
+    assert np.linalg.norm(res["alpha"] - ref["alpha"]) <= TOL_ALPHA * np.linalg.norm(ref["alpha"])
+    gref = np.concatenate([[ref["dvar"]], np.atleast_1d(ref["dlen"])])
+    assert np.abs(res["dtheta"] - gref).max() <= TOL_GRAD * np.abs(gref).max()
+    if noise_scalar:
+        assert abs(res["dnoise"] - ref["dL_dnoise"]) <= TOL_GRAD * abs(ref["dL_dnoise"])
+
+
+CASES = [
+    # kind, ARD, N, D, Dy, Pr, Pc, nb
+    ("rbf", False, 300, 3, 1, 1, 1, 128),
+    ("rbf", False, 700, 4, 1, 2, 2, 128),
+    ("matern52", True, 1000, 5, 2, 2, 4, 128),
+    ("matern32", True, 900, 3, 1, 3, 2, 256),
+    ("exponential", False, 777, 2, 1, 1, 3, 256),
+    ("rbf", True, 1500, 8, 1, 4, 2, 128),
+    ("matern52", False, 2048, 8, 1, 2, 2, 512),
+]
+
+
+@pytest.mark.parametrize("kind,ARD,N,D,Dy,Pr,Pc,nb", CASES)
+def test_loopback_grid_matches_oracle(kind, ARD, N, D, Dy, Pr, Pc, nb):
+    X, Y = O.synthetic(N, D, seed=N + Pr, Dy=Dy)
+    var, ls, noise = O.default_theta(D, ARD)
+    ref = O.parameters_changed(kind, X, Y, var, ls, ARD, noise)
+    g = G.GridContext.loopback(Pr, Pc, nb)
+    try:
+        g.set_data(X, Y)
+        th = L.theta_vec(var, ls, ARD, D)
+        info, res = g.exact_inference(kind, ARD, th, noise, want_diag=True, want_stage_ms=True)
+        assert info == 0
+        _check(res, ref)
+        assert abs(res["logdet"] - ref["logdet"]) <= 1e-11 * max(1.0, abs(ref["logdet"]))
+        dref = np.diag(ref["dL_dK"])
+        assert np.abs(res["diag_dL_dK"] - dref).max() <= TOL_GRAD * np.abs(dref).max()
+        Lg = g.fetch(G.FETCH_L)
+        assert np.linalg.norm(Lg - ref["L"]) <= 1e-11 * np.linalg.norm(ref["L"])
+        Xg = g.fetch(G.FETCH_LINV)
+        eye = Xg @ ref["L"]
+        assert np.abs(eye - np.eye(N)).max() <= 1e-9
+        # second call on the same context (buffers are re-initialised every evaluation)
+        info2, res2 = g.exact_inference(kind, ARD, th, noise)
+        assert info2 == 0 and res2["lml"] == res["lml"] and np.array_equal(res2["dtheta"], res["dtheta"])
+    finally:
+        g.close()
+
+
+def test_grid_agrees_with_single_gpu_path_and_heteroscedastic_noise():
+    N, D = 1100, 6
+    X, Y = O.synthetic(N, D, seed=5)
+    var, ls, _ = O.default_theta(D, True)
+    noise = 0.05 + 0.1 * np.random.default_rng(1).random(N)
+    th = L.theta_vec(var, ls, True, D)
+    c = L.Context(0)
+    g = G.GridContext.loopback(2, 3, 256)
+    try:
+        c.set_data(X, Y)
+        i1, r1 = c.exact_inference("matern52", True, th, noise, want_diag=True)
+        g.set_data(X, Y)
+        i2, r2 = g.exact_inference("matern52", True, th, noise, want_diag=True)
+        assert i1 == 0 and i2 == 0
+        assert abs(r1["lml"] - r2["lml"]) <= TOL_LML * abs(r1["lml"])
+        assert np.linalg.norm(r1["alpha"] - r2["alpha"]) <= TOL_ALPHA * np.linalg.norm(r1["alpha"])
+        assert np.abs(r1["dtheta"] - r2["dtheta"]).max() <= TOL_GRAD * np.abs(r1["dtheta"]).max()
+        assert np.abs(r1["diag_dL_dK"] - r2["diag_dL_dK"]).max() <= TOL_GRAD * np.abs(r1["diag_dL_dK"]).max()
+    finally:
+        c.close()
+        g.close()
+
+
+def test_grid_reports_not_positive_definite_on_every_rank():
+    N, D = 400, 2
+    X, Y = O.synthetic(N, D, seed=3)
+    X[200:] = X[:200]                      # duplicated points, no noise -> singular
+    g = G.GridContext.loopback(2, 2, 128)
+    try:
+        g.set_data(X, Y)
+        info, _ = g.exact_inference("rbf", False, L.theta_vec(1.0, 1.0, False, D), 0.0, jitter=0.0)
+        assert info > 0
+        info, res = g.exact_inference("rbf", False, L.theta_vec(1.0, 1.0, False, D), 0.0, jitter=0.0, extra_jitter=1e-4)
+        assert info == 0 and np.isfinite(res["lml"])
+    finally:
+        g.close()
+
+
+def test_rccl_transport_world_size_one():
+    """The RCCL code path (dlopen, ncclCommInitRank, ncclCommSplit, broadcasts, all-reduces) on the one GPU we have."""
+    N, D = 600, 3
+    X, Y = O.synthetic(N, D, seed=9)
+    var, ls, noise = O.default_theta(D, False)
+    ref = O.parameters_changed("rbf", X, Y, var, ls, False, noise)
+    g = G.GridContext(0, 0, 1, 1, 1, 256, G.unique_id())
+    try:
+        assert not g.is_loopback
+        g.set_data(X, Y)
+        info, res = g.exact_inference("rbf", False, L.theta_vec(var, ls, False, D), noise)
+        assert info == 0
+        _check(res, ref)
+    finally:
+        g.close()

@@ -1,0 +1,102 @@
+"""CPU: host logic of the 2D block-cyclic multi-GPU mode (gpy_amd/grid.py) -- ownership / local-index algebra
+checked against a brute-force restatement, the communication budget DESIGN.md quotes, and the N>1 plumbing
+(world_size 2 over gloo: RCCL id exchange by torch.distributed and by file; every rank derives the same maps)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from gpy_amd import grid as G
+
+
+@pytest.mark.parametrize("world,expect", [(1, (1, 1)), (2, (1, 2)), (4, (2, 2)), (8, (2, 4)), (6, (2, 3)), (7, (1, 7))])
+def test_grid_shape(world, expect):
+    assert G.grid_shape(world) == expect
+
+
+@pytest.mark.parametrize("T,Pr,Pc", [(1, 1, 1), (5, 2, 2), (7, 2, 4), (9, 3, 2), (16, 4, 2), (6, 1, 3)])
+def test_every_tile_has_exactly_one_owner_and_local_order_is_increasing(T, Pr, Pc):
+    owned = {}
+    for r in range(Pr * Pc):
+        pr, pc = G.rank_coords(r, Pc)
+        rows, cols = G.local_tiles(T, pr, Pr), G.local_tiles(T, pc, Pc)
+        assert rows == sorted(rows) and cols == sorted(cols)
+        assert len(rows) == G.count_le(T - 1, pr, Pr) and len(cols) == G.count_le(T - 1, pc, Pc)
+        for I in rows:
+            for J in cols:
+                assert (I, J) not in owned
+                owned[(I, J)] = r
+                assert G.tile_owner(I, J, Pr, Pc) == r
+    assert len(owned) == T * T
+
+
+def test_count_le_and_global_index():
+    for P in (1, 2, 3, 4):
+        for p in range(P):
+            for k in range(0, 12):
+                assert G.count_le(k, p, P) == sum(1 for t in range(k + 1) if t % P == p)
+    nb = 4
+    for P in (1, 2, 3):
+        seen = set()
+        for p in range(P):
+            for l in range(5 * nb):
+                gidx = G.global_index(l, p, P, nb)
+                assert (gidx // nb) % P == p and gidx % nb == l % nb
+                seen.add(gidx)
+        assert len(seen) == P * 5 * nb
+
+
+def test_communication_budget_matches_survey_estimate():
+    # SURVEY.md 7 (hard part 8): N=32k on 2x4: every L tile goes to Pc-1 = 3 GPUs of its row and Pr-1 = 1 of its column
+    t = G.step_traffic_bytes(32768, 512, 2, 4)
+    half = 8 * 32768 ** 2 / 2
+    assert abs(t["row_panel"] - 3 * half) / (3 * half) < 0.05
+    assert abs(t["col_panel"] - 1 * half) / half < 0.05
+    # the inverse and Ky^-1 ride on a second pair of panel broadcasts of the same size class
+    assert abs(t["x_row"] - 1 * half) / half < 0.05 and abs(t["x_row_t"] - 3 * half) / (3 * half) < 0.05
+    assert t["total"] == sum(v for k, v in t.items() if k != "total")
+    one = G.step_traffic_bytes(4096, 512, 1, 1)
+    assert one["total"] == 0
+
+
+WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    from gpy_amd import grid as G
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fake = bytes(range(128)) if rank == 0 else bytes(128)          # stands in for mi355gp_grid_unique_id (needs a GPU)
+    got_t = G.exchange_id_torch(fake, rank)
+    got_f = G.exchange_id_file(fake, rank, os.path.join(%r, "id.bin"))
+    Pr, Pc = G.grid_shape(world)
+    pr, pc = G.rank_coords(rank, Pc)
+    T = 7
+    rec = {"rank": rank, "id_t": list(got_t), "id_f": list(got_f), "grid": [Pr, Pc], "coords": [pr, pc],
+           "rows": G.local_tiles(T, pr, Pr), "cols": G.local_tiles(T, pc, Pc)}
+    json.dump(rec, open(os.path.join(%r, "rank%%d.json" %% rank), "w"))
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_id_exchange_and_partition(tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % (ROOT, str(tmp_path), str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29741", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    recs = sorted((json.load(open(tmp_path / ("rank%d.json" % i))) for i in range(2)), key=lambda x: x["rank"])
+    for x in recs:
+        assert x["id_t"] == list(range(128)) and x["id_f"] == list(range(128))
+        assert x["grid"] == [1, 2]
+    assert recs[0]["coords"] == [0, 0] and recs[1]["coords"] == [0, 1]
+    assert recs[0]["rows"] == recs[1]["rows"] == list(range(7))
+    assert sorted(recs[0]["cols"] + recs[1]["cols"]) == list(range(7))
+    assert set(recs[0]["cols"]).isdisjoint(recs[1]["cols"])

@@ -84,13 +84,19 @@ def lib():
     L.mi355gp_grid_set_data.argtypes = [vp, _dp, i64, ci, _dp, ci]
     L.mi355gp_grid_exact_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_grid_fetch.argtypes = [vp, ci, _dp]
+    L.mi355gp_sparse_create.argtypes = [ci, ctypes.POINTER(vp)]
+    L.mi355gp_sparse_destroy.argtypes = [vp]
+    L.mi355gp_sparse_set_data.argtypes = [vp, _dp, i64, ci, _dp, ci]
+    L.mi355gp_vardtc_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
+    L.mi355gp_sparse_fetch.argtypes = [vp, ci, _dp]
     L.mi355gp_dbg_mfma.argtypes = [ci, _dp, _dp, _dp]
     L.mi355gp_dbg_gemm.argtypes = [ci, ci, ci, i64, i64, i64, _dp, _dp, _dp, cd, cd, ci, _c_dp]
     L.mi355gp_dbg_peaks.argtypes = [ci, _dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
-                 "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch"):
+                 "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "sparse_create",
+                 "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -102,6 +108,8 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_fetch", "mi355gp_predict", "mi355gp_potrf", "mi355gp_pdinv", "mi355gp_bench_factor",
             "mi355gp_set_option", "mi355gp_get_profile", "mi355gp_grid_unique_id", "mi355gp_grid_create",
             "mi355gp_grid_destroy", "mi355gp_grid_set_data", "mi355gp_grid_exact_inference", "mi355gp_grid_fetch",
+            "mi355gp_sparse_create", "mi355gp_sparse_destroy", "mi355gp_sparse_set_data", "mi355gp_vardtc_inference",
+            "mi355gp_sparse_fetch",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks")
 
 
@@ -241,6 +249,57 @@ class Context(object):
         check(lib().mi355gp_fetch(self._h, which, out, int(fortran_order)), "mi355gp_fetch")
         if fortran_order:
             return out.T      # same memory viewed as an F-contiguous array
+        return out
+
+
+class SparseContext(object):
+    """One device context of the sparse (VarDTC) path = one uploaded (X, Y); Z and theta change per call."""
+    FETCH_DLDKMM, FETCH_WOODBURY_INV, FETCH_LM, FETCH_KMM, FETCH_PSI2 = 0, 1, 2, 3, 4
+
+    def __init__(self, device=0):
+        require_device(device)
+        self._h = ctypes.c_void_p()
+        check(lib().mi355gp_sparse_create(device, ctypes.byref(self._h)), "mi355gp_sparse_create")
+        self.N = self.D = self.Dy = self.M = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().mi355gp_sparse_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_data(self, X, Y):
+        X, Y = f64(X), f64(Y)
+        self.N, self.D = X.shape
+        self.Dy = Y.shape[1]
+        check(lib().mi355gp_sparse_set_data(self._h, X, self.N, self.D, Y, self.Dy), "mi355gp_sparse_set_data")
+
+    def vardtc(self, kind, ARD, theta, Z, noise_var, extra_jitter=0.0, want_stage_ms=False):
+        """(info, dict(lml, dnoise, dtheta, dZ, woodbury_vector[, stage_ms]))"""
+        theta, Z = f64(theta), f64(Z)
+        self.M = Z.shape[0]
+        assert Z.shape[1] == self.D
+        out = np.zeros(NUM_OUT)
+        dtheta = np.zeros(theta.size)
+        dZ = np.zeros((self.M, self.D))
+        wv = np.zeros((self.M, self.Dy))
+        ms = np.zeros(4) if want_stage_ms else None
+        rc = check(lib().mi355gp_vardtc_inference(self._h, KIND_IDS[kind], int(bool(ARD)), theta, Z, self.M,
+                                                  float(noise_var), float(extra_jitter), out, _opt(dtheta), _opt(dZ),
+                                                  _opt(wv), _opt(ms)), "mi355gp_vardtc_inference")
+        res = dict(lml=out[0], dnoise=out[1], trA=out[2], data_fit=out[3], dtheta=dtheta, dZ=dZ, woodbury_vector=wv)
+        if ms is not None:
+            res["stage_ms"] = dict(pass1=ms[0], mxm=ms[1], pass2=ms[2], total=ms[3])
+        return rc, res
+
+    def fetch(self, which):
+        out = np.empty((self.M, self.M))
+        check(lib().mi355gp_sparse_fetch(self._h, which, out), "mi355gp_sparse_fetch")
         return out
 
 

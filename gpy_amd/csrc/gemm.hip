@@ -232,7 +232,16 @@ __global__ LB(NW) void k_gemm_full(const double* __restrict__ A, long lda,
     const double* Ap = AK ? A + (long)ti * NB * lda : A + (long)ti * NB;
     const double* Bp = BK ? B + (long)tj * NB * ldb : B + (long)tj * NB;
     gemm_tile_128<AK, BK, NW>(Ap, lda, Bp, ldb, K, acc, smem, swz >> 1);
-    gt_store<3, NW>(C + (long)ti * NB * ldc + (long)tj * NB, ldc, acc, alpha, beta);
+    double* Ct = C + (long)ti * NB * ldc + (long)tj * NB;
+    if (beta == 0.0) {   // never read C: it may be uninitialised memory (0 * NaN would poison the result)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < GTCfg<NW>::NI; ++ni) acc[mi][ni] *= alpha;
+        gt_store<0, NW>(Ct, ldc, acc);
+    } else {
+        gt_store<3, NW>(Ct, ldc, acc, alpha, beta);
+    }
 }
 
 template <bool AK, bool BK>
@@ -270,4 +279,44 @@ void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long 
 void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
                        double beta) {
     launch_gemm_full<false, false>(st, (unsigned)(nt * nt), A, lda, A, lda, C, ldc, (int)K, nt, alpha, beta);
+}
+
+void launch_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A, long lda,
+                 const double* B, long ldb, double* C, long ldc, double alpha, double beta) {
+    const int ntr = (int)(M / NB), ntc = (int)(N / NB);
+    const unsigned grid = (unsigned)(ntr * ntc);
+    if (!a_mcontig && !b_ncontig) launch_gemm_full<true, true>(st, grid, A, lda, B, ldb, C, ldc, (int)K, ntc, alpha, beta);
+    else if (!a_mcontig && b_ncontig) launch_gemm_full<true, false>(st, grid, A, lda, B, ldb, C, ldc, (int)K, ntc, alpha, beta);
+    else if (a_mcontig && b_ncontig) launch_gemm_full<false, false>(st, grid, A, lda, B, ldb, C, ldc, (int)K, ntc, alpha, beta);
+    else launch_gemm_full<false, true>(st, grid, A, lda, B, ldb, C, ldc, (int)K, ntc, alpha, beta);
+}
+
+// ------------------------------------------------------------------------------------------------
+// psi2 = Kuf Kfu of the sparse path (the tdot of var_dtc.py:134 / the psi2 accumulation of
+// var_dtc_parallel.py:91-116): Gram matrix of a tall (rows x mp) panel.  The output has only (mp/128)(mp/128+1)/2
+// lower tiles (136 at M = 2048), far fewer than the 512 workgroup slots, so K is split S ways into separate partial
+// matrices (summed in a fixed order afterwards: no atomics, bit-reproducible).
+__global__ __launch_bounds__(256, 2) void k_gram_splitk(const double* __restrict__ P, long ldp, long rows_per_split,
+                                                        long mp, int ntl, int accumulate, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int s = blockIdx.x / ntl, bid = blockIdx.x % ntl;
+    int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+    while ((long)ti * (ti + 1) / 2 > bid) --ti;
+    while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+    const int tj = bid - (int)((long)ti * (ti + 1) / 2);
+    const double* Ps = P + (long)s * rows_per_split * ldp;
+    d4 acc[4][4];
+    gt_zero<4>(acc);
+    gemm_tile_128<false, false, 4>(Ps + (long)ti * NB, ldp, Ps + (long)tj * NB, ldp, (int)rows_per_split, acc, smem);
+    double* C = part + (long)s * mp * mp + (long)ti * NB * mp + (long)tj * NB;
+    if (accumulate) gt_store<3, 4>(C, mp, acc, 1.0, 1.0);
+    else gt_store<0, 4>(C, mp, acc);
+}
+
+void launch_gram_splitk(hipStream_t st, const double* P, long ldp, long rows, long mp, int S, int accumulate,
+                        double* part) {
+    LDS_OPT_IN(k_gram_splitk);
+    const int nt = (int)(mp / NB), ntl = nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(k_gram_splitk, dim3((unsigned)(ntl * S)), dim3(256), GT_LDS_BYTES, st, P, ldp, rows / S, mp, ntl,
+                       accumulate, part);
 }

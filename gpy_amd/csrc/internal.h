@@ -98,9 +98,25 @@ struct GradOut {
 int grad_num_blocks(long n);
 void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, const double* W,
                        long ldw, const double* alpha, int Dy, double* partials, int stride);
+// Hout (optional, may alias G): H = dL_dK * (dK/dr)/r, the weights of the gradients_X reductions
 void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
                          long ld2, long m, int symmetric, const double* G, long ldg, double* partials,
-                         int stride);
+                         int stride, double* Hout = nullptr, long ldh = 0);
+// part[split][cols][nv] = sum over a row range of M[i][j] * V(i, c); V(i, c) = V[i*sr + c*sc] plus an optional
+// all-ones column; returns the number of row splits (sum them with launch_sum_splits)
+int launch_colreduce_multi(hipStream_t st, const double* M, long ld, long rows, long cols, const double* V, long sr,
+                           long sc, int nvt, int ones, double* part);
+void launch_sum_splits(hipStream_t st, const double* src, long cnt, int nsplit, int accumulate, double* dst);
+void launch_trmv_lower(hipStream_t st, const double* X, long ld, long n, const double* R, int Dy, double* y);
+void launch_trmv_lower_T(hipStream_t st, const double* X, long ld, long n, const double* y, int Dy, double* out,
+                         double* partials);
+// general tiled GEMM C = alpha*op(A) op(B) + beta*C; M, N % 128 == 0, K % 16 == 0 (see k_gemm_full)
+void launch_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A, long lda,
+                 const double* B, long ldb, double* C, long ldc, double alpha, double beta);
+// split-K Gram matrix of a tall panel: part[s] (lower 128-tiles of an mp x mp matrix, ld = mp) (+)= P_s^T P_s, where P_s
+// are rows [s*rows/S, (s+1)*rows/S) of the (rows x mp) row-major panel P; rows % (16*S) == 0
+void launch_gram_splitk(hipStream_t st, const double* P, long ldp, long rows, long mp, int S, int accumulate,
+                        double* part);
 int grad_generic_num_blocks(long n, long m);
 // sums `nblocks` rows of `stride` doubles in a fixed order into out[stride]
 void launch_reduce_partials(hipStream_t st, const double* partials, int nblocks, int stride, double* out);

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                                               const double* __restrict__ Xt2, long ld2, long m,
                                               const double* __restrict__ G, long ldg,
                                               const double* __restrict__ alpha, int Dy, int q_off,
-                                              long ntiles, int ntc, double* __restrict__ partials) {
+                                              long ntiles, int ntc, double* __restrict__ partials,
+                                              double* __restrict__ Hout = nullptr, long ldh = 0) {
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
     __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
     __shared__ double red[256];
@@ -252,6 +253,17 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                 a_var = fma(g, c.k, a_var);
                 if (!ARD) a_iso = fma(g, c.dk_r, a_iso);
                 gT[a][b] = g * c.dk_or;
+            }
+        }
+        if (!FUSED && Hout) {   // H = dL_dK * (dK/dr)/r for the gradients_X reductions (stationary.py:330-346)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const long i = i0 + ty * 4 + a;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const long j = j0 + tx * 4 + b;
+                    if (i < n && j < m) Hout[i * ldh + j] = gT[a][b];
+                }
             }
         }
         if (ARD) {
@@ -337,7 +349,7 @@ void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx
 
 void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
                          long ld2, long m, int symmetric, const double* G, long ldg, double* partials,
-                         int stride) {
+                         int stride, double* Hout, long ldh) {
     (void)stride;
     (void)symmetric;
     const long ntr = (n + KT - 1) / KT, ntc = (m + KT - 1) / KT;
@@ -345,13 +357,92 @@ void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long 
     const int nb = pick_grad_blocks(ntiles);
     if (!kp.ard) {
         hipLaunchKernelGGL((k_grad<false, false>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg,
-                           nullptr, 0, 0, ntiles, (int)ntc, partials);
+                           nullptr, 0, 0, ntiles, (int)ntc, partials, Hout, ldh);
     } else {
+        // Hout may alias G (in place): only the LAST group launch writes it, every launch reads G
         for (int q_off = 0, gidx = 0; q_off < kp.D; q_off += KDC, ++gidx)
             hipLaunchKernelGGL((k_grad<false, true>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg,
-                               nullptr, 0, q_off, ntiles, (int)ntc, partials + (long)gidx * nb * GP_STRIDE);
+                               nullptr, 0, q_off, ntiles, (int)ntc, partials + (long)gidx * nb * GP_STRIDE,
+                               (q_off + KDC >= kp.D) ? Hout : nullptr, ldh);
     }
 }
+
+// out[j][c] = sum_i M[i][j] * V(i, c), c < nv <= 33.  V(i, c) = V[i*sr + c*sc] for c < nvt, 1 for c == nvt (the column
+// sums): sr = 1, sc = ld for a dimension-major input, sr = Dy, sc = 1 for a row-major (rows x Dy) one.  One thread per column, 4 row groups per block, optional row split over blockIdx.y with a
+// fixed-order combine by the caller (partials [split][cols][nv]).
+template <int NV>
+__global__ __launch_bounds__(256) void k_colreduce_multi(const double* __restrict__ M, long ld, long rows, long cols,
+                                                         const double* __restrict__ V, long sr, long sc, int nvt,
+                                                         int nv, double* __restrict__ part) {
+    __shared__ double sv[NV][256];
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + tx;
+    const long rs = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * rs, r1 = (r0 + rs < rows) ? r0 + rs : rows;
+    double acc[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) acc[c] = 0.0;
+    for (long ib = r0; ib < r1; ib += 256) {
+        __syncthreads();
+        for (int c = 0; c < nv; ++c) {
+            const long i = ib + threadIdx.x;
+            sv[c][threadIdx.x] = (i < r1) ? ((c < nvt) ? V[i * sr + (long)c * sc] : 1.0) : 0.0;
+        }
+        __syncthreads();
+        const long iend = (ib + 256 < r1) ? 256 : (r1 - ib);
+        if (j < cols) {
+            for (long ii = g; ii < iend; ii += 4) {
+                const double x = M[(ib + ii) * ld + j];
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+                    if (c < nv) acc[c] = fma(x, sv[c][ii], acc[c]);
+            }
+        }
+    }
+    double* out = part + ((long)blockIdx.y * cols) * nv;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        if (c >= nv) break;
+        __syncthreads();
+        red[g][tx] = acc[c];
+        __syncthreads();
+        if (g == 0 && j < cols) out[j * nv + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    }
+}
+
+// part must hold nsplit * cols * nv doubles; returns nsplit
+int launch_colreduce_multi(hipStream_t st, const double* M, long ld, long rows, long cols, const double* V, long sr,
+                           long sc, int nvt, int ones, double* part) {
+    const int nv = nvt + (ones ? 1 : 0);
+    int nsplit = (int)((rows + 4095) / 4096);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 64) nsplit = 64;
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)nsplit);
+    if (nv <= 9)
+        hipLaunchKernelGGL((k_colreduce_multi<9>), grid, dim3(256), 0, st, M, ld, rows, cols, V, sr, sc, nvt, nv, part);
+    else if (nv <= 17)
+        hipLaunchKernelGGL((k_colreduce_multi<17>), grid, dim3(256), 0, st, M, ld, rows, cols, V, sr, sc, nvt, nv, part);
+    else
+        hipLaunchKernelGGL((k_colreduce_multi<33>), grid, dim3(256), 0, st, M, ld, rows, cols, V, sr, sc, nvt, nv, part);
+    return nsplit;
+}
+
+// dst[i] (+)= sum_s src[s*cnt + i]  (fixed order)
+__global__ void k_sum_splits(const double* __restrict__ src, long cnt, int nsplit, int accumulate,
+                             double* __restrict__ dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    double s = accumulate ? dst[i] : 0.0;
+    for (int k = 0; k < nsplit; ++k) s += src[(long)k * cnt + i];
+    dst[i] = s;
+}
+void launch_sum_splits(hipStream_t st, const double* src, long cnt, int nsplit, int accumulate, double* dst) {
+    hipLaunchKernelGGL(k_sum_splits, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, src, cnt, nsplit, accumulate,
+                       dst);
+}
+
+
 
 // out[c] = sum_b partials[b][c], fixed order (bit-reproducible run to run)
 __global__ void k_reduce_partials(const double* __restrict__ partials, int nblocks, int stride,
@@ -572,4 +663,19 @@ void launch_col_reduce(hipStream_t st, const double* M, long ld, long rows, long
     } else {
         hipLaunchKernelGGL(k_col_reduce, dim3(nb), dim3(256), 0, st, M, ld, rows, cols, v, 1, 0, c0, 1, out);
     }
+}
+
+// y = X r (lower-triangular X) and a = X^T y as separate products (sparse path: LB^-1 Lm^-1 psi1Y etc.)
+void launch_trmv_lower(hipStream_t st, const double* X, long ld, long n, const double* R, int Dy, double* y) {
+    for (int d0 = 0; d0 < Dy; d0 += 4)
+        hipLaunchKernelGGL((k_trmv_rows<4>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, X, ld, n, R, Dy, d0, y);
+}
+void launch_trmv_lower_T(hipStream_t st, const double* X, long ld, long n, const double* y, int Dy, double* out,
+                         double* partials) {
+    const long nchunks = (n + 255) / 256;
+    for (int d0 = 0; d0 < Dy; d0 += 4)
+        hipLaunchKernelGGL((k_trmv_cols<4>), dim3((unsigned)nchunks, (unsigned)nchunks), dim3(256), 0, st, X, ld, n, y,
+                           Dy, d0, partials);
+    hipLaunchKernelGGL(k_trmv_finish, dim3((unsigned)((n * Dy + 255) / 256)), dim3(256), 0, st, partials, n, Dy,
+                       nchunks, out);
 }

@@ -157,6 +157,27 @@ int mi355gp_grid_exact_inference(mi355gp_grid* g, int kind, int ard, const doubl
 #define MI355GP_FETCH_LINV 100
 int mi355gp_grid_fetch(mi355gp_grid* g, int which, double* out);
 
+/* ---- sparse GP (VarDTC) path: BASELINE config 5 -----------------------------------------------------------------
+ * One SparseGP.parameters_changed (core/sparse_gp.py:76-119) for certain inputs and a homoscedastic Gaussian likelihood:
+ * VarDTC.inference (inference/latent_function_inference/var_dtc.py:66-215, helpers :217-276) + the kernel and
+ * inducing-input gradient assembly of SparseGP._update_gradients (sparse_gp.py:108-118), streamed over row chunks of X
+ * like the reference's own VarDTC_minibatch (var_dtc_parallel.py:72-133).  X: N x D (D <= 32), Y: N x Dy, Z: M x D.
+ *   out_scalars: [0] log marginal likelihood, [1] dL/d(noise variance), [2] trace(A), [3] data_fit,
+ *                [4] sum(log diag LB), [5] beta
+ *   dtheta_out: 1 + (ard ? D : 1) (variance, lengthscales; diag + Knm + Kmm terms summed as sparse_gp.py:110-115)
+ *   dZ_out: M x D = gradients_X(dL_dKmm, Z) + gradients_X(dL_dKnm^T, Z, X) (sparse_gp.py:116-118)
+ *   wv_out (optional): woodbury_vector M x Dy;  stage_ms (optional, 4): pass 1, M x M algebra, pass 2, total
+ * Returns info > 0 if Kmm or B is not positive definite (the caller runs the jitchol ladder via extra_jitter). */
+typedef struct mi355gp_sparse mi355gp_sparse;
+int mi355gp_sparse_create(int device, mi355gp_sparse** out);
+int mi355gp_sparse_destroy(mi355gp_sparse* s);
+int mi355gp_sparse_set_data(mi355gp_sparse* s, const double* X, int64_t N, int D, const double* Y, int Dy);
+int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double* theta, const double* Z, int64_t M,
+                             double noise_var, double extra_jitter, double* out_scalars, double* dtheta_out,
+                             double* dZ_out, double* wv_out, double* stage_ms);
+/* M x M results of the last call: 0 dL_dKmm, 1 woodbury_inv (var_dtc.py:206-210), 2 Lm, 3 Kmm (+1e-8 I), 4 psi2 */
+int mi355gp_sparse_fetch(mi355gp_sparse* s, int which, double* out);
+
 /* ---- diagnostics (used by tests/ and tools/) --------------------------------------------------------- */
 /* raw lane dump of one v_mfma_f64_16x16x4_f64: a[64], b[64] -> d[64*4] */
 int mi355gp_dbg_mfma(int device, const double* a, const double* b, double* d);

@@ -1,0 +1,115 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the sparse (VarDTC) path; NOT part of the product.
+
+NumPy/SciPy restatement of what `SparseGP.parameters_changed` runs for certain inputs and a homoscedastic
+Gaussian likelihood (reference `GPy/core/sparse_gp.py:76-119`):
+    VarDTC.inference                       `GPy/inference/latent_function_inference/var_dtc.py:66-215`
+    _compute_dL_dpsi / _compute_dL_dR / _compute_log_marginal_likelihood      `var_dtc.py:217-276`
+    kernel gradients  update_gradients_diag + update_gradients_full(dL_dKnm, X, Z) + (dL_dKmm, Z)
+                                           `sparse_gp.py:108-115`, `stationary.py:175-213`
+    inducing-input gradients  gradients_X(dL_dKmm, Z) + gradients_X(dL_dKnm.T, Z, X)
+                                           `sparse_gp.py:116-118`, `stationary.py:245-252,330-358`
+Pinned against the reference's own code through `oracle/ref_loader.py` (tests/test_oracle_vs_reference.py)
+and `tests/golden/sparse_*.npz` (generator: `oracle/make_golden_sparse.py`).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import numpy as np
+from scipy.linalg import lapack
+
+from . import gp_oracle as O
+
+CONST_JITTER = 1e-8        # var_dtc.py:24
+
+
+def _dtrtrs(L, B, trans=0):
+    """util/linalg.py:95-114"""
+    return lapack.dtrtrs(np.asfortranarray(L), np.asfortranarray(B), lower=1, trans=trans)[0]
+
+
+def backsub_both_sides(L, X):
+    """L^-T X L^-1 (util/linalg.py:381-387, transpose='left')"""
+    tmp = _dtrtrs(L, X, trans=1)
+    return _dtrtrs(L, tmp.T, trans=1).T
+
+
+def gradients_X(kind, dL_dK, X, X2, variance, lengthscale, ARD):
+    """`Stationary._gradients_X_pure` (stationary.py:330-346): derivative w.r.t. the rows of X."""
+    ls = O._as_ls(lengthscale, X.shape[1], ARD)
+    r = O.scaled_dist(X, X2, ls, ARD)
+    inv = 1.0 / np.where(r != 0.0, r, np.inf)
+    tmp = inv * O.dK_dr(kind, r, float(variance)) * dL_dK
+    if X2 is None:
+        tmp = tmp + tmp.T
+        X2 = X
+    grad = np.empty(X.shape)
+    for q in range(X.shape[1]):
+        grad[:, q] = np.sum(tmp * (X[:, q][:, None] - X2[:, q][None, :]), axis=1)
+    lsq = ls if ARD else np.full(X.shape[1], ls[0])
+    return grad / lsq ** 2
+
+
+def vardtc(kind, X, Z, Y, variance, lengthscale, ARD, noise_var):
+    """One `SparseGP.parameters_changed`.  Returns dict(lml, dtheta=[dvar, dlen...], dnoise, dZ, woodbury_vector,
+    woodbury_inv, dL_dKmm, Lm, Kmm, psi2, A, LB)."""
+    N, Dy = Y.shape
+    M = Z.shape[0]
+    variance = float(variance)
+    ls = O._as_ls(lengthscale, X.shape[1], ARD)
+    beta = 1.0 / max(float(noise_var), CONST_JITTER)                       # var_dtc.py:78-80
+    VVT = beta * Y                                                          # :88
+    trYYT = float(np.sum(np.square(Y)))                                     # :89 (get_trYYT)
+    Kmm = O.kern_K(kind, Z, None, variance, ls, ARD).copy()                 # :93
+    Kmm[np.arange(M), np.arange(M)] += CONST_JITTER                         # :94
+    Lm = O.jitchol(Kmm)                                                     # :95
+    psi0 = np.full(N, variance)                                             # :125-126 (Kdiag)
+    psi1 = O.kern_K(kind, X, Z, variance, ls, ARD)                          # :127-128
+    tmp = _dtrtrs(Lm, (psi1 * np.sqrt(beta)).T)                             # :129-133
+    A = tmp @ tmp.T                                                         # :134 (tdot)
+    B = np.eye(M) + A                                                       # :137
+    LB = O.jitchol(B)                                                       # :138
+    tmp = _dtrtrs(Lm, psi1.T)                                               # :141
+    LBi_Lmi_psi1 = _dtrtrs(LB, tmp)                                         # :142
+    c = LBi_Lmi_psi1 @ VVT                                                  # :143  (_LBi_Lmi_psi1Vf)
+    tmp = _dtrtrs(LB, c, trans=1)                                           # :144
+    Cpsi1Vf = _dtrtrs(Lm, tmp, trans=1)                                     # :145
+    delit = c @ c.T                                                         # :150
+    data_fit = float(np.trace(delit))                                       # :151
+    P = backsub_both_sides(LB, Dy * np.eye(M) + delit)                      # :152  (DBi_plus_BiPBi)
+    dL_dKmm = backsub_both_sides(Lm, -0.5 * P - 0.5 * B * Dy + Dy * np.eye(M))   # :153-158
+    # _compute_dL_dpsi (var_dtc.py:217-233), homoscedastic, certain inputs
+    dL_dpsi0 = -0.5 * Dy * beta * np.ones(N)
+    dL_dpsi1 = VVT @ Cpsi1Vf.T
+    dL_dpsi2 = beta * 0.5 * backsub_both_sides(Lm, Dy * np.eye(M) - P)
+    dL_dpsi1 = dL_dpsi1 + 2.0 * psi1 @ dL_dpsi2
+    # _compute_log_marginal_likelihood (var_dtc.py:264-276)
+    lik_1 = -0.5 * N * Dy * (np.log(2.0 * np.pi) - np.log(beta)) - 0.5 * beta * trYYT
+    lik_2 = -0.5 * Dy * (np.sum(beta * psi0) - np.trace(A))
+    lik_3 = -Dy * np.sum(np.log(np.diag(LB)))
+    lml = lik_1 + lik_2 + lik_3 + 0.5 * data_fit
+    # _compute_dL_dR (var_dtc.py:258-261)
+    dL_dR = -0.5 * N * Dy * beta + 0.5 * trYYT * beta ** 2
+    dL_dR += 0.5 * Dy * (psi0.sum() * beta ** 2 - np.trace(A) * beta)
+    dL_dR += beta * (0.5 * np.sum(A * P) - data_fit)
+    # posterior (var_dtc.py:198-214)
+    Bi = -lapack.dpotri(np.asfortranarray(LB), lower=1)[0]
+    Bi = np.tril(Bi) + np.tril(Bi, -1).T
+    Bi[np.arange(M), np.arange(M)] += 1.0
+    woodbury_inv = backsub_both_sides(Lm, Bi)
+    # SparseGP._update_gradients (sparse_gp.py:108-118)
+    dvar = float(np.sum(dL_dpsi0))                                          # update_gradients_diag (stationary.py:175-184)
+    dlen = np.zeros(ls.size)
+    dv, dl = O.update_gradients_full(kind, dL_dpsi1, X, Z, variance, ls, ARD)
+    dvar += float(dv)
+    dlen = dlen + np.asarray(dl, float)
+    dv, dl = O.update_gradients_full(kind, dL_dKmm, Z, None, variance, ls, ARD)
+    dvar += float(dv)
+    dlen = dlen + np.asarray(dl, float)
+    dZ = gradients_X(kind, dL_dKmm, Z, None, variance, ls, ARD) + gradients_X(kind, dL_dpsi1.T, Z, X, variance, ls, ARD)
+    return dict(lml=float(lml), dtheta=np.concatenate([[dvar], dlen]), dnoise=float(dL_dR), dZ=dZ,
+                woodbury_vector=Cpsi1Vf, woodbury_inv=woodbury_inv, dL_dKmm=dL_dKmm, Lm=Lm, Kmm=Kmm,
+                psi2=psi1.T @ psi1, A=A, LB=LB, dL_dKnm=dL_dpsi1)
+
+
+def synthetic_Z(X, M, seed=0):
+    """Z = X[perm[:M]] (reference models/sparse_gp_regression.py:41-43)"""
+    rng = np.random.default_rng(seed + 77)
+    return np.ascontiguousarray(X[rng.permutation(X.shape[0])[:M]].copy())

@@ -13,6 +13,7 @@ from .kern import RBF, Exponential, Matern32, Matern52, Stationary
 from .likelihoods import Gaussian
 from .models import GP, GPRegression
 from .posterior import PosteriorExact
+from .sparse import SparseGP, SparseGPRegression, VarDTC
 
 __all__ = ["RBF", "Matern52", "Matern32", "Exponential", "Stationary", "Gaussian", "ExactGaussianInference",
-           "PosteriorExact", "GP", "GPRegression", "MI355GPError", "build", "device_count"]
+           "PosteriorExact", "GP", "GPRegression", "VarDTC", "SparseGP", "SparseGPRegression", "MI355GPError", "build", "device_count"]

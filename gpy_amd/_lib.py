@@ -70,6 +70,7 @@ def lib():
     L.mi355gp_kern_K.argtypes = [ci, ci, ci, _dp, _dp, i64, _c_dp, i64, ci, _dp]
     L.mi355gp_kern_Kdiag.argtypes = [ci, _dp, i64, _dp]
     L.mi355gp_update_gradients_full.argtypes = [ci, ci, ci, _dp, _dp, _dp, i64, _c_dp, i64, ci, _dp]
+    L.mi355gp_gradients_X.argtypes = [ci, ci, ci, _dp, _dp, _dp, i64, _c_dp, i64, ci, _dp]
     L.mi355gp_exact_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_inference_given_K.argtypes = [vp, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_fetch.argtypes = [vp, ci, _dp, ci]
@@ -96,7 +97,7 @@ def lib():
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
                  "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "sparse_create",
-                 "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch"):
+                 "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -109,7 +110,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_set_option", "mi355gp_get_profile", "mi355gp_grid_unique_id", "mi355gp_grid_create",
             "mi355gp_grid_destroy", "mi355gp_grid_set_data", "mi355gp_grid_exact_inference", "mi355gp_grid_fetch",
             "mi355gp_sparse_create", "mi355gp_sparse_destroy", "mi355gp_sparse_set_data", "mi355gp_vardtc_inference",
-            "mi355gp_sparse_fetch",
+            "mi355gp_sparse_fetch", "mi355gp_gradients_X",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks")
 
 
@@ -340,6 +341,24 @@ def update_gradients_full(kind, ARD, theta, dL_dK, X, X2=None, device=0):
     out = np.zeros(theta.size)
     check(lib().mi355gp_update_gradients_full(device, KIND_IDS[kind], int(bool(ARD)), theta, G, X, N, p2, M, D, out),
           "mi355gp_update_gradients_full")
+    return out
+
+
+def gradients_X(kind, ARD, theta, dL_dK, X, X2=None, device=0):
+    """dL/dX (N x D) from dL_dK (N x M) (reference `Stationary.gradients_X`, stationary.py:245-252)."""
+    require_device(device)
+    X = f64(X)
+    N, D = X.shape
+    if X2 is None:
+        M, p2 = N, None
+    else:
+        X2 = f64(X2)
+        M, p2 = X2.shape[0], X2.ctypes.data_as(_c_dp)
+    G = f64(dL_dK)
+    assert G.shape == (N, M), "dL_dK must be N x M"
+    out = np.zeros((N, D))
+    check(lib().mi355gp_gradients_X(device, KIND_IDS[kind], int(bool(ARD)), f64(theta), G, X, N, p2, M, D, out),
+          "mi355gp_gradients_X")
     return out
 
 

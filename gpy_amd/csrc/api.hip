@@ -419,6 +419,56 @@ int mi355gp_update_gradients_full(int device, int kind, int ard, const double* t
     return 0;
 }
 
+// dL/dX from dL_dK: Stationary.gradients_X (kern/src/stationary.py:245-252,330-358; C kernel stationary_utils.c).
+//   out[i][q] = sum_j T[i][j] (x_iq - x2_jq) / l_q^2,  T = dL_dK * dK/dr / r  (X2 == NULL: T + T^T against X itself)
+// Runs as the column reduction H^T [X2~ | 1] of the transposed problem (the same kernels as the sparse path's dL/dZ).
+int mi355gp_gradients_X(int device, int kind, int ard, const double* theta, const double* dL_dK, const double* X,
+                        int64_t N, const double* X2, int64_t M, int D, double* out) {
+    ARG_CHECK(dL_dK && X && out && N > 0 && D > 0 && D <= 32, "mi355gp_gradients_X: bad arguments (D <= 32)");
+    HIP_CHECK(hipSetDevice(device));
+    std::vector<double> inv_ls;
+    if (int rc = check_theta(kind, ard, theta, D, &inv_ls)) return rc;
+    const bool sym = (X2 == nullptr);
+    if (sym) { M = N; X2 = X; }
+    ARG_CHECK(M > 0, "mi355gp_gradients_X: M must be positive");
+    // transposed weights G' (M x N): rows = X2 points, columns = X points
+    std::vector<double> Gt((size_t)M * N);
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = 0; j < M; ++j)
+            Gt[(size_t)j * N + i] = sym ? dL_dK[i * M + j] + dL_dK[j * M + i] : dL_dK[i * M + j];
+    const long ldr = round_up(M, 64), ldc = round_up(N, 64);
+    double *dXr, *dXc, *dXtR, *dXtC, *dIl, *dG, *dPart, *dCol, *dHX;
+    HIP_CHECK(hipMalloc(&dXr, sizeof(double) * M * D));
+    HIP_CHECK(hipMalloc(&dXc, sizeof(double) * N * D));
+    HIP_CHECK(hipMalloc(&dXtR, sizeof(double) * D * ldr));
+    HIP_CHECK(hipMalloc(&dXtC, sizeof(double) * D * ldc));
+    HIP_CHECK(hipMalloc(&dIl, sizeof(double) * D));
+    HIP_CHECK(hipMalloc(&dG, sizeof(double) * M * N));
+    HIP_CHECK(hipMalloc(&dPart, sizeof(double) * 2048 * GP_STRIDE));
+    HIP_CHECK(hipMalloc(&dCol, sizeof(double) * 64 * N * (D + 1)));
+    HIP_CHECK(hipMalloc(&dHX, sizeof(double) * N * (D + 1)));
+    HIP_CHECK(hipMemcpy(dXr, X2, sizeof(double) * M * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dXc, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dIl, inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dG, Gt.data(), sizeof(double) * M * N, hipMemcpyHostToDevice));
+    launch_scale_inputs(0, dXr, M, D, dIl, ard ? 1 : 0, dXtR, ldr);
+    launch_scale_inputs(0, dXc, N, D, dIl, ard ? 1 : 0, dXtC, ldc);
+    KernParams kp{kind, ard ? 1 : 0, D, theta[0]};
+    launch_grad_generic(0, kp, dXtR, ldr, M, dXtC, ldc, N, 0, dG, N, dPart, GP_STRIDE, dG, N);   // H in place
+    const int ns = launch_colreduce_multi(0, dG, N, M, N, dXtR, 1, ldr, D, 1, dCol);
+    launch_sum_splits(0, dCol, N * (D + 1), ns, 0, dHX);
+    std::vector<double> HX((size_t)N * (D + 1)), Xs((size_t)D * ldc);
+    HIP_CHECK(hipMemcpy(HX.data(), dHX, sizeof(double) * HX.size(), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(Xs.data(), dXtC, sizeof(double) * Xs.size(), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipGetLastError());
+    for (int64_t i = 0; i < N; ++i)
+        for (int q = 0; q < D; ++q)
+            out[i * D + q] = (Xs[(size_t)q * ldc + i] * HX[i * (D + 1) + D] - HX[i * (D + 1) + q]) * inv_ls[ard ? q : 0];
+    (void)hipFree(dXr); (void)hipFree(dXc); (void)hipFree(dXtR); (void)hipFree(dXtC); (void)hipFree(dIl);
+    (void)hipFree(dG); (void)hipFree(dPart); (void)hipFree(dCol); (void)hipFree(dHX);
+    return 0;
+}
+
 // ---- standalone dense routines ------------------------------------------------------------------------
 static int dense_factor(int device, const double* A_host, int64_t N, bool invert, double* L_out, double* Ainv_out,
                         double* logdet, double* ms) {

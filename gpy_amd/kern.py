@@ -95,6 +95,20 @@ class Stationary(Parameterized):
         self.variance.gradient = np.sum(dL_dKdiag)
         self.lengthscale.gradient = 0.
 
+    def gradients_X(self, dL_dK, X, X2=None):
+        """dL/dX from dL_dK (reference `stationary.py:245-252,330-358`), reduced on the device."""
+        g = _lib.gradients_X(self.kind, self.ARD, self._theta(), np.asarray(dL_dK), self._slice_X(X),
+                             None if X2 is None else self._slice_X(X2), device=self.device)
+        if g.shape[1] == np.asarray(X).shape[1]:
+            return g
+        full = np.zeros(np.asarray(X).shape)          # active_dims slicing (kernel_slice_operations.py:113-136)
+        full[:, self.active_dims] = g
+        return full
+
+    def gradients_X_diag(self, dL_dKdiag, X):
+        """(reference `stationary.py:360-361`)"""
+        return np.zeros(np.asarray(X).shape)
+
     def reset_gradients(self):
         self.variance.gradient = 0.
         self.lengthscale.gradient = np.zeros(self.input_dim) if self.ARD else 0.

@@ -1,0 +1,241 @@
+"""Sparse GP regression (VarDTC) backed by libmi355gp.so -- drop-in for the hot path of
+`GPy.inference.latent_function_inference.VarDTC` + `GPy.core.SparseGP` / `GPy.models.SparseGPRegression`
+(reference `var_dtc.py:66-215`, `core/sparse_gp.py:76-119`, `models/sparse_gp_regression.py:20-60`) for certain inputs
+and a homoscedastic Gaussian likelihood (BASELINE config 5).
+
+`VarDTC.inference(kern, X, Z, likelihood, Y, ...)` returns `(Posterior, log_marginal, grad_dict)` with the reference's
+keys.  The N x M matrix `dL_dKnm` is never materialised: the kernel and inducing-input gradients that
+`SparseGP._update_gradients` derives from it are reduced on the device in the second streaming pass and travel in
+`grad_dict['fused']`; `dL_dKmm` is a lazy device view.  A foreign consumer that insists on `dL_dKnm` gets a clear error.
+"""
+import numpy as np
+
+from . import _lib
+from .kern import RBF, Stationary
+from .likelihoods import Gaussian
+from .param import Param, Parameterized
+
+LinAlgError = np.linalg.LinAlgError
+
+
+class _LazyMM(object):
+    """Lazy M x M result of the last VarDTC call (fetched on np.asarray)."""
+    __array_priority__ = 100.0
+
+    def __init__(self, ctx, which, M, token, owner):
+        self._ctx, self._which, self._M, self._token, self._owner = ctx, which, M, token, owner
+        self._host = None
+
+    shape = property(lambda self: (self._M, self._M))
+    ndim = 2
+    dtype = np.dtype(np.float64)
+
+    def fetch(self):
+        if self._host is None:
+            if self._owner._token != self._token:
+                raise RuntimeError("device-resident result overwritten by a later inference call")
+            self._host = self._ctx.fetch(self._which)
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.fetch()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getitem__(self, idx):
+        return self.fetch()[idx]
+
+    @property
+    def T(self):
+        return self.fetch().T
+
+
+class _NotMaterialised(object):
+    def __init__(self, what, shape):
+        self.what, self.shape = what, shape
+
+    def __array__(self, dtype=None, copy=None):
+        raise RuntimeError("%s (%d x %d) is never materialised by the MI355X sparse path; its reductions "
+                           "(kernel and inducing-input gradients) are in grad_dict['fused']" % ((self.what,) + self.shape))
+
+
+class SparsePosterior(object):
+    """`Posterior(woodbury_inv, woodbury_vector, K=Kmm, K_chol=Lm)` of the reference (`var_dtc.py:213`,
+    `posterior.py:21-77`); prediction follows `Posterior._raw_predict` (`posterior.py:198-232`)."""
+
+    def __init__(self, woodbury_inv, woodbury_vector, K, K_chol):
+        self.woodbury_inv, self.woodbury_vector, self.K, self.K_chol = woodbury_inv, woodbury_vector, K, K_chol
+
+    def _raw_predict(self, kern, Xnew, pred_var, full_cov=False):
+        Kx = kern.K(pred_var, Xnew)                                   # (M, N*)
+        mu = np.dot(Kx.T, self.woodbury_vector)
+        Wi = np.asarray(self.woodbury_inv)
+        if full_cov:
+            var = kern.K(Xnew) - np.dot(Kx.T, np.dot(Wi, Kx))
+        else:
+            var = (kern.Kdiag(Xnew) - np.sum(np.dot(Wi.T, Kx) * Kx, 0))[:, None]
+        return mu, var
+
+
+class VarDTC(object):
+    const_jitter = 1e-8
+
+    def __init__(self, device=0, maxtries=5):
+        self.device, self.maxtries = device, maxtries
+        self._ctx = None
+        self._X = self._Y = None
+        self._token = 0
+        self.last_stage_ms = None
+        self.collect_stage_ms = False
+
+    def on_optimization_start(self):
+        pass
+
+    def on_optimization_end(self):
+        pass
+
+    def to_dict(self):
+        return {"class": "GPy.inference.latent_function_inference.var_dtc.VarDTC"}
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_ctx"] = None
+        d["_X"] = d["_Y"] = None
+        return d
+
+    def _ensure(self, X, Y):
+        if self._ctx is None:
+            self._ctx = _lib.SparseContext(self.device)
+        if self._X is None or self._X.shape != X.shape or self._Y.shape != Y.shape or \
+                not (np.array_equal(self._X, X) and np.array_equal(self._Y, Y)):
+            self._ctx.set_data(X, Y)
+            self._X, self._Y = X.copy(), Y.copy()
+
+    def inference(self, kern, X, Z, likelihood, Y, Y_metadata=None, mean_function=None, precision=None, Lm=None,
+                  dL_dKmm=None, psi0=None, psi1=None, psi2=None, Z_tilde=None):
+        if not isinstance(kern, Stationary):
+            raise NotImplementedError("the MI355X sparse path covers the stationary kernels of gpy_amd.kern")
+        if any(a is not None for a in (precision, Lm, dL_dKmm, psi0, psi1, psi2)):
+            raise NotImplementedError("precomputed statistics are not accepted by the MI355X sparse path")
+        Y = np.asarray(Y, dtype=np.float64)
+        m = 0 if mean_function is None else mean_function.f(X)
+        noise = np.atleast_1d(np.asarray(likelihood.gaussian_variance(Y_metadata), dtype=np.float64)).ravel()
+        if noise.size != 1:
+            raise NotImplementedError("heteroscedastic noise is not supported by the MI355X sparse path")
+        Xs, Zs, R = kern._slice_X(X), kern._slice_X(np.asarray(Z)), _lib.f64(Y - m)
+        self._ensure(Xs, R)
+        theta = kern._theta()
+        extra, tries, info = 0.0, 0, 1
+        while True:                                   # jitchol's ladder (util/linalg.py:56-75) for Kmm / B
+            info, r = self._ctx.vardtc(kern.kind, kern.ARD, theta, Zs, float(noise[0]), extra_jitter=extra,
+                                       want_stage_ms=self.collect_stage_ms)
+            if info == 0:
+                break
+            if tries >= self.maxtries:
+                raise LinAlgError("not positive definite, even with jitter.")
+            extra = float(theta[0]) * 1e-6 * 10 ** tries
+            tries += 1
+        self._token += 1
+        self.last_stage_ms = r.get("stage_ms")
+        M, N = Zs.shape[0], Xs.shape[0]
+        lml = r["lml"] + (0.0 if Z_tilde is None else Z_tilde)
+        C = _lib.SparseContext
+        post = SparsePosterior(woodbury_inv=_LazyMM(self._ctx, C.FETCH_WOODBURY_INV, M, self._token, self),
+                               woodbury_vector=r["woodbury_vector"],
+                               K=_LazyMM(self._ctx, C.FETCH_KMM, M, self._token, self),
+                               K_chol=_LazyMM(self._ctx, C.FETCH_LM, M, self._token, self))
+        beta = 1.0 / max(float(noise[0]), self.const_jitter)
+        grad_dict = {"dL_dKmm": _LazyMM(self._ctx, C.FETCH_DLDKMM, M, self._token, self),
+                     "dL_dKdiag": np.full(N, -0.5 * Y.shape[1] * beta),
+                     "dL_dKnm": _NotMaterialised("dL_dKnm", (N, M)),
+                     "dL_dthetaL": r["dnoise"],
+                     "fused": {"dtheta": r["dtheta"], "dZ": r["dZ"]}}
+        return post, lml, grad_dict
+
+
+class SparseGP(Parameterized):
+    """Model driver: the `SparseGP.parameters_changed` sequence (reference `core/sparse_gp.py:76-119`).
+    Flat parameter order follows GPy's links: [Z, kern.variance, kern.lengthscale..., noise variance]
+    (`sparse_gp.py:59`: Z is linked at index 0)."""
+
+    def __init__(self, X, Y, Z, kernel, likelihood, inference_method=None, name="sparse gp", device=0):
+        super(SparseGP, self).__init__(name)
+        self.X, self.Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+        self.Y_normalized = self.Y
+        self.num_data, self.input_dim = self.X.shape
+        self.Z = Param("inducing inputs", np.asarray(Z, dtype=np.float64), positive=False)
+        self.num_inducing = self.Z.shape[0]
+        self.kern, self.likelihood = kernel, likelihood
+        self.inference_method = inference_method or VarDTC(device=device)
+        self.link_parameter(self.Z)
+        self.link_parameter(self.kern)
+        self.link_parameter(self.likelihood)
+        self.posterior = None
+        self.parameters_changed()
+
+    def parameters_changed(self):
+        self.posterior, self._log_marginal_likelihood, self.grad_dict = self.inference_method.inference(
+            self.kern, self.X, self.Z.values, self.likelihood, self.Y_normalized)
+        self.likelihood.update_gradients(self.grad_dict["dL_dthetaL"])
+        fused = self.grad_dict["fused"]
+        self.kern._install_gradients(fused["dtheta"])
+        self.Z.gradient = fused["dZ"] if fused["dZ"].shape == self.Z.shape else self._scatter_dZ(fused["dZ"])
+
+    def _scatter_dZ(self, dZ):
+        full = np.zeros(self.Z.shape)
+        full[:, self.kern.active_dims] = dZ
+        return full
+
+    def log_likelihood(self):
+        return self._log_marginal_likelihood
+
+    def objective_function(self):
+        return -float(self._log_marginal_likelihood)
+
+    def objective_function_gradients(self):
+        return -self.gradient
+
+    def _raw_predict(self, Xnew, full_cov=False):
+        return self.posterior._raw_predict(self.kern, np.asarray(Xnew), self.Z.values, full_cov=full_cov)
+
+    def predict(self, Xnew, full_cov=False, include_likelihood=True):
+        mu, var = self._raw_predict(Xnew, full_cov)
+        if include_likelihood:
+            mu, var = self.likelihood.predictive_values(mu, var, full_cov=full_cov)
+        return mu, var
+
+    def optimize(self, max_iters=100, messages=False, gtol=1e-6):
+        """L-BFGS-B; positive parameters (kernel, noise) in log space, Z untransformed."""
+        from scipy.optimize import minimize
+        pos = np.concatenate([np.full(p.size, bool(p.positive)) for p in self.flattened_parameters()])
+
+        def to_x(p):
+            return np.where(pos, np.log(np.where(pos, p, 1.0)), p)
+
+        def from_x(x):
+            return np.where(pos, np.exp(np.where(pos, x, 0.0)), x)
+
+        def f(x):
+            try:
+                self.param_array = from_x(x)
+            except LinAlgError:
+                return 1e300, np.zeros_like(x)
+            g = self.objective_function_gradients()
+            return self.objective_function(), np.where(pos, g * self.param_array, g)
+        res = minimize(f, to_x(self.param_array), jac=True, method="L-BFGS-B",
+                       options={"maxiter": max_iters, "gtol": gtol, "disp": bool(messages)})
+        self.param_array = from_x(res.x)
+        return res
+
+
+class SparseGPRegression(SparseGP):
+    """(reference `GPy/models/sparse_gp_regression.py:20-60`): Z defaults to a random subset of X."""
+
+    def __init__(self, X, Y, kernel=None, Z=None, num_inducing=10, noise_var=1., device=0, seed=None):
+        X = np.asarray(X, dtype=np.float64)
+        if kernel is None:
+            kernel = RBF(X.shape[1], device=device)
+        if Z is None:
+            i = np.random.default_rng(seed).permutation(X.shape[0])[:min(num_inducing, X.shape[0])]
+            Z = X[i].copy()
+        super(SparseGPRegression, self).__init__(X, Y, Z, kernel, Gaussian(variance=noise_var),
+                                                 name="sparse_gp", device=device)

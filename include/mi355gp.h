@@ -79,6 +79,11 @@ int mi355gp_update_gradients_full(int device, int kind, int ard, const double* t
                                   const double* X, int64_t N, const double* X2, int64_t M, int D,
                                   double* dtheta_out);
 
+/* dL/dX (N x D) from dL_dK (N x M): Stationary.gradients_X (kern/src/stationary.py:245-252,330-358, native loop
+ * kern/src/stationary_utils.c:1-14).  X2 == NULL: the symmetric form (tmp + tmp^T against X itself).  D <= 32. */
+int mi355gp_gradients_X(int device, int kind, int ard, const double* theta, const double* dL_dK, const double* X,
+                        int64_t N, const double* X2, int64_t M, int D, double* out);
+
 /* ---- the fused hot path ---------------------------------------------------------------------------- */
 /* One GP.parameters_changed (core/gp.py:278-280) with everything N x N resident in HBM:
  *   K = kern.K(X); Ky = K + (noise + jitter + extra_jitter) I; L = chol(Ky); alpha = Ky^-1 R;

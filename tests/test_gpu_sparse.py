@@ -55,3 +55,46 @@ def test_sparse_matches_oracle_multichunk(kind, ARD, N, M, D, Dy, sctx):
     # M = 513 inducing points in D = 3 with longer lengthscales: cond(Kmm + 1e-8 I) ~ 1e12; the reference's own two
     # implementations (VarDTC vs VarDTC_minibatch) only agree to ~1e-4 here -> 1e-5 on the gradients
     check_sparse(r2, ref2, tol_g=1e-5)
+
+
+def test_gradients_X_through_the_c_abi():
+    rng = np.random.default_rng(4)
+    for kind, ARD, N, M, D in (("rbf", True, 150, 70, 4), ("matern52", False, 90, 130, 2), ("exponential", True, 64, 64, 3)):
+        X, X2 = rng.standard_normal((N, D)), rng.standard_normal((M, D))
+        var, ls, _ = O.default_theta(D, ARD)
+        th = L.theta_vec(var, ls, ARD, D)
+        G = rng.standard_normal((N, M))
+        ref = S.gradients_X(kind, G, X, X2, var, ls, ARD)
+        got = L.gradients_X(kind, ARD, th, G, X, X2)
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+        Gs = rng.standard_normal((N, N))
+        ref = S.gradients_X(kind, Gs, X, None, var, ls, ARD)
+        got = L.gradients_X(kind, ARD, th, Gs, X, None)
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+def test_sparse_gp_regression_host_classes_and_checkgrad():
+    import gpy_amd
+    X, Y = O.synthetic(600, 2, seed=8)
+    k = gpy_amd.Matern52(2, variance=1.2, lengthscale=[0.8, 1.4], ARD=True)
+    m = gpy_amd.SparseGPRegression(X, Y, kernel=k, num_inducing=24, noise_var=0.15, seed=3)
+    ref = S.vardtc("matern52", X, m.Z.values, Y, 1.2, np.array([0.8, 1.4]), True, 0.15)
+    assert abs(m.log_likelihood() - ref["lml"]) <= 1e-9 * abs(ref["lml"])
+    g = m.gradient
+    gref = np.concatenate([ref["dZ"].ravel(), ref["dtheta"], [ref["dnoise"]]])
+    assert np.abs(g - gref).max() <= 1e-6 * np.abs(gref).max()
+    # finite differences through the whole driver (what GPy's checkgrad does, test_model.py:790-898)
+    x0 = m.param_array.copy()
+    for i in (0, 5, x0.size - 4, x0.size - 1):
+        e = np.zeros_like(x0); e[i] = 1e-6 * max(1.0, abs(x0[i]))
+        m.param_array = x0 + e; fp = m.log_likelihood()
+        m.param_array = x0 - e; fm = m.log_likelihood()
+        m.param_array = x0
+        assert abs((fp - fm) / (2 * e[i]) - m.gradient[i]) <= 2e-4 * max(1.0, abs(m.gradient[i]))
+    mu, var = m.predict(X[:7])
+    mu_ref = O.kern_K("matern52", X[:7], m.Z.values, 1.2, np.array([0.8, 1.4]), True) @ ref["woodbury_vector"]
+    assert np.abs(mu - mu_ref).max() <= 1e-6 * np.abs(mu_ref).max()
+    assert np.all(var > 0)
+    f0 = m.objective_function()
+    m.optimize(max_iters=8)
+    assert m.objective_function() < f0

@@ -136,9 +136,14 @@ def main():
                     "broadcasts, strong scaling) instead of the default independent replicas; with one process the "
                     "logical ranks share the GPU (loopback transport)")
     ap.add_argument("--nb", type=int, default=512, help="tile edge of the block-cyclic layout")
+    ap.add_argument("--sparse", action="store_true", help="BASELINE configs[4]: SparseGPRegression (VarDTC) N=200000 "
+                    "rows per GPU, M=2048, D=16; rows sharded across GPUs with one RCCL all-reduce per pass")
+    ap.add_argument("--m", type=int, default=2048, help="inducing points (--sparse)")
     args = ap.parse_args()
     if args.grid:
         return main_grid(args)
+    if args.sparse:
+        return main_sparse(args)
 
     comm = Comm()
     assert comm.world == max(1, args.gpus) or comm.world == 1, "launch with torch.distributed.run for --gpus > 1"
@@ -192,6 +197,52 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.kind, ARD, D, min(args.cpu_sample_n, N), N)
         print(json.dumps(out), flush=True)
     ctx.close()
+    comm.close()
+
+
+def main_sparse(args):
+    """BASELINE configs[4]: one SparseGP.parameters_changed (VarDTC + all gradients) per step; rows sharded over ranks
+    (weak scaling: N rows PER GPU), Z / theta replicated, psi2 + gradient sums all-reduced over RCCL."""
+    comm = Comm()
+    from gpy_amd import _lib as L
+    from gpy_amd import grid as G
+    from gpy_amd.datasets import default_theta, synthetic
+    n_per = 200000 if args.n == WORKLOAD["N"] else args.n
+    D = 16 if args.d == WORKLOAD["D"] else args.d
+    M, world = args.m, comm.world
+    X, Y = synthetic(n_per * world, D, seed=0)                 # every rank generates the same global set ...
+    Z = X[np.random.default_rng(1).permutation(X.shape[0])[:M]].copy()
+    lo, hi = G.shard_rows(X.shape[0], comm.rank, world)        # ... and uploads only its shard
+    var, ls, noise = default_theta(D, False)
+    theta = L.theta_vec(var, ls, False, D)
+    c = L.SparseContext(comm.local_rank)
+    if world > 1:
+        idb = G.unique_id() if comm.rank == 0 else b"\0" * G.ID_BYTES
+        c.attach_comm(comm.rank, world, G.exchange_id_torch(idb, comm.rank))
+    c.set_data(X[lo:hi], Y[lo:hi])
+    last = {}
+
+    def step():
+        info, r = c.vardtc("rbf", False, theta, Z, noise, want_stage_ms=True)
+        assert info == 0
+        last["r"] = r
+
+    dt = timed_region(comm, step, args.steps, args.warmup)
+    if comm.rank == 0:
+        r = last["r"]
+        N = X.shape[0]
+        flops = 3.0 * N * M * M                               # psi2 (lower half) N M^2 + Kfu dL_dpsi2 2 N M^2
+        out = {"metric": "sparse-GP (VarDTC) log_lik+grad iters/sec", "value": args.steps / dt, "unit": "iters/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "RBF SparseGPRegression (VarDTC), one parameters_changed incl. kernel and "
+                                      "inducing-input gradients, N=%d (%d per GPU) M=%d D=%d" % (N, n_per, M, D),
+                          "N": N, "M": M, "D": D, "parallelism": "rows sharded x%d" % world},
+               "rows_per_s": N * args.steps / dt, "gemm_tflops": flops / (dt / args.steps) / 1e12,
+               "gemm_frac_of_fp64_peak": flops / (dt / args.steps) / 1e12 / (PEAK_FP64_TFLOPS * world),
+               "stage_ms": {k: round(float(v), 3) for k, v in r["stage_ms"].items()}, "lml": r["lml"]}
+        print(json.dumps(out), flush=True)
+    c.close()
     comm.close()
 
 

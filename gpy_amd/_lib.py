@@ -90,6 +90,7 @@ def lib():
     L.mi355gp_sparse_set_data.argtypes = [vp, _dp, i64, ci, _dp, ci]
     L.mi355gp_vardtc_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_sparse_fetch.argtypes = [vp, ci, _dp]
+    L.mi355gp_sparse_attach_comm.argtypes = [vp, ci, ci, ctypes.c_char_p]
     L.mi355gp_dbg_mfma.argtypes = [ci, _dp, _dp, _dp]
     L.mi355gp_dbg_gemm.argtypes = [ci, ci, ci, i64, i64, i64, _dp, _dp, _dp, cd, cd, ci, _c_dp]
     L.mi355gp_dbg_peaks.argtypes = [ci, _dp]
@@ -97,7 +98,7 @@ def lib():
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
                  "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "sparse_create",
-                 "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X"):
+                 "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -110,7 +111,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_set_option", "mi355gp_get_profile", "mi355gp_grid_unique_id", "mi355gp_grid_create",
             "mi355gp_grid_destroy", "mi355gp_grid_set_data", "mi355gp_grid_exact_inference", "mi355gp_grid_fetch",
             "mi355gp_sparse_create", "mi355gp_sparse_destroy", "mi355gp_sparse_set_data", "mi355gp_vardtc_inference",
-            "mi355gp_sparse_fetch", "mi355gp_gradients_X",
+            "mi355gp_sparse_fetch", "mi355gp_gradients_X", "mi355gp_sparse_attach_comm",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks")
 
 
@@ -273,6 +274,10 @@ class SparseContext(object):
             self.close()
         except Exception:
             pass
+
+    def attach_comm(self, rank, world, id_bytes):
+        """Row-sharded multi-GPU mode: this rank will upload only its slice of (X, Y) (see gpy_amd.grid.shard_rows)."""
+        check(lib().mi355gp_sparse_attach_comm(self._h, rank, world, id_bytes), "mi355gp_sparse_attach_comm")
 
     def set_data(self, X, Y):
         X, Y = f64(X), f64(Y)

@@ -593,7 +593,7 @@ int mi355gp_predict(mi355gp_ctx* c, int kind, int ard, const double* theta, cons
 int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
     ARG_CHECK(c != nullptr, "mi355gp_set_option: NULL context");
     if (option == MI355GP_OPT_PROFILE) { c->ws.prof.on = (value != 0); c->ws.prof.mask = (value == 1) ? 0xffu : (unsigned)value >> 1; }
-    else if (option == MI355GP_OPT_LOOKAHEAD) c->ws.lookahead = (value != 0);
+    else if (option == MI355GP_OPT_LOOKAHEAD) c->ws.lookahead = (value < 0 || value > 2) ? 1 : value;
     else { mi355gp_set_error("mi355gp_set_option: unknown option %d", option); return -1; }
     return 0;
 }

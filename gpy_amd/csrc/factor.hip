@@ -138,15 +138,14 @@ static void update_cols(hipStream_t s, double* A, long npad, long K0, long W, lo
     ws->prof.end(s);
 }
 
-// Two-level right-looking Cholesky.  Outer panels of NBO = 512 columns keep the big trailing update at K = 512
-// (64 flop per byte of C traffic).  The schedule follows the true dependencies at column-chunk granularity instead
-// of serialising whole steps on one stream:
+// Alternative schedule (option LOOKAHEAD = 2; measured equal to the default on MI355X, kept as an experiment switch):
+// the true dependencies at column-chunk granularity instead of whole steps on one stream:
 //   - panel p is factored on a high-priority stream as soon as the updates of ITS columns are done (look-ahead);
 //   - the trailing columns are cut into chunks of ~512 tiles; chunk c is always updated on stream c % n_upd, so
 //     step p+1's update of a chunk only waits for panel p+1 and for the same chunk's step-p update.  The tail of
 //     one launch (fewer tiles left than CU slots) therefore overlaps the head of the next chunk's launch, and
 //     the latency-bound diag/trsm chain hides behind MFMA-bound work.
-void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
+static void potrf_chunked(hipStream_t st, double* A, long npad, FactorWs* ws) {
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
     const long P = (npad + NBO - 1) / NBO;                       // outer panels
     auto pcol = [&](long p) { return (p * NBO < npad) ? p * NBO : npad; };
@@ -198,6 +197,37 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     for (int i = 0; i < ws->n_upd; ++i) {
         (void)hipEventRecord(ws->ev_join[i], ws->st_upd[i]);
         (void)hipStreamWaitEvent(st, ws->ev_join[i], 0);
+    }
+    (void)hipEventRecord(ws->ev_panel[P], sp);
+    (void)hipStreamWaitEvent(st, ws->ev_panel[P], 0);
+}
+
+// Two-level right-looking Cholesky with one panel of look-ahead (default).  Outer panels of NBO = 512 columns keep
+// the big trailing update at K = 512 (64 flop per byte of C traffic).  The update of outer step p is split into the
+// next panel's 512 columns (part 1) and the rest (part 2); panel p+1 is factored on a second, high-priority stream
+// while part 2 of step p still runs, so the latency-bound diag/trsm chain hides behind MFMA-bound work.  All
+// trailing updates stay in order on `st`: their launch durations are not inflated by overlapping each other.
+void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
+    if (ws->lookahead != 1) {
+        potrf_chunked(st, A, npad, ws);                          // 0: serial reference schedule, 2: chunk streams
+        return;
+    }
+    (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
+    const long P = (npad + NBO - 1) / NBO;
+    auto pcol = [&](long p) { return (p * NBO < npad) ? p * NBO : npad; };
+    hipStream_t sp = ws->st_panel;
+    (void)hipEventRecord(ws->ev_fork, st);                      // panel 0 follows everything queued on st so far
+    (void)hipStreamWaitEvent(sp, ws->ev_fork, 0);
+    factor_panel(sp, A, npad, 0, pcol(1), ws);
+    for (long p = 0; p + 1 < P; ++p) {
+        const long K0 = pcol(p), W = pcol(p + 1) - K0;
+        (void)hipEventRecord(ws->ev_panel[p], sp);
+        (void)hipStreamWaitEvent(st, ws->ev_panel[p], 0);
+        update_cols(st, A, npad, K0, W, pcol(p + 1), pcol(p + 2), ws);       // part 1: the next panel's columns
+        (void)hipEventRecord(ws->ev_cols[p + 1], st);
+        (void)hipStreamWaitEvent(sp, ws->ev_cols[p + 1], 0);
+        factor_panel(sp, A, npad, pcol(p + 1), pcol(p + 2) - pcol(p + 1), ws);
+        update_cols(st, A, npad, K0, W, pcol(p + 2), npad, ws);              // part 2: everything to the right
     }
     (void)hipEventRecord(ws->ev_panel[P], sp);
     (void)hipStreamWaitEvent(st, ws->ev_panel[P], 0);

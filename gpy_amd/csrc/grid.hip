@@ -98,6 +98,24 @@ static Rccl g_rccl;
         }                                                                                                 \
     } while (0)
 
+// plain world communicator for the row-sharded sparse path (sparse.hip): one all-reduce per streaming pass
+int rccl_comm_create(int rank, int world, const void* id128, void** comm) {
+    if (!g_rccl.load()) return -20;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    NCCL_CHECK(g_rccl.CommInitRank(&c, world, id, rank));
+    *comm = c;
+    return 0;
+}
+int rccl_allreduce_sum(void* comm, double* buf, size_t count, hipStream_t st) {
+    NCCL_CHECK(g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, (ncclComm_t)comm, st));
+    return 0;
+}
+void rccl_comm_destroy(void* comm) {
+    if (comm && g_rccl.h) g_rccl.CommDestroy((ncclComm_t)comm);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // device kernels specific to the distributed layout
 

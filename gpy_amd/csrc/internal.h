@@ -133,3 +133,8 @@ void launch_pad_from_dense(hipStream_t st, const double* src, long n, double* A,
 // column reductions over a (rows x ld) matrix: mode 0: out[j*Dy+d] = sum_i M[i][j]*v[i*Dy+d]; mode 1: out[j] = c0 - sum_i M[i][j]^2
 void launch_col_reduce(hipStream_t st, const double* M, long ld, long rows, long cols, const double* v, int Dy,
                        double c0, int mode, double* out);
+
+// ---- grid.hip : RCCL (dlopen'ed) world communicator for row-sharded paths ---------------------------------------
+int rccl_comm_create(int rank, int world, const void* id128, void** comm);
+int rccl_allreduce_sum(void* comm, double* buf, size_t count, hipStream_t st);
+void rccl_comm_destroy(void* comm);

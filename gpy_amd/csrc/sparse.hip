@@ -111,6 +111,11 @@ struct mi355gp_sparse {
     long n = 0, chunk = 0;
     int D = 0, Dy = 0;
     double trYYT = 0.0;
+    // row-sharded multi-GPU mode (the reference's MPI design: var_dtc_parallel.py:121-130,387-394):
+    // this rank holds n of n_global rows; psi2 / psi1Y and the pass-2 sums are all-reduced, M x M algebra is replicated
+    void* comm = nullptr;
+    int world = 1, rank = 0;
+    long n_global = 0;
     double *dX = nullptr, *dY = nullptr, *XtC = nullptr, *Kfu = nullptr, *T = nullptr;
     // M-dependent
     long m = 0, mp = 0;
@@ -205,6 +210,7 @@ int mi355gp_sparse_destroy(mi355gp_sparse* s) {
     if (s->dX) (void)hipFree(s->dX);
     if (s->dY) (void)hipFree(s->dY);
     if (s->XtC) (void)hipFree(s->XtC);
+    if (s->comm) rccl_comm_destroy(s->comm);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     if (s->st) (void)hipStreamDestroy(s->st);
@@ -236,6 +242,31 @@ int mi355gp_sparse_set_data(mi355gp_sparse* s, const double* X, int64_t N, int D
     double t = 0.0;
     for (int64_t i = 0; i < N * Dy; ++i) t += Y[i] * Y[i];     // get_trYYT (var_dtc.py:48-54)
     s->trYYT = t;
+    s->n_global = N;
+    if (s->comm) {                                             // global N and tr(Y Y^T) over the shards
+        double h[2] = {(double)N, t}, *d = nullptr;
+        HIP_CHECK(hipMalloc(&d, sizeof(h)));
+        HIP_CHECK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
+        if (int rc = rccl_allreduce_sum(s->comm, d, 2, s->st)) return rc;
+        HIP_CHECK(hipStreamSynchronize(s->st));
+        HIP_CHECK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        s->n_global = (long)(h[0] + 0.5);
+        s->trYYT = h[1];
+    }
+    return 0;
+}
+
+// Row-sharded mode: call once, before set_data, on every rank (id128 from mi355gp_grid_unique_id on rank 0).
+// Each rank then passes ITS rows to mi355gp_sparse_set_data; Z and theta are replicated; results are identical on all ranks.
+int mi355gp_sparse_attach_comm(mi355gp_sparse* s, int rank, int world, const void* id128) {
+    ARGCHK(s && id128 && world >= 1 && rank >= 0 && rank < world, "mi355gp_sparse_attach_comm: bad arguments");
+    HIP_CHECK(hipSetDevice(s->device));
+    if (s->comm) rccl_comm_destroy(s->comm);
+    s->comm = nullptr;
+    if (int rc = rccl_comm_create(rank, world, id128, &s->comm)) return rc;
+    s->rank = rank;
+    s->world = world;
     return 0;
 }
 
@@ -290,6 +321,10 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
         launch_sum_splits(st, s->colPart, mp * Dy, ns, 1, s->psi1Y);               // psi1Y += Kuf Y_chunk
     }
     hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->psi2part, mp, SPLITK, s->psi2);
+    if (s->comm) {                                              // the one exchange step of pass 1
+        if (int rc = rccl_allreduce_sum(s->comm, s->psi2, (size_t)mp * mp, st)) return rc;
+        if (int rc = rccl_allreduce_sum(s->comm, s->psi1Y, (size_t)mp * Dy, st)) return rc;
+    }
     HIP_CHECK(hipEventRecord(s->ev[1], st));
     // ---- M x M algebra ----------------------------------------------------------------------------------------
     // A = beta * Lm^-1 psi2 Lm^-T (var_dtc.py:129-134), B = I + A (:137), LB = chol(B) (:138), XB = LB^-1
@@ -348,6 +383,10 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
         const int ns = launch_colreduce_multi(st, s->T, mp, rc, mp, s->XtC, 1, chunk, D, 1, s->colPart);
         launch_sum_splits(st, s->colPart, mp * (D + 1), ns, 1, s->HX);
     }
+    if (s->comm) {                                              // the one exchange step of pass 2
+        if (int rc = rccl_allreduce_sum(s->comm, s->gradNM, (size_t)groups * GP_STRIDE, st)) return rc;
+        if (int rc = rccl_allreduce_sum(s->comm, s->HX, (size_t)mp * (D + 1), st)) return rc;
+    }
     // the M x M part: update_gradients_full(dL_dKmm, Z) and gradients_X(dL_dKmm, Z) (sparse_gp.py:114-117)
     {
         const int nbk = grad_generic_num_blocks(m, m);
@@ -384,7 +423,8 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
     if (info_m > 0) return info_m > m ? (int)m : info_m;                 // Kmm not positive definite: caller adds jitter
     if (info_b > 0) return info_b > m ? (int)m : info_b;
     const double trA = scal[0], sumAP = scal[1], logLB = scal[2], data_fit = scal[3];
-    const double variance = theta[0], psi0sum = (double)n * variance, nd = (double)n * Dy;
+    const double ng = (double)s->n_global;                       // all shards
+    const double variance = theta[0], psi0sum = ng * variance, nd = ng * Dy;
     // _compute_log_marginal_likelihood (var_dtc.py:264-276)
     const double lik_1 = -0.5 * nd * (log(2.0 * M_PI) - log(beta)) - 0.5 * beta * s->trYYT;
     const double lik_2 = -0.5 * Dy * (beta * psi0sum - trA);
@@ -402,7 +442,7 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
     out_scalars[5] = beta;
     if (dtheta_out) {
         // update_gradients_diag(dL_dKdiag = -0.5 Dy beta) (sparse_gp.py:110, stationary.py:175-184): variance only
-        dtheta_out[0] = -0.5 * Dy * beta * (double)n + (gnm[0] + gmm[0]) / variance;
+        dtheta_out[0] = -0.5 * Dy * beta * ng + (gnm[0] + gmm[0]) / variance;
         if (!kp.ard) dtheta_out[1] = -(gnm[1] + gmm[1]) / theta[1];
         else
             for (int q = 0; q < D; ++q) {

@@ -73,6 +73,14 @@ def step_traffic_bytes(N, nb, Pr, Pc):
                 total=row_panel + col_panel + xrow + xrowT + diag)
 
 
+def shard_rows(N, rank, world):
+    """Contiguous row range [lo, hi) of rank `rank` (the reference's divide_data, util/parallel.py:14-30: the first
+    N % world ranks get one extra row)."""
+    base, rem = divmod(N, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
 # ---- id exchange ---------------------------------------------------------------------------------------------
 def exchange_id_torch(id_bytes, rank):
     """Broadcast rank 0's RCCL id over an initialised torch.distributed process group (gloo or nccl)."""

@@ -124,8 +124,8 @@ int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* 
 
 /* Options.  PROFILE: bracket launches of the factorisation kernels with hipEvents on the launching stream (adds
  * ~2 us per timed launch).  value 0 = off, 1 = all families, otherwise (bitmask of 1 << MI355GP_PF_*) << 1;
- * LOOKAHEAD (default 1): factor panel k+1 on a second stream while the trailing update of
- * step k still runs. */
+ * LOOKAHEAD: 1 (default) factor panel k+1 on a second, high-priority stream while the trailing update of
+ * step k still runs; 0 = everything in order on one stream; 2 = column-chunk streams (experiment). */
 enum { MI355GP_OPT_PROFILE = 0, MI355GP_OPT_LOOKAHEAD = 1 };
 int mi355gp_set_option(mi355gp_ctx* ctx, int option, int value);
 /* kernel families of mi355gp_get_profile */
@@ -180,6 +180,10 @@ int mi355gp_sparse_set_data(mi355gp_sparse* s, const double* X, int64_t N, int D
 int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double* theta, const double* Z, int64_t M,
                              double noise_var, double extra_jitter, double* out_scalars, double* dtheta_out,
                              double* dZ_out, double* wv_out, double* stage_ms);
+/* Row-sharded multi-GPU mode (the reference's MPI design, var_dtc_parallel.py:121-130,387-394): every rank holds a
+ * slice of the rows of (X, Y); psi2/psi1Y after pass 1 and the gradient sums after pass 2 are all-reduced over RCCL,
+ * the M x M algebra is replicated.  Call on every rank before set_data (id128: mi355gp_grid_unique_id on rank 0). */
+int mi355gp_sparse_attach_comm(mi355gp_sparse* s, int rank, int world, const void* id128);
 /* M x M results of the last call: 0 dL_dKmm, 1 woodbury_inv (var_dtc.py:206-210), 2 Lm, 3 Kmm (+1e-8 I), 4 psi2 */
 int mi355gp_sparse_fetch(mi355gp_sparse* s, int which, double* out);
 

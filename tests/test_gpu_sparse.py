@@ -98,3 +98,21 @@ def test_sparse_gp_regression_host_classes_and_checkgrad():
     f0 = m.objective_function()
     m.optimize(max_iters=8)
     assert m.objective_function() < f0
+
+
+def test_row_sharded_mode_rccl_world_one(sctx):
+    """The RCCL all-reduce path of the sharded sparse mode on the one GPU we have (world size 1)."""
+    from gpy_amd import grid as G
+    X, Y = O.synthetic(3000, 4, seed=2)
+    Z = S.synthetic_Z(X, 96, 0)
+    var, ls, noise = O.default_theta(4, False)
+    ref = S.vardtc("rbf", X, Z, Y, var, ls, False, noise)
+    c = L.SparseContext(0)
+    try:
+        c.attach_comm(0, 1, G.unique_id())
+        c.set_data(X, Y)
+        info, r = c.vardtc("rbf", False, L.theta_vec(var, ls, False, 4), Z, noise)
+        assert info == 0
+        check_sparse(r, ref)
+    finally:
+        c.close()

@@ -100,3 +100,17 @@ def test_two_rank_id_exchange_and_partition(tmp_path):
     assert recs[0]["rows"] == recs[1]["rows"] == list(range(7))
     assert sorted(recs[0]["cols"] + recs[1]["cols"]) == list(range(7))
     assert set(recs[0]["cols"]).isdisjoint(recs[1]["cols"])
+
+
+@pytest.mark.parametrize("N,world", [(10, 1), (10, 3), (200000, 8), (7, 7), (5, 8)])
+def test_shard_rows_partitions_like_divide_data(N, world):
+    """gpy_amd.grid.shard_rows == the reference's divide_data (GPy/util/parallel.py:14-30)."""
+    covered = []
+    for r in range(world):
+        lo, hi = G.shard_rows(N, r, world)
+        residue = N % world
+        size = N // world + (1 if r < residue else 0)
+        offset = size * r if r < residue else size * r + residue
+        assert (lo, hi) == (offset, offset + size)
+        covered.extend(range(lo, hi))
+    assert covered == list(range(N))

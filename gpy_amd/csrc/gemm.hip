@@ -63,11 +63,15 @@ __global__ LB(NW) void k_update_nt(double* __restrict__ C, long ldc,
     }
     d4 acc[4][GTCfg<NW>::NI];
     double* Ct = C + (long)ti * NB * ldc + (long)tj * NB;
-    if (PRE) gt_load_neg<NW>(Ct, ldc, acc);
-    else gt_zero<NW>(acc);
-    gemm_tile_128<true, true, NW>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
-    if (PRE) gt_store<1, NW>(Ct, ldc, acc);
-    else gt_store<2, NW>(Ct, ldc, acc);
+    if (PRE) {
+        gt_load_buf<NW>(Ct, ldc, acc);
+        gemm_tile_128<true, true, NW, true>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
+        gt_store<0, NW>(Ct, ldc, acc);
+    } else {
+        gt_zero<NW>(acc);
+        gemm_tile_128<true, true, NW>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
+        gt_store<2, NW>(Ct, ldc, acc);
+    }
 }
 
 template <int NW, bool PRE>

@@ -85,7 +85,7 @@ __device__ __forceinline__ double gt_frag(const double* s, int idx, int kk) {
 
 // acc[mi][ni] += sum_{k<K} opA(i,k) * opB(k,j) for this wave's part of the 128x128 tile.
 // A points at the tile's first row (k-contig) / first column (m-contig) at k = 0; same for B.  K % 16 == 0.
-template <bool AK, bool BK, int NW>
+template <bool AK, bool BK, int NW, bool NEGA = false>
 __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long lda,
                                               const double* __restrict__ B, long ldb, int K,
                                               d4 (&acc)[4][GTCfg<NW>::NI], double* smem, int dbg_nosync = 0) {
@@ -112,7 +112,7 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
             const int kk = 4 * s + kq;
             double af[4], bf[NI];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[mi] = gt_frag<AK>(a_s, arow + mi * 16, kk);
+            for (int mi = 0; mi < 4; ++mi) af[mi] = NEGA ? -gt_frag<AK>(a_s, arow + mi * 16, kk) : gt_frag<AK>(a_s, arow + mi * 16, kk);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) bf[ni] = gt_frag<BK>(b_s, bcol + ni * 16, kk);
 #pragma unroll
@@ -142,6 +142,30 @@ template <int NW>
 __device__ __forceinline__ double* gt_cbase(double* C, long ldc) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / GTCfg<NW>::WPR, wc = w % GTCfg<NW>::WPR;
     return C + (long)(wr * 64 + (lane >> 4)) * ldc + wc * GTCfg<NW>::WCOLS + (lane & 15);
+}
+
+// acc = C through buffer loads: one 32-bit lane offset + scalar row offsets + immediate column offsets, so the 64
+// loads of a wave cost no address VGPRs (64-bit flat addresses for them spill the 128-register accumulator budget).
+// Ct must be workgroup-uniform.  Issued before the k-loop, the read half of "C -= A*B" hides behind the operand
+// prologue; the k-loop then runs with negated A fragments and the epilogue is a plain store.
+template <int NW>
+__device__ __forceinline__ void gt_load_buf(const double* Ct, long ldc, d4 (&acc)[4][GTCfg<NW>::NI]) {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / GTCfg<NW>::WPR, wc = w % GTCfg<NW>::WPR;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Ct), 0, 0x7fffffff, 0x00020000);
+    const int ldb = (int)ldc * 8;
+    const int voff = (wr * 64 + (lane >> 4)) * ldb + (wc * GTCfg<NW>::WCOLS + (lane & 15)) * 8;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int soff = (mi * 16 + 4 * r) * ldb;
+#pragma unroll
+            for (int ni = 0; ni < GTCfg<NW>::NI; ++ni) {
+                const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + ni * 128, soff, 0);
+                acc[mi][ni][r] = __builtin_bit_cast(double, v);
+            }
+        }
 }
 
 // acc = -C: the read half of "C -= A*B" issued before the k-loop, so its HBM latency hides behind the

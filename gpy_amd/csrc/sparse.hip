@@ -18,7 +18,7 @@
 #include "internal.h"
 
 #define GP_STRIDE 34
-#define SPLITK 8
+#define SPLITK_MAX 16
 #define CHUNK_MAX 32768
 #define ARGCHK(cond, msg)                 \
     do {                                  \
@@ -60,25 +60,42 @@ __global__ void k_form_P(const double* __restrict__ Wlow, const double* __restri
     P[i * mp + j] = v;
 }
 // out[0] = trace(A) ; out[1] = sum(A * P) ; out[2] = sum_i log(LB_ii) ; out[3] = sum(c^2)   over the leading m x m / m x Dy
-__global__ __launch_bounds__(1024) void k_sparse_scalars(const double* __restrict__ A, const double* __restrict__ P,
-                                                         const double* __restrict__ LB, const double* __restrict__ c,
-                                                         int Dy, long mp, long m, double* __restrict__ out) {
-    __shared__ double red[4][1024];
+// stage 1: one block per row i: rowpart[i] = {A_ii, sum_j A_ij P_ij, log LB_ii, sum_d c_id^2}
+__global__ __launch_bounds__(256) void k_sparse_scalars_rows(const double* __restrict__ A, const double* __restrict__ P,
+                                                             const double* __restrict__ LB,
+                                                             const double* __restrict__ c, int Dy, long mp, long m,
+                                                             double* __restrict__ rowpart) {
+    __shared__ double red[256];
     const int t = threadIdx.x;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (long e = t; e < m * m; e += 1024) {
-        const long i = e / m, j = e % m;
-        const double a = A[i * mp + j];
-        s1 = fma(a, P[i * mp + j], s1);
-        if (i == j) {
-            s0 += a;
-            s2 += log(LB[i * mp + i]);
-        }
-    }
-    for (long e = t; e < m * Dy; e += 1024) s3 = fma(c[e], c[e], s3);
-    red[0][t] = s0; red[1][t] = s1; red[2][t] = s2; red[3][t] = s3;
+    const long i = blockIdx.x;
+    double s1 = 0.0;
+    for (long j = t; j < m; j += 256) s1 = fma(A[i * mp + j], P[i * mp + j], s1);
+    red[t] = s1;
     __syncthreads();
-    for (int k = 512; k > 0; k >>= 1) {
+    for (int k = 128; k > 0; k >>= 1) {
+        if (t < k) red[t] += red[t + k];
+        __syncthreads();
+    }
+    if (t == 0) {
+        double c2 = 0.0;
+        for (int d = 0; d < Dy; ++d) c2 = fma(c[i * Dy + d], c[i * Dy + d], c2);
+        rowpart[i * 4 + 0] = A[i * mp + i];
+        rowpart[i * 4 + 1] = red[0];
+        rowpart[i * 4 + 2] = log(LB[i * mp + i]);
+        rowpart[i * 4 + 3] = c2;
+    }
+}
+// stage 2 (fixed order): out[q] = sum_i rowpart[i][q]
+__global__ __launch_bounds__(256) void k_sparse_scalars(const double* __restrict__ rowpart, long m,
+                                                        double* __restrict__ out) {
+    __shared__ double red[4][256];
+    const int t = threadIdx.x;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long i = t; i < m; i += 256)
+        for (int q = 0; q < 4; ++q) s[q] += rowpart[i * 4 + q];
+    for (int q = 0; q < 4; ++q) red[q][t] = s[q];
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
         if (t < k)
             for (int q = 0; q < 4; ++q) red[q][t] += red[q][t + k];
         __syncthreads();
@@ -109,7 +126,7 @@ struct mi355gp_sparse {
     int device = 0;
     hipStream_t st = nullptr;
     long n = 0, chunk = 0;
-    int D = 0, Dy = 0;
+    int D = 0, Dy = 0, splitk = 8;
     double trYYT = 0.0;
     // row-sharded multi-GPU mode (the reference's MPI design: var_dtc_parallel.py:121-130,387-394):
     // this rank holds n of n_global rows; psi2 / psi1Y and the pass-2 sums are all-reduced, M x M algebra is replicated
@@ -150,8 +167,29 @@ static void free_m(mi355gp_sparse* s) {
 
 static int alloc_m(mi355gp_sparse* s, long M) {
     free_m(s);
+    if (s->XtC) (void)hipFree(s->XtC);
+    s->XtC = nullptr;
     s->m = M;
     s->mp = round_up(M, NB);
+    {
+        // The Gram matrix has only ntl = (mp/128)(mp/128+1)/2 output tiles (136 at M = 2048) against 512 workgroup slots:
+        // split K into S partial matrices, S chosen so that ntl*S fills whole rounds of the machine.
+        const long nt = s->mp / NB, ntl = nt * (nt + 1) / 2;
+        int best = 1;
+        double beff = 0.0;
+        for (int S = 1; S <= SPLITK_MAX; ++S) {
+            const double wg = (double)ntl * S, eff = wg / (ceil(wg / 512.0) * 512.0);
+            if (eff > beff + 1e-9 || (eff > beff - 0.02 && S < best)) { best = S; beff = eff; }
+        }
+        if (ntl >= 2048) best = 1;
+        s->splitk = best;
+        const long gran = 128L * best;                        // every split a multiple of 128 rows
+        long chunk = round_up(s->n, gran);
+        const long cmax = (CHUNK_MAX / gran) * gran;
+        if (chunk > cmax) chunk = cmax;
+        s->chunk = chunk;
+    }
+    HIP_CHECK(hipMalloc(&s->XtC, sizeof(double) * s->D * s->chunk));
     const long mp = s->mp, D = s->D, Dy = s->Dy;
     const size_t mm = sizeof(double) * mp * mp;
     const int groups = (int)((D + 31) / 32);
@@ -163,7 +201,7 @@ static int alloc_m(mi355gp_sparse* s, long M) {
     double** mats[] = {&s->Lm, &s->Xm, &s->Tm, &s->psi2, &s->Amat, &s->LB, &s->XB, &s->Bi, &s->P, &s->E, &s->T1, &s->Q2,
                        &s->dLdKmm, &s->Winv};
     for (auto p : mats) HIP_CHECK(hipMalloc(p, mm));
-    HIP_CHECK(hipMalloc(&s->psi2part, mm * SPLITK));
+    HIP_CHECK(hipMalloc(&s->psi2part, mm * SPLITK_MAX));
     HIP_CHECK(hipMalloc(&s->Kfu, sizeof(double) * s->chunk * mp));
     HIP_CHECK(hipMalloc(&s->T, sizeof(double) * s->chunk * mp));
     double** vecs[] = {&s->psi1Y, &s->vecA, &s->vecB, &s->cvec, &s->wvec, &s->vvec};
@@ -230,13 +268,9 @@ int mi355gp_sparse_set_data(mi355gp_sparse* s, const double* X, int64_t N, int D
     s->n = N;
     s->D = D;
     s->Dy = Dy;
-    const long gran = 16 * SPLITK * 8;                       // 1024: keeps every split a multiple of 128 rows
-    long chunk = round_up(N, gran);
-    if (chunk > CHUNK_MAX) chunk = CHUNK_MAX;
-    s->chunk = chunk;
     HIP_CHECK(hipMalloc(&s->dX, sizeof(double) * N * D));
     HIP_CHECK(hipMalloc(&s->dY, sizeof(double) * N * Dy));
-    HIP_CHECK(hipMalloc(&s->XtC, sizeof(double) * D * chunk));
+    s->XtC = nullptr;                                         // sized with the chunk (alloc_m)
     HIP_CHECK(hipMemcpy(s->dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(s->dY, Y, sizeof(double) * N * Dy, hipMemcpyHostToDevice));
     double t = 0.0;
@@ -316,11 +350,11 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
         launch_scale_inputs(st, s->dX + r0 * D, rc, D, s->invls, kp.ard, s->XtC, chunk);
         if (rc < chunk || nch == 0) HIP_CHECK(hipMemsetAsync(s->Kfu, 0, sizeof(double) * chunk * mp, st));
         launch_kbuild_cross(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, s->Kfu, mp);
-        launch_gram_splitk(st, s->Kfu, mp, chunk, mp, SPLITK, nch > 0, s->psi2part);
+        launch_gram_splitk(st, s->Kfu, mp, chunk, mp, s->splitk, nch > 0, s->psi2part);
         const int ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, s->dY + r0 * Dy, Dy, 1, Dy, 0, s->colPart);
         launch_sum_splits(st, s->colPart, mp * Dy, ns, 1, s->psi1Y);               // psi1Y += Kuf Y_chunk
     }
-    hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->psi2part, mp, SPLITK, s->psi2);
+    hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->psi2part, mp, s->splitk, s->psi2);
     if (s->comm) {                                              // the one exchange step of pass 1
         if (int rc = rccl_allreduce_sum(s->comm, s->psi2, (size_t)mp * mp, st)) return rc;
         if (int rc = rccl_allreduce_sum(s->comm, s->psi1Y, (size_t)mp * Dy, st)) return rc;
@@ -356,7 +390,9 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
                        0.5 * beta * Dy, mp, s->E);
     launch_gemm(st, 1, 1, mp, mp, mp, s->Xm, mp, s->E, mp, s->T1, mp, 1.0, 0.0);
     launch_gemm(st, 0, 1, mp, mp, mp, s->T1, mp, s->Xm, mp, s->Q2, mp, 1.0, 0.0);
-    hipLaunchKernelGGL(k_sparse_scalars, dim3(1), dim3(1024), 0, st, s->Amat, s->P, s->LB, s->cvec, Dy, mp, m, s->scal);
+    hipLaunchKernelGGL(k_sparse_scalars_rows, dim3((unsigned)m), dim3(256), 0, st, s->Amat, s->P, s->LB, s->cvec, Dy, mp, m,
+                       s->colPart);
+    hipLaunchKernelGGL(k_sparse_scalars, dim3(1), dim3(256), 0, st, s->colPart, m, s->scal);
     HIP_CHECK(hipEventRecord(s->ev[2], st));
     // ---- pass 2: dL_dKnm = beta Y v^T + 2 Kfu dL_dpsi2 (:219,233), its theta reductions and H^T [X~ | 1] ---------
     HIP_CHECK(hipMemsetAsync(s->gradNM, 0, sizeof(double) * groups * GP_STRIDE, st));

@@ -121,6 +121,24 @@ def cpu_baseline(kind, ARD, D, n_sample, n_full):
             "measured_seconds": dt, "sample_N": n_sample}
 
 
+def profiled_traffic(kernel_prefix):
+    """HBM-side bytes per launch of the roofline kernel from the committed PMC summary (profiles/*_traffic.json, written
+    by tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if no summary is committed."""
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")) if "sparse" not in f)
+    if not files:
+        return None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+        for name, v in ks.items():
+            if name.startswith(kernel_prefix):
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,7 +206,9 @@ def main():
             "stage_ms": {k: round(float(v), 4) for k, v in st.items()},
             "roofline": {"bound": "mfma", "kernel": "k_update_nt (fp64 MFMA trailing update of the blocked Cholesky)",
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP64_TFLOPS,
+                         "traffic": profiled_traffic("k_update_nt") if (N, D, args.kind) == (16384, 32, "matern52")
+                         else None,
                          "launches_per_step": upd_n, "avg_launch_ms": upd_ms / max(upd_n, 1),
                          "algorithmic_flops_per_step": upd_flops},
             "lml": r["lml"],

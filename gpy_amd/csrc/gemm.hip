@@ -103,7 +103,7 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
 // stage 2: X21 = -X22 * T21  (X22 lower triangular -> k from the start of the right block to ti)
 template <int STAGE, int NW>
 __global__ LB(NW) void k_trtri_stage(const double* __restrict__ L, double* __restrict__ X,
-                                                        double* __restrict__ T, long ld, int nt, int nbt) {
+                                                        double* __restrict__ T, long ld, int nt, int nbt, int rev) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int per = nbt * nbt;
     const int p = blockIdx.x / per;
@@ -124,7 +124,7 @@ __global__ LB(NW) void k_trtri_stage(const double* __restrict__ L, double* __res
     if (STAGE == 1) {
         const int K = (right0 - tj) * NB;
         gemm_tile_128<true, false, NW>(L + (long)ti * NB * ld + (long)tj * NB, ld,
-                                   X + (long)tj * NB * ld + (long)tj * NB, ld, K, acc, smem);
+                                   X + (long)tj * NB * ld + (long)tj * NB, ld, K, acc, smem, 0, rev);
         gt_store<0, NW>(T + (long)ti * NB * ld + (long)tj * NB, ld, acc);
     } else {
         const int K = (ti - right0 + 1) * NB;
@@ -137,10 +137,11 @@ __global__ LB(NW) void k_trtri_stage(const double* __restrict__ L, double* __res
 template <int NW>
 static void launch_trtri_level_t(hipStream_t st, long nblocks, const double* L, double* X, double* T, long ld, int nt,
                                  int nbt) {
+    static const int rev = env_int("MI355GP_REVERSE_K", GEMM_DEFAULT_REVERSE_K);
     LDS_OPT_IN((k_trtri_stage<1, NW>));
     LDS_OPT_IN((k_trtri_stage<2, NW>));
-    hipLaunchKernelGGL((k_trtri_stage<1, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt);
-    hipLaunchKernelGGL((k_trtri_stage<2, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt);
+    hipLaunchKernelGGL((k_trtri_stage<1, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev);
+    hipLaunchKernelGGL((k_trtri_stage<2, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev);
 }
 
 void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level) {
@@ -156,7 +157,7 @@ void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, l
 // W = X^T X for lower-triangular X (the dlauum half of LAPACK dpotri): W[ti,tj] = sum_{tk>=ti} X[tk,ti]^T X[tk,tj].
 template <int NW>
 __global__ LB(NW) void k_lauum(const double* __restrict__ X, double* __restrict__ W, long ld,
-                                                  int nt) {
+                                                  int nt, int rev) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int bid = blockIdx.x;
     int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
@@ -167,14 +168,15 @@ __global__ LB(NW) void k_lauum(const double* __restrict__ X, double* __restrict_
     gt_zero<NW>(acc);
     const int K = (nt - ti) * NB;
     gemm_tile_128<false, false, NW>(X + (long)ti * NB * ld + (long)ti * NB, ld, X + (long)ti * NB * ld + (long)tj * NB, ld,
-                                K, acc, smem);
+                                K, acc, smem, 0, rev);
     gt_store<0, NW>(W + (long)ti * NB * ld + (long)tj * NB, ld, acc);
 }
 
 template <int NW>
 static void launch_lauum_t(hipStream_t st, long nblocks, const double* X, double* W, long ld, int nt) {
+    static const int rev = env_int("MI355GP_REVERSE_K", GEMM_DEFAULT_REVERSE_K);
     LDS_OPT_IN((k_lauum<NW>));
-    hipLaunchKernelGGL((k_lauum<NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, X, W, ld, nt);
+    hipLaunchKernelGGL((k_lauum<NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, X, W, ld, nt, rev);
 }
 
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt) {

@@ -88,13 +88,17 @@ __device__ __forceinline__ double gt_frag(const double* s, int idx, int kk) {
 template <bool AK, bool BK, int NW, bool NEGA = false>
 __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long lda,
                                               const double* __restrict__ B, long ldb, int K,
-                                              d4 (&acc)[4][GTCfg<NW>::NI], double* smem, int dbg_nosync = 0) {
+                                              d4 (&acc)[4][GTCfg<NW>::NI], double* smem, int dbg_nosync = 0,
+                                              int reverse_k = 0) {
     constexpr int NI = GTCfg<NW>::NI;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / GTCfg<NW>::WPR, wc = w % GTCfg<NW>::WPR;
     d2 ra[GTCfg<NW>::NLD], rb[GTCfg<NW>::NLD];
     const int nk = K / GT_BK;
-    gt_g2r<AK, NW>(A, lda, 0, ra, t);
-    gt_g2r<BK, NW>(B, ldb, 0, rb, t);
+    // reverse_k: walk the slabs from k = K-16 down to 0.  Tiles of one launch whose k-ranges END at a common point
+    // (lauum, trtri stage 1) then sweep the same operand slabs at the same time, which is what keeps them in L2.
+    const int kbeg = reverse_k ? K - GT_BK : 0, kinc = reverse_k ? -GT_BK : GT_BK;
+    gt_g2r<AK, NW>(A, lda, kbeg, ra, t);
+    gt_g2r<BK, NW>(B, ldb, kbeg, rb, t);
     gt_r2s<AK, NW>(smem, ra, t);
     gt_r2s<BK, NW>(smem + GT_TILE, rb, t);
     __syncthreads();
@@ -102,8 +106,8 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            gt_g2r<AK, NW>(A, lda, (kt + 1) * GT_BK, ra, t);
-            gt_g2r<BK, NW>(B, ldb, (kt + 1) * GT_BK, rb, t);
+            gt_g2r<AK, NW>(A, lda, kbeg + (kt + 1) * kinc, ra, t);
+            gt_g2r<BK, NW>(B, ldb, kbeg + (kt + 1) * kinc, rb, t);
         }
         const double* a_s = smem + cur * 2 * GT_TILE;
         const double* b_s = a_s + GT_TILE;

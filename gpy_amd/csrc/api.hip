@@ -184,6 +184,8 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
     const long n = c->n, np = c->npad;
     c->ws.prof.reset();
     HIP_CHECK(hipEventRecord(c->ev[1], st));
+    c->ws.scratchX = c->B;                                   // free until trtri / lauum overwrite them
+    c->ws.scratchT = c->C;
     potrf_device(st, c->A, np, &c->ws);
     HIP_CHECK(hipEventRecord(c->ev[2], st));
     trtri_device(st, c->A, c->B, c->C, np, &c->ws);
@@ -484,6 +486,8 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
         HIP_CHECK(hipMalloc(&C, sizeof(double) * np * np));
     }
     if (factor_ws_alloc(&ws, np) != 0) return -3;
+    ws.scratchX = B;                                          // both null without `invert`: trsm128-based panels
+    ws.scratchT = C;
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
@@ -594,6 +598,7 @@ int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
     ARG_CHECK(c != nullptr, "mi355gp_set_option: NULL context");
     if (option == MI355GP_OPT_PROFILE) { c->ws.prof.on = (value != 0); c->ws.prof.mask = (value == 1) ? 0xffu : (unsigned)value >> 1; }
     else if (option == MI355GP_OPT_LOOKAHEAD) c->ws.lookahead = (value < 0 || value > 2) ? 1 : value;
+    else if (option == MI355GP_OPT_PANEL) c->ws.panel_inv = (value != 0);
     else { mi355gp_set_error("mi355gp_set_option: unknown option %d", option); return -1; }
     return 0;
 }

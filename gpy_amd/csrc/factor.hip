@@ -4,6 +4,7 @@
 // Layout: one padded (npad x npad, npad % 128 == 0) row-major fp64 buffer per matrix, lower triangle
 // significant; padding rows/cols carry the identity, which factorises and inverts to itself.
 #include <cstdlib>
+#include <vector>
 
 #include "internal.h"
 
@@ -54,6 +55,38 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     int least = 0, greatest = 0;
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIP_CHECK(hipStreamCreateWithPriority(&ws->st_panel, hipStreamNonBlocking, greatest));
+    {
+        // Express lane for the panel chain: the big trailing updates run on a stream whose CU mask leaves `reserve_cus`
+        // CUs out, so k_diag128 (one workgroup, dependent fp64 VALU chain) never shares a CU with an fp64-MFMA-saturating
+        // update workgroup (measured: 42 us alone, 125-300 us when co-resident).  MI355GP_RESERVE_CUS=0 disables it.
+        const char* envr = getenv("MI355GP_RESERVE_CUS");
+        ws->reserve_cus = (envr && *envr) ? atoi(envr) : FACTOR_DEFAULT_RESERVE_CUS;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        const int ncu = prop.multiProcessorCount;
+        if (ws->reserve_cus > 0 && ws->reserve_cus < ncu / 2) {
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            const int stride = ncu / ws->reserve_cus;            // spread the reserved CUs over the whole index range
+            for (int cu = 0; cu < ncu; ++cu) {
+                const bool reserved = (cu % stride == 0) && (cu / stride < ws->reserve_cus);
+                if (!reserved) mask[cu / 32] |= 1u << (cu % 32);
+            }
+            hipError_t e = hipExtStreamCreateWithCUMask(&ws->st_bulk, (uint32_t)mask.size(), mask.data());
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                ws->st_bulk = nullptr;
+            }
+        }
+        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_bulk, hipEventDisableTiming));
+    }
+    const char* envw = getenv("MI355GP_PART2_WGS");
+    if (envw && *envw) ws->part2_wgs = atoi(envw);
+    const char* envt = getenv("MI355GP_PART2_TILES");
+    if (envt && *envt) ws->part2_tiles = atol(envt);
+    const char* envp = getenv("MI355GP_PANEL_INV");
+    if (envp && *envp) ws->panel_inv = atoi(envp) ? 1 : 0;
     const char* env = getenv("MI355GP_UPD_STREAMS");
     if (env && *env) ws->n_upd = atoi(env);
     if (ws->n_upd < 1) ws->n_upd = 1;
@@ -93,6 +126,10 @@ void factor_ws_free(FactorWs* ws) {
     }
     if (ws->st_panel) (void)hipStreamDestroy(ws->st_panel);
     ws->st_panel = nullptr;
+    if (ws->st_bulk) (void)hipStreamDestroy(ws->st_bulk);
+    ws->st_bulk = nullptr;
+    if (ws->ev_bulk) (void)hipEventDestroy(ws->ev_bulk);
+    ws->ev_bulk = nullptr;
     ws->prof.destroy();
 }
 
@@ -102,7 +139,12 @@ static double gemm_flops(double m, double n, double K) { return 2.0 * m * n * K;
 
 // One outer panel: columns [K0, K0+W), rows [K0, npad).  128-column steps:
 //   diag128 (one CU) -> trsm128 on the rows below -> rank-128 update of the remaining columns of the panel.
+static void factor_panel_inv(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws);
 static void factor_panel(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws) {
+    if (ws->panel_inv && ws->scratchX && ws->scratchT) {
+        factor_panel_inv(s, A, npad, K0, W, ws);
+        return;
+    }
     const long ld = npad;
     for (long j = 0; j < W; j += NB) {
         const long c = K0 + j, blk = c / NB;
@@ -127,14 +169,60 @@ static void factor_panel(hipStream_t s, double* A, long npad, long K0, long W, F
     }
 }
 
+// Inverse-based panel (needs ws->scratchX / scratchT): the chain kernels that must win workgroup slots against a
+// machine-filling trailing update shrink from 4 x (trsm128 + in-panel update) over the whole panel height to ONE GEMM.
+//   D phase : the W x W diagonal block is factored with the 128-step loop restricted to its own rows (<= 6-tile kernels)
+//   I phase : XD = L_D^-1 (inv128 + log2(W/128) batched levels) into scratchX at the block's own position
+//   R phase : rows below:  L_R = R * XD^T  (k_panel_trmm) into scratchT, copied back into A
+// rocprof: the trsm128-based chain takes 0.75 ms per panel on an idle GPU but ~1.7 ms under a trailing update.
+static void factor_panel_inv(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws) {
+    const long ld = npad, end = K0 + W;
+    for (long j = 0; j < W; j += NB) {
+        const long c = K0 + j, blk = c / NB;
+        double* dv = ws->dinv + blk * 8 * 256;
+        ws->prof.begin(s, PF_DIAG, (double)NB * NB * NB / 3.0);
+        launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info);
+        ws->prof.end(s);
+        const long below = end - (c + NB);                      // rows of the diagonal block still to do
+        if (below <= 0) continue;
+        ws->prof.begin(s, PF_TRSM, (double)below * NB * NB);
+        launch_trsm128(s, A, ld, c, c + NB, below, dv);
+        ws->prof.end(s);
+        double* C = A + (c + NB) * ld + (c + NB);
+        const double* P = A + (c + NB) * ld + c;
+        ws->prof.begin(s, PF_UPDATE, syrk_flops((double)below, NB));
+        launch_update_nt(s, C, ld, P, ld, P, ld, NB, (int)(below / NB), (int)(below / NB), (int)((c + NB) / NB),
+                         (int)((c + NB) / NB));
+        ws->prof.end(s);
+    }
+    const long rows = npad - end;
+    if (rows <= 0) return;
+    double* XD = ws->scratchX + K0 * ld + K0;
+    double* TD = ws->scratchT + K0 * ld + K0;
+    const int nt = (int)(W / NB);
+    (void)hipMemset2DAsync(XD, sizeof(double) * ld, 0, sizeof(double) * W, W, s);      // upper blocks of XD must be zero
+    ws->prof.begin(s, PF_TRTRI, (double)W * W * W / 3.0);
+    launch_inv128(s, A + K0 * ld + K0, XD, ld, nt, ws->dinv + (K0 / NB) * 8 * 256);
+    for (int level = 0; (1 << level) < nt; ++level) launch_trtri_level(s, A + K0 * ld + K0, XD, TD, ld, nt, level);
+    ws->prof.end(s);
+    double* R = A + end * ld + K0;
+    double* Rt = ws->scratchT + end * ld + K0;
+    ws->prof.begin(s, PF_TRSM, (double)rows * W * W);
+    launch_panel_trmm(s, R, XD, Rt, ld, (int)(rows / NB), nt);
+    ws->prof.end(s);
+    (void)hipMemcpy2DAsync(R, sizeof(double) * ld, Rt, sizeof(double) * ld, sizeof(double) * W, rows,
+                           hipMemcpyDeviceToDevice, s);
+}
+
 // rank-W update of the trailing columns [c0, c1) (rows c0 .. npad) with the panel at columns [K0, K0+W)
-static void update_cols(hipStream_t s, double* A, long npad, long K0, long W, long c0, long c1, FactorWs* ws) {
+static void update_cols(hipStream_t s, double* A, long npad, long K0, long W, long c0, long c1, FactorWs* ws,
+                        int max_wgs = 0) {
     if (c1 <= c0) return;
     const long ld = npad, rows = npad - c0, cols = c1 - c0;
     const double* P = A + c0 * ld + K0;
     ws->prof.begin(s, PF_UPDATE, syrk_flops((double)cols, (double)W) + gemm_flops((double)(rows - cols), (double)cols, (double)W));
     launch_update_nt(s, A + c0 * ld + c0, ld, P, ld, P, ld, (int)W, (int)(rows / NB), (int)(cols / NB), (int)(c0 / NB),
-                     (int)(c0 / NB));
+                     (int)(c0 / NB), max_wgs);
     ws->prof.end(s);
 }
 
@@ -216,21 +304,30 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     const long P = (npad + NBO - 1) / NBO;
     auto pcol = [&](long p) { return (p * NBO < npad) ? p * NBO : npad; };
     hipStream_t sp = ws->st_panel;
+    hipStream_t su = ws->st_bulk ? ws->st_bulk : st;            // trailing updates (CU-masked when an express lane is set)
     (void)hipEventRecord(ws->ev_fork, st);                      // panel 0 follows everything queued on st so far
     (void)hipStreamWaitEvent(sp, ws->ev_fork, 0);
+    if (su != st) (void)hipStreamWaitEvent(su, ws->ev_fork, 0);
     factor_panel(sp, A, npad, 0, pcol(1), ws);
     for (long p = 0; p + 1 < P; ++p) {
         const long K0 = pcol(p), W = pcol(p + 1) - K0;
         (void)hipEventRecord(ws->ev_panel[p], sp);
-        (void)hipStreamWaitEvent(st, ws->ev_panel[p], 0);
-        update_cols(st, A, npad, K0, W, pcol(p + 1), pcol(p + 2), ws);       // part 1: the next panel's columns
-        (void)hipEventRecord(ws->ev_cols[p + 1], st);
+        (void)hipStreamWaitEvent(su, ws->ev_panel[p], 0);
+        update_cols(su, A, npad, K0, W, pcol(p + 1), pcol(p + 2), ws);       // part 1: the next panel's columns
+        (void)hipEventRecord(ws->ev_cols[p + 1], su);
         (void)hipStreamWaitEvent(sp, ws->ev_cols[p + 1], 0);
         factor_panel(sp, A, npad, pcol(p + 1), pcol(p + 2) - pcol(p + 1), ws);
-        update_cols(st, A, npad, K0, W, pcol(p + 2), npad, ws);              // part 2: everything to the right
+        // part 2: everything to the right (optionally with a bounded number of resident workgroups, see part2_wgs)
+        const long t2 = (npad - pcol(p + 2)) / NB, tiles2 = t2 * (t2 + 1) / 2;
+        update_cols(su, A, npad, K0, W, pcol(p + 2), npad, ws,
+                    (ws->part2_wgs > 0 && tiles2 < ws->part2_tiles) ? ws->part2_wgs : 0);
     }
     (void)hipEventRecord(ws->ev_panel[P], sp);
     (void)hipStreamWaitEvent(st, ws->ev_panel[P], 0);
+    if (su != st) {
+        (void)hipEventRecord(ws->ev_bulk, su);
+        (void)hipStreamWaitEvent(st, ws->ev_bulk, 0);
+    }
 }
 
 // X = L^-1: diagonal 128-blocks on single CUs (all blocks concurrently), then log2(nt) batched levels.

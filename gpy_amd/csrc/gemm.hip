@@ -47,52 +47,57 @@ template <int NW, bool PRE>
 __global__ LB(NW) void k_update_nt(double* __restrict__ C, long ldc,
                                                       const double* __restrict__ A, long lda,
                                                       const double* __restrict__ B, long ldb, int K, int ntc,
-                                                      int row0t, int col0t, int tri) {
+                                                      int row0t, int col0t, int tri, long ntiles) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    int ti, tj;
-    const int bid = blockIdx.x;
-    if (tri) {
-        ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
-        while ((long)ti * (ti + 1) / 2 > bid) --ti;
-        while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
-        tj = bid - (int)((long)ti * (ti + 1) / 2);
-    } else {
-        ti = bid / ntc;
-        tj = bid - ti * ntc;
-        if (col0t + tj > row0t + ti) return;
-    }
-    d4 acc[4][GTCfg<NW>::NI];
-    double* Ct = C + (long)ti * NB * ldc + (long)tj * NB;
-    if (PRE) {
-        gt_load_buf<NW>(Ct, ldc, acc);
-        gemm_tile_128<true, true, NW, true>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
-        gt_store<0, NW>(Ct, ldc, acc);
-    } else {
-        gt_zero<NW>(acc);
-        gemm_tile_128<true, true, NW>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
-        gt_store<2, NW>(Ct, ldc, acc);
+    // grid-stride over the tile list: gridDim.x == ntiles is the one-tile-per-workgroup launch; a smaller grid
+    // (launch_update_nt `max_wgs`) keeps only that many workgroups resident so that the panel chain of the
+    // look-ahead schedule finds free slots on every CU while a trailing update is running.
+    for (long bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
+        int ti, tj;
+        if (tri) {
+            ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+            while ((long)ti * (ti + 1) / 2 > bid) --ti;
+            while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+            tj = (int)(bid - (long)ti * (ti + 1) / 2);
+        } else {
+            ti = (int)(bid / ntc);
+            tj = (int)(bid - (long)ti * ntc);
+            if (col0t + tj > row0t + ti) continue;
+        }
+        d4 acc[4][GTCfg<NW>::NI];
+        double* Ct = C + (long)ti * NB * ldc + (long)tj * NB;
+        if (PRE) {
+            gt_load_buf<NW>(Ct, ldc, acc);
+            gemm_tile_128<true, true, NW, true>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
+            gt_store<0, NW>(Ct, ldc, acc);
+        } else {
+            gt_zero<NW>(acc);
+            gemm_tile_128<true, true, NW>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
+            gt_store<2, NW>(Ct, ldc, acc);
+        }
     }
 }
 
 template <int NW, bool PRE>
-static void launch_update_nt_t(hipStream_t st, long nblocks, double* C, long ldc, const double* A, long lda,
+static void launch_update_nt_t(hipStream_t st, long nblocks, long grid, double* C, long ldc, const double* A, long lda,
                                const double* B, long ldb, int K, int ntc, int row0t, int col0t, int tri) {
     LDS_OPT_IN((k_update_nt<NW, PRE>));
-    hipLaunchKernelGGL((k_update_nt<NW, PRE>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, C, ldc, A, lda,
-                       B, ldb, K, ntc, row0t, col0t, tri);
+    hipLaunchKernelGGL((k_update_nt<NW, PRE>), dim3((unsigned)grid), dim3(NW * 64), GT_LDS_BYTES, st, C, ldc, A, lda,
+                       B, ldb, K, ntc, row0t, col0t, tri, nblocks);
 }
 
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
-                      int K, int ntr, int ntc, int row0t, int col0t) {
+                      int K, int ntr, int ntc, int row0t, int col0t, int max_wgs) {
     if (ntr <= 0 || ntc <= 0) return;
     const int tri = (row0t == col0t && ntr == ntc) ? 1 : 0;
     const long nblocks = tri ? (long)ntr * (ntr + 1) / 2 : (long)ntr * ntc;
+    const long grid = (max_wgs > 0 && max_wgs < nblocks) ? max_wgs : nblocks;
     if (gemm_variant_preload())
-        NW_DISPATCH((launch_update_nt_t<4, true>(st, nblocks, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)),
-                    (launch_update_nt_t<8, true>(st, nblocks, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)));
+        NW_DISPATCH((launch_update_nt_t<4, true>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)),
+                    (launch_update_nt_t<8, true>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)));
     else
-        NW_DISPATCH((launch_update_nt_t<4, false>(st, nblocks, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)),
-                    (launch_update_nt_t<8, false>(st, nblocks, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)));
+        NW_DISPATCH((launch_update_nt_t<4, false>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)),
+                    (launch_update_nt_t<8, false>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -211,6 +216,26 @@ void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* 
                        int ntr, int ntc) {
     NW_DISPATCH((launch_trmm_lower_t<4>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc)),
                 (launch_trmm_lower_t<8>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Panel solve through the explicit inverse of the (<= 512 x 512) diagonal block: L_R = R * L_D^-T = R * XD^T.
+// One launch for the whole panel height instead of four trsm128 + three in-panel updates on the critical chain.
+template <int NW>
+__global__ LB(NW) void k_panel_trmm(const double* __restrict__ R, const double* __restrict__ XD,
+                                    double* __restrict__ Out, long ld, int ntc) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ti = blockIdx.x / ntc, tj = ntc - 1 - (int)(blockIdx.x % ntc);      // long-K column tiles first
+    d4 acc[4][GTCfg<NW>::NI];
+    gt_zero<NW>(acc);
+    gemm_tile_128<true, true, NW>(R + (long)ti * NB * ld, ld, XD + (long)tj * NB * ld, ld, (tj + 1) * NB, acc, smem);
+    gt_store<0, NW>(Out + (long)ti * NB * ld + (long)tj * NB, ld, acc);
+}
+
+void launch_panel_trmm(hipStream_t st, const double* R, const double* XD, double* Out, long ld, int ntr, int ntc) {
+    if (ntr <= 0 || ntc <= 0) return;
+    LDS_OPT_IN((k_panel_trmm<4>));
+    hipLaunchKernelGGL((k_panel_trmm<4>), dim3((unsigned)(ntr * ntc)), dim3(256), GT_LDS_BYTES, st, R, XD, Out, ld, ntc);
 }
 
 // C (mpad x mpad, ldc) = alpha * A^T A + beta * C with A (K x mpad): the K** - tmp^T tmp of full_cov prediction

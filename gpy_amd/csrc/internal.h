@@ -6,12 +6,16 @@
 
 // ---- gemm.hip : tiled fp64 MFMA GEMM family (all dimensions multiples of 128) -------------------
 // C[ti,tj] -= A[ti,:] * B[tj,:]^T over a (ntr x ntc)-tile region; tiles with (col0t+tj) > (row0t+ti) skipped.
+// max_wgs > 0: at most that many resident workgroups, each walking the tile list with a grid stride
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
-                      int K, int ntr, int ntc, int row0t, int col0t);
+                      int K, int ntr, int ntc, int row0t, int col0t, int max_wgs = 0);
 // one bottom-up level of the batched triangular inverse: X21 = -X22 * (L21 * X11) for every block pair
 void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level);
 // W (lower tiles) = X^T X for lower-triangular X
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt);
+// rows-below-the-diagonal-block part of a panel: Out[ti, tj] = sum_{k < (tj+1)*128} R[ti, k] * XD[tj, k]  (= R * XD^T with XD
+// lower triangular, w/128 column tiles), ntr row tiles; R, XD, Out share the leading dimension ld
+void launch_panel_trmm(hipStream_t st, const double* R, const double* XD, double* Out, long ld, int ntr, int ntc);
 void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
                        int ntr, int ntc);
 void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
@@ -60,6 +64,17 @@ struct FactorWs {
     std::vector<hipEvent_t> ev_cols;         // [p]: every update of panel p's columns has been issued (-> its factorisation)
     hipEvent_t ev_fork = nullptr, ev_join[MAX_UPD] = {};
     int lookahead = 1;
+    // Optional scratch for the inverse-based panel solve (factor.hip: factor_panel_inv): two npad x npad buffers with the
+    // same leading dimension as A that are free during the factorisation (the context's X = L^-1 and W buffers).
+    // nullptr -> the trsm128-based panel path.
+    double* scratchX = nullptr;
+    double* scratchT = nullptr;
+    int panel_inv = 0;          // option MI355GP_OPT_PANEL: 1 = inverse-based panel when scratch is available (measured slower)
+    hipStream_t st_bulk = nullptr;   // trailing updates of the look-ahead schedule: CU-masked so that `reserve_cus` CUs stay
+    int reserve_cus = 0;             // free of MFMA-saturating workgroups and the latency-bound panel kernels run there
+    hipEvent_t ev_bulk = nullptr;
+    int part2_wgs = 0;          // > 0: trailing updates that overlap a panel factorisation keep only this many workgroups
+    long part2_tiles = 0;       //      resident (one per CU) once the update has fewer tiles than this
     KernelProf prof;
 };
 int factor_ws_alloc(FactorWs* ws, long npad);

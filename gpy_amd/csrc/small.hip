@@ -12,6 +12,7 @@
 #include "common.h"
 #include "internal.h"
 
+#define PRIO_CHAIN 0        // s_setprio 3 in the chain kernels: no measurable effect (fp64 VALU shares the DP pipe with MFMA)
 #define TS 18                 // row stride (doubles) inside a 16x16 tile
 #define TSZ (16 * TS)         // doubles per tile image
 #define NTILE 36              // lower tiles of a 128x128 block
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void k_diag128(double* __restrict__ A, long ld
                                                   double* __restrict__ dinv, double* __restrict__ logsum,
                                                   int* __restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (PRIO_CHAIN) __builtin_amdgcn_s_setprio(3);   // win instruction arbitration against co-resident update waves
     double* Tt = sm;                       // [36][16][18]
     double* Dv = sm + NTILE * TSZ;         // [16][18] inverse of the current diagonal tile
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -190,6 +192,7 @@ void launch_diag128(hipStream_t st, double* A, long ld, long c0, double* dinv, d
 // (L2-resident, shared by every wave) then carry no dependence on earlier steps and the compiler hoists them.
 __global__ __launch_bounds__(256) void k_trsm128(double* __restrict__ A, long ld, long c0, long r0, long mrows,
                                                  const double* __restrict__ dinv) {
+    if (PRIO_CHAIN) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long prow0 = r0 + ((long)blockIdx.x * 4 + w) * 16;
     if (prow0 >= r0 + mrows) return;

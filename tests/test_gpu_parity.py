@@ -251,3 +251,28 @@ def test_size_independent_properties_at_baseline_sizes(kind, ARD, N, D, ctx):
     fp = ctx.exact_inference(kind, ARD, L.theta_vec(var + h, ls, ARD, D), noise)[1]["lml"]
     fm = ctx.exact_inference(kind, ARD, L.theta_vec(var - h, ls, ARD, D), noise)[1]["lml"]
     assert abs((fp - fm) / (2 * h) - r["dtheta"][0]) <= 1e-5 * abs(r["dtheta"][0]) + 1e-6
+
+
+def test_config4_size_on_one_gpu_without_fetching_n_squared(ctx):
+    """BASELINE configs[3] size (RBF, N=32768, D=8) on a single MI355X (3 x 8.6 GB resident): the checks that need
+    no N^2 transfer -- Ky alpha = Y on sampled rows, LML from its parts, variance gradient by central differences."""
+    kind, ARD, N, D = "rbf", False, 32768, 8
+    X, Y = O.synthetic(N, D, seed=0)
+    var, ls, noise = O.default_theta(D, ARD)
+    th = L.theta_vec(var, ls, ARD, D)
+    ctx.set_data(X, Y)
+    info, r = ctx.exact_inference(kind, ARD, th, noise, want_diag=True)
+    assert info == 0
+    rows = np.sort(np.random.default_rng(2).choice(N, 16, replace=False))
+    Ky_rows = L.kern_K(kind, ARD, th, X[rows], X)
+    Ky_rows[np.arange(rows.size), rows] += noise + 1e-8
+    assert np.abs(Ky_rows @ r["alpha"] - Y[rows]).max() <= 1e-9 * max(1.0, np.abs(Y).max())
+    lml = 0.5 * (-N * np.log(2 * np.pi) - r["logdet"] - float(np.sum(r["alpha"] * Y)))
+    assert abs(lml - r["lml"]) <= 1e-12 * abs(lml)
+    assert abs(r["diag_dL_dK"].sum() - r["dnoise"]) <= 1e-9 * abs(r["dnoise"])
+    assert abs(r["dnoise"] - 0.5 * (np.sum(r["alpha"] ** 2) - r["trKinv"])) <= 1e-9 * abs(r["dnoise"])
+    h = 1e-5 * var
+    fp = ctx.exact_inference(kind, ARD, L.theta_vec(var + h, ls, ARD, D), noise)[1]["lml"]
+    fm = ctx.exact_inference(kind, ARD, L.theta_vec(var - h, ls, ARD, D), noise)[1]["lml"]
+    assert abs((fp - fm) / (2 * h) - r["dtheta"][0]) <= 1e-5 * abs(r["dtheta"][0]) + 1e-6
+    ctx.set_data(X[:256], Y[:256])            # release the 26 GB before the next test

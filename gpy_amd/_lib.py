@@ -15,7 +15,35 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355gp.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-KIND_IDS = {"rbf": 0, "matern52": 1, "matern32": 2, "exponential": 3}
+KIND_IDS = {"rbf": 0, "matern52": 1, "matern32": 2, "exponential": 3, "white": 4, "bias": 5}
+
+
+class Part(ctypes.Structure):
+    """`mi355gp_part` of include/mi355gp.h: one term of a sum kernel."""
+    _fields_ = [("kind", ctypes.c_int), ("ard", ctypes.c_int), ("n_active", ctypes.c_int),
+                ("active_dims", ctypes.POINTER(ctypes.c_int)), ("theta", ctypes.POINTER(ctypes.c_double))]
+
+
+def make_parts(specs):
+    """specs: [(kind_name, ARD, theta array, active_dims array or None)] -> (ctypes array, keep-alive list, n_theta)"""
+    arr = (Part * len(specs))()
+    keep, ntheta = [], 0
+    for i, (kind, ARD, theta, dims) in enumerate(specs):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        keep.append(th)
+        arr[i].kind = KIND_IDS[kind]
+        arr[i].ard = int(bool(ARD))
+        arr[i].theta = th.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        if dims is None:
+            arr[i].n_active = 0
+            arr[i].active_dims = None
+        else:
+            d = np.ascontiguousarray(dims, dtype=np.int32)
+            keep.append(d)
+            arr[i].n_active = d.size
+            arr[i].active_dims = d.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+        ntheta += th.size
+    return arr, keep, ntheta
 FETCH_L, FETCH_KINV, FETCH_DLDK, FETCH_K = 0, 1, 2, 3
 OUT_LML, OUT_LOGDET, OUT_DATAFIT, OUT_DNOISE, OUT_TRKINV, NUM_OUT = 0, 1, 2, 3, 4, 8
 STAGE_NAMES = ("kbuild", "potrf", "trtri", "lauum", "solve", "grad", "total")
@@ -72,6 +100,9 @@ def lib():
     L.mi355gp_update_gradients_full.argtypes = [ci, ci, ci, _dp, _dp, _dp, i64, _c_dp, i64, ci, _dp]
     L.mi355gp_gradients_X.argtypes = [ci, ci, ci, _dp, _dp, _dp, i64, _c_dp, i64, ci, _dp]
     L.mi355gp_exact_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
+    L.mi355gp_exact_inference_sum.argtypes = [vp, ci, ctypes.POINTER(Part), _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp,
+                                              _c_dp]
+    L.mi355gp_predict_sum.argtypes = [vp, ci, ctypes.POINTER(Part), _dp, i64, _c_dp, _c_dp, ci]
     L.mi355gp_inference_given_K.argtypes = [vp, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_fetch.argtypes = [vp, ci, _dp, ci]
     L.mi355gp_predict.argtypes = [vp, ci, ci, _dp, _dp, i64, _c_dp, _c_dp, ci]
@@ -98,7 +129,8 @@ def lib():
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
                  "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "sparse_create",
-                 "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm"):
+                 "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm", "exact_inference_sum",
+                 "predict_sum"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -112,6 +144,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_grid_destroy", "mi355gp_grid_set_data", "mi355gp_grid_exact_inference", "mi355gp_grid_fetch",
             "mi355gp_sparse_create", "mi355gp_sparse_destroy", "mi355gp_sparse_set_data", "mi355gp_vardtc_inference",
             "mi355gp_sparse_fetch", "mi355gp_gradients_X", "mi355gp_sparse_attach_comm",
+            "mi355gp_exact_inference_sum", "mi355gp_predict_sum",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks")
 
 
@@ -204,6 +237,38 @@ class Context(object):
         if ms is not None:
             res["stage_ms"] = dict(zip(STAGE_NAMES, ms[:len(STAGE_NAMES)]))
         return rc, res
+
+    def exact_inference_sum(self, specs, noise, jitter=1e-8, extra_jitter=0.0, want_alpha=True, want_diag=False,
+                            want_stage_ms=False):
+        """Sum kernel: specs = [(kind, ARD, theta, active_dims or None)]; dtheta is the concatenation over the parts."""
+        arr, keep, ntheta = make_parts(specs)
+        noise = f64(np.atleast_1d(noise))
+        out = np.zeros(NUM_OUT)
+        alpha = np.empty((self.N, self.Dy)) if want_alpha else None
+        dtheta = np.zeros(ntheta)
+        diag = np.empty(self.N) if want_diag else None
+        ms = np.zeros(NUM_T) if want_stage_ms else None
+        rc = check(lib().mi355gp_exact_inference_sum(self._h, len(specs), arr, noise, noise.size, jitter, extra_jitter,
+                                                     out, _opt(alpha), _opt(dtheta), _opt(diag), _opt(ms)),
+                   "mi355gp_exact_inference_sum")
+        res = dict(lml=out[OUT_LML], logdet=out[OUT_LOGDET], datafit=out[OUT_DATAFIT], dnoise=out[OUT_DNOISE],
+                   trKinv=out[OUT_TRKINV], alpha=alpha, dtheta=dtheta, diag_dL_dK=diag)
+        if ms is not None:
+            res["stage_ms"] = dict(zip(STAGE_NAMES, ms[:len(STAGE_NAMES)]))
+        return rc, res
+
+    def predict_sum(self, specs, Xnew, full_cov=False, want_var=True):
+        arr, keep, _ = make_parts(specs)
+        Xnew = f64(Xnew)
+        M = Xnew.shape[0]
+        assert Xnew.shape[1] == self.D
+        mu = np.empty((M, self.Dy))
+        var = (np.empty((M, M)) if full_cov else np.empty(M)) if want_var else None
+        check(lib().mi355gp_predict_sum(self._h, len(specs), arr, Xnew, M, mu.ctypes.data_as(_c_dp), _opt(var),
+                                        int(bool(full_cov))), "mi355gp_predict_sum")
+        if var is not None and not full_cov:
+            var = var[:, None]
+        return mu, var
 
     def inference_given_K(self, K, noise, jitter=1e-8, extra_jitter=0.0, want_diag=False, want_stage_ms=False):
         K = f64(K)

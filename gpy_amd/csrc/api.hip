@@ -34,6 +34,19 @@ void mi355gp_set_error(const char* fmt, ...) {
 #define GP_STRIDE 34
 #define LOG_2_PI 1.8378770664093454836
 
+// Scoped device allocation for the stateless entry points: every early return (HIP_CHECK) releases what was acquired.
+struct DevBuf {
+    double* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t doubles) { return hipMalloc(&p, sizeof(double) * (doubles ? doubles : 1)); }
+    operator double*() const { return p; }
+};
+
 struct mi355gp_ctx {
     int device = 0;
     hipStream_t st = nullptr;
@@ -50,9 +63,30 @@ struct mi355gp_ctx {
     bool have_factor = false, have_kernel = false;
     KernParams kp = {0, 0, 0, 1.0};
     std::vector<double> theta;
+    // The covariance function of the last fused call as a SUM of parts (GPy/kern/src/add.py; one part = plain kernel).
+    struct Part {
+        KernParams kp = {0, 0, 0, 1.0};
+        std::vector<double> theta;      // [variance, lengthscale(s)]  (static kinds: [variance])
+        std::vector<int> dims;          // active input dimensions (kern.py:49-53), indices into the D columns of X
+        std::vector<double> inv_ls;     // length D: 1/l on active dimensions, 0 elsewhere (= the slicing of kern.py:112-117)
+        double* dXt = nullptr;          // D x npad scaled, dimension-major inputs of this part
+    };
+    std::vector<Part> parts;
+    double* dGradOutAll = nullptr;      // [part][groups][GP_STRIDE]
+    size_t gradOutAllParts = 0;
 };
 
+static void free_parts(mi355gp_ctx* c) {
+    for (auto& p : c->parts)
+        if (p.dXt) (void)hipFree(p.dXt);
+    c->parts.clear();
+    if (c->dGradOutAll) (void)hipFree(c->dGradOutAll);
+    c->dGradOutAll = nullptr;
+    c->gradOutAllParts = 0;
+}
+
 static void free_data(mi355gp_ctx* c) {
+    free_parts(c);
     double** ptrs[] = {&c->dX, &c->dR, &c->dXt, &c->dInvLs, &c->dNoise, &c->A, &c->B, &c->C, &c->dAlpha,
                        &c->dTmp, &c->dTrmvPart, &c->dGradPart, &c->dGradOut, &c->dScal, &c->dDiag};
     for (auto p : ptrs) {
@@ -196,23 +230,33 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
     launch_scalars(st, c->dAlpha, c->dR, c->C, np, n, c->Dy, c->ws.logsum, c->ws.nblk, c->dScal, c->dDiag);
     HIP_CHECK(hipEventRecord(c->ev[5], st));
     const int groups = (c->D + 31) / 32;
-    int nb = 0;
-    if (with_kernel_grads) {
-        nb = grad_num_blocks(n);
-        launch_grad_fused(st, c->kp, c->dXt, np, n, c->C, np, c->dAlpha, c->Dy, c->dGradPart, GP_STRIDE);
-        for (int g = 0; g < (c->kp.ard ? groups : 1); ++g)
-            launch_reduce_partials(st, c->dGradPart + (long)g * nb * GP_STRIDE, nb, GP_STRIDE,
-                                   c->dGradOut + (long)g * GP_STRIDE);
+    const size_t nparts = with_kernel_grads ? c->parts.size() : 0;
+    if (nparts > 0) {
+        if (c->gradOutAllParts < nparts) {
+            if (c->dGradOutAll) (void)hipFree(c->dGradOutAll);
+            c->dGradOutAll = nullptr;
+            HIP_CHECK(hipMalloc(&c->dGradOutAll, sizeof(double) * nparts * groups * GP_STRIDE));
+            c->gradOutAllParts = nparts;
+        }
+        HIP_CHECK(hipMemsetAsync(c->dGradOutAll, 0, sizeof(double) * nparts * groups * GP_STRIDE, st));
+        const int nb = grad_num_blocks(n);
+        for (size_t p = 0; p < nparts; ++p) {       // every part reduces the same dL_dK against its own dK/dtheta
+            const mi355gp_ctx::Part& pt = c->parts[p];
+            launch_grad_fused(st, pt.kp, pt.dXt, np, n, c->C, np, c->dAlpha, c->Dy, c->dGradPart, GP_STRIDE);
+            for (int g = 0; g < (pt.kp.ard ? groups : 1); ++g)
+                launch_reduce_partials(st, c->dGradPart + (long)g * nb * GP_STRIDE, nb, GP_STRIDE,
+                                       c->dGradOutAll + ((long)p * groups + g) * GP_STRIDE);
+        }
     }
     HIP_CHECK(hipEventRecord(c->ev[6], st));
     // small D2H transfers
     double scal[8];
     int info[4];
-    std::vector<double> sums((size_t)groups * GP_STRIDE, 0.0);
+    std::vector<double> sums((nparts ? nparts : 1) * (size_t)groups * GP_STRIDE, 0.0);
     HIP_CHECK(hipMemcpyAsync(scal, c->dScal, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(info, c->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (with_kernel_grads)
-        HIP_CHECK(hipMemcpyAsync(sums.data(), c->dGradOut, sizeof(double) * groups * GP_STRIDE,
+    if (nparts > 0)
+        HIP_CHECK(hipMemcpyAsync(sums.data(), c->dGradOutAll, sizeof(double) * nparts * groups * GP_STRIDE,
                                  hipMemcpyDeviceToHost, st));
     if (alpha_out)
         HIP_CHECK(hipMemcpyAsync(alpha_out, c->dAlpha, sizeof(double) * n * c->Dy, hipMemcpyDeviceToHost, st));
@@ -245,7 +289,23 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
     out_scalars[MI355GP_OUT_DATAFIT] = datafit;
     out_scalars[MI355GP_OUT_DNOISE] = 0.5 * (alpha2 - Dy * trw);
     out_scalars[MI355GP_OUT_TRKINV] = trw;
-    if (with_kernel_grads && dtheta_out) finish_dtheta(c->kp, theta, sums.data(), dtheta_out);
+    if (nparts > 0 && dtheta_out) {
+        // post-scaling of the raw sums (stationary.py:199,210-213): dvar = S/variance, dl = -S/l, per part, concatenated
+        double* o = dtheta_out;
+        for (size_t p = 0; p < nparts; ++p) {
+            const mi355gp_ctx::Part& pt = c->parts[p];
+            const double* sp = sums.data() + p * (size_t)groups * GP_STRIDE;
+            *o++ = sp[0] / pt.kp.variance;
+            if (pt.kp.kind >= 4) continue;                                   // static kernels: variance only
+            if (!pt.kp.ard) *o++ = -sp[1] / pt.theta[1];
+            else
+                for (size_t a = 0; a < pt.dims.size(); ++a) {
+                    const int q = pt.dims[a];
+                    *o++ = -sp[(q / 32) * GP_STRIDE + 2 + (q % 32)] / pt.theta[1 + a];
+                }
+        }
+    }
+    (void)theta;
     return 0;
 }
 
@@ -258,25 +318,79 @@ static int upload_noise(mi355gp_ctx* c, const double* noise, int64_t noise_len) 
 
 extern "C" {
 
-int mi355gp_exact_inference(mi355gp_ctx* c, int kind, int ard, const double* theta, const double* noise,
-                            int64_t noise_len, double jitter, double extra_jitter, double* out_scalars,
-                            double* alpha_out, double* dtheta_out, double* diag_dLdK_out, double* stage_ms) {
+// validates the part list and (re)builds the per-part device inputs
+static int prepare_parts(mi355gp_ctx* c, int nparts, const mi355gp_part* parts) {
+    ARG_CHECK(nparts >= 1 && nparts <= 16 && parts, "between 1 and 16 kernel parts");
+    if ((int)c->parts.size() != nparts) {
+        free_parts(c);
+        c->parts.resize((size_t)nparts);
+        for (auto& p : c->parts) HIP_CHECK(hipMalloc(&p.dXt, sizeof(double) * c->D * c->npad));
+    }
+    for (int i = 0; i < nparts; ++i) {
+        const mi355gp_part& in = parts[i];
+        mi355gp_ctx::Part& p = c->parts[(size_t)i];
+        ARG_CHECK(in.kind >= 0 && in.kind <= 5 && in.theta, "unknown covariance kind / NULL theta in a kernel part");
+        ARG_CHECK(in.theta[0] > 0.0, "variance must be positive");
+        p.dims.clear();
+        if (in.active_dims && in.n_active > 0) {
+            for (int a = 0; a < in.n_active; ++a) {
+                ARG_CHECK(in.active_dims[a] >= 0 && in.active_dims[a] < c->D, "active dimension out of range");
+                p.dims.push_back(in.active_dims[a]);
+            }
+        } else {
+            for (int q = 0; q < c->D; ++q) p.dims.push_back(q);
+        }
+        const int na = (int)p.dims.size();
+        const bool stationary = in.kind <= 3;
+        const int nl = stationary ? (in.ard ? na : 1) : 0;
+        p.kp = KernParams{in.kind, (stationary && in.ard) ? 1 : 0, c->D, in.theta[0]};
+        p.theta.assign(in.theta, in.theta + 1 + nl);
+        p.inv_ls.assign((size_t)c->D, 0.0);
+        for (int a = 0; a < na && stationary; ++a) {
+            const double l = in.theta[1 + (in.ard ? a : 0)];
+            ARG_CHECK(l > 0.0, "lengthscales must be positive");
+            p.inv_ls[(size_t)p.dims[a]] = 1.0 / l;
+        }
+    }
+    return 0;
+}
+
+// scaled inputs of every part (inactive dimensions scaled by 0: they drop out of r), on the context's stream
+static int scale_parts(mi355gp_ctx* c) {
+    for (auto& p : c->parts) {
+        HIP_CHECK(hipMemcpyAsync(c->dInvLs, p.inv_ls.data(), sizeof(double) * c->D, hipMemcpyHostToDevice, c->st));
+        launch_scale_inputs(c->st, c->dX, c->n, c->D, c->dInvLs, /*per-dimension vector*/ 1, p.dXt, c->npad);
+    }
+    return 0;
+}
+
+int mi355gp_exact_inference_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, const double* noise,
+                                int64_t noise_len, double jitter, double extra_jitter, double* out_scalars,
+                                double* alpha_out, double* dtheta_out, double* diag_dLdK_out, double* stage_ms) {
     ARG_CHECK(c && c->n > 0, "mi355gp_exact_inference: set_data first");
     ARG_CHECK(out_scalars != nullptr, "out_scalars is NULL");
     HIP_CHECK(hipSetDevice(c->device));
-    std::vector<double> inv_ls;
-    if (int rc = check_theta(kind, ard, theta, c->D, &inv_ls)) return rc;
+    if (int rc = prepare_parts(c, nparts, parts)) return rc;
     if (int rc = upload_noise(c, noise, noise_len)) return rc;
     hipStream_t st = c->st;
-    c->kp = KernParams{kind, ard ? 1 : 0, c->D, theta[0]};
-    c->theta.assign(theta, theta + 1 + (ard ? c->D : 1));
+    c->kp = c->parts[0].kp;
+    c->theta = c->parts[0].theta;
     c->have_kernel = true;
-    HIP_CHECK(hipMemcpyAsync(c->dInvLs, inv_ls.data(), sizeof(double) * c->D, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipEventRecord(c->ev[0], st));
-    launch_scale_inputs(st, c->dX, c->n, c->D, c->dInvLs, c->kp.ard, c->dXt, c->npad);
-    launch_kbuild_sym(st, c->kp, c->dXt, c->npad, c->n, c->npad, c->A, c->dNoise, noise_len, jitter + extra_jitter,
-                      /*lower_only=*/1, /*add_diag=*/1);
-    return run_pipeline(c, true, theta, out_scalars, alpha_out, dtheta_out, diag_dLdK_out, stage_ms);
+    if (int rc = scale_parts(c)) return rc;
+    for (size_t p = 0; p < c->parts.size(); ++p)          // Ky = sum_p K_p + (noise + jitter) I   (add.py:58-72)
+        launch_kbuild_sym(st, c->parts[p].kp, c->parts[p].dXt, c->npad, c->n, c->npad, c->A, c->dNoise, noise_len,
+                          jitter + extra_jitter, /*lower_only=*/1, /*add_diag=*/p == 0, /*accumulate=*/p > 0);
+    return run_pipeline(c, true, nullptr, out_scalars, alpha_out, dtheta_out, diag_dLdK_out, stage_ms);
+}
+
+int mi355gp_exact_inference(mi355gp_ctx* c, int kind, int ard, const double* theta, const double* noise,
+                            int64_t noise_len, double jitter, double extra_jitter, double* out_scalars,
+                            double* alpha_out, double* dtheta_out, double* diag_dLdK_out, double* stage_ms) {
+    ARG_CHECK(kind >= 0 && kind <= 3, "unknown covariance kind");
+    const mi355gp_part part{kind, ard, 0, nullptr, theta};
+    return mi355gp_exact_inference_sum(c, 1, &part, noise, noise_len, jitter, extra_jitter, out_scalars, alpha_out,
+                                       dtheta_out, diag_dLdK_out, stage_ms);
 }
 
 int mi355gp_inference_given_K(mi355gp_ctx* c, const double* K_host, const double* noise, int64_t noise_len,
@@ -308,7 +422,9 @@ int mi355gp_fetch(mi355gp_ctx* c, int which, double* out, int fortran_order) {
             mi355gp_set_error("mi355gp_fetch(K): no device kernel evaluation in this context");
             rc = -4;
         } else {
-            launch_kbuild_cross(st, c->kp, c->dXt, np, n, c->dXt, np, n, tmp, n);   // symmetric: no transpose needed
+            for (size_t p = 0; p < c->parts.size(); ++p)                           // symmetric: no transpose needed
+                launch_kbuild_cross(st, c->parts[p].kp, c->parts[p].dXt, np, n, c->parts[p].dXt, np, n, tmp, n,
+                                    /*accumulate=*/p > 0, /*diag_same=*/1);
         }
     } else if (!c->have_factor) {
         mi355gp_set_error("mi355gp_fetch: no successful factorisation in this context");
@@ -346,27 +462,26 @@ int mi355gp_kern_K(int device, int kind, int ard, const double* theta, const dou
     if (sym) M = N;
     ARG_CHECK(M > 0, "mi355gp_kern_K: M must be positive");
     const long ld1 = round_up(N, 64), ld2 = round_up(M, 64);
-    double *dX = nullptr, *dX2 = nullptr, *dXt1 = nullptr, *dXt2 = nullptr, *dIl = nullptr, *dK = nullptr;
-    HIP_CHECK(hipMalloc(&dX, sizeof(double) * N * D));
-    HIP_CHECK(hipMalloc(&dXt1, sizeof(double) * D * ld1));
-    HIP_CHECK(hipMalloc(&dIl, sizeof(double) * D));
-    HIP_CHECK(hipMalloc(&dK, sizeof(double) * N * M));
+    DevBuf dX, dX2, dXt1, dXt2, dIl, dK;
+    HIP_CHECK(dX.alloc(N * D));
+    HIP_CHECK(dXt1.alloc(D * ld1));
+    HIP_CHECK(dIl.alloc(D));
+    HIP_CHECK(dK.alloc(N * M));
     HIP_CHECK(hipMemcpy(dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dIl, inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice));
     launch_scale_inputs(0, dX, N, D, dIl, ard ? 1 : 0, dXt1, ld1);
-    dXt2 = dXt1;
+    const double* pXt2 = dXt1;
     if (!sym) {
-        HIP_CHECK(hipMalloc(&dX2, sizeof(double) * M * D));
-        HIP_CHECK(hipMalloc(&dXt2, sizeof(double) * D * ld2));
+        HIP_CHECK(dX2.alloc(M * D));
+        HIP_CHECK(dXt2.alloc(D * ld2));
         HIP_CHECK(hipMemcpy(dX2, X2, sizeof(double) * M * D, hipMemcpyHostToDevice));
         launch_scale_inputs(0, dX2, M, D, dIl, ard ? 1 : 0, dXt2, ld2);
+        pXt2 = dXt2;
     }
     KernParams kp{kind, ard ? 1 : 0, D, theta[0]};
-    launch_kbuild_cross(0, kp, dXt1, ld1, N, dXt2, sym ? ld1 : ld2, M, dK, M);
+    launch_kbuild_cross(0, kp, dXt1, ld1, N, pXt2, sym ? ld1 : ld2, M, dK, M);
     HIP_CHECK(hipMemcpy(K_out, dK, sizeof(double) * N * M, hipMemcpyDeviceToHost));
     HIP_CHECK(hipGetLastError());
-    (void)hipFree(dX); (void)hipFree(dXt1); (void)hipFree(dIl); (void)hipFree(dK);
-    if (!sym) { (void)hipFree(dX2); (void)hipFree(dXt2); }
     return 0;
 }
 
@@ -387,37 +502,34 @@ int mi355gp_update_gradients_full(int device, int kind, int ard, const double* t
     if (sym) M = N;
     const long ld1 = round_up(N, 64), ld2 = round_up(M, 64);
     const int groups = (D + 31) / 32;
-    double *dX = nullptr, *dX2 = nullptr, *dXt1 = nullptr, *dXt2 = nullptr, *dIl = nullptr, *dG = nullptr,
-           *dPart = nullptr, *dOut = nullptr;
-    HIP_CHECK(hipMalloc(&dX, sizeof(double) * N * D));
-    HIP_CHECK(hipMalloc(&dXt1, sizeof(double) * D * ld1));
-    HIP_CHECK(hipMalloc(&dIl, sizeof(double) * D));
-    HIP_CHECK(hipMalloc(&dG, sizeof(double) * N * M));
-    HIP_CHECK(hipMalloc(&dPart, sizeof(double) * groups * 2048 * GP_STRIDE));
-    HIP_CHECK(hipMalloc(&dOut, sizeof(double) * groups * GP_STRIDE));
+    DevBuf dX, dX2, dXt1, dXt2, dIl, dG, dPart, dOut;
+    HIP_CHECK(dX.alloc(N * D));
+    HIP_CHECK(dXt1.alloc(D * ld1));
+    HIP_CHECK(dIl.alloc(D));
+    HIP_CHECK(dG.alloc(N * M));
+    HIP_CHECK(dPart.alloc(groups * 2048 * GP_STRIDE));
+    HIP_CHECK(dOut.alloc(groups * GP_STRIDE));
     HIP_CHECK(hipMemcpy(dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dIl, inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dG, dL_dK, sizeof(double) * N * M, hipMemcpyHostToDevice));
     launch_scale_inputs(0, dX, N, D, dIl, ard ? 1 : 0, dXt1, ld1);
-    dXt2 = dXt1;
+    const double* pXt2 = dXt1;
     if (!sym) {
-        HIP_CHECK(hipMalloc(&dX2, sizeof(double) * M * D));
-        HIP_CHECK(hipMalloc(&dXt2, sizeof(double) * D * ld2));
+        HIP_CHECK(dX2.alloc(M * D));
+        HIP_CHECK(dXt2.alloc(D * ld2));
         HIP_CHECK(hipMemcpy(dX2, X2, sizeof(double) * M * D, hipMemcpyHostToDevice));
         launch_scale_inputs(0, dX2, M, D, dIl, ard ? 1 : 0, dXt2, ld2);
+        pXt2 = dXt2;
     }
     KernParams kp{kind, ard ? 1 : 0, D, theta[0]};
     const int nb = grad_generic_num_blocks(N, M);
-    launch_grad_generic(0, kp, dXt1, ld1, N, dXt2, sym ? ld1 : ld2, M, sym ? 1 : 0, dG, M, dPart, GP_STRIDE);
+    launch_grad_generic(0, kp, dXt1, ld1, N, pXt2, sym ? ld1 : ld2, M, sym ? 1 : 0, dG, M, dPart, GP_STRIDE);
     for (int g = 0; g < (kp.ard ? groups : 1); ++g)
         launch_reduce_partials(0, dPart + (long)g * nb * GP_STRIDE, nb, GP_STRIDE, dOut + (long)g * GP_STRIDE);
     std::vector<double> sums((size_t)groups * GP_STRIDE, 0.0);
     HIP_CHECK(hipMemcpy(sums.data(), dOut, sizeof(double) * groups * GP_STRIDE, hipMemcpyDeviceToHost));
     HIP_CHECK(hipGetLastError());
     finish_dtheta(kp, theta, sums.data(), dtheta_out);
-    (void)hipFree(dX); (void)hipFree(dXt1); (void)hipFree(dIl); (void)hipFree(dG); (void)hipFree(dPart);
-    (void)hipFree(dOut);
-    if (!sym) { (void)hipFree(dX2); (void)hipFree(dXt2); }
     return 0;
 }
 
@@ -439,16 +551,16 @@ int mi355gp_gradients_X(int device, int kind, int ard, const double* theta, cons
         for (int64_t j = 0; j < M; ++j)
             Gt[(size_t)j * N + i] = sym ? dL_dK[i * M + j] + dL_dK[j * M + i] : dL_dK[i * M + j];
     const long ldr = round_up(M, 64), ldc = round_up(N, 64);
-    double *dXr, *dXc, *dXtR, *dXtC, *dIl, *dG, *dPart, *dCol, *dHX;
-    HIP_CHECK(hipMalloc(&dXr, sizeof(double) * M * D));
-    HIP_CHECK(hipMalloc(&dXc, sizeof(double) * N * D));
-    HIP_CHECK(hipMalloc(&dXtR, sizeof(double) * D * ldr));
-    HIP_CHECK(hipMalloc(&dXtC, sizeof(double) * D * ldc));
-    HIP_CHECK(hipMalloc(&dIl, sizeof(double) * D));
-    HIP_CHECK(hipMalloc(&dG, sizeof(double) * M * N));
-    HIP_CHECK(hipMalloc(&dPart, sizeof(double) * 2048 * GP_STRIDE));
-    HIP_CHECK(hipMalloc(&dCol, sizeof(double) * 64 * N * (D + 1)));
-    HIP_CHECK(hipMalloc(&dHX, sizeof(double) * N * (D + 1)));
+    DevBuf dXr, dXc, dXtR, dXtC, dIl, dG, dPart, dCol, dHX;
+    HIP_CHECK(dXr.alloc(M * D));
+    HIP_CHECK(dXc.alloc(N * D));
+    HIP_CHECK(dXtR.alloc(D * ldr));
+    HIP_CHECK(dXtC.alloc(D * ldc));
+    HIP_CHECK(dIl.alloc(D));
+    HIP_CHECK(dG.alloc(M * N));
+    HIP_CHECK(dPart.alloc(2048 * GP_STRIDE));
+    HIP_CHECK(dCol.alloc(64 * N * (D + 1)));
+    HIP_CHECK(dHX.alloc(N * (D + 1)));
     HIP_CHECK(hipMemcpy(dXr, X2, sizeof(double) * M * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dXc, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dIl, inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice));
@@ -466,8 +578,6 @@ int mi355gp_gradients_X(int device, int kind, int ard, const double* theta, cons
     for (int64_t i = 0; i < N; ++i)
         for (int q = 0; q < D; ++q)
             out[i * D + q] = (Xs[(size_t)q * ldc + i] * HX[i * (D + 1) + D] - HX[i * (D + 1) + q]) * inv_ls[ard ? q : 0];
-    (void)hipFree(dXr); (void)hipFree(dXc); (void)hipFree(dXtR); (void)hipFree(dXtC); (void)hipFree(dIl);
-    (void)hipFree(dG); (void)hipFree(dPart); (void)hipFree(dCol); (void)hipFree(dHX);
     return 0;
 }
 
@@ -544,39 +654,44 @@ int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* 
     return dense_factor(device, A, N, true, L_out, Ainv, logdet, ms);
 }
 
-int mi355gp_predict(mi355gp_ctx* c, int kind, int ard, const double* theta, const double* Xnew, int64_t M,
-                    double* mu_out, double* var_out, int full_cov) {
+int mi355gp_predict_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, const double* Xnew, int64_t M,
+                        double* mu_out, double* var_out, int full_cov) {
     ARG_CHECK(c && c->n > 0 && c->have_factor, "mi355gp_predict: run an inference call first");
     ARG_CHECK(Xnew && M > 0 && mu_out, "mi355gp_predict: bad arguments");
     HIP_CHECK(hipSetDevice(c->device));
-    std::vector<double> inv_ls;
-    if (int rc = check_theta(kind, ard, theta, c->D, &inv_ls)) return rc;
+    if (int rc = prepare_parts(c, nparts, parts)) return rc;
     hipStream_t st = c->st;
     const long n = c->n, np = c->npad, D = c->D, mp = round_up(M, NB), ld2 = round_up(M, 64);
-    // (re)scale the training inputs for this theta (normally identical to the inference call's)
-    c->kp = KernParams{kind, ard ? 1 : 0, c->D, theta[0]};
-    c->theta.assign(theta, theta + 1 + (ard ? c->D : 1));
+    // (re)scale the training inputs for these parameters (normally identical to the inference call's)
+    c->kp = c->parts[0].kp;
+    c->theta = c->parts[0].theta;
     c->have_kernel = true;
-    HIP_CHECK(hipMemcpyAsync(c->dInvLs, inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
-    launch_scale_inputs(st, c->dX, n, c->D, c->dInvLs, c->kp.ard, c->dXt, np);
-    double *dXn = nullptr, *dXt2 = nullptr, *dKx = nullptr, *dTmp = nullptr, *dMu = nullptr, *dVar = nullptr;
-    HIP_CHECK(hipMalloc(&dXn, sizeof(double) * M * D));
-    HIP_CHECK(hipMalloc(&dXt2, sizeof(double) * D * ld2));
-    HIP_CHECK(hipMalloc(&dKx, sizeof(double) * np * mp));
-    HIP_CHECK(hipMalloc(&dTmp, sizeof(double) * np * mp));
-    HIP_CHECK(hipMalloc(&dMu, sizeof(double) * M * c->Dy));
-    HIP_CHECK(hipMalloc(&dVar, sizeof(double) * (full_cov ? mp * mp : M)));
+    if (int rc = scale_parts(c)) return rc;
+    DevBuf dXn, dXt2, dKx, dTmp, dMu, dVar;
+    HIP_CHECK(dXn.alloc(M * D));
+    HIP_CHECK(dXt2.alloc(D * ld2));
+    HIP_CHECK(dKx.alloc(np * mp));
+    HIP_CHECK(dTmp.alloc(np * mp));
+    HIP_CHECK(dMu.alloc(M * c->Dy));
+    HIP_CHECK(dVar.alloc((full_cov ? mp * mp : M)));
     HIP_CHECK(hipMemcpyAsync(dXn, Xnew, sizeof(double) * M * D, hipMemcpyHostToDevice, st));
-    launch_scale_inputs(st, dXn, M, c->D, c->dInvLs, c->kp.ard, dXt2, ld2);
     HIP_CHECK(hipMemsetAsync(dKx, 0, sizeof(double) * np * mp, st));
-    launch_kbuild_cross(st, c->kp, c->dXt, np, n, dXt2, ld2, M, dKx, mp);                 // K(X, X*)  (n x M)
+    if (full_cov && var_out) HIP_CHECK(hipMemsetAsync(dVar, 0, sizeof(double) * mp * mp, st));
+    double kdiag = 0.0;                                                                   // Kdiag(X*) = sum of variances
+    for (size_t p = 0; p < c->parts.size(); ++p) {
+        const mi355gp_ctx::Part& pt = c->parts[p];
+        kdiag += pt.kp.variance;
+        HIP_CHECK(hipMemcpyAsync(c->dInvLs, pt.inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
+        launch_scale_inputs(st, dXn, M, c->D, c->dInvLs, 1, dXt2, ld2);
+        launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, dXt2, ld2, M, dKx, mp, /*accumulate=*/1);   // K(X, X*) (n x M)
+        if (full_cov && var_out)
+            launch_kbuild_cross(st, pt.kp, dXt2, ld2, M, dXt2, ld2, M, dVar, mp, 1, /*diag_same=*/1);   // K(X*, X*)
+    }
     launch_col_reduce(st, dKx, mp, n, M, c->dAlpha, c->Dy, 0.0, 0, dMu);                  // mu = Kx^T alpha
     launch_trmm_lower(st, c->B, np, dKx, mp, dTmp, mp, (int)(np / NB), (int)(mp / NB));   // tmp = L^-1 Kx
     if (!full_cov) {
-        if (var_out) launch_col_reduce(st, dTmp, mp, n, M, nullptr, 1, theta[0], 1, dVar);
+        if (var_out) launch_col_reduce(st, dTmp, mp, n, M, nullptr, 1, kdiag, 1, dVar);
     } else if (var_out) {
-        HIP_CHECK(hipMemsetAsync(dVar, 0, sizeof(double) * mp * mp, st));
-        launch_kbuild_cross(st, c->kp, dXt2, ld2, M, dXt2, ld2, M, dVar, mp);             // K(X*, X*)
         launch_gemm_tn_sq(st, dTmp, mp, np, dVar, mp, (int)(mp / NB), -1.0, 1.0);         // - tmp^T tmp
     }
     HIP_CHECK(hipMemcpyAsync(mu_out, dMu, sizeof(double) * M * c->Dy, hipMemcpyDeviceToHost, st));
@@ -589,9 +704,14 @@ int mi355gp_predict(mi355gp_ctx* c, int kind, int ard, const double* theta, cons
     }
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipGetLastError());
-    (void)hipFree(dXn); (void)hipFree(dXt2); (void)hipFree(dKx); (void)hipFree(dTmp); (void)hipFree(dMu);
-    (void)hipFree(dVar);
     return 0;
+}
+
+int mi355gp_predict(mi355gp_ctx* c, int kind, int ard, const double* theta, const double* Xnew, int64_t M,
+                    double* mu_out, double* var_out, int full_cov) {
+    ARG_CHECK(kind >= 0 && kind <= 3, "unknown covariance kind");
+    const mi355gp_part part{kind, ard, 0, nullptr, theta};
+    return mi355gp_predict_sum(c, 1, &part, Xnew, M, mu_out, var_out, full_cov);
 }
 
 int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
@@ -624,15 +744,14 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
 // ---- diagnostics ------------------------------------------------------------------------------------------
 int mi355gp_dbg_mfma(int device, const double* a, const double* b, double* d) {
     HIP_CHECK(hipSetDevice(device));
-    double *da, *db, *dd;
-    HIP_CHECK(hipMalloc(&da, 64 * 8));
-    HIP_CHECK(hipMalloc(&db, 64 * 8));
-    HIP_CHECK(hipMalloc(&dd, 256 * 8));
+    DevBuf da, db, dd;
+    HIP_CHECK(da.alloc(64));
+    HIP_CHECK(db.alloc(64));
+    HIP_CHECK(dd.alloc(256));
     HIP_CHECK(hipMemcpy(da, a, 64 * 8, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(db, b, 64 * 8, hipMemcpyHostToDevice));
     launch_dbg_mfma(0, da, db, dd);
     HIP_CHECK(hipMemcpy(d, dd, 256 * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dd);
     return 0;
 }
 
@@ -640,10 +759,10 @@ int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_
                      const double* B, double* C, double alpha, double beta, int reps, double* ms) {
     ARG_CHECK(M % NB == 0 && N % NB == 0 && K % 16 == 0 && M > 0 && N > 0 && K > 0, "dbg_gemm: M,N % 128, K % 16");
     HIP_CHECK(hipSetDevice(device));
-    double *dA, *dB, *dC;
-    HIP_CHECK(hipMalloc(&dA, sizeof(double) * M * K));
-    HIP_CHECK(hipMalloc(&dB, sizeof(double) * N * K));
-    HIP_CHECK(hipMalloc(&dC, sizeof(double) * M * N));
+    DevBuf dA, dB, dC;
+    HIP_CHECK(dA.alloc(M * K));
+    HIP_CHECK(dB.alloc(N * K));
+    HIP_CHECK(dC.alloc(M * N));
     HIP_CHECK(hipMemcpy(dA, A, sizeof(double) * M * K, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dB, B, sizeof(double) * N * K, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dC, C, sizeof(double) * M * N, hipMemcpyHostToDevice));
@@ -662,7 +781,6 @@ int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_
         *ms = t / reps;
     }
     HIP_CHECK(hipGetLastError());
-    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 0;
 }

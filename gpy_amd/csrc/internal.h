@@ -97,10 +97,12 @@ struct KernParams {
 // (npad x npad); rows/cols >= n get the identity.
 void launch_scale_inputs(hipStream_t st, const double* X, long n, int D, const double* inv_ls, int ard,
                          double* Xt, long ldx);
+// accumulate != 0: add this kernel's covariance to what A / Kout already hold (sum kernels)
 void launch_kbuild_sym(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, long npad, double* A,
-                       const double* noise, long noise_len, double jit, int lower_only, int add_diag);
+                       const double* noise, long noise_len, double jit, int lower_only, int add_diag,
+                       int accumulate = 0);
 void launch_kbuild_cross(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
-                         long ld2, long m, double* Kout, long ldk);
+                         long ld2, long m, double* Kout, long ldk, int accumulate = 0, int diag_same = 0);
 // y = X r (lower-triangular X, n x n within npad), then a = X^T y   (Dy right-hand sides, row-major n x Dy)
 void launch_tri_matvec(hipStream_t st, const double* X, long ld, long n, const double* R, int Dy, double* tmp,
                        double* alpha, double* partials);

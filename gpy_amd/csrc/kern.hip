@@ -18,7 +18,11 @@ struct CovVal {
     double dk_or;    // dK/dr / r   (0 where r == 0 for the exponential kernel)
 };
 
-__device__ __forceinline__ double cov_k(int kind, double var, double r2) {
+// kinds 4 / 5 are the static kernels of GPy/kern/src/static.py: White (variance on coinciding points of the symmetric
+// case, :77-81) and Bias (constant, :165-167); `same` = the entry is a diagonal entry of a symmetric evaluation.
+__device__ __forceinline__ double cov_k(int kind, double var, double r2, bool same = false) {
+    if (kind == 4) return same ? var : 0.0;
+    if (kind == 5) return var;
     if (kind == 0) return var * exp(-0.5 * r2);
     const double r = sqrt(r2);
     if (kind == 1) {
@@ -32,8 +36,14 @@ __device__ __forceinline__ double cov_k(int kind, double var, double r2) {
     return var * exp(-r);
 }
 
-__device__ __forceinline__ CovVal cov_all(int kind, double var, double r2) {
+__device__ __forceinline__ CovVal cov_all(int kind, double var, double r2, bool same = false) {
     CovVal c;
+    if (kind >= 4) {
+        c.k = (kind == 5 || same) ? var : 0.0;
+        c.dk_r = 0.0;
+        c.dk_or = 0.0;
+        return c;
+    }
     if (kind == 0) {
         c.k = var * exp(-0.5 * r2);
         c.dk_r = -r2 * c.k;
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256) void k_kbuild(KernParams kp, const double* __r
                                                 const double* __restrict__ Xt2, long ld2, long m,
                                                 double* __restrict__ out, long ldo, long nrows_out,
                                                 const double* __restrict__ noise, long noise_len, double jit,
-                                                int lower_only, int add_diag, int ntc) {
+                                                int lower_only, int add_diag, int ntc, int accumulate, int diag_same) {
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
     __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
@@ -145,36 +155,41 @@ __global__ __launch_bounds__(256) void k_kbuild(KernParams kp, const double* __r
         for (int b = 0; b < 4; ++b) {
             const long j = j0 + tx * 4 + b;
             if (i < n && j < m) {
-                v[b] = cov_k(kp.kind, kp.variance, r2[a][b]);
+                v[b] = cov_k(kp.kind, kp.variance, r2[a][b], (SYM || diag_same) && i == j);
                 if (SYM && add_diag && i == j) v[b] += noise[noise_len > 1 ? i : 0] + jit;
             } else {
-                v[b] = (SYM && i == j) ? 1.0 : 0.0;
+                v[b] = (SYM && i == j && !accumulate) ? 1.0 : 0.0;
             }
         }
         if (SYM) {
-            if (i < nrows_out) *reinterpret_cast<d4*>(out + i * ldo + j0 + tx * 4) = (d4){v[0], v[1], v[2], v[3]};
+            if (i < nrows_out) {
+                d4* p = reinterpret_cast<d4*>(out + i * ldo + j0 + tx * 4);
+                d4 o = (d4){v[0], v[1], v[2], v[3]};
+                if (accumulate) o += *p;                       // sum kernels (GPy/kern/src/add.py:58-72): K += K_part
+                *p = o;
+            }
         } else if (i < n) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const long j = j0 + tx * 4 + b;
-                if (j < m) out[i * ldo + j] = v[b];
+                if (j < m) out[i * ldo + j] = accumulate ? out[i * ldo + j] + v[b] : v[b];
             }
         }
     }
 }
 
 void launch_kbuild_sym(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, long npad, double* A,
-                       const double* noise, long noise_len, double jit, int lower_only, int add_diag) {
+                       const double* noise, long noise_len, double jit, int lower_only, int add_diag, int accumulate) {
     const int nt = (int)(npad / KT);
     hipLaunchKernelGGL((k_kbuild<true>), dim3((unsigned)((long)nt * nt)), dim3(256), 0, st, kp, Xt, ldx, n, Xt, ldx, n,
-                       A, npad, npad, noise, noise_len, jit, lower_only, add_diag, nt);
+                       A, npad, npad, noise, noise_len, jit, lower_only, add_diag, nt, accumulate, 0);
 }
 
 void launch_kbuild_cross(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
-                         long ld2, long m, double* Kout, long ldk) {
+                         long ld2, long m, double* Kout, long ldk, int accumulate, int diag_same) {
     const int ntr = (int)((n + KT - 1) / KT), ntc = (int)((m + KT - 1) / KT);
     hipLaunchKernelGGL((k_kbuild<false>), dim3((unsigned)((long)ntr * ntc)), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2,
-                       ld2, m, Kout, ldk, n, nullptr, 0, 0.0, 0, 0, ntc);
+                       ld2, m, Kout, ldk, n, nullptr, 0, 0.0, 0, 0, ntc, accumulate, diag_same);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                                               const double* __restrict__ G, long ldg,
                                               const double* __restrict__ alpha, int Dy, int q_off,
                                               long ntiles, int ntc, double* __restrict__ partials,
-                                              double* __restrict__ Hout = nullptr, long ldh = 0) {
+                                              double* __restrict__ Hout = nullptr, long ldh = 0, int diag_same = 0) {
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
     __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
     __shared__ double red[256];
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                         g = G[i * ldg + j];
                     }
                 }
-                const CovVal c = cov_all(kp.kind, kp.variance, r2[a][b]);
+                const CovVal c = cov_all(kp.kind, kp.variance, r2[a][b], (FUSED || diag_same) && i == j);
                 a_var = fma(g, c.k, a_var);
                 if (!ARD) a_iso = fma(g, c.dk_r, a_iso);
                 gT[a][b] = g * c.dk_or;
@@ -351,19 +366,18 @@ void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long 
                          long ld2, long m, int symmetric, const double* G, long ldg, double* partials,
                          int stride, double* Hout, long ldh) {
     (void)stride;
-    (void)symmetric;
     const long ntr = (n + KT - 1) / KT, ntc = (m + KT - 1) / KT;
     const long ntiles = ntr * ntc;
     const int nb = pick_grad_blocks(ntiles);
     if (!kp.ard) {
         hipLaunchKernelGGL((k_grad<false, false>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg,
-                           nullptr, 0, 0, ntiles, (int)ntc, partials, Hout, ldh);
+                           nullptr, 0, 0, ntiles, (int)ntc, partials, Hout, ldh, symmetric);
     } else {
         // Hout may alias G (in place): only the LAST group launch writes it, every launch reads G
         for (int q_off = 0, gidx = 0; q_off < kp.D; q_off += KDC, ++gidx)
             hipLaunchKernelGGL((k_grad<false, true>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg,
                                nullptr, 0, q_off, ntiles, (int)ntc, partials + (long)gidx * nb * GP_STRIDE,
-                               (q_off + KDC >= kp.D) ? Hout : nullptr, ldh);
+                               (q_off + KDC >= kp.D) ? Hout : nullptr, ldh, symmetric);
     }
 }
 

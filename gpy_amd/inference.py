@@ -12,7 +12,7 @@ the same `numpy.linalg.LinAlgError` messages.
 import numpy as np
 
 from . import _lib
-from .kern import Stationary
+from .kern import Add, Stationary
 from .lazy import DeviceResult, kernel_signature
 from .likelihoods import Gaussian
 from .posterior import PosteriorExact
@@ -42,6 +42,8 @@ class _DeviceState(object):
         return self.ctx.fetch(which, fortran_order=fortran_order)
 
     def predict(self, kern, Xnew, full_cov=False):
+        if isinstance(kern, Add):
+            return self.ctx.predict_sum(kern.part_specs(), _lib.f64(Xnew), full_cov=full_cov)
         return self.ctx.predict(kern.kind, kern.ARD, kern._theta(), kern._slice_X(Xnew), full_cov=full_cov)
 
 
@@ -95,7 +97,8 @@ class ExactGaussianInference(object):
         noise = np.atleast_1d(np.asarray(variance, dtype=np.float64)).ravel()
         R = _lib.f64(Y - m)
         n = X.shape[0]
-        fused = K is None and isinstance(kern, Stationary)
+        is_sum = isinstance(kern, Add)
+        fused = K is None and (isinstance(kern, Stationary) or is_sum)
         Xdev = kern._slice_X(X) if fused else _lib.f64(X)
         if self._state is None:
             self._state = _DeviceState(self.device)
@@ -109,13 +112,21 @@ class ExactGaussianInference(object):
         scalar_noise_lik = trace_only
 
         if fused:
-            theta = kern._theta()
-            diagA = float(theta[0]) + noise + 1e-8
+            if is_sum:
+                specs = kern.part_specs()
+                diagA = sum(float(sp[2][0]) for sp in specs) + noise + 1e-8
 
-            def attempt(extra):
-                return st.ctx.exact_inference(kern.kind, kern.ARD, theta, noise, jitter=1e-8, extra_jitter=extra,
-                                              want_alpha=True, want_diag=not scalar_noise_lik,
-                                              want_stage_ms=want_ms)
+                def attempt(extra):
+                    return st.ctx.exact_inference_sum(specs, noise, jitter=1e-8, extra_jitter=extra, want_alpha=True,
+                                                      want_diag=not scalar_noise_lik, want_stage_ms=want_ms)
+            else:
+                theta = kern._theta()
+                diagA = float(theta[0]) + noise + 1e-8
+
+                def attempt(extra):
+                    return st.ctx.exact_inference(kern.kind, kern.ARD, theta, noise, jitter=1e-8, extra_jitter=extra,
+                                                  want_alpha=True, want_diag=not scalar_noise_lik,
+                                                  want_stage_ms=want_ms)
             res = self._run_with_ladder(attempt, diagA)
             sig = kernel_signature(kern)
             K_view = DeviceResult(st, _lib.FETCH_K, n, st.call_token)

@@ -109,6 +109,9 @@ class Stationary(Parameterized):
         """(reference `stationary.py:360-361`)"""
         return np.zeros(np.asarray(X).shape)
 
+    def __add__(self, other):
+        return Add([self, other])
+
     def reset_gradients(self):
         self.variance.gradient = 0.
         self.lengthscale.gradient = np.zeros(self.input_dim) if self.ARD else 0.
@@ -193,4 +196,132 @@ class Exponential(Stationary):
         super(Exponential, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name, **kw)
 
 
-KERNEL_CLASSES = {"rbf": RBF, "matern52": Matern52, "matern32": Matern32, "exponential": Exponential}
+class Static(Parameterized):
+    """White / Bias (reference `GPy/kern/src/static.py:10-60`): one `variance` parameter, no input dependence."""
+    kind = None
+    _gpy_class = None
+
+    def __init__(self, input_dim, variance=1., active_dims=None, name=None, device=0):
+        super(Static, self).__init__(name or self.kind)
+        self.input_dim = int(input_dim)
+        self.device = device
+        self.ARD = False
+        self.active_dims = np.arange(self.input_dim) if active_dims is None else np.atleast_1d(
+            np.asarray(active_dims, dtype=np.int_))
+        self.variance = Param("variance", variance)
+        self.link_parameter(self.variance)
+
+    def _theta(self):
+        return np.array([float(self.variance.values[0])])
+
+    def Kdiag(self, X):
+        return np.full(np.asarray(X).shape[0], float(self.variance.values[0]))
+
+    def update_gradients_diag(self, dL_dKdiag, X):
+        self.variance.gradient = np.sum(dL_dKdiag)
+
+    def _install_gradients(self, g):
+        self.variance.gradient = g[0]
+
+    def gradients_X(self, dL_dK, X, X2=None):
+        return np.zeros(np.asarray(X).shape)
+
+    def to_dict(self):
+        return {"class": self._gpy_class, "name": self.name, "input_dim": self.input_dim,
+                "active_dims": self.active_dims.tolist(), "variance": self.variance.values.tolist()}
+
+    def __add__(self, other):
+        return Add([self, other])
+
+
+class White(Static):
+    """(reference `static.py:63-98`): variance on the diagonal of K(X), zero cross-covariance."""
+    kind = "white"
+    _gpy_class = "GPy.kern.White"
+
+    def K(self, X, X2=None):
+        n = np.asarray(X).shape[0]
+        return np.eye(n) * float(self.variance.values[0]) if X2 is None else np.zeros((n, np.asarray(X2).shape[0]))
+
+    def update_gradients_full(self, dL_dK, X, X2=None):
+        self.variance.gradient = np.trace(np.asarray(dL_dK)) if X2 is None else 0.
+
+
+class Bias(Static):
+    """(reference `static.py:151-173`): constant covariance."""
+    kind = "bias"
+    _gpy_class = "GPy.kern.Bias"
+
+    def K(self, X, X2=None):
+        n = np.asarray(X).shape[0]
+        return np.full((n, n if X2 is None else np.asarray(X2).shape[0]), float(self.variance.values[0]))
+
+    def update_gradients_full(self, dL_dK, X, X2=None):
+        self.variance.gradient = np.sum(np.asarray(dL_dK))
+
+
+class Add(Parameterized):
+    """Sum of kernels (reference `GPy/kern/src/add.py:12-100`).  With `gpy_amd.ExactGaussianInference` the sum is
+    assembled and differentiated on the device in the same fused call as a single kernel (C-ABI
+    `mi355gp_exact_inference_sum`); parameter / gradient order = the parts' link order."""
+
+    def __init__(self, parts, name="sum"):
+        super(Add, self).__init__(name)
+        flat = []
+        for p in parts:
+            flat.extend(p.parts if isinstance(p, Add) else [p])          # add.py:24-33 flattens nested sums
+        assert all(isinstance(p, (Stationary, Static)) for p in flat), "Add supports stationary, White and Bias parts"
+        self.parts = flat
+        self.input_dim = max(int(p.active_dims.max()) + 1 for p in flat)
+        self.active_dims = np.arange(self.input_dim)
+        self.device = flat[0].device
+        for p in flat:
+            self.link_parameter(p)
+
+    def __add__(self, other):
+        return Add([self, other])
+
+    def part_specs(self):
+        """[(kind, ARD, theta, active_dims)] for the C-ABI (active_dims index the columns of the model's X)."""
+        return [(p.kind, p.ARD, p._theta(), p.active_dims) for p in self.parts]
+
+    def _slice_X(self, X):
+        return _lib.f64(np.asarray(X))
+
+    def K(self, X, X2=None):
+        out = None
+        for p in self.parts:
+            Kp = p.K(X, X2)
+            out = Kp if out is None else out + Kp
+        return out
+
+    def Kdiag(self, X):
+        return sum(p.Kdiag(X) for p in self.parts)
+
+    def update_gradients_full(self, dL_dK, X, X2=None):
+        """(reference `add.py:81-82`).  A device-resident dL_dK of the fused sum call carries every part's gradient."""
+        if isinstance(dL_dK, DeviceResult) and X2 is None and dL_dK.matches_kernel(self):
+            g, i = dL_dK.fused_dtheta, 0
+            for p in self.parts:
+                k = p._theta().size
+                p._install_gradients(g[i:i + k])
+                i += k
+            return
+        G = np.asarray(dL_dK)
+        for p in self.parts:
+            p.update_gradients_full(G, X, X2)
+
+    def update_gradients_diag(self, dL_dKdiag, X):
+        for p in self.parts:
+            p.update_gradients_diag(dL_dKdiag, X)
+
+    def gradients_X(self, dL_dK, X, X2=None):
+        G = np.asarray(dL_dK)
+        return sum(p.gradients_X(G, X, X2) for p in self.parts)
+
+    def to_dict(self):
+        return {"class": "GPy.kern.Add", "name": self.name, "parts": [p.to_dict() for p in self.parts]}
+
+
+KERNEL_CLASSES = {"rbf": RBF, "matern52": Matern52, "matern32": Matern32, "exponential": Exponential,
+                  "white": White, "bias": Bias}

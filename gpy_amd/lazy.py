@@ -83,6 +83,8 @@ for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", 
 
 
 def kernel_signature(kern):
-    """Identity of a kernel evaluation: class, ARD flag, active dims and the exact parameter bits."""
-    return (kern.kind, bool(kern.ARD), tuple(int(i) for i in kern.active_dims),
-            kern.variance.values.tobytes(), kern.lengthscale.values.tobytes())
+    """Identity of a kernel evaluation: class, ARD flag, active dims and the exact parameter bits (per part for sums)."""
+    parts = getattr(kern, "parts", None)
+    if parts is not None:
+        return ("sum",) + tuple(kernel_signature(p) for p in parts)
+    return (kern.kind, bool(kern.ARD), tuple(int(i) for i in kern.active_dims), kern._theta().tobytes())

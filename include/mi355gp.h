@@ -24,7 +24,19 @@ extern "C" {
 
 typedef struct mi355gp_ctx mi355gp_ctx;
 
-enum { MI355GP_RBF = 0, MI355GP_MATERN52 = 1, MI355GP_MATERN32 = 2, MI355GP_EXPONENTIAL = 3 };
+enum { MI355GP_RBF = 0, MI355GP_MATERN52 = 1, MI355GP_MATERN32 = 2, MI355GP_EXPONENTIAL = 3,
+       MI355GP_WHITE = 4, MI355GP_BIAS = 5 /* static kernels, only as parts of a sum (kern/src/static.py:63-98,151-173) */ };
+
+/* One term of a sum kernel (GPy.kern.Add, kern/src/add.py:58-84).  theta = [variance, lengthscale (1, or n_active if ard)]
+ * (static kinds: [variance]); active_dims: the input columns this term acts on (kern/src/kern.py:49-53,112-117),
+ * NULL / n_active == 0 = all columns. */
+typedef struct {
+    int kind;
+    int ard;
+    int n_active;
+    const int* active_dims;
+    const double* theta;
+} mi355gp_part;
 
 /* which device-resident matrix mi355gp_fetch() materialises on the host (all N x N) */
 enum {
@@ -101,6 +113,13 @@ int mi355gp_exact_inference(mi355gp_ctx* ctx, int kind, int ard, const double* t
                             double* out_scalars, double* alpha_out, double* dtheta_out,
                             double* diag_dLdK_out, double* stage_ms);
 
+/* The same evaluation for a SUM of kernels: Ky = sum_p K_p(X) + (noise + jitter) I.  dtheta_out is the concatenation of the
+ * parts' gradients, each [variance, lengthscale(s)] ([variance] for White / Bias), in part order -- the order
+ * GPy's Add links its parts (kern/src/add.py:24-45). */
+int mi355gp_exact_inference_sum(mi355gp_ctx* ctx, int nparts, const mi355gp_part* parts, const double* noise,
+                                int64_t noise_len, double jitter, double extra_jitter, double* out_scalars,
+                                double* alpha_out, double* dtheta_out, double* diag_dLdK_out, double* stage_ms);
+
 /* Same with a caller-supplied covariance matrix (the `K=` argument of ExactGaussianInference.inference,
  * exact_gaussian_inference.py:52-53; used by EP and by foreign kernels).  K_host: N x N row-major. No dtheta. */
 int mi355gp_inference_given_K(mi355gp_ctx* ctx, const double* K_host, const double* noise, int64_t noise_len,
@@ -114,6 +133,10 @@ int mi355gp_fetch(mi355gp_ctx* ctx, int which, double* out, int fortran_order);
  * mu (M x Dy) = K(Xnew,X) alpha; full_cov == 0: var (M) = Kdiag - sum((L^-1 Kx)^2, 0); else var (M x M). */
 int mi355gp_predict(mi355gp_ctx* ctx, int kind, int ard, const double* theta, const double* Xnew, int64_t M,
                     double* mu_out, double* var_out, int full_cov);
+
+/* the same for a sum kernel (White parts contribute to Kdiag only, as GPy's White.K(X, X2) = 0: static.py:77-81) */
+int mi355gp_predict_sum(mi355gp_ctx* ctx, int nparts, const mi355gp_part* parts, const double* Xnew, int64_t M,
+                        double* mu_out, double* var_out, int full_cov);
 
 /* ---- standalone dense routines (dpotrf / dpotri equivalents; also what bench.py times in isolation) --- */
 /* In-place lower Cholesky of a host matrix (row-major N x N, lower triangle read), strict upper zeroed on return.

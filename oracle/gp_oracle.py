@@ -302,3 +302,50 @@ def default_theta(D, ARD):
     else:
         ls = np.array([0.7 * np.sqrt(D)])
     return 1.3, ls, 0.1
+
+
+# ----------------------------------------------------------------------------- sum kernels (GPy.kern.Add)
+def sum_kern_K(parts, X, X2=None):
+    """`Add.K` (reference `kern/src/add.py:58-72`) over parts = [(kind, ARD, variance, lengthscale, active_dims)];
+    kinds 'white' / 'bias' follow `kern/src/static.py:77-81,165-167`; `active_dims` slices X (`kern.py:112-117`)."""
+    n, m = X.shape[0], (X if X2 is None else X2).shape[0]
+    K = np.zeros((n, m))
+    for kind, ARD, var, ls, dims in parts:
+        if kind == "white":
+            if X2 is None:
+                K[np.arange(n), np.arange(n)] += var
+        elif kind == "bias":
+            K += var
+        else:
+            Xs = X[:, dims]
+            K += kern_K(kind, Xs, None if X2 is None else X2[:, dims], var, ls, ARD)
+    return K
+
+
+def sum_parameters_changed(parts, X, Y, noise):
+    """One `GP.parameters_changed` with a sum kernel: inference on K = sum of parts, then every part's
+    `update_gradients_full(dL_dK, X)` (`add.py:81-82`; White: trace, Bias: sum, `static.py:89-93,169-170`)."""
+    K = sum_kern_K(parts, X)
+    res = exact_inference(K, Y, noise)
+    grads = []
+    for kind, ARD, var, ls, dims in parts:
+        if kind == "white":
+            grads.append(np.array([np.trace(res["dL_dK"])]))
+        elif kind == "bias":
+            grads.append(np.array([np.sum(res["dL_dK"])]))
+        else:
+            dv, dl = update_gradients_full(kind, res["dL_dK"], X[:, dims], None, var, ls, ARD)
+            grads.append(np.concatenate([[dv], np.atleast_1d(dl)]))
+    res.update(K=K, dtheta=np.concatenate(grads))
+    return res
+
+
+def sum_predict(parts, X, Xs, L, alpha):
+    """`PosteriorExact._raw_predict` (posterior.py:273-302) with a sum kernel."""
+    Kx = sum_kern_K(parts, X, Xs)
+    mu = Kx.T @ alpha
+    tmp = lapack.dtrtrs(np.asfortranarray(L), np.asfortranarray(Kx), lower=1)[0]
+    kdiag = sum(p[2] for p in parts)
+    var = (kdiag - np.sum(tmp * tmp, 0))[:, None]
+    cov = sum_kern_K(parts, Xs) - tmp.T @ tmp
+    return mu, var, cov

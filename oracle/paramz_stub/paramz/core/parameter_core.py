@@ -21,6 +21,21 @@ class Parameterizable(object):
     def add_index_operation(self, *a, **k):
         pass
 
+    def copy(self):
+        """paramz's Parameterized.copy: a deep copy detached from any parent (used by GPy.kern.Add, add.py:28)."""
+        import copy
+        return copy.deepcopy(self)
+
+    def __getstate__(self):
+        return dict(self.__dict__)
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    @property
+    def is_fixed(self):
+        return False
+
     def parameters_changed(self):
         pass
 

@@ -109,6 +109,23 @@ def load(cython_build_dir=None):
     return ns
 
 
+def load_sum_kernels(ns):
+    """Adds the reference's `Add`, `White`, `Bias` (GPy/kern/src/add.py, static.py) to the namespace.  `Add.__init__` does
+    `from .. import RBF, Linear, Bias, White` (add.py:34), so those names are put on the stub `GPy.kern` package."""
+    if hasattr(ns, "Add"):
+        return ns
+    st = importlib.import_module("GPy.kern.src.static")
+    K = sys.modules["GPy.kern"]
+    K.RBF, K.White, K.Bias = ns.RBF, st.White, st.Bias
+    try:
+        K.Linear = importlib.import_module("GPy.kern.src.linear").Linear
+    except Exception:
+        K.Linear = type("Linear", (), {})                 # only used in isinstance checks of the psi-statistics path
+    add = importlib.import_module("GPy.kern.src.add")
+    ns.Add, ns.White, ns.Bias = add.Add, st.White, st.Bias
+    return ns
+
+
 KERNELS = {"rbf": "RBF", "matern52": "Matern52", "matern32": "Matern32", "exponential": "Exponential"}
 
 

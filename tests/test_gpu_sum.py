@@ -1,0 +1,73 @@
+"""GPU (-m gpu): sum kernels (GPy.kern.Add of stationary + White + Bias parts, with active_dims) through the fused C-ABI
+call `mi355gp_exact_inference_sum` / `mi355gp_predict_sum` and through the host classes, against golden vectors from the
+reference's own Add / White / Bias code.  Tolerances as for single kernels."""
+import numpy as np
+import pytest
+
+import gpy_amd
+from gpy_amd import _lib as L
+from oracle import gp_oracle as O
+from test_oracle_sum import load_sum_golden, sum_golden_names
+
+pytestmark = pytest.mark.gpu
+TOL_LML, TOL_ALPHA, TOL_GRAD = 1e-10, 1e-9, 1e-8
+
+
+def _specs(g):
+    out = []
+    for kind, ARD, var, ls, dims in g["parts"]:
+        th = np.array([var]) if ls is None else np.concatenate([[var], np.atleast_1d(ls)])
+        out.append((kind, ARD, th, dims))
+    return out
+
+
+@pytest.mark.parametrize("name", sum_golden_names())
+def test_sum_golden_through_the_c_abi(name):
+    g = load_sum_golden(name)
+    c = L.Context(0)
+    try:
+        c.set_data(g["X"], g["Y"])
+        info, r = c.exact_inference_sum(_specs(g), g["noise"], want_diag=True)
+        assert info == 0
+        assert abs(r["lml"] - g["lml"]) <= TOL_LML * abs(g["lml"])
+        assert np.linalg.norm(r["alpha"] - g["alpha"]) <= TOL_ALPHA * np.linalg.norm(g["alpha"])
+        assert np.abs(r["dtheta"] - g["dtheta"]).max() <= TOL_GRAD * np.abs(g["dtheta"]).max()
+        assert abs(r["dnoise"] - g["dnoise"]) <= TOL_GRAD * abs(g["dnoise"])
+        K = c.fetch(L.FETCH_K)
+        assert np.abs(K[0] - g["K_row0"]).max() <= 1e-13
+        mu, var = c.predict_sum(_specs(g), g["Xs"])
+        assert np.abs(mu - g["pred_mu"]).max() <= 1e-9 and np.abs(var - g["pred_var"]).max() <= 1e-9
+        _, cov = c.predict_sum(_specs(g), g["Xs"], full_cov=True)
+        assert np.abs(cov - g["pred_cov"]).max() <= 1e-9
+    finally:
+        c.close()
+
+
+def test_add_kernel_host_classes_in_gpregression():
+    g = load_sum_golden("sum_n200_rbfard02_m52_white_bias")
+    k = (gpy_amd.RBF(2, variance=1.3, lengthscale=[0.7, 1.1], ARD=True, active_dims=[0, 2])
+         + gpy_amd.Matern52(3, variance=0.6, lengthscale=1.5) + gpy_amd.White(3, 0.05) + gpy_amd.Bias(3, 0.4))
+    m = gpy_amd.GPRegression(g["X"], g["Y"], k, noise_var=g["noise"])
+    assert abs(m.log_likelihood() - g["lml"]) <= TOL_LML * abs(g["lml"])
+    gref = np.concatenate([g["dtheta"], [g["dnoise"]]])
+    assert np.abs(m.gradient - gref).max() <= TOL_GRAD * np.abs(gref).max()
+    mu, var = m.predict_noiseless(g["Xs"])
+    assert np.abs(mu - g["pred_mu"]).max() <= 1e-9 and np.abs(var - g["pred_var"]).max() <= 1e-9
+    # generic path: a foreign dL_dK goes part by part through the C-ABI / host formulas (add.py:81-82)
+    A = np.random.default_rng(0).standard_normal((200, 200))
+    k.update_gradients_full(A, g["X"])
+    parts = g["parts"]
+    ref = []
+    for kind, ARD, var_, ls, dims in parts:
+        if kind == "white":
+            ref.append([np.trace(A)])
+        elif kind == "bias":
+            ref.append([A.sum()])
+        else:
+            dv, dl = O.update_gradients_full(kind, A, g["X"][:, dims], None, var_, ls, ARD)
+            ref.append(np.concatenate([[dv], np.atleast_1d(dl)]))
+    ref = np.concatenate(ref)
+    assert np.abs(k.gradient - ref).max() <= TOL_GRAD * np.abs(ref).max()
+    f0 = m.objective_function()
+    m.optimize(max_iters=5)
+    assert m.objective_function() < f0

@@ -8,7 +8,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define NB 128            // base block: diagonal blocks, GEMM tiles and padding granule
 #define NBO 512           // outer panel width of the two-level right-looking Cholesky
-#define FACTOR_DEFAULT_RESERVE_CUS 0   // CUs kept free of trailing-update workgroups (express lane of the panel chain)
+#define FACTOR_DEFAULT_RESERVE_CUS 0   // CUs (a multiple of 8: the same count per XCD) kept free of trailing-update workgroups; measured: no gain
 #define GEMM_DEFAULT_NW 4        // wave arrangement of the 128x128 tile kernels (see gemm_tile.h); env MI355GP_GEMM_NW
 #define GEMM_DEFAULT_REVERSE_K 0 // lauum / trtri stage 1 walk k downwards (common end point); env MI355GP_REVERSE_K
 #define GEMM_DEFAULT_PRELOAD 0   // trailing update reads C before the k-loop; env MI355GP_PRELOAD_C

@@ -67,12 +67,13 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
         HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         const int ncu = prop.multiProcessorCount;
         if (ws->reserve_cus > 0 && ws->reserve_cus < ncu / 2) {
+            // Workgroups are dealt round-robin to the 8 XCDs, so the mask must take the SAME number of CUs from every XCD
+            // (an XCD with fewer CUs becomes the straggler of every launch: measured 2x slower).  Logical CU i sits on
+            // XCD i % 8, so the first 8*r indices are r CUs per XCD.
+            const int nx = 8, r = (ws->reserve_cus + nx - 1) / nx;
             std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-            const int stride = ncu / ws->reserve_cus;            // spread the reserved CUs over the whole index range
-            for (int cu = 0; cu < ncu; ++cu) {
-                const bool reserved = (cu % stride == 0) && (cu / stride < ws->reserve_cus);
-                if (!reserved) mask[cu / 32] |= 1u << (cu % 32);
-            }
+            for (int cu = 0; cu < ncu; ++cu)
+                if (cu >= nx * r) mask[cu / 32] |= 1u << (cu % 32);
             hipError_t e = hipExtStreamCreateWithCUMask(&ws->st_bulk, (uint32_t)mask.size(), mask.data());
             if (e != hipSuccess) {
                 (void)hipGetLastError();

@@ -429,7 +429,8 @@ __global__ __launch_bounds__(256) void k_colreduce_multi(const double* __restric
 int launch_colreduce_multi(hipStream_t st, const double* M, long ld, long rows, long cols, const double* V, long sr,
                            long sc, int nvt, int ones, double* part) {
     const int nv = nvt + (ones ? 1 : 0);
-    int nsplit = (int)((rows + 4095) / 4096);
+    // 64 columns per block: the row split supplies the parallelism (>= 2048 blocks for a 32k x 2k panel)
+    int nsplit = (int)((rows + 511) / 512);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 64) nsplit = 64;
     const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)nsplit);

@@ -9,7 +9,7 @@
 //   M x M algebra (M <= a few thousand): Lm, Lm^-1, A, LB, LB^-1, B^-1, dL_dKmm, dL_dpsi2, woodbury_inv
 //   pass 2 over the same chunks:   T = Kfu dL_dpsi2 (MFMA), dL_dKnm = beta Y v^T + 2 T formed in place,
 //                                  theta reductions + H = dL_dKnm * dK/dr / r, then H^T [X~ | 1] for dL/dZ
-// The N x M matrices never exist as a whole: the chunk buffers are bounded (<= 32768 rows).
+// The N x M matrices never exist as a whole: the chunk buffers are bounded (<= 65536 rows).
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -19,7 +19,7 @@
 
 #define GP_STRIDE 34
 #define SPLITK_MAX 16
-#define CHUNK_MAX 32768
+#define CHUNK_MAX 65536
 #define ARGCHK(cond, msg)                 \
     do {                                  \
         if (!(cond)) {                    \
@@ -184,10 +184,9 @@ static int alloc_m(mi355gp_sparse* s, long M) {
         if (ntl >= 2048) best = 1;
         s->splitk = best;
         const long gran = 128L * best;                        // every split a multiple of 128 rows
-        long chunk = round_up(s->n, gran);
         const long cmax = (CHUNK_MAX / gran) * gran;
-        if (chunk > cmax) chunk = cmax;
-        s->chunk = chunk;
+        const long nchunks = (s->n + cmax - 1) / cmax;        // balanced chunks: no nearly-empty last chunk
+        s->chunk = round_up((s->n + nchunks - 1) / nchunks, gran);
     }
     HIP_CHECK(hipMalloc(&s->XtC, sizeof(double) * s->D * s->chunk));
     const long mp = s->mp, D = s->D, Dy = s->Dy;
@@ -350,7 +349,7 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
         launch_scale_inputs(st, s->dX + r0 * D, rc, D, s->invls, kp.ard, s->XtC, chunk);
         if (rc < chunk || nch == 0) HIP_CHECK(hipMemsetAsync(s->Kfu, 0, sizeof(double) * chunk * mp, st));
         launch_kbuild_cross(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, s->Kfu, mp);
-        launch_gram_splitk(st, s->Kfu, mp, chunk, mp, s->splitk, nch > 0, s->psi2part);
+        launch_gram_splitk(st, s->Kfu, mp, round_up(rc, 16L * s->splitk), mp, s->splitk, nch > 0, s->psi2part);   // rows >= rc are zero
         const int ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, s->dY + r0 * Dy, Dy, 1, Dy, 0, s->colPart);
         launch_sum_splits(st, s->colPart, mp * Dy, ns, 1, s->psi1Y);               // psi1Y += Kuf Y_chunk
     }

@@ -125,12 +125,13 @@ def lib():
     L.mi355gp_dbg_mfma.argtypes = [ci, _dp, _dp, _dp]
     L.mi355gp_dbg_gemm.argtypes = [ci, ci, ci, i64, i64, i64, _dp, _dp, _dp, cd, cd, ci, _c_dp]
     L.mi355gp_dbg_peaks.argtypes = [ci, _dp]
+    L.mi355gp_dbg_gemm_clock.argtypes = [_c_dp, _c_dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
                  "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "sparse_create",
                  "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm", "exact_inference_sum",
-                 "predict_sum"):
+                 "predict_sum", "dbg_gemm_clock"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -144,7 +145,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_grid_destroy", "mi355gp_grid_set_data", "mi355gp_grid_exact_inference", "mi355gp_grid_fetch",
             "mi355gp_sparse_create", "mi355gp_sparse_destroy", "mi355gp_sparse_set_data", "mi355gp_vardtc_inference",
             "mi355gp_sparse_fetch", "mi355gp_gradients_X", "mi355gp_sparse_attach_comm",
-            "mi355gp_exact_inference_sum", "mi355gp_predict_sum",
+            "mi355gp_exact_inference_sum", "mi355gp_predict_sum", "mi355gp_dbg_gemm_clock",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks")
 
 
@@ -470,6 +471,12 @@ def dbg_gemm(A, B, C, a_mcontig, b_ncontig, alpha=1.0, beta=0.0, reps=0, device=
     check(lib().mi355gp_dbg_gemm(device, int(a_mcontig), int(b_ncontig), M, N, K, A, B, C, alpha, beta, reps,
                                  ctypes.byref(ms)), "dbg_gemm")
     return C, ms.value
+
+
+def dbg_gemm_clock():
+    mhz, cyc = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    check(lib().mi355gp_dbg_gemm_clock(ctypes.byref(mhz), ctypes.byref(cyc)), "dbg_gemm_clock")
+    return mhz.value, cyc.value
 
 
 def dbg_peaks(device=0):

@@ -787,4 +787,6 @@ int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_
 
 int mi355gp_dbg_peaks(int device, double* out4) { return run_peaks(device, out4); }
 
+int mi355gp_dbg_gemm_clock(double* mhz, double* cycles) { return gemm_last_clock(mhz, cycles); }
+
 }  // extern "C"

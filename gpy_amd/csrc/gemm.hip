@@ -244,6 +244,9 @@ void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double
 
 // ------------------------------------------------------------------------------------------------
 // General C = alpha*op(A)*op(B) + beta*C on full tiles (diagnostics / prediction).
+// shader / wall clock ticks of workgroup 0 of the last k_gemm_full launch (effective shader MHz under the GEMM's own load)
+__device__ long long g_gemm_clk[2];
+
 template <bool AK, bool BK, int NW>
 __global__ LB(NW) void k_gemm_full(const double* __restrict__ A, long lda,
                                                       const double* __restrict__ B, long ldb, double* __restrict__ C,
@@ -262,7 +265,12 @@ __global__ LB(NW) void k_gemm_full(const double* __restrict__ A, long lda,
     gt_zero<NW>(acc);
     const double* Ap = AK ? A + (long)ti * NB * lda : A + (long)ti * NB;
     const double* Bp = BK ? B + (long)tj * NB * ldb : B + (long)tj * NB;
+    const long long c0 = clock64(), w0 = wall_clock64();
     gemm_tile_128<AK, BK, NW>(Ap, lda, Bp, ldb, K, acc, smem, swz >> 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_gemm_clk[0] = clock64() - c0;
+        g_gemm_clk[1] = wall_clock64() - w0;
+    }
     double* Ct = C + (long)ti * NB * ldc + (long)tj * NB;
     if (beta == 0.0) {   // never read C: it may be uninitialised memory (0 * NaN would poison the result)
 #pragma unroll
@@ -310,6 +318,15 @@ void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long 
 void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
                        double beta) {
     launch_gemm_full<false, false>(st, (unsigned)(nt * nt), A, lda, A, lda, C, ldc, (int)K, nt, alpha, beta);
+}
+
+// effective shader clock (MHz) and shader cycles seen by workgroup 0 of the last k_gemm_full launch
+int gemm_last_clock(double* mhz, double* cycles) {
+    long long h[2] = {0, 0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_clk), sizeof(h)) != hipSuccess) return -1;
+    *mhz = h[1] > 0 ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    *cycles = (double)h[0];
+    return 0;
 }
 
 void launch_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A, long lda,

@@ -127,6 +127,7 @@ void launch_sum_splits(hipStream_t st, const double* src, long cnt, int nsplit, 
 void launch_trmv_lower(hipStream_t st, const double* X, long ld, long n, const double* R, int Dy, double* y);
 void launch_trmv_lower_T(hipStream_t st, const double* X, long ld, long n, const double* y, int Dy, double* out,
                          double* partials);
+int gemm_last_clock(double* mhz, double* cycles);
 // general tiled GEMM C = alpha*op(A) op(B) + beta*C; M, N % 128 == 0, K % 16 == 0 (see k_gemm_full)
 void launch_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A, long lda,
                  const double* B, long ldb, double* C, long ldc, double alpha, double beta);

@@ -223,6 +223,8 @@ int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_
  * [3] HBM fill GB/s, [4] shader cycles per v_mfma_f64_16x16x4 at one wave/SIMD, [5] effective shader MHz under the
  * full MFMA load, [6] MFMA TFLOP/s at one wave/SIMD, [7] shader cycles per MFMA per SIMD under the full load */
 int mi355gp_dbg_peaks(int device, double* out8);
+/* effective shader clock (MHz) and shader cycles of workgroup 0 of the last mi355gp_dbg_gemm launch */
+int mi355gp_dbg_gemm_clock(double* mhz, double* cycles);
 
 #ifdef __cplusplus
 }

@@ -15,4 +15,8 @@ for (M, N, K) in shapes:
         B = rng.standard_normal((K, N) if bn else (N, K))
         C0 = np.zeros((M, N))
         _, ms = L.dbg_gemm(A, B, C0, am, bn, reps=10)
-        print("gemm %s %dx%dx%d: %.3f ms  %.1f TF/s" % (name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9), flush=True)
+        mhz, cyc = L.dbg_gemm_clock()
+        # workgroup 0: K/4 MFMA steps of 16 MFMAs per wave, 64 pipe cycles each, two waves per SIMD
+        ideal = (K / 4.0) * 16 * 64
+        print("gemm %s %dx%dx%d: %.3f ms  %.1f TF/s | wg0: %.0f MHz, %.0f cycles for the k-loop = %.2fx one wave's MFMA "
+              "pipe time" % (name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9, mhz, cyc, cyc / ideal), flush=True)

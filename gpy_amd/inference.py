@@ -54,6 +54,8 @@ class ExactGaussianInference(object):
         self._state = None
         self.last_stage_ms = None
         self.collect_stage_ms = False
+        self.keep_diag = True      # N doubles per call: diag(Ky^-1) for LOO without fetching the N x N inverse
+        self._last = None
 
     # GPy's LatentFunctionInference hooks (reference latent_function_inference/__init__.py:38-49)
     def on_optimization_start(self):
@@ -69,6 +71,19 @@ class ExactGaussianInference(object):
         d = dict(self.__dict__)
         d["_state"] = None
         return d
+
+    def LOO(self, kern, X, Y, likelihood, posterior, Y_metadata=None, K=None):
+        """Leave-one-out log predictive densities (reference `exact_gaussian_inference.py:76-88`):
+        -(0.5 log 2pi - 0.5 log c_ii + 0.5 g_i^2 / c_ii) with g = woodbury_vector, c = Ky^-1.  diag(Ky^-1) comes from the
+        device's diag(dL_dK) = 0.5 (|alpha_i|^2 - Dy c_ii); the N x N inverse is never fetched."""
+        g = np.asarray(posterior.woodbury_vector)
+        last = self._last
+        if last is not None and last["diag_dL_dK"] is not None and last["alpha"] is g:
+            c_diag = ((np.sum(g * g, axis=1) - 2.0 * last["diag_dL_dK"]) / last["Dy"])[:, None]
+        else:
+            c_diag = np.diag(np.asarray(posterior.woodbury_inv))[:, None]
+        neg = 0.5 * np.log(2 * np.pi) - 0.5 * np.log(c_diag) + 0.5 * (g ** 2) / c_diag
+        return -neg
 
     def _run_with_ladder(self, attempt, diagA):
         """`attempt(extra_jitter)` -> (info, result).  Mirrors jitchol: plain try, then mean(diag)*1e-6 * 10^k."""
@@ -118,14 +133,15 @@ class ExactGaussianInference(object):
 
                 def attempt(extra):
                     return st.ctx.exact_inference_sum(specs, noise, jitter=1e-8, extra_jitter=extra, want_alpha=True,
-                                                      want_diag=not scalar_noise_lik, want_stage_ms=want_ms)
+                                                      want_diag=self.keep_diag or not scalar_noise_lik,
+                                                      want_stage_ms=want_ms)
             else:
                 theta = kern._theta()
                 diagA = float(theta[0]) + noise + 1e-8
 
                 def attempt(extra):
                     return st.ctx.exact_inference(kern.kind, kern.ARD, theta, noise, jitter=1e-8, extra_jitter=extra,
-                                                  want_alpha=True, want_diag=not scalar_noise_lik,
+                                                  want_alpha=True, want_diag=self.keep_diag or not scalar_noise_lik,
                                                   want_stage_ms=want_ms)
             res = self._run_with_ladder(attempt, diagA)
             sig = kernel_signature(kern)
@@ -139,7 +155,7 @@ class ExactGaussianInference(object):
 
             def attempt(extra):
                 return st.ctx.inference_given_K(K, noise, jitter=1e-8, extra_jitter=extra,
-                                                want_diag=not scalar_noise_lik, want_stage_ms=want_ms)
+                                                want_diag=self.keep_diag or not scalar_noise_lik, want_stage_ms=want_ms)
             res = self._run_with_ladder(attempt, diagA)
             K_view = K
             dL_dK = DeviceResult(st, _lib.FETCH_DLDK, n, st.call_token)
@@ -153,6 +169,8 @@ class ExactGaussianInference(object):
             dL_dthetaL = res["dnoise"]
         else:
             dL_dthetaL = likelihood.exact_inference_gradients(res["diag_dL_dK"], Y_metadata)
+        self._last = {"alpha": alpha, "diag_dL_dK": res.get("diag_dL_dK"), "Dy": R.shape[1], "state": st,
+                      "token": st.call_token}
         post = PosteriorExact(
             woodbury_chol=DeviceResult(st, _lib.FETCH_L, n, st.call_token, fortran_order=True),
             woodbury_vector=alpha, K=K_view,

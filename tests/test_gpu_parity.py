@@ -276,3 +276,16 @@ def test_config4_size_on_one_gpu_without_fetching_n_squared(ctx):
     fm = ctx.exact_inference(kind, ARD, L.theta_vec(var - h, ls, ARD, D), noise)[1]["lml"]
     assert abs((fp - fm) / (2 * h) - r["dtheta"][0]) <= 1e-5 * abs(r["dtheta"][0]) + 1e-6
     ctx.set_data(X[:256], Y[:256])            # release the 26 GB before the next test
+
+
+def test_loo_matches_reference_formula_without_fetching_the_inverse():
+    """ExactGaussianInference.LOO (reference exact_gaussian_inference.py:76-88) from the device's diag(dL_dK)."""
+    import gpy_amd
+    X, Y = O.synthetic(400, 3, seed=6)
+    k = gpy_amd.RBF(3, variance=1.2, lengthscale=0.9)
+    m = gpy_amd.GPRegression(X, Y, k, noise_var=0.1)
+    loo = m.inference_method.LOO(k, X, Y, m.likelihood, m.posterior)
+    ref = O.parameters_changed("rbf", X, Y, 1.2, 0.9, False, 0.1)
+    c = np.diag(ref["Wi"])[:, None]
+    expect = -(0.5 * np.log(2 * np.pi) - 0.5 * np.log(c) + 0.5 * ref["alpha"] ** 2 / c)
+    assert loo.shape == expect.shape and np.abs(loo - expect).max() <= 1e-9 * np.abs(expect).max()

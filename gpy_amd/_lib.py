@@ -102,6 +102,8 @@ def lib():
     L.mi355gp_exact_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_exact_inference_sum.argtypes = [vp, ci, ctypes.POINTER(Part), _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp,
                                               _c_dp]
+    L.mi355gp_exact_studentt_sum.argtypes = [vp, ci, ctypes.POINTER(Part), cd, cd, cd, _dp, _c_dp, _c_dp, _c_dp]
+    L.mi355gp_covariance_between_points.argtypes = [vp, ci, ctypes.POINTER(Part), _dp, i64, _dp, i64, _dp]
     L.mi355gp_predict_sum.argtypes = [vp, ci, ctypes.POINTER(Part), _dp, i64, _c_dp, _c_dp, ci]
     L.mi355gp_inference_given_K.argtypes = [vp, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_fetch.argtypes = [vp, ci, _dp, ci]
@@ -131,7 +133,7 @@ def lib():
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
                  "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "sparse_create",
                  "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm", "exact_inference_sum",
-                 "predict_sum", "dbg_gemm_clock"):
+                 "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -146,6 +148,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_sparse_create", "mi355gp_sparse_destroy", "mi355gp_sparse_set_data", "mi355gp_vardtc_inference",
             "mi355gp_sparse_fetch", "mi355gp_gradients_X", "mi355gp_sparse_attach_comm",
             "mi355gp_exact_inference_sum", "mi355gp_predict_sum", "mi355gp_dbg_gemm_clock",
+            "mi355gp_covariance_between_points", "mi355gp_exact_studentt_sum",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks")
 
 
@@ -270,6 +273,25 @@ class Context(object):
         if var is not None and not full_cov:
             var = var[:, None]
         return mu, var
+
+    def exact_studentt_sum(self, specs, nu, jitter=1e-8, extra_jitter=0.0):
+        """Student-t process: (info, dict(lml, logdet, beta, scale, alpha, dtheta))"""
+        arr, keep, ntheta = make_parts(specs)
+        out = np.zeros(NUM_OUT)
+        alpha = np.empty((self.N, self.Dy))
+        dtheta = np.zeros(ntheta)
+        rc = check(lib().mi355gp_exact_studentt_sum(self._h, len(specs), arr, float(nu), jitter, extra_jitter, out,
+                                                    _opt(alpha), _opt(dtheta), None), "mi355gp_exact_studentt_sum")
+        return rc, dict(lml=out[OUT_LML], logdet=out[OUT_LOGDET], beta=out[OUT_DATAFIT], scale=out[5], alpha=alpha,
+                        dtheta=dtheta)
+
+    def covariance_between_points(self, specs, X1, X2):
+        arr, keep, _ = make_parts(specs)
+        X1, X2 = f64(X1), f64(X2)
+        out = np.empty((X1.shape[0], X2.shape[0]))
+        check(lib().mi355gp_covariance_between_points(self._h, len(specs), arr, X1, X1.shape[0], X2, X2.shape[0], out),
+              "mi355gp_covariance_between_points")
+        return out
 
     def inference_given_K(self, K, noise, jitter=1e-8, extra_jitter=0.0, want_diag=False, want_stage_ms=False):
         K = f64(K)

@@ -213,7 +213,8 @@ static void finish_dtheta(const KernParams& kp, const double* theta, const doubl
 
 // Shared tail: given Ky (lower) in c->A: factor, invert, alpha, scalars [, kernel gradients].
 static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* theta, double* out_scalars,
-                        double* alpha_out, double* dtheta_out, double* diag_out, double* stage_ms) {
+                        double* alpha_out, double* dtheta_out, double* diag_out, double* stage_ms,
+                        double studentt_nu = 0.0) {
     hipStream_t st = c->st;
     const long n = c->n, np = c->npad;
     c->ws.prof.reset();
@@ -228,6 +229,7 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
     HIP_CHECK(hipEventRecord(c->ev[4], st));
     launch_tri_matvec(st, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
     launch_scalars(st, c->dAlpha, c->dR, c->C, np, n, c->Dy, c->ws.logsum, c->ws.nblk, c->dScal, c->dDiag);
+    if (studentt_nu > 0.0) launch_studentt_scale(st, c->dScal, studentt_nu, n, c->dScal + 4);
     HIP_CHECK(hipEventRecord(c->ev[5], st));
     const int groups = (c->D + 31) / 32;
     const size_t nparts = with_kernel_grads ? c->parts.size() : 0;
@@ -242,7 +244,8 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
         const int nb = grad_num_blocks(n);
         for (size_t p = 0; p < nparts; ++p) {       // every part reduces the same dL_dK against its own dK/dtheta
             const mi355gp_ctx::Part& pt = c->parts[p];
-            launch_grad_fused(st, pt.kp, pt.dXt, np, n, c->C, np, c->dAlpha, c->Dy, c->dGradPart, GP_STRIDE);
+            launch_grad_fused(st, pt.kp, pt.dXt, np, n, c->C, np, c->dAlpha, c->Dy, c->dGradPart, GP_STRIDE,
+                              studentt_nu > 0.0 ? c->dScal + 4 : nullptr);
             for (int g = 0; g < (pt.kp.ard ? groups : 1); ++g)
                 launch_reduce_partials(st, c->dGradPart + (long)g * nb * GP_STRIDE, nb, GP_STRIDE,
                                        c->dGradOutAll + ((long)p * groups + g) * GP_STRIDE);
@@ -289,6 +292,14 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
     out_scalars[MI355GP_OUT_DATAFIT] = datafit;
     out_scalars[MI355GP_OUT_DNOISE] = 0.5 * (alpha2 - Dy * trw);
     out_scalars[MI355GP_OUT_TRKINV] = trw;
+    if (studentt_nu > 0.0) {
+        // Student-t process (exact_studentt_inference.py:36-52): beta = sum(alpha * R)
+        const double nu = studentt_nu, N = (double)n, beta = datafit;
+        out_scalars[MI355GP_OUT_LML] = 0.5 * (-N * log((nu - 2.0) * M_PI) - logdet - (nu + N) * log(1.0 + beta / (nu - 2.0))) +
+                                       lgamma(0.5 * (nu + N)) - lgamma(0.5 * nu);
+        out_scalars[5] = (nu + N) / (nu + beta - 2.0);                       // factor of dL_dm = factor * alpha
+        out_scalars[MI355GP_OUT_DNOISE] = 0.0;
+    }
     if (nparts > 0 && dtheta_out) {
         // post-scaling of the raw sums (stationary.py:199,210-213): dvar = S/variance, dl = -S/l, per part, concatenated
         double* o = dtheta_out;
@@ -382,6 +393,30 @@ int mi355gp_exact_inference_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* 
         launch_kbuild_sym(st, c->parts[p].kp, c->parts[p].dXt, c->npad, c->n, c->npad, c->A, c->dNoise, noise_len,
                           jitter + extra_jitter, /*lower_only=*/1, /*add_diag=*/p == 0, /*accumulate=*/p > 0);
     return run_pipeline(c, true, nullptr, out_scalars, alpha_out, dtheta_out, diag_dLdK_out, stage_ms);
+}
+
+// Student-t PROCESS inference (ExactStudentTInference.inference, exact_studentt_inference.py:20-52): the same pdinv +
+// dpotrs skeleton with Ky = K + 1e-8 I and dL_dK = 0.5 ((nu+N)/(nu+beta-2) alpha alpha^T - Dy Ky^-1).
+// out_scalars: LML (Student-t), LOGDET, DATAFIT (= beta), [5] = (nu+N)/(nu+beta-2); dL_dnu is O(1) host arithmetic on beta.
+int mi355gp_exact_studentt_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, double nu, double jitter,
+                               double extra_jitter, double* out_scalars, double* alpha_out, double* dtheta_out,
+                               double* stage_ms) {
+    ARG_CHECK(c && c->n > 0, "mi355gp_exact_studentt_sum: set_data first");
+    ARG_CHECK(out_scalars != nullptr && nu > 2.0, "mi355gp_exact_studentt_sum: nu must exceed 2");
+    HIP_CHECK(hipSetDevice(c->device));
+    if (int rc = prepare_parts(c, nparts, parts)) return rc;
+    const double zero = 0.0;
+    if (int rc = upload_noise(c, &zero, 1)) return rc;
+    hipStream_t st = c->st;
+    c->kp = c->parts[0].kp;
+    c->theta = c->parts[0].theta;
+    c->have_kernel = true;
+    HIP_CHECK(hipEventRecord(c->ev[0], st));
+    if (int rc = scale_parts(c)) return rc;
+    for (size_t p = 0; p < c->parts.size(); ++p)
+        launch_kbuild_sym(st, c->parts[p].kp, c->parts[p].dXt, c->npad, c->n, c->npad, c->A, c->dNoise, 1,
+                          jitter + extra_jitter, 1, p == 0, p > 0);
+    return run_pipeline(c, true, nullptr, out_scalars, alpha_out, dtheta_out, nullptr, stage_ms, nu);
 }
 
 int mi355gp_exact_inference(mi355gp_ctx* c, int kind, int ard, const double* theta, const double* noise,
@@ -702,6 +737,53 @@ int mi355gp_predict_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, c
             HIP_CHECK(hipMemcpy2DAsync(var_out, sizeof(double) * M, dVar, sizeof(double) * mp, sizeof(double) * M, M,
                                        hipMemcpyDeviceToHost, st));
     }
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Posterior covariance between two point sets (Posterior.covariance_between_points, posterior.py:109-130):
+//   K(X1, X2) - (L^-1 K(X, X1))^T (L^-1 K(X, X2)),  out: M1 x M2 row-major
+int mi355gp_covariance_between_points(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, const double* X1,
+                                      int64_t M1, const double* X2, int64_t M2, double* out) {
+    ARG_CHECK(c && c->n > 0 && c->have_factor, "mi355gp_covariance_between_points: run an inference call first");
+    ARG_CHECK(X1 && X2 && M1 > 0 && M2 > 0 && out, "mi355gp_covariance_between_points: bad arguments");
+    HIP_CHECK(hipSetDevice(c->device));
+    if (int rc = prepare_parts(c, nparts, parts)) return rc;
+    hipStream_t st = c->st;
+    const long n = c->n, np = c->npad, D = c->D;
+    const long m1p = round_up(M1, NB), m2p = round_up(M2, NB), l1 = round_up(M1, 64), l2 = round_up(M2, 64);
+    c->have_kernel = true;
+    if (int rc = scale_parts(c)) return rc;
+    DevBuf dA, dB, dXtA, dXtB, dK1, dK2, dT1, dT2, dC;
+    HIP_CHECK(dA.alloc(M1 * D));
+    HIP_CHECK(dB.alloc(M2 * D));
+    HIP_CHECK(dXtA.alloc(D * l1));
+    HIP_CHECK(dXtB.alloc(D * l2));
+    HIP_CHECK(dK1.alloc(np * m1p));
+    HIP_CHECK(dK2.alloc(np * m2p));
+    HIP_CHECK(dT1.alloc(np * m1p));
+    HIP_CHECK(dT2.alloc(np * m2p));
+    HIP_CHECK(dC.alloc(m1p * m2p));
+    HIP_CHECK(hipMemcpyAsync(dA, X1, sizeof(double) * M1 * D, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(dB, X2, sizeof(double) * M2 * D, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(dK1, 0, sizeof(double) * np * m1p, st));
+    HIP_CHECK(hipMemsetAsync(dK2, 0, sizeof(double) * np * m2p, st));
+    HIP_CHECK(hipMemsetAsync(dC, 0, sizeof(double) * m1p * m2p, st));
+    for (size_t p = 0; p < c->parts.size(); ++p) {
+        const mi355gp_ctx::Part& pt = c->parts[p];
+        HIP_CHECK(hipMemcpyAsync(c->dInvLs, pt.inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
+        launch_scale_inputs(st, dA, M1, c->D, c->dInvLs, 1, dXtA, l1);
+        launch_scale_inputs(st, dB, M2, c->D, c->dInvLs, 1, dXtB, l2);
+        launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, dXtA, l1, M1, dK1, m1p, 1);
+        launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, dXtB, l2, M2, dK2, m2p, 1);
+        launch_kbuild_cross(st, pt.kp, dXtA, l1, M1, dXtB, l2, M2, dC, m2p, 1);
+    }
+    launch_trmm_lower(st, c->B, np, dK1, m1p, dT1, m1p, (int)(np / NB), (int)(m1p / NB));
+    launch_trmm_lower(st, c->B, np, dK2, m2p, dT2, m2p, (int)(np / NB), (int)(m2p / NB));
+    launch_gemm(st, 1, 1, m1p, m2p, np, dT1, m1p, dT2, m2p, dC, m2p, -1.0, 1.0);
+    HIP_CHECK(hipMemcpy2DAsync(out, sizeof(double) * M2, dC, sizeof(double) * m2p, sizeof(double) * M2, M1,
+                               hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipGetLastError());
     return 0;

@@ -113,8 +113,11 @@ struct GradOut {
     int nblocks;
 };
 int grad_num_blocks(long n);
+// aa_scale (optional, device): factor on the alpha alpha^T term of dL_dK (Student-t process)
 void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, const double* W,
-                       long ldw, const double* alpha, int Dy, double* partials, int stride);
+                       long ldw, const double* alpha, int Dy, double* partials, int stride,
+                       const double* aa_scale = nullptr);
+void launch_studentt_scale(hipStream_t st, const double* scal, double nu, long n, double* out);
 // Hout (optional, may alias G): H = dL_dK * (dK/dr)/r, the weights of the gradients_X reductions
 void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
                          long ld2, long m, int symmetric, const double* G, long ldg, double* partials,

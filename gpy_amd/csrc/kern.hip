@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                                               const double* __restrict__ G, long ldg,
                                               const double* __restrict__ alpha, int Dy, int q_off,
                                               long ntiles, int ntc, double* __restrict__ partials,
-                                              double* __restrict__ Hout = nullptr, long ldh = 0, int diag_same = 0) {
+                                              double* __restrict__ Hout = nullptr, long ldh = 0, int diag_same = 0,
+                                              const double* __restrict__ aa_scale = nullptr) {
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
     __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
     __shared__ double red[256];
@@ -215,6 +216,9 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
 #pragma unroll
     for (int q = 0; q < KDC; ++q) a_q[q] = 0.0;
     const int qcnt = ARD ? ((kp.D - q_off < KDC) ? (kp.D - q_off) : KDC) : 0;
+    // dL_dK = 0.5 (sc * alpha alpha^T - Dy W): sc = 1 for the Gaussian process, (nu+N)/(nu+beta-2) for the Student-t
+    // process (exact_studentt_inference.py:46), read from device memory because beta is produced on the device
+    const double sc = (FUSED && aa_scale) ? aa_scale[0] : 1.0;
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         long ti, tj;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                         if (j <= i) {
                             double aa = 0.0;
                             for (int d = 0; d < Dy; ++d) aa = fma(alpha[i * Dy + d], alpha[j * Dy + d], aa);
-                            g = 0.5 * (aa - (double)Dy * G[i * ldg + j]);
+                            g = 0.5 * (sc * aa - (double)Dy * G[i * ldg + j]);
                             if (j < i) g *= 2.0;
                         }
                     } else {
@@ -347,19 +351,28 @@ int grad_generic_num_blocks(long n, long m) {
 
 // one launch per group of 32 lengthscale dimensions (ARD); partials for group gidx at partials + gidx*nblocks*GP_STRIDE
 void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, const double* W,
-                       long ldw, const double* alpha, int Dy, double* partials, int stride) {
+                       long ldw, const double* alpha, int Dy, double* partials, int stride, const double* aa_scale) {
     (void)stride;
     const long nt = (n + KT - 1) / KT;
     const long ntiles = nt * (nt + 1) / 2;
     const int nb = pick_grad_blocks(ntiles);
     if (!kp.ard) {
         hipLaunchKernelGGL((k_grad<true, false>), dim3(nb), dim3(256), 0, st, kp, Xt, ldx, n, Xt, ldx, n, W, ldw,
-                           alpha, Dy, 0, ntiles, (int)nt, partials);
+                           alpha, Dy, 0, ntiles, (int)nt, partials, nullptr, 0, 0, aa_scale);
     } else {
         for (int q_off = 0, gidx = 0; q_off < kp.D; q_off += KDC, ++gidx)
             hipLaunchKernelGGL((k_grad<true, true>), dim3(nb), dim3(256), 0, st, kp, Xt, ldx, n, Xt, ldx, n, W, ldw,
-                               alpha, Dy, q_off, ntiles, (int)nt, partials + (long)gidx * nb * GP_STRIDE);
+                               alpha, Dy, q_off, ntiles, (int)nt, partials + (long)gidx * nb * GP_STRIDE, nullptr, 0, 0,
+                               aa_scale);
     }
+}
+
+// out[0] = (nu + n) / (nu + beta - 2) with beta = scal[0] = sum(alpha * R)   (exact_studentt_inference.py:46,51)
+__global__ void k_studentt_scale(const double* __restrict__ scal, double nu, double n, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (nu + n) / (nu + scal[0] - 2.0);
+}
+void launch_studentt_scale(hipStream_t st, const double* scal, double nu, long n, double* out) {
+    hipLaunchKernelGGL(k_studentt_scale, dim3(1), dim3(64), 0, st, scal, nu, (double)n, out);
 }
 
 void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,

@@ -41,6 +41,13 @@ class _DeviceState(object):
     def fetch(self, which, fortran_order=False):
         return self.ctx.fetch(which, fortran_order=fortran_order)
 
+    def covariance_between_points(self, kern, X1, X2):
+        if isinstance(kern, Add):
+            return self.ctx.covariance_between_points(kern.part_specs(), _lib.f64(X1), _lib.f64(X2))
+        # a single kernel's active_dims were applied when X was uploaded: slice the new points the same way
+        return self.ctx.covariance_between_points([(kern.kind, kern.ARD, kern._theta(), None)], kern._slice_X(X1),
+                                                  kern._slice_X(X2))
+
     def predict(self, kern, Xnew, full_cov=False):
         if isinstance(kern, Add):
             return self.ctx.predict_sum(kern.part_specs(), _lib.f64(Xnew), full_cov=full_cov)
@@ -176,3 +183,66 @@ class ExactGaussianInference(object):
             woodbury_vector=alpha, K=K_view,
             woodbury_inv=DeviceResult(st, _lib.FETCH_KINV, n, st.call_token), state=st)
         return post, log_marginal, {"dL_dK": dL_dK, "dL_dthetaL": dL_dthetaL, "dL_dm": alpha}
+
+
+class ExactStudentTInference(object):
+    """Student-t PROCESS inference (reference `exact_studentt_inference.py:13-52`): `inference(kern, X, Y, nu, mean_function=None,
+    K=None)` -> (posterior, log_marginal, {'dL_dK', 'dL_dnu', 'dL_dm'}).  Same device pipeline as the Gaussian case
+    (C-ABI `mi355gp_exact_studentt_sum`); the kernel gradients ride on the lazy dL_dK like in `ExactGaussianInference`."""
+
+    def __init__(self, device=0, maxtries=5):
+        self.device, self.maxtries = device, maxtries
+        self._state = None
+
+    def on_optimization_start(self):
+        pass
+
+    def on_optimization_end(self):
+        pass
+
+    def to_dict(self):
+        return {"class": "GPy.inference.latent_function_inference.exact_studentt_inference.ExactStudentTInference"}
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_state"] = None
+        return d
+
+    def inference(self, kern, X, Y, nu, mean_function=None, K=None):
+        from scipy.special import digamma
+        if K is not None or not isinstance(kern, (Stationary, Add)):
+            raise NotImplementedError("the MI355X Student-t path evaluates gpy_amd kernels on the device")
+        X = np.asarray(X)
+        Y = np.asarray(Y, dtype=np.float64)
+        m = 0 if mean_function is None else mean_function.f(X)
+        R = _lib.f64(Y - m)
+        is_sum = isinstance(kern, Add)
+        Xdev = kern._slice_X(X)
+        specs = kern.part_specs() if is_sum else [(kern.kind, kern.ARD, kern._theta(), None)]
+        if self._state is None:
+            self._state = _DeviceState(self.device)
+        st = self._state
+        st.ensure_data(Xdev, R)
+        st.call_token += 1
+        nu = float(np.asarray(nu).ravel()[0])
+        extra, tries = 0.0, 0
+        while True:                                   # jitchol's ladder (util/linalg.py:56-75)
+            info, r = st.ctx.exact_studentt_sum(specs, nu, jitter=1e-8, extra_jitter=extra)
+            if info == 0:
+                break
+            if tries >= self.maxtries:
+                raise LinAlgError("not positive definite, even with jitter.")
+            extra = sum(float(sp[2][0]) for sp in specs) * 1e-6 * 10 ** tries
+            tries += 1
+        N, beta = Y.shape[0], r["beta"]
+        dL_dnu = -N / (nu - 2.0) + digamma(0.5 * (nu + N)) - digamma(0.5 * nu)
+        dL_dnu -= np.log(1 + beta / (nu - 2.0))
+        dL_dnu += ((nu + N) * beta) / ((nu - 2) * (beta + nu - 2))
+        dL_dnu *= 0.5
+        sig = kernel_signature(kern)
+        dL_dK = DeviceResult(st, _lib.FETCH_DLDK, N, st.call_token, kernel_sig=sig, fused_dtheta=r["dtheta"])
+        post = PosteriorExact(woodbury_chol=DeviceResult(st, _lib.FETCH_L, N, st.call_token, fortran_order=True),
+                              woodbury_vector=r["alpha"], K=DeviceResult(st, _lib.FETCH_K, N, st.call_token),
+                              woodbury_inv=DeviceResult(st, _lib.FETCH_KINV, N, st.call_token), state=st)
+        post.nu = nu
+        return post, r["lml"], {"dL_dK": dL_dK, "dL_dnu": dL_dnu, "dL_dm": r["scale"] * r["alpha"]}

@@ -15,14 +15,49 @@ from .likelihoods import Gaussian
 from .param import Parameterized
 
 
+class Standardize(object):
+    """Output normaliser (reference `GPy/util/normalizer.py:85-112`): zero mean, unit standard deviation per column."""
+
+    def __init__(self):
+        self.mean = self.std = None
+
+    def scale_by(self, Y):
+        self.mean, self.std = np.nanmean(Y, 0), np.nanstd(Y, 0)
+        self.std = np.where(self.std == 0, 1.0, self.std)
+
+    def scaled(self):
+        return self.mean is not None
+
+    def normalize(self, Y):
+        return (Y - self.mean) / self.std
+
+    def inverse_mean(self, X):
+        return X * self.std + self.mean
+
+    def inverse_variance(self, var):
+        return var * self.std ** 2
+
+    def inverse_covariance(self, cov):
+        return cov[..., np.newaxis] * self.std ** 2
+
+    def to_dict(self):
+        return {"class": "GPy.util.normalizer.Standardize", "mean": self.mean.tolist(), "std": self.std.tolist()}
+
+
 class GP(Parameterized):
     def __init__(self, X, Y, kernel, likelihood, mean_function=None, inference_method=None, name="gp",
-                 Y_metadata=None, device=0):
+                 Y_metadata=None, device=0, normalizer=False):
         super(GP, self).__init__(name)
         X, Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
         assert X.ndim == 2 and Y.ndim == 2
         self.X, self.Y = X, Y
-        self.Y_normalized = Y
+        # (reference `core/gp.py:49-60`): normalizer=True -> Standardize
+        self.normalizer = Standardize() if normalizer is True else (None if normalizer is False else normalizer)
+        if self.normalizer is not None:
+            self.normalizer.scale_by(Y)
+            self.Y_normalized = self.normalizer.normalize(Y)
+        else:
+            self.Y_normalized = Y
         self.num_data, self.input_dim = X.shape
         self.output_dim = Y.shape[1]
         self.Y_metadata = Y_metadata
@@ -61,7 +96,12 @@ class GP(Parameterized):
             self.X = np.asarray(X, dtype=np.float64)
             self.num_data = self.X.shape[0]
         if Y is not None:
-            self.Y = self.Y_normalized = np.asarray(Y, dtype=np.float64)
+            self.Y = np.asarray(Y, dtype=np.float64)
+            if self.normalizer is not None:
+                self.normalizer.scale_by(self.Y)
+                self.Y_normalized = self.normalizer.normalize(self.Y)
+            else:
+                self.Y_normalized = self.Y
         self.parameters_changed()
 
     def _raw_predict(self, Xnew, full_cov=False, kern=None):
@@ -76,6 +116,12 @@ class GP(Parameterized):
         mu, var = self._raw_predict(Xnew, full_cov=full_cov)
         if include_likelihood:
             mu, var = self.likelihood.predictive_values(mu, var, full_cov=full_cov, Y_metadata=self.Y_metadata)
+        if self.normalizer is not None:              # (reference `core/gp.py:353-363`)
+            mu = self.normalizer.inverse_mean(mu)
+            if full_cov and mu.shape[1] > 1:
+                var = self.normalizer.inverse_covariance(var)
+            else:
+                var = self.normalizer.inverse_variance(var)
         return mu, var
 
     def predict_noiseless(self, Xnew, full_cov=False):
@@ -101,8 +147,11 @@ class GP(Parameterized):
 class GPRegression(GP):
     """Gaussian-process regression with Gaussian noise (reference `GPy/models/gp_regression.py:29-36`)."""
 
-    def __init__(self, X, Y, kernel=None, Y_metadata=None, noise_var=1., mean_function=None, device=0):
+    def __init__(self, X, Y, kernel=None, Y_metadata=None, normalizer=None, noise_var=1., mean_function=None,
+                 device=0):
         if kernel is None:
             kernel = RBF(np.asarray(X).shape[1], device=device)
         super(GPRegression, self).__init__(X, Y, kernel, Gaussian(variance=noise_var), name="GP regression",
-                                           Y_metadata=Y_metadata, mean_function=mean_function, device=device)
+                                           Y_metadata=Y_metadata, mean_function=mean_function, device=device,
+                                           normalizer=bool(normalizer) if normalizer in (None, True, False)
+                                           else normalizer)

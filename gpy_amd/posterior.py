@@ -43,3 +43,9 @@ class PosteriorExact(object):
         if self._state is None:
             raise RuntimeError("this posterior is not attached to a device context")
         return self._state.predict(kern, Xnew, full_cov=full_cov)
+
+    def covariance_between_points(self, kern, X, X1, X2):
+        """K(X1,X2) - (L^-1 K(X,X1))^T (L^-1 K(X,X2)) (reference `posterior.py:109-130`), on the device."""
+        if self._state is None:
+            raise RuntimeError("this posterior is not attached to a device context")
+        return self._state.covariance_between_points(kern, X1, X2)

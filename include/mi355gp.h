@@ -120,6 +120,13 @@ int mi355gp_exact_inference_sum(mi355gp_ctx* ctx, int nparts, const mi355gp_part
                                 int64_t noise_len, double jitter, double extra_jitter, double* out_scalars,
                                 double* alpha_out, double* dtheta_out, double* diag_dLdK_out, double* stage_ms);
 
+/* Student-t PROCESS inference (ExactStudentTInference.inference, exact_studentt_inference.py:20-52) for a sum of parts:
+ * Ky = K + jitter I (the reference's 1e-8), dL_dK = 0.5 ((nu+N)/(nu+beta-2) alpha alpha^T - Dy Ky^-1), beta = sum(alpha*R).
+ * out_scalars: [LML] Student-t log marginal, [LOGDET], [DATAFIT] = beta, [5] = (nu+N)/(nu+beta-2) (dL_dm = that * alpha). */
+int mi355gp_exact_studentt_sum(mi355gp_ctx* ctx, int nparts, const mi355gp_part* parts, double nu, double jitter,
+                               double extra_jitter, double* out_scalars, double* alpha_out, double* dtheta_out,
+                               double* stage_ms);
+
 /* Same with a caller-supplied covariance matrix (the `K=` argument of ExactGaussianInference.inference,
  * exact_gaussian_inference.py:52-53; used by EP and by foreign kernels).  K_host: N x N row-major. No dtheta. */
 int mi355gp_inference_given_K(mi355gp_ctx* ctx, const double* K_host, const double* noise, int64_t noise_len,
@@ -137,6 +144,10 @@ int mi355gp_predict(mi355gp_ctx* ctx, int kind, int ard, const double* theta, co
 /* the same for a sum kernel (White parts contribute to Kdiag only, as GPy's White.K(X, X2) = 0: static.py:77-81) */
 int mi355gp_predict_sum(mi355gp_ctx* ctx, int nparts, const mi355gp_part* parts, const double* Xnew, int64_t M,
                         double* mu_out, double* var_out, int full_cov);
+
+/* Posterior covariance between two point sets (Posterior.covariance_between_points, posterior.py:109-130) */
+int mi355gp_covariance_between_points(mi355gp_ctx* ctx, int nparts, const mi355gp_part* parts, const double* X1,
+                                      int64_t M1, const double* X2, int64_t M2, double* out);
 
 /* ---- standalone dense routines (dpotrf / dpotri equivalents; also what bench.py times in isolation) --- */
 /* In-place lower Cholesky of a host matrix (row-major N x N, lower triangle read), strict upper zeroed on return.

@@ -349,3 +349,23 @@ def sum_predict(parts, X, Xs, L, alpha):
     var = (kdiag - np.sum(tmp * tmp, 0))[:, None]
     cov = sum_kern_K(parts, Xs) - tmp.T @ tmp
     return mu, var, cov
+
+
+def studentt_inference(K, Y, nu):
+    """`ExactStudentTInference.inference` given K (reference `exact_studentt_inference.py:20-52`)."""
+    from scipy.special import digamma, gammaln
+    Ky = K.copy()
+    n, D = Y.shape
+    Ky[np.arange(n), np.arange(n)] += 1e-8
+    Wi, L, _Li, logdet = pdinv(Ky)
+    alpha = dpotrs(L, Y)
+    beta = float(np.sum(alpha * Y))
+    lml = 0.5 * (-n * np.log((nu - 2) * np.pi) - logdet - (nu + n) * np.log(1 + beta / (nu - 2)))
+    lml += gammaln((nu + n) / 2) - gammaln(nu / 2)
+    dL_dK = 0.5 * ((nu + n) / (nu + beta - 2) * tdot(alpha) - D * Wi)
+    dL_dnu = -n / (nu - 2.0) + digamma(0.5 * (nu + n)) - digamma(0.5 * nu)
+    dL_dnu -= np.log(1 + beta / (nu - 2.0))
+    dL_dnu += ((nu + n) * beta) / ((nu - 2) * (beta + nu - 2))
+    dL_dnu *= 0.5
+    return dict(L=L, alpha=alpha, lml=float(lml), dL_dK=dL_dK, dL_dnu=float(dL_dnu),
+                dL_dm=(nu + n) / (nu + beta - 2) * alpha, beta=beta)

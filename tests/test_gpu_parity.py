@@ -289,3 +289,21 @@ def test_loo_matches_reference_formula_without_fetching_the_inverse():
     c = np.diag(ref["Wi"])[:, None]
     expect = -(0.5 * np.log(2 * np.pi) - 0.5 * np.log(c) + 0.5 * ref["alpha"] ** 2 / c)
     assert loo.shape == expect.shape and np.abs(loo - expect).max() <= 1e-9 * np.abs(expect).max()
+
+
+def test_covariance_between_points_on_device():
+    """Posterior.covariance_between_points (reference posterior.py:109-130)."""
+    import gpy_amd
+    from scipy.linalg import solve_triangular
+    X, Y = O.synthetic(500, 4, seed=7)
+    var, ls, noise = O.default_theta(4, True)
+    k = gpy_amd.Matern52(4, variance=var, lengthscale=ls, ARD=True)
+    m = gpy_amd.GPRegression(X, Y, k, noise_var=noise)
+    rng = np.random.default_rng(3)
+    X1, X2 = rng.standard_normal((37, 4)), rng.standard_normal((150, 4))
+    got = m.posterior.covariance_between_points(k, X, X1, X2)
+    ref = O.parameters_changed("matern52", X, Y, var, ls, True, noise)
+    t1 = solve_triangular(ref["L"], O.kern_K("matern52", X, X1, var, ls, True), lower=True)
+    t2 = solve_triangular(ref["L"], O.kern_K("matern52", X, X2, var, ls, True), lower=True)
+    expect = O.kern_K("matern52", X1, X2, var, ls, True) - t1.T @ t2
+    assert got.shape == (37, 150) and np.abs(got - expect).max() <= 1e-10

@@ -132,3 +132,22 @@ def test_theta_vec_and_dataset_helpers():
     for a, b in zip(synthetic(40, 3, seed=1, Dy=2), O.synthetic(40, 3, seed=1, Dy=2)):
         assert np.array_equal(a, b)
     assert np.array_equal(default_theta(5, True)[1], O.default_theta(5, True)[1])
+
+
+def test_standardize_normalizer_matches_reference_formulas():
+    """gpy_amd.models.Standardize == GPy/util/normalizer.py:85-112 (host-only bookkeeping)."""
+    from gpy_amd.models import Standardize
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((50, 3)) * [1.0, 5.0, 0.1] + [3.0, -2.0, 0.5]
+    s = Standardize()
+    assert not s.scaled()
+    s.scale_by(Y)
+    Z = s.normalize(Y)
+    assert np.allclose(Z.mean(0), 0) and np.allclose(Z.std(0), 1)
+    assert np.allclose(s.inverse_mean(Z), Y)
+    v = rng.random((50, 1))
+    assert np.allclose(s.inverse_variance(v), v * Y.std(0) ** 2)
+    assert s.inverse_covariance(np.eye(4)).shape == (4, 4, 3)
+    const = Standardize()
+    const.scale_by(np.ones((5, 1)))
+    assert const.std[0] == 1.0                      # zero standard deviation resets to 1 (normalizer.py:94-97)

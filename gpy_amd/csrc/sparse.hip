@@ -9,7 +9,8 @@
 //   M x M algebra (M <= a few thousand): Lm, Lm^-1, A, LB, LB^-1, B^-1, dL_dKmm, dL_dpsi2, woodbury_inv
 //   pass 2 over the same chunks:   T = Kfu dL_dpsi2 (MFMA), dL_dKnm = beta Y v^T + 2 T formed in place,
 //                                  theta reductions + H = dL_dKnm * dK/dr / r, then H^T [X~ | 1] for dL/dZ
-// The N x M matrices never exist as a whole: the chunk buffers are bounded (<= 65536 rows).
+// Larger N streams through bounded chunk buffers (<= 262144 rows: 2 x 4.3 GB at M = 2048); up to that size the Kfu
+// chunk of pass 1 is still resident in pass 2 and is not rebuilt.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -19,7 +20,7 @@
 
 #define GP_STRIDE 34
 #define SPLITK_MAX 16
-#define CHUNK_MAX 65536
+#define CHUNK_MAX 262144                    // rows per chunk: 2 x (chunk x Mp) doubles of HBM (8.6 GB at M = 2048)
 #define ARGCHK(cond, msg)                 \
     do {                                  \
         if (!(cond)) {                    \
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_sparse_scalars(const double* __restrict
 // G[i][j] = beta * sum_d Y[i][d] v[j][d] + 2 G[i][j] for i < rows, j < m; 0 in the padding
 __global__ void k_form_dLdKnm(double* __restrict__ G, long ld, long rows, long rows_pad, long m,
                               const double* __restrict__ Y, const double* __restrict__ v, int Dy, double beta) {
-    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    const long j = (long)blockIdx.y * blockDim.x + threadIdx.x, i = blockIdx.x;   // rows on x: no 65535 limit
     if (j >= ld || i >= rows_pad) return;
     double g = 0.0;
     if (i < rows && j < m) {
@@ -407,7 +408,7 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
             launch_kbuild_cross(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, s->Kfu, mp);
         }
         launch_gemm(st, 0, 1, rcp, mp, mp, s->Kfu, mp, s->Q2, mp, s->T, mp, 1.0, 0.0);
-        hipLaunchKernelGGL(k_form_dLdKnm, grid2d(mp, rcp), dim3(256), 0, st, s->T, mp, rc, rcp, m, s->dY + r0 * Dy,
+        hipLaunchKernelGGL(k_form_dLdKnm, dim3((unsigned)rcp, (unsigned)((mp + 255) / 256)), dim3(256), 0, st, s->T, mp, rc, rcp, m, s->dY + r0 * Dy,
                            s->vvec, Dy, beta);
         const int nbk = grad_generic_num_blocks(rc, m);
         launch_grad_generic(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, 0, s->T, mp, s->gradPart, GP_STRIDE, s->T, mp);

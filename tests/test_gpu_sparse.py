@@ -34,7 +34,7 @@ def test_sparse_golden_through_the_c_abi(name, sctx):
     assert np.abs(Wi - g["woodbury_inv"]).max() <= 1e-4 * np.abs(g["woodbury_inv"]).max()
 
 
-@pytest.mark.parametrize("kind,ARD,N,M,D,Dy", [("rbf", True, 40000, 300, 8, 1),       # two chunks of 32768 rows
+@pytest.mark.parametrize("kind,ARD,N,M,D,Dy", [("rbf", True, 300000, 130, 4, 1),      # two chunks (> 262144 rows)
                                                ("matern52", False, 5000, 513, 3, 2)])
 def test_sparse_matches_oracle_multichunk(kind, ARD, N, M, D, Dy, sctx):
     X, Y = O.synthetic(N, D, seed=N % 97, Dy=Dy)

@@ -78,6 +78,30 @@ __global__ LB(NW) void k_update_nt(double* __restrict__ C, long ldc,
     }
 }
 
+// the same update on the v2 pipeline (gemm_tile.h): NT is the one layout where it measured faster (+4 %)
+__global__ __launch_bounds__(256, 2) void k_update_nt_v2(double* __restrict__ C, long ldc, const double* __restrict__ A,
+                                                         long lda, const double* __restrict__ B, long ldb, int K, int ntc,
+                                                         int row0t, int col0t, int tri, long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    for (long bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
+        int ti, tj;
+        if (tri) {
+            ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+            while ((long)ti * (ti + 1) / 2 > bid) --ti;
+            while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+            tj = (int)(bid - (long)ti * (ti + 1) / 2);
+        } else {
+            ti = (int)(bid / ntc);
+            tj = (int)(bid - (long)ti * ntc);
+            if (col0t + tj > row0t + ti) continue;
+        }
+        d4 acc[4][4];
+        gt_zero<4>(acc);
+        gemm_tile_128_v2<true, true>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
+        gt_store<2, 4>(C + (long)ti * NB * ldc + (long)tj * NB, ldc, acc);
+    }
+}
+
 template <int NW, bool PRE>
 static void launch_update_nt_t(hipStream_t st, long nblocks, long grid, double* C, long ldc, const double* A, long lda,
                                const double* B, long ldb, int K, int ntc, int row0t, int col0t, int tri) {
@@ -92,6 +116,12 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
     const int tri = (row0t == col0t && ntr == ntc) ? 1 : 0;
     const long nblocks = tri ? (long)ntr * (ntr + 1) / 2 : (long)ntr * ntc;
     const long grid = (max_wgs > 0 && max_wgs < nblocks) ? max_wgs : nblocks;
+    static const int v2 = env_int("MI355GP_UPDATE_V2", GEMM_DEFAULT_UPDATE_V2);
+    if (v2) {
+        hipLaunchKernelGGL(k_update_nt_v2, dim3((unsigned)grid), dim3(256), GT2_LDS_BYTES, st, C, ldc, A, lda, B, ldb, K, ntc,
+                           row0t, col0t, tri, nblocks);
+        return;
+    }
     if (gemm_variant_preload())
         NW_DISPATCH((launch_update_nt_t<4, true>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)),
                     (launch_update_nt_t<8, true>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)));

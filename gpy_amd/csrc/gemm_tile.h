@@ -307,6 +307,7 @@ __device__ __forceinline__ void gemm_tile_128_v2(const double* __restrict__ A, l
         }
     __syncthreads();
     load_frags(0, fa[0], fb[0]);
+    __syncthreads();                // iteration 0 overwrites stage 0: every wave must hold slab 0's fragments first
     // iteration j (ONE barrier):  request slab j+1's fragments (stage (j+1)&1, written in iteration j-1)
     //                             | slab j+2: registers -> stage j&1 (its previous content, slab j, was read in iteration j-1)
     //                             | global loads of slab j+4 | 32 MFMAs on slab j's fragments | barrier

@@ -348,7 +348,12 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
     for (long r0 = 0; r0 < n; r0 += chunk, ++nch) {
         const long rc = (n - r0 < chunk) ? (n - r0) : chunk;
         launch_scale_inputs(st, s->dX + r0 * D, rc, D, s->invls, kp.ard, s->XtC, chunk);
-        if (rc < chunk || nch == 0) HIP_CHECK(hipMemsetAsync(s->Kfu, 0, sizeof(double) * chunk * mp, st));
+        // the cross-covariance kernel writes rows < rc, columns < m: zero only what it leaves out
+        if (m < mp) {
+            if (rc < chunk || nch == 0) HIP_CHECK(hipMemsetAsync(s->Kfu, 0, sizeof(double) * chunk * mp, st));
+        } else if (rc < chunk) {
+            HIP_CHECK(hipMemsetAsync(s->Kfu + rc * mp, 0, sizeof(double) * (chunk - rc) * mp, st));
+        }
         launch_kbuild_cross(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, s->Kfu, mp);
         launch_gram_splitk(st, s->Kfu, mp, round_up(rc, 16L * s->splitk), mp, s->splitk, nch > 0, s->psi2part);   // rows >= rc are zero
         const int ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, s->dY + r0 * Dy, Dy, 1, Dy, 0, s->colPart);
@@ -404,7 +409,7 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
         const long rcp = round_up(rc, NB);
         if (!one_chunk) {                                    // a single chunk is still resident from pass 1
             launch_scale_inputs(st, s->dX + r0 * D, rc, D, s->invls, kp.ard, s->XtC, chunk);
-            if (rc < chunk) HIP_CHECK(hipMemsetAsync(s->Kfu, 0, sizeof(double) * chunk * mp, st));
+            if (rc < chunk) HIP_CHECK(hipMemsetAsync(s->Kfu + rc * mp, 0, sizeof(double) * (chunk - rc) * mp, st));
             launch_kbuild_cross(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, s->Kfu, mp);
         }
         launch_gemm(st, 0, 1, rcp, mp, mp, s->Kfu, mp, s->Q2, mp, s->T, mp, 1.0, 0.0);

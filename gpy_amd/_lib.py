@@ -111,6 +111,8 @@ def lib():
     L.mi355gp_potrf.argtypes = [ci, _dp, i64, _c_dp]
     L.mi355gp_pdinv.argtypes = [ci, _dp, i64, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_set_option.argtypes = [vp, ci, ci]
+    L.mi355gp_bench_factor.argtypes = [ci, i64, ci, _c_dp, _c_dp, _c_dp]
+    L.mi355gp_bench_factor.restype = ci
     L.mi355gp_get_profile.argtypes = [vp, _dp, _dp, ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
     L.mi355gp_grid_unique_id.argtypes = [ctypes.c_char_p]
     L.mi355gp_grid_create.argtypes = [ci, ci, ci, ci, ci, ci, ctypes.c_char_p, ctypes.POINTER(vp)]
@@ -474,6 +476,17 @@ def pdinv(A, device=0):
     info = check(lib().mi355gp_pdinv(device, A, n, Ai.ctypes.data_as(_c_dp), L.ctypes.data_as(_c_dp),
                                      ctypes.byref(ld), ctypes.byref(ms)), "mi355gp_pdinv")
     return Ai, L, ld.value, info, ms.value
+
+
+def bench_factor(N, reps=3, device=0):
+    """Device-only timing of potrf / trtri / lauum on a synthetic SPD matrix: dict of ms and TFLOP/s (N^3/3 each)."""
+    require_device(device)
+    p, t, l = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    check(lib().mi355gp_bench_factor(device, N, reps, ctypes.byref(p), ctypes.byref(t), ctypes.byref(l)),
+          "mi355gp_bench_factor")
+    fl = float(N) ** 3 / 3.0
+    return {"potrf_ms": p.value, "trtri_ms": t.value, "lauum_ms": l.value,
+            "potrf_tflops": fl / p.value / 1e9, "trtri_tflops": fl / t.value / 1e9, "lauum_tflops": fl / l.value / 1e9}
 
 
 def dbg_mfma(a, b, device=0):

@@ -818,9 +818,67 @@ int mi355gp_get_profile(mi355gp_ctx* c, double* ms, double* flops, int* launches
 }
 
 int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, double* ms_trtri, double* ms_lauum) {
-    (void)device; (void)N; (void)reps; (void)ms_potrf; (void)ms_trtri; (void)ms_lauum;
-    mi355gp_set_error("mi355gp_bench_factor: use mi355gp_exact_inference stage_ms");
-    return -99;
+    ARG_CHECK(N >= NB && reps >= 1 && ms_potrf && ms_trtri && ms_lauum, "mi355gp_bench_factor: N >= 128, reps >= 1");
+    HIP_CHECK(hipSetDevice(device));
+    const long np = round_up(N, NB);
+    const int D = 4;
+    // synthetic SPD matrix resident in HBM: RBF covariance of pseudo-random points + 0.1 I, rebuilt before every repetition
+    std::vector<double> X((size_t)N * D);
+    unsigned long long state = 0x9E3779B97F4A7C15ull;
+    for (double& v : X) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        v = ((double)(state >> 11) / 9007199254740992.0 - 0.5) * 4.0;
+    }
+    DevBuf dX, dXt, dIl, dNoise, A, B, C;
+    HIP_CHECK(dX.alloc(N * D));
+    HIP_CHECK(dXt.alloc(D * np));
+    HIP_CHECK(dIl.alloc(D));
+    HIP_CHECK(dNoise.alloc(1));
+    HIP_CHECK(A.alloc(np * np));
+    HIP_CHECK(B.alloc(np * np));
+    HIP_CHECK(C.alloc(np * np));
+    const double il[4] = {0.7, 0.7, 0.7, 0.7}, noise = 0.1;
+    HIP_CHECK(hipMemcpy(dX, X.data(), sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dIl, il, sizeof(il), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dNoise, &noise, sizeof(double), hipMemcpyHostToDevice));
+    FactorWs ws;
+    if (factor_ws_alloc(&ws, np) != 0) return -3;
+    ws.scratchX = B;
+    ws.scratchT = C;
+    hipStream_t st;
+    HIP_CHECK(hipStreamCreate(&st));
+    hipEvent_t e[4];
+    for (auto& ev : e) HIP_CHECK(hipEventCreate(&ev));
+    const KernParams kp{MI355GP_RBF, 0, D, 1.0};
+    launch_scale_inputs(st, dX, N, D, dIl, 0, dXt, np);
+    double acc[3] = {0.0, 0.0, 0.0};
+    int info = 0;
+    for (int r = -1; r < reps; ++r) {                          // r = -1: warm-up
+        launch_kbuild_sym(st, kp, dXt, np, N, np, A, dNoise, 1, 1e-8, 1, 1);
+        HIP_CHECK(hipEventRecord(e[0], st));
+        potrf_device(st, A, np, &ws);
+        HIP_CHECK(hipEventRecord(e[1], st));
+        trtri_device(st, A, B, C, np, &ws);
+        HIP_CHECK(hipEventRecord(e[2], st));
+        lauum_device(st, B, C, np, &ws);
+        HIP_CHECK(hipEventRecord(e[3], st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipMemcpy(&info, ws.info, sizeof(int), hipMemcpyDeviceToHost));
+        if (r < 0) continue;
+        for (int i = 0; i < 3; ++i) {
+            float ms;
+            HIP_CHECK(hipEventElapsedTime(&ms, e[i], e[i + 1]));
+            acc[i] += ms;
+        }
+    }
+    *ms_potrf = acc[0] / reps;
+    *ms_trtri = acc[1] / reps;
+    *ms_lauum = acc[2] / reps;
+    for (auto& ev : e) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(st);
+    factor_ws_free(&ws);
+    HIP_CHECK(hipGetLastError());
+    return info > 0 ? info : 0;
 }
 
 // ---- diagnostics ------------------------------------------------------------------------------------------

@@ -307,3 +307,9 @@ def test_covariance_between_points_on_device():
     t2 = solve_triangular(ref["L"], O.kern_K("matern52", X, X2, var, ls, True), lower=True)
     expect = O.kern_K("matern52", X1, X2, var, ls, True) - t1.T @ t2
     assert got.shape == (37, 150) and np.abs(got - expect).max() <= 1e-10
+
+
+def test_bench_factor_entry_point_reports_sane_rates():
+    r = L.bench_factor(2048, reps=2)
+    assert all(r[k] > 0 for k in ("potrf_ms", "trtri_ms", "lauum_ms"))
+    assert 0.5 < r["lauum_tflops"] < 78.6 and 0.5 < r["potrf_tflops"] < 78.6

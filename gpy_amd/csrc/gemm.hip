@@ -348,7 +348,8 @@ static void launch_gemm_full(hipStream_t st, unsigned nblocks, const double* A, 
     static const int dbg_ld0 = env_int("MI355GP_DBG_LD0", 0), dbg_swz = env_int("MI355GP_DBG_SWZ", 0);
     if (dbg_ld0) lda = ldb = 0;                           // every operand row aliases row 0: cache-resident loads
     static const int dbg_nosync = env_int("MI355GP_DBG_NOSYNC", 0), dbg_1wg = env_int("MI355GP_DBG_1WG", 0);
-    const int swz = ((dbg_swz && (ntc % 8 == 0) && ((nblocks / ntc) % 8 == 0)) ? 1 : 0) | (dbg_nosync ? 2 : 0);
+    // MI355GP_DBG_NOSYNC: 1 = no staging and no barrier in the k-loop, 2 = staging but no barrier (racy; timing only)
+    const int swz = ((dbg_swz && (ntc % 8 == 0) && ((nblocks / ntc) % 8 == 0)) ? 1 : 0) | ((dbg_nosync & 3) << 1);
     const size_t lds = dbg_1wg ? 100 * 1024 : GT_LDS_BYTES;
     static const int v2 = env_int("MI355GP_GEMM_V2", 0);
     if (v2) {

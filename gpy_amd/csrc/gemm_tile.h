@@ -124,12 +124,13 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma_f64(af[mi], bf[ni], acc[mi][ni]);
         }
-        if (dbg_nosync) continue;       // diagnostics only: MFMA + LDS-read steady state without staging / barriers
+        if (dbg_nosync & 1) continue;   // diagnostics only: MFMA + LDS-read steady state without staging / barriers
         if (kt + 1 < nk) {
             double* nxt = smem + (cur ^ 1) * 2 * GT_TILE;
             gt_r2s<AK, NW>(nxt, ra, t);
             gt_r2s<BK, NW>(nxt + GT_TILE, rb, t);
         }
+        if (dbg_nosync & 2) continue;   // diagnostics only (racy, wrong results): staging but no barrier
         __syncthreads();
     }
 }

@@ -82,6 +82,16 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
         }
         HIP_CHECK(hipEventCreateWithFlags(&ws->ev_bulk, hipEventDisableTiming));
     }
+    {
+        const char* envs = getenv("MI355GP_PANEL_SPLIT");
+        if (envs && *envs) ws->panel_split = atoi(envs) ? 1 : 0;
+        HIP_CHECK(hipStreamCreateWithPriority(&ws->st_rest, hipStreamNonBlocking, greatest));
+        for (int i = 0; i < 4; ++i) {
+            HIP_CHECK(hipEventCreateWithFlags(&ws->ev_d[i], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&ws->ev_t[i], hipEventDisableTiming));
+        }
+        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_rest, hipEventDisableTiming));
+    }
     const char* envw = getenv("MI355GP_PART2_WGS");
     if (envw && *envw) ws->part2_wgs = atoi(envw);
     const char* envt = getenv("MI355GP_PART2_TILES");
@@ -127,6 +137,15 @@ void factor_ws_free(FactorWs* ws) {
     }
     if (ws->st_panel) (void)hipStreamDestroy(ws->st_panel);
     ws->st_panel = nullptr;
+    if (ws->st_rest) (void)hipStreamDestroy(ws->st_rest);
+    ws->st_rest = nullptr;
+    for (int i = 0; i < 4; ++i) {
+        if (ws->ev_d[i]) (void)hipEventDestroy(ws->ev_d[i]);
+        if (ws->ev_t[i]) (void)hipEventDestroy(ws->ev_t[i]);
+        ws->ev_d[i] = ws->ev_t[i] = nullptr;
+    }
+    if (ws->ev_rest) (void)hipEventDestroy(ws->ev_rest);
+    ws->ev_rest = nullptr;
     if (ws->st_bulk) (void)hipStreamDestroy(ws->st_bulk);
     ws->st_bulk = nullptr;
     if (ws->ev_bulk) (void)hipEventDestroy(ws->ev_bulk);
@@ -141,9 +160,14 @@ static double gemm_flops(double m, double n, double K) { return 2.0 * m * n * K;
 // One outer panel: columns [K0, K0+W), rows [K0, npad).  128-column steps:
 //   diag128 (one CU) -> trsm128 on the rows below -> rank-128 update of the remaining columns of the panel.
 static void factor_panel_inv(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws);
+static void factor_panel_split(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws);
 static void factor_panel(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws) {
     if (ws->panel_inv && ws->scratchX && ws->scratchT) {
         factor_panel_inv(s, A, npad, K0, W, ws);
+        return;
+    }
+    if (ws->panel_split && ws->st_rest && ws->lookahead == 1 && W <= 4 * NB) {
+        factor_panel_split(s, A, npad, K0, W, ws);
         return;
     }
     const long ld = npad;
@@ -213,6 +237,52 @@ static void factor_panel_inv(hipStream_t s, double* A, long npad, long K0, long 
     ws->prof.end(s);
     (void)hipMemcpy2DAsync(R, sizeof(double) * ld, Rt, sizeof(double) * ld, sizeof(double) * W, rows,
                            hipMemcpyDeviceToDevice, s);
+}
+
+// Split panel (experiment, MI355GP_PANEL_SPLIT=1; measured slower: potrf 33.1 -> 33.6 ms at N=16384, 3.85 -> 4.19 ms at
+// N=4096, the cross-stream event waits cost more than the pipelining hides): the dependency chain of a panel only runs
+// through its W x W diagonal block
+//   chain stream `s` : for each 128-column step  diag128 -> trsm of the diagonal block's remaining rows -> K=128 update
+//                      of the diagonal block's remaining tiles          (kernels of <= 6 workgroups)
+//   rest stream      : trsm of all rows BELOW the diagonal block (after that step's diag128) -> K=128 update of those
+//                      rows' remaining panel columns (after that step's small trsm), pipelined behind the chain
+// so diag128(j+1) no longer waits for the wide kernels of step j.  `s` waits for the rest stream before returning.
+static void factor_panel_split(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws) {
+    const long ld = npad, end = K0 + W, rows_below = npad - end;
+    hipStream_t sr = ws->st_rest;
+    int nsteps = 0;
+    for (long j = 0; j < W; j += NB, ++nsteps) {
+        const long c = K0 + j, blk = c / NB;
+        double* dv = ws->dinv + blk * 8 * 256;
+        ws->prof.begin(s, PF_DIAG, (double)NB * NB * NB / 3.0);
+        launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info);
+        ws->prof.end(s);
+        const long in_block = end - (c + NB);                  // rows of the diagonal block below this step
+        if (rows_below > 0) {
+            (void)hipEventRecord(ws->ev_d[nsteps], s);
+            (void)hipStreamWaitEvent(sr, ws->ev_d[nsteps], 0);
+            launch_trsm128(sr, A, ld, c, end, rows_below, dv);
+        }
+        if (in_block <= 0) continue;
+        ws->prof.begin(s, PF_TRSM, (double)in_block * NB * NB);
+        launch_trsm128(s, A, ld, c, c + NB, in_block, dv);
+        ws->prof.end(s);
+        const double* Pd = A + (c + NB) * ld + c;               // freshly solved rows of the diagonal block
+        if (rows_below > 0) {
+            (void)hipEventRecord(ws->ev_t[nsteps], s);
+            (void)hipStreamWaitEvent(sr, ws->ev_t[nsteps], 0);
+            launch_update_nt(sr, A + end * ld + (c + NB), ld, A + end * ld + c, ld, Pd, ld, NB, (int)(rows_below / NB),
+                             (int)(in_block / NB), (int)(end / NB), (int)((c + NB) / NB));
+        }
+        ws->prof.begin(s, PF_UPDATE, syrk_flops((double)in_block, NB));
+        launch_update_nt(s, A + (c + NB) * ld + (c + NB), ld, Pd, ld, Pd, ld, NB, (int)(in_block / NB),
+                         (int)(in_block / NB), (int)((c + NB) / NB), (int)((c + NB) / NB));
+        ws->prof.end(s);
+    }
+    if (rows_below > 0) {
+        (void)hipEventRecord(ws->ev_rest, sr);
+        (void)hipStreamWaitEvent(s, ws->ev_rest, 0);
+    }
 }
 
 // rank-W update of the trailing columns [c0, c1) (rows c0 .. npad) with the panel at columns [K0, K0+W)

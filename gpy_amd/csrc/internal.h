@@ -70,6 +70,9 @@ struct FactorWs {
     double* scratchX = nullptr;
     double* scratchT = nullptr;
     int panel_inv = 0;          // option MI355GP_OPT_PANEL: 1 = inverse-based panel when scratch is available (measured slower)
+    hipStream_t st_rest = nullptr;   // split panel: the wide below-the-diagonal-block kernels of a panel (factor_panel_split)
+    hipEvent_t ev_d[4] = {}, ev_t[4] = {}, ev_rest = nullptr;
+    int panel_split = 0;             // env MI355GP_PANEL_SPLIT: measured slower (cross-stream event waits cost more than they hide)
     hipStream_t st_bulk = nullptr;   // trailing updates of the look-ahead schedule: CU-masked so that `reserve_cus` CUs stay
     int reserve_cus = 0;             // free of MFMA-saturating workgroups and the latency-bound panel kernels run there
     hipEvent_t ev_bulk = nullptr;

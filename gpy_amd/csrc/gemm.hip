@@ -343,6 +343,35 @@ __global__ __launch_bounds__(256, 2) void k_gemm_full_v2(const double* __restric
 }
 
 template <bool AK, bool BK>
+__global__ __launch_bounds__(256, 2) void k_gemm_full_v3(const double* __restrict__ A, long lda,
+                                                         const double* __restrict__ B, long ldb,
+                                                         double* __restrict__ C, long ldc, int K, int ntc, double alpha,
+                                                         double beta) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
+    d4 acc[4][4];
+    gt_zero<4>(acc);
+    const double* Ap = AK ? A + (long)ti * NB * lda : A + (long)ti * NB;
+    const double* Bp = BK ? B + (long)tj * NB * ldb : B + (long)tj * NB;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    gemm_tile_128_v3<AK, BK>(Ap, lda, Bp, ldb, K, acc, smem);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_gemm_clk[0] = clock64() - c0;
+        g_gemm_clk[1] = wall_clock64() - w0;
+    }
+    double* Ct = C + (long)ti * NB * ldc + (long)tj * NB;
+    if (beta == 0.0) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] *= alpha;
+        gt_store<0, 4>(Ct, ldc, acc);
+    } else {
+        gt_store<3, 4>(Ct, ldc, acc, alpha, beta);
+    }
+}
+
+template <bool AK, bool BK>
 static void launch_gemm_full(hipStream_t st, unsigned nblocks, const double* A, long lda, const double* B, long ldb,
                              double* C, long ldc, int K, int ntc, double alpha, double beta) {
     static const int dbg_ld0 = env_int("MI355GP_DBG_LD0", 0), dbg_swz = env_int("MI355GP_DBG_SWZ", 0);
@@ -352,6 +381,13 @@ static void launch_gemm_full(hipStream_t st, unsigned nblocks, const double* A, 
     const int swz = ((dbg_swz && (ntc % 8 == 0) && ((nblocks / ntc) % 8 == 0)) ? 1 : 0) | ((dbg_nosync & 3) << 1);
     const size_t lds = dbg_1wg ? 100 * 1024 : GT_LDS_BYTES;
     static const int v2 = env_int("MI355GP_GEMM_V2", 0);
+    if (v2 == 3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_full_v3<AK, BK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, GT3_LDS_BYTES);
+        hipLaunchKernelGGL((k_gemm_full_v3<AK, BK>), dim3(nblocks), dim3(256), GT3_LDS_BYTES, st, A, lda, B, ldb, C, ldc, K,
+                           ntc, alpha, beta);
+        return;
+    }
     if (v2) {
         hipLaunchKernelGGL((k_gemm_full_v2<AK, BK>), dim3(nblocks), dim3(256), GT2_LDS_BYTES, st, A, lda, B, ldb, C, ldc, K,
                            ntc, alpha, beta);

@@ -18,6 +18,9 @@
 #include "common.h"
 
 #define GT_BK 16
+#ifndef GT_USE_V3
+#define GT_USE_V3 1                       // 4-wave tile kernels take the LDS-DMA pipeline (v3); 0 = register-staged v1
+#endif
 #define GT_SKC 18
 #define GT_SMN 144
 #define GT_TILE 2304                      // doubles per staged operand slab (128*18 == 16*144)
@@ -83,6 +86,10 @@ __device__ __forceinline__ double gt_frag(const double* s, int idx, int kk) {
     return KC ? s[idx * GT_SKC + kk] : s[kk * GT_SMN + idx];
 }
 
+template <bool AK, bool BK>
+__device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                                 long ldb, int K, d4 (&acc)[4][4], double* smem);
+
 // acc[mi][ni] += sum_{k<K} opA(i,k) * opB(k,j) for this wave's part of the 128x128 tile.
 // A points at the tile's first row (k-contig) / first column (m-contig) at k = 0; same for B.  K % 16 == 0.
 template <bool AK, bool BK, int NW, bool NEGA = false>
@@ -91,6 +98,12 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
                                               d4 (&acc)[4][GTCfg<NW>::NI], double* smem, int dbg_nosync = 0,
                                               int reverse_k = 0) {
     constexpr int NI = GTCfg<NW>::NI;
+    if constexpr (GT_USE_V3 && NW == 4 && !NEGA) {           // LDS-DMA pipeline (see the v3 block at the end of this file)
+        if (!dbg_nosync && !reverse_k) {
+            gemm_tile_128_v3<AK, BK>(A, lda, B, ldb, K, acc, smem);
+            return;
+        }
+    }
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / GTCfg<NW>::WPR, wc = w % GTCfg<NW>::WPR;
     d2 ra[GTCfg<NW>::NLD], rb[GTCfg<NW>::NLD];
     const int nk = K / GT_BK;
@@ -337,5 +350,109 @@ __device__ __forceinline__ void gemm_tile_128_v2(const double* __restrict__ A, l
                     }
             __syncthreads();
         }
+    }
+}
+
+// =====================================================================================================================
+// v3 pipeline (experiment, NW = 4): operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
+// VGPRs, no ds_write pass.  The DMA destination is wave-uniform base + lane*16 B (linear), so the bank-conflict-free
+// layout is obtained by permuting the per-lane SOURCE address:
+//   k-contiguous operand : [128][16] unpadded; one DMA moves 8 rows x 128 B; lane l = (row l>>3, slot l&7) fetches the
+//                          16-byte granule (slot ^ h(row)) of its row, h(r) = ((r>>1)&7) ^ (2 if 4 <= r&15 <= 11);
+//                          the fragment of lane (row, kq) is two ds_read_b128 at slots (2kq+e) ^ h(row), e = 0,1
+//                          -> physical k = 4kq + s for slice s (all four 16-lane b128 groups hit 16 distinct bank quads)
+//   m/n-contiguous       : [16][132]; one DMA moves one k-row of 128 doubles; fragments are ds_read_b64 at row 4kq + s
+//                          (stride 132 = 4 mod 8 puts the kq = 0 / 1 halves of a 32-lane group 32 banks apart)
+// Two LDS stages; the DMAs of slab kt+1 are issued at the top of slab kt and retired (vmcnt(0)) before its barrier.
+#define GT3_SMN 132
+#define GT3_OP 2176                         // doubles reserved per operand per stage (max(128*16, 16*132) rounded up)
+#define GT3_LDS_BYTES (2 * 2 * GT3_OP * 8)  // 69,632 B
+
+__device__ __forceinline__ int gt3_h(int r) { return ((r >> 1) & 7) ^ ((((r & 15) >= 4) && ((r & 15) <= 11)) ? 2 : 0); }
+
+// per-lane byte offsets (relative to the operand tile's base pointer at k = 0) of this wave's four DMAs per slab
+template <bool KC>
+__device__ __forceinline__ void gt3_src_offsets(long ld, int lane, int w, int (&voff)[4]) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int i = 4 * w + ii;
+        if (KC) {
+            const int row = 8 * i + (lane >> 3), g = (lane & 7) ^ gt3_h(row);
+            voff[ii] = (int)((row * ld + 2 * g) * 8);
+        } else {
+            voff[ii] = (int)((i * ld + 2 * lane) * 8);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void gt3_issue(__amdgpu_buffer_rsrc_t rs, const int (&voff)[4], int soff, double* sdst, int w) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int i = 4 * w + ii;
+        double* d = KC ? sdst + i * 128 : sdst + i * GT3_SMN;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, d, 16, voff[ii], soff, 0, 0);
+    }
+}
+
+template <bool AK, bool BK>
+__device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, long lda,
+                                                 const double* __restrict__ B, long ldb, int K, d4 (&acc)[4][4],
+                                                 double* smem) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+    const int nk = K / 16;
+    const int arow = wr * 64 + (lane & 15), bcol = wc * 64 + (lane & 15), kq = lane >> 4;
+    auto rsrc = [](const double* p) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000);
+    };
+    int va[4], vb[4];
+    gt3_src_offsets<AK>(lda, lane, w, va);
+    gt3_src_offsets<BK>(ldb, lane, w, vb);
+    // the descriptor base advances with k (a 32-bit offset K*ld*8 overflows from N = 16384 on): 16 columns or 16 rows per slab
+    const long sa = AK ? 16 : 16 * lda, sb = BK ? 16 : 16 * ldb;
+    // fragment read offsets (doubles) inside an operand image
+    int fa0[4], fb0[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int r = arow + mi * 16, c = bcol + mi * 16;
+        fa0[mi] = AK ? r * 16 : r;
+        fb0[mi] = BK ? c * 16 : c;
+    }
+    const int ha = gt3_h(arow), hb = gt3_h(bcol);            // h depends on row & 15 only: the same for all mi / ni
+    gt3_issue<AK>(rsrc(A), va, 0, smem, w);
+    gt3_issue<BK>(rsrc(B), vb, 0, smem + GT3_OP, w);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the DMAs have landed
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            double* nxt = smem + (cur ^ 1) * 2 * GT3_OP;
+            gt3_issue<AK>(rsrc(A + (kt + 1) * sa), va, 0, nxt, w);
+            gt3_issue<BK>(rsrc(B + (kt + 1) * sb), vb, 0, nxt + GT3_OP, w);
+        }
+        const double* a_s = smem + cur * 2 * GT3_OP;
+        const double* b_s = a_s + GT3_OP;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                        // slices 2e, 2e+1
+            d2 af[4], bf[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                if (AK) af[mi] = *reinterpret_cast<const d2*>(a_s + fa0[mi] + 2 * ((2 * kq + e) ^ ha));
+                else af[mi] = (d2){a_s[(4 * kq + 2 * e) * GT3_SMN + fa0[mi]], a_s[(4 * kq + 2 * e + 1) * GT3_SMN + fa0[mi]]};
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                if (BK) bf[ni] = *reinterpret_cast<const d2*>(b_s + fb0[ni] + 2 * ((2 * kq + e) ^ hb));
+                else bf[ni] = (d2){b_s[(4 * kq + 2 * e) * GT3_SMN + fb0[ni]], b_s[(4 * kq + 2 * e + 1) * GT3_SMN + fb0[ni]]};
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_f64(af[mi][s], bf[ni][s], acc[mi][ni]);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) before the barrier: slab kt+1 is in LDS
+        __syncthreads();
     }
 }

@@ -12,7 +12,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GEMM_DEFAULT_NW 4        // wave arrangement of the 128x128 tile kernels (see gemm_tile.h); env MI355GP_GEMM_NW
 #define GEMM_DEFAULT_REVERSE_K 0 // lauum / trtri stage 1 walk k downwards (common end point); env MI355GP_REVERSE_K
 #define GEMM_DEFAULT_UPDATE_V2 0 // trailing update on the v2 tile pipeline (BK = 8, fragments prefetched across the barrier)
-#define GEMM_DEFAULT_PRELOAD 0   // trailing update reads C before the k-loop; env MI355GP_PRELOAD_C
+#define GEMM_DEFAULT_PRELOAD 1   // trailing update reads C before the k-loop; env MI355GP_PRELOAD_C
 
 // v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) * B(4x16) + C.  Per lane (l = 0..63):
 //   A operand: A[row = l & 15][k = l >> 4]        (one double)

@@ -86,7 +86,7 @@ __device__ __forceinline__ double gt_frag(const double* s, int idx, int kk) {
     return KC ? s[idx * GT_SKC + kk] : s[kk * GT_SMN + idx];
 }
 
-template <bool AK, bool BK>
+template <bool AK, bool BK, bool NEGA = false>
 __device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, long lda, const double* __restrict__ B,
                                                  long ldb, int K, d4 (&acc)[4][4], double* smem);
 
@@ -98,9 +98,9 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
                                               d4 (&acc)[4][GTCfg<NW>::NI], double* smem, int dbg_nosync = 0,
                                               int reverse_k = 0) {
     constexpr int NI = GTCfg<NW>::NI;
-    if constexpr (GT_USE_V3 && NW == 4 && !NEGA) {           // LDS-DMA pipeline (see the v3 block at the end of this file)
+    if constexpr (GT_USE_V3 && NW == 4) {                    // LDS-DMA pipeline (see the v3 block at the end of this file)
         if (!dbg_nosync && !reverse_k) {
-            gemm_tile_128_v3<AK, BK>(A, lda, B, ldb, K, acc, smem);
+            gemm_tile_128_v3<AK, BK, NEGA>(A, lda, B, ldb, K, acc, smem);
             return;
         }
     }
@@ -395,7 +395,7 @@ __device__ __forceinline__ void gt3_issue(__amdgpu_buffer_rsrc_t rs, const int (
     }
 }
 
-template <bool AK, bool BK>
+template <bool AK, bool BK, bool NEGA>
 __device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb, int K, d4 (&acc)[4][4],
                                                  double* smem) {
@@ -450,7 +450,8 @@ __device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, l
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_f64(af[mi][s], bf[ni][s], acc[mi][ni]);
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = mfma_f64(NEGA ? -af[mi][s] : af[mi][s], bf[ni][s], acc[mi][ni]);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) before the barrier: slab kt+1 is in LDS
         __syncthreads();

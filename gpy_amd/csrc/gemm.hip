@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_full_v3(const double* __restric
     const double* Ap = AK ? A + (long)ti * NB * lda : A + (long)ti * NB;
     const double* Bp = BK ? B + (long)tj * NB * ldb : B + (long)tj * NB;
     const long long c0 = clock64(), w0 = wall_clock64();
-    gemm_tile_128_v3<AK, BK>(Ap, lda, Bp, ldb, K, acc, smem);
+    if (K < 0) gemm_tile_128_v4<AK, BK>(Ap, lda, Bp, ldb, -K, acc, smem);     // K < 0 selects the v4 pipeline (diagnostics)
+    else gemm_tile_128_v3<AK, BK>(Ap, lda, Bp, ldb, K, acc, smem);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         g_gemm_clk[0] = clock64() - c0;
         g_gemm_clk[1] = wall_clock64() - w0;
@@ -381,7 +382,8 @@ static void launch_gemm_full(hipStream_t st, unsigned nblocks, const double* A, 
     const int swz = ((dbg_swz && (ntc % 8 == 0) && ((nblocks / ntc) % 8 == 0)) ? 1 : 0) | ((dbg_nosync & 3) << 1);
     const size_t lds = dbg_1wg ? 100 * 1024 : GT_LDS_BYTES;
     static const int v2 = env_int("MI355GP_GEMM_V2", 0);
-    if (v2 == 3) {
+    if (v2 == 3 || v2 == 4) {
+        if (v2 == 4) K = -K;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_full_v3<AK, BK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, GT3_LDS_BYTES);
         hipLaunchKernelGGL((k_gemm_full_v3<AK, BK>), dim3(nblocks), dim3(256), GT3_LDS_BYTES, st, A, lda, B, ldb, C, ldc, K,

@@ -457,3 +457,87 @@ __device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, l
         __syncthreads();
     }
 }
+
+// =====================================================================================================================
+// v4 pipeline (experiment): LDS-DMA as v3 but K in slabs of 8 on a 4-stage LDS ring with the DMAs running three slabs
+// ahead: counted s_waitcnt vmcnt(8/4/0) + a raw s_barrier per slab (a __syncthreads() would drain the DMA queue), so the
+// loads of slabs j+1, j+2 stay in flight across the barrier of slab j.  Layouts: k-contiguous [128][8] with the XOR
+// swizzle of gt2_kc_pos applied on the DMA source side, one ds_read_b128 per fragment (physical k = 2kq + s);
+// m/n-contiguous [8][136], ds_read_b64.
+#define GT4_NS 4
+#define GT4_OP 1088
+#define GT4_LDS_BYTES (GT4_NS * 2 * GT4_OP * 8)     // 69,632 B
+
+template <bool KC>
+__device__ __forceinline__ void gt4_src_offsets(long ld, int lane, int w, int (&voff)[2]) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * w + ii;
+        if (KC) {
+            const int row = 16 * i + (lane >> 2);
+            const int h = (0x1230 >> (((row >> 2) & 3) * 4)) & 3;
+            voff[ii] = (int)((row * ld + 2 * ((lane & 3) ^ h)) * 8);
+        } else {
+            voff[ii] = (int)((i * ld + 2 * lane) * 8);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void gt4_issue(const double* P, const int (&voff)[2], double* sdst, int w) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * w + ii;
+        double* d = KC ? sdst + i * 128 : sdst + i * GT2_SMN;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, d, 16, voff[ii], 0, 0, 0);
+    }
+}
+
+template <bool AK, bool BK, bool NEGA = false>
+__device__ __forceinline__ void gemm_tile_128_v4(const double* __restrict__ A, long lda,
+                                                 const double* __restrict__ B, long ldb, int K, d4 (&acc)[4][4],
+                                                 double* smem) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+    const int nk = K / 8;
+    const int arow = wr * 64 + (lane & 15), bcol = wc * 64 + (lane & 15), kq = lane >> 4;
+    int va[2], vb[2];
+    gt4_src_offsets<AK>(lda, lane, w, va);
+    gt4_src_offsets<BK>(ldb, lane, w, vb);
+    const long sa = AK ? 8 : 8 * lda, sb = BK ? 8 : 8 * ldb;
+    auto stage = [&](int j) { return smem + (j & (GT4_NS - 1)) * 2 * GT4_OP; };
+    auto issue = [&](int j) {
+        gt4_issue<AK>(A + j * sa, va, stage(j), w);
+        gt4_issue<BK>(B + j * sb, vb, stage(j) + GT4_OP, w);
+    };
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (j < nk) issue(j);
+    for (int j = 0; j < nk; ++j) {
+        // slab j's DMAs (issued three iterations ago) must have landed; those of slabs j+1, j+2 may stay in flight
+        if (j + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+        else if (j + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's share of slab j is in LDS, and nobody still reads slab j-1
+        asm volatile("" ::: "memory");
+        if (j + 3 < nk) issue(j + 3);          // into the stage slab j-1 occupied
+        const double* a_s = stage(j);
+        const double* b_s = a_s + GT4_OP;
+        d2 af[4], bf[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = gt2_frag<AK>(a_s, arow + mi * 16, kq);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = gt2_frag<BK>(b_s, bcol + ni * 16, kq);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = mfma_f64(NEGA ? -af[mi][s] : af[mi][s], bf[ni][s], acc[mi][ni]);
+    }
+    // the workgroup may reuse the LDS ring for its next tile: nobody may still be reading the last slabs
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}

@@ -19,16 +19,20 @@ KIND_IDS = {"rbf": 0, "matern52": 1, "matern32": 2, "exponential": 3, "white": 4
 
 
 class Part(ctypes.Structure):
-    """`mi355gp_part` of include/mi355gp.h: one term of a sum kernel."""
+    """`mi355gp_part` of include/mi355gp.h: one part of a sum-of-products kernel expression."""
     _fields_ = [("kind", ctypes.c_int), ("ard", ctypes.c_int), ("n_active", ctypes.c_int),
-                ("active_dims", ctypes.POINTER(ctypes.c_int)), ("theta", ctypes.POINTER(ctypes.c_double))]
+                ("active_dims", ctypes.POINTER(ctypes.c_int)), ("theta", ctypes.POINTER(ctypes.c_double)),
+                ("term", ctypes.c_int)]
 
 
 def make_parts(specs):
-    """specs: [(kind_name, ARD, theta array, active_dims array or None)] -> (ctypes array, keep-alive list, n_theta)"""
+    """specs: [(kind_name, ARD, theta array, active_dims array or None[, term])] -> (ctypes array, keep-alive list,
+    n_theta).  term (optional, default 0): parts with the same non-zero term id are multiplied (product kernels)."""
     arr = (Part * len(specs))()
     keep, ntheta = [], 0
-    for i, (kind, ARD, theta, dims) in enumerate(specs):
+    for i, spec in enumerate(specs):
+        kind, ARD, theta, dims = spec[:4]
+        arr[i].term = int(spec[4]) if len(spec) > 4 else 0
         th = np.ascontiguousarray(theta, dtype=np.float64)
         keep.append(th)
         arr[i].kind = KIND_IDS[kind]

@@ -1,5 +1,6 @@
 // api.hip -- the extern "C" boundary of libmi355gp.so (declared in include/mi355gp.h) and the
 // orchestration of one exact-GP objective+gradient evaluation with everything N x N resident in HBM.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -70,8 +71,11 @@ struct mi355gp_ctx {
         std::vector<int> dims;          // active input dimensions (kern.py:49-53), indices into the D columns of X
         std::vector<double> inv_ls;     // length D: 1/l on active dimensions, 0 elsewhere (= the slicing of kern.py:112-117)
         double* dXt = nullptr;          // D x npad scaled, dimension-major inputs of this part
+        int term = 0;                   // parts with the same term id are multiplied (GPy/kern/src/prod.py), terms are summed
     };
     std::vector<Part> parts;
+    std::vector<std::vector<int>> terms;   // part indices per term, in order of first appearance
+    double* Mbuf = nullptr;             // npad x npad product of the OTHER factors of a term (allocated on first product kernel)
     double* dGradOutAll = nullptr;      // [part][groups][GP_STRIDE]
     size_t gradOutAllParts = 0;
 };
@@ -87,7 +91,7 @@ static void free_parts(mi355gp_ctx* c) {
 
 static void free_data(mi355gp_ctx* c) {
     free_parts(c);
-    double** ptrs[] = {&c->dX, &c->dR, &c->dXt, &c->dInvLs, &c->dNoise, &c->A, &c->B, &c->C, &c->dAlpha,
+    double** ptrs[] = {&c->dX, &c->dR, &c->dXt, &c->dInvLs, &c->dNoise, &c->A, &c->B, &c->C, &c->Mbuf, &c->dAlpha,
                        &c->dTmp, &c->dTrmvPart, &c->dGradPart, &c->dGradOut, &c->dScal, &c->dDiag};
     for (auto p : ptrs) {
         if (*p) (void)hipFree(*p);
@@ -244,8 +248,20 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
         const int nb = grad_num_blocks(n);
         for (size_t p = 0; p < nparts; ++p) {       // every part reduces the same dL_dK against its own dK/dtheta
             const mi355gp_ctx::Part& pt = c->parts[p];
+            // factor of a product: dL_dK is weighted by the covariances of the term's other factors (prod.py:86-99),
+            // rebuilt into Mbuf (lower tiles) by one K-build pass per other factor
+            const double* Mul = nullptr;
+            for (const auto& t : c->terms) {
+                if (t.size() < 2 || std::find(t.begin(), t.end(), (int)p) == t.end()) continue;
+                for (int g : t) {
+                    if (g == (int)p) continue;
+                    launch_kbuild_sym(st, c->parts[(size_t)g].kp, c->parts[(size_t)g].dXt, np, n, np, c->Mbuf, nullptr, 0,
+                                      0.0, /*lower_only=*/1, /*add_diag=*/0, /*accumulate=*/0, Mul);
+                    Mul = c->Mbuf;
+                }
+            }
             launch_grad_fused(st, pt.kp, pt.dXt, np, n, c->C, np, c->dAlpha, c->Dy, c->dGradPart, GP_STRIDE,
-                              studentt_nu > 0.0 ? c->dScal + 4 : nullptr);
+                              studentt_nu > 0.0 ? c->dScal + 4 : nullptr, Mul, np);
             for (int g = 0; g < (pt.kp.ard ? groups : 1); ++g)
                 launch_reduce_partials(st, c->dGradPart + (long)g * nb * GP_STRIDE, nb, GP_STRIDE,
                                        c->dGradOutAll + ((long)p * groups + g) * GP_STRIDE);
@@ -320,6 +336,35 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
     return 0;
 }
 
+// K = sum over terms of the element-wise product of the term's factors (add.py:58-72, prod.py:58-65).
+// emit(part, dst, mul, accumulate, first_into_out) launches one factor: dst (+)= k_part * mul.  The leading factors
+// of a multi-factor term are multiplied up in `scratch` (same shape as `out`), the last one lands in `out`.
+template <class Emit>
+static void build_expression(const mi355gp_ctx* c, double* out, double* scratch, bool out_holds_data, Emit emit) {
+    bool first = !out_holds_data;
+    for (const auto& t : c->terms) {
+        const size_t k = t.size();
+        for (size_t f = 0; f + 1 < k; ++f) emit(t[f], scratch, f > 0 ? scratch : nullptr, 0, false);
+        emit(t[k - 1], out, k > 1 ? scratch : nullptr, first ? 0 : 1, first);
+        first = false;
+    }
+}
+static bool has_product(const mi355gp_ctx* c) {
+    for (const auto& t : c->terms)
+        if (t.size() > 1) return true;
+    return false;
+}
+// Kdiag of the expression: sum over terms of the product of the factors' variances
+static double expression_kdiag(const mi355gp_ctx* c) {
+    double s = 0.0;
+    for (const auto& t : c->terms) {
+        double v = 1.0;
+        for (int f : t) v *= c->parts[(size_t)f].kp.variance;
+        s += v;
+    }
+    return s;
+}
+
 static int upload_noise(mi355gp_ctx* c, const double* noise, int64_t noise_len) {
     ARG_CHECK(noise != nullptr && (noise_len == 1 || noise_len == c->n),
               "noise must have 1 or N entries");
@@ -354,6 +399,7 @@ static int prepare_parts(mi355gp_ctx* c, int nparts, const mi355gp_part* parts) 
         const int na = (int)p.dims.size();
         const bool stationary = in.kind <= 3;
         const int nl = stationary ? (in.ard ? na : 1) : 0;
+        p.term = in.term;
         p.kp = KernParams{in.kind, (stationary && in.ard) ? 1 : 0, c->D, in.theta[0]};
         p.theta.assign(in.theta, in.theta + 1 + nl);
         p.inv_ls.assign((size_t)c->D, 0.0);
@@ -363,6 +409,23 @@ static int prepare_parts(mi355gp_ctx* c, int nparts, const mi355gp_part* parts) 
             p.inv_ls[(size_t)p.dims[a]] = 1.0 / l;
         }
     }
+    c->terms.clear();
+    std::vector<int> ids;
+    bool any_product = false;
+    for (int i = 0; i < nparts; ++i) {
+        const int id = c->parts[(size_t)i].term;
+        size_t t = ids.size();
+        if (id != 0)                                   // term 0 = a plain summand of its own
+            for (t = 0; t < ids.size() && ids[t] != id; ++t) {}
+        if (t == ids.size()) {
+            ids.push_back(id);
+            c->terms.emplace_back();
+        } else {
+            any_product = true;
+        }
+        c->terms[t].push_back(i);
+    }
+    if (any_product && !c->Mbuf) HIP_CHECK(hipMalloc(&c->Mbuf, sizeof(double) * c->npad * c->npad));
     return 0;
 }
 
@@ -389,9 +452,11 @@ int mi355gp_exact_inference_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* 
     c->have_kernel = true;
     HIP_CHECK(hipEventRecord(c->ev[0], st));
     if (int rc = scale_parts(c)) return rc;
-    for (size_t p = 0; p < c->parts.size(); ++p)          // Ky = sum_p K_p + (noise + jitter) I   (add.py:58-72)
-        launch_kbuild_sym(st, c->parts[p].kp, c->parts[p].dXt, c->npad, c->n, c->npad, c->A, c->dNoise, noise_len,
-                          jitter + extra_jitter, /*lower_only=*/1, /*add_diag=*/p == 0, /*accumulate=*/p > 0);
+    // Ky = sum_t prod_f K_f + (noise + jitter) I   (add.py:58-72, prod.py:58-65)
+    build_expression(c, c->A, c->Mbuf, false, [&](int p, double* dst, const double* mul, int acc, bool first) {
+        launch_kbuild_sym(st, c->parts[(size_t)p].kp, c->parts[(size_t)p].dXt, c->npad, c->n, c->npad, dst, c->dNoise,
+                          noise_len, jitter + extra_jitter, /*lower_only=*/1, /*add_diag=*/first, acc, mul);
+    });
     return run_pipeline(c, true, nullptr, out_scalars, alpha_out, dtheta_out, diag_dLdK_out, stage_ms);
 }
 
@@ -413,9 +478,10 @@ int mi355gp_exact_studentt_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* p
     c->have_kernel = true;
     HIP_CHECK(hipEventRecord(c->ev[0], st));
     if (int rc = scale_parts(c)) return rc;
-    for (size_t p = 0; p < c->parts.size(); ++p)
-        launch_kbuild_sym(st, c->parts[p].kp, c->parts[p].dXt, c->npad, c->n, c->npad, c->A, c->dNoise, 1,
-                          jitter + extra_jitter, 1, p == 0, p > 0);
+    build_expression(c, c->A, c->Mbuf, false, [&](int p, double* dst, const double* mul, int acc, bool first) {
+        launch_kbuild_sym(st, c->parts[(size_t)p].kp, c->parts[(size_t)p].dXt, c->npad, c->n, c->npad, dst, c->dNoise, 1,
+                          jitter + extra_jitter, 1, first, acc, mul);
+    });
     return run_pipeline(c, true, nullptr, out_scalars, alpha_out, dtheta_out, nullptr, stage_ms, nu);
 }
 
@@ -457,9 +523,16 @@ int mi355gp_fetch(mi355gp_ctx* c, int which, double* out, int fortran_order) {
             mi355gp_set_error("mi355gp_fetch(K): no device kernel evaluation in this context");
             rc = -4;
         } else {
-            for (size_t p = 0; p < c->parts.size(); ++p)                           // symmetric: no transpose needed
-                launch_kbuild_cross(st, c->parts[p].kp, c->parts[p].dXt, np, n, c->parts[p].dXt, np, n, tmp, n,
-                                    /*accumulate=*/p > 0, /*diag_same=*/1);
+            double* scratch = nullptr;
+            if (has_product(c)) HIP_CHECK(hipMalloc(&scratch, sizeof(double) * n * n));
+            build_expression(c, tmp, scratch, false, [&](int p, double* dst, const double* mul, int acc, bool) {
+                const mi355gp_ctx::Part& pt = c->parts[(size_t)p];                 // symmetric: no transpose needed
+                launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, pt.dXt, np, n, dst, n, acc, /*diag_same=*/1, mul);
+            });
+            if (scratch) {
+                HIP_CHECK(hipStreamSynchronize(st));
+                (void)hipFree(scratch);
+            }
         }
     } else if (!c->have_factor) {
         mi355gp_set_error("mi355gp_fetch: no successful factorisation in this context");
@@ -712,16 +785,30 @@ int mi355gp_predict_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, c
     HIP_CHECK(hipMemcpyAsync(dXn, Xnew, sizeof(double) * M * D, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(dKx, 0, sizeof(double) * np * mp, st));
     if (full_cov && var_out) HIP_CHECK(hipMemsetAsync(dVar, 0, sizeof(double) * mp * mp, st));
-    double kdiag = 0.0;                                                                   // Kdiag(X*) = sum of variances
-    for (size_t p = 0; p < c->parts.size(); ++p) {
-        const mi355gp_ctx::Part& pt = c->parts[p];
-        kdiag += pt.kp.variance;
-        HIP_CHECK(hipMemcpyAsync(c->dInvLs, pt.inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
-        launch_scale_inputs(st, dXn, M, c->D, c->dInvLs, 1, dXt2, ld2);
-        launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, dXt2, ld2, M, dKx, mp, /*accumulate=*/1);   // K(X, X*) (n x M)
-        if (full_cov && var_out)
-            launch_kbuild_cross(st, pt.kp, dXt2, ld2, M, dXt2, ld2, M, dVar, mp, 1, /*diag_same=*/1);   // K(X*, X*)
+    const double kdiag = expression_kdiag(c);                   // Kdiag(X*): sum over terms of the product of variances
+    DevBuf dScr1, dScr2;
+    if (has_product(c)) {
+        HIP_CHECK(dScr1.alloc(np * mp));
+        if (full_cov && var_out) HIP_CHECK(dScr2.alloc(mp * mp));
     }
+    hipError_t herr = hipSuccess;
+    auto scale_new = [&](const mi355gp_ctx::Part& pt) {
+        hipError_t e = hipMemcpyAsync(c->dInvLs, pt.inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) herr = e;
+        launch_scale_inputs(st, dXn, M, c->D, c->dInvLs, 1, dXt2, ld2);
+    };
+    build_expression(c, dKx, dScr1, true, [&](int p, double* dst, const double* mul, int acc, bool) {
+        const mi355gp_ctx::Part& pt = c->parts[(size_t)p];
+        scale_new(pt);
+        launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, dXt2, ld2, M, dst, mp, acc, 0, mul);                 // K(X, X*) (n x M)
+    });
+    if (full_cov && var_out)
+        build_expression(c, dVar, dScr2, true, [&](int p, double* dst, const double* mul, int acc, bool) {
+            const mi355gp_ctx::Part& pt = c->parts[(size_t)p];
+            scale_new(pt);
+            launch_kbuild_cross(st, pt.kp, dXt2, ld2, M, dXt2, ld2, M, dst, mp, acc, /*diag_same=*/1, mul);  // K(X*, X*)
+        });
+    HIP_CHECK(herr);
     launch_col_reduce(st, dKx, mp, n, M, c->dAlpha, c->Dy, 0.0, 0, dMu);                  // mu = Kx^T alpha
     launch_trmm_lower(st, c->B, np, dKx, mp, dTmp, mp, (int)(np / NB), (int)(mp / NB));   // tmp = L^-1 Kx
     if (!full_cov) {
@@ -770,15 +857,35 @@ int mi355gp_covariance_between_points(mi355gp_ctx* c, int nparts, const mi355gp_
     HIP_CHECK(hipMemsetAsync(dK1, 0, sizeof(double) * np * m1p, st));
     HIP_CHECK(hipMemsetAsync(dK2, 0, sizeof(double) * np * m2p, st));
     HIP_CHECK(hipMemsetAsync(dC, 0, sizeof(double) * m1p * m2p, st));
-    for (size_t p = 0; p < c->parts.size(); ++p) {
-        const mi355gp_ctx::Part& pt = c->parts[p];
-        HIP_CHECK(hipMemcpyAsync(c->dInvLs, pt.inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
+    DevBuf dS1, dS2, dS3;
+    if (has_product(c)) {
+        HIP_CHECK(dS1.alloc(np * m1p));
+        HIP_CHECK(dS2.alloc(np * m2p));
+        HIP_CHECK(dS3.alloc(m1p * m2p));
+    }
+    hipError_t herr = hipSuccess;
+    auto scale_new = [&](const mi355gp_ctx::Part& pt) {
+        hipError_t e = hipMemcpyAsync(c->dInvLs, pt.inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) herr = e;
         launch_scale_inputs(st, dA, M1, c->D, c->dInvLs, 1, dXtA, l1);
         launch_scale_inputs(st, dB, M2, c->D, c->dInvLs, 1, dXtB, l2);
-        launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, dXtA, l1, M1, dK1, m1p, 1);
-        launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, dXtB, l2, M2, dK2, m2p, 1);
-        launch_kbuild_cross(st, pt.kp, dXtA, l1, M1, dXtB, l2, M2, dC, m2p, 1);
-    }
+    };
+    build_expression(c, dK1, dS1, true, [&](int p, double* dst, const double* mul, int acc, bool) {
+        const mi355gp_ctx::Part& pt = c->parts[(size_t)p];
+        scale_new(pt);
+        launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, dXtA, l1, M1, dst, m1p, acc, 0, mul);
+    });
+    build_expression(c, dK2, dS2, true, [&](int p, double* dst, const double* mul, int acc, bool) {
+        const mi355gp_ctx::Part& pt = c->parts[(size_t)p];
+        scale_new(pt);
+        launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, dXtB, l2, M2, dst, m2p, acc, 0, mul);
+    });
+    build_expression(c, dC, dS3, true, [&](int p, double* dst, const double* mul, int acc, bool) {
+        const mi355gp_ctx::Part& pt = c->parts[(size_t)p];
+        scale_new(pt);
+        launch_kbuild_cross(st, pt.kp, dXtA, l1, M1, dXtB, l2, M2, dst, m2p, acc, 0, mul);
+    });
+    HIP_CHECK(herr);
     launch_trmm_lower(st, c->B, np, dK1, m1p, dT1, m1p, (int)(np / NB), (int)(m1p / NB));
     launch_trmm_lower(st, c->B, np, dK2, m2p, dT2, m2p, (int)(np / NB), (int)(m2p / NB));
     launch_gemm(st, 1, 1, m1p, m2p, np, dT1, m1p, dT2, m2p, dC, m2p, -1.0, 1.0);

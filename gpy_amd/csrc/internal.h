@@ -100,12 +100,14 @@ struct KernParams {
 // (npad x npad); rows/cols >= n get the identity.
 void launch_scale_inputs(hipStream_t st, const double* X, long n, int D, const double* inv_ls, int ard,
                          double* Xt, long ldx);
-// accumulate != 0: add this kernel's covariance to what A / Kout already hold (sum kernels)
+// accumulate != 0: add this kernel's covariance to what A / Kout already hold (sum kernels);
+// mul (same layout as the output, may alias it): element-wise multiplier applied first (product kernels)
 void launch_kbuild_sym(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, long npad, double* A,
                        const double* noise, long noise_len, double jit, int lower_only, int add_diag,
-                       int accumulate = 0);
+                       int accumulate = 0, const double* mul = nullptr);
 void launch_kbuild_cross(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
-                         long ld2, long m, double* Kout, long ldk, int accumulate = 0, int diag_same = 0);
+                         long ld2, long m, double* Kout, long ldk, int accumulate = 0, int diag_same = 0,
+                         const double* mul = nullptr);
 // y = X r (lower-triangular X, n x n within npad), then a = X^T y   (Dy right-hand sides, row-major n x Dy)
 void launch_tri_matvec(hipStream_t st, const double* X, long ld, long n, const double* R, int Dy, double* tmp,
                        double* alpha, double* partials);
@@ -119,7 +121,7 @@ int grad_num_blocks(long n);
 // aa_scale (optional, device): factor on the alpha alpha^T term of dL_dK (Student-t process)
 void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, const double* W,
                        long ldw, const double* alpha, int Dy, double* partials, int stride,
-                       const double* aa_scale = nullptr);
+                       const double* aa_scale = nullptr, const double* Mul = nullptr, long ldm = 0);
 void launch_studentt_scale(hipStream_t st, const double* scal, double nu, long n, double* out);
 // Hout (optional, may alias G): H = dL_dK * (dK/dr)/r, the weights of the gradients_X reductions
 void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,

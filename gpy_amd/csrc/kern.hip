@@ -124,7 +124,9 @@ __global__ __launch_bounds__(256) void k_kbuild(KernParams kp, const double* __r
                                                 const double* __restrict__ Xt2, long ld2, long m,
                                                 double* __restrict__ out, long ldo, long nrows_out,
                                                 const double* __restrict__ noise, long noise_len, double jit,
-                                                int lower_only, int add_diag, int ntc, int accumulate, int diag_same) {
+                                                int lower_only, int add_diag, int ntc, int accumulate, int diag_same,
+                                                const double* mul) {
+    // mul (may alias out): element-wise multiplier with out's layout -- product kernels (GPy/kern/src/prod.py:58-65)
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
     __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
@@ -154,17 +156,18 @@ __global__ __launch_bounds__(256) void k_kbuild(KernParams kp, const double* __r
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const long j = j0 + tx * 4 + b;
-            if (i < n && j < m) {
-                v[b] = cov_k(kp.kind, kp.variance, r2[a][b], (SYM || diag_same) && i == j);
-                if (SYM && add_diag && i == j) v[b] += noise[noise_len > 1 ? i : 0] + jit;
-            } else {
-                v[b] = (SYM && i == j && !accumulate) ? 1.0 : 0.0;
-            }
+            if (i < n && j < m) v[b] = cov_k(kp.kind, kp.variance, r2[a][b], (SYM || diag_same) && i == j);
+            else v[b] = (SYM && i == j && !accumulate) ? 1.0 : 0.0;
         }
         if (SYM) {
             if (i < nrows_out) {
                 d4* p = reinterpret_cast<d4*>(out + i * ldo + j0 + tx * 4);
                 d4 o = (d4){v[0], v[1], v[2], v[3]};
+                if (mul) o *= *reinterpret_cast<const d4*>(mul + i * ldo + j0 + tx * 4);
+                if (add_diag && i < n) {                        // noise + jitter enter once, outside any product
+                    const long d = i - (j0 + tx * 4);
+                    if (d >= 0 && d < 4) o[d] += noise[noise_len > 1 ? i : 0] + jit;
+                }
                 if (accumulate) o += *p;                       // sum kernels (GPy/kern/src/add.py:58-72): K += K_part
                 *p = o;
             }
@@ -172,24 +175,28 @@ __global__ __launch_bounds__(256) void k_kbuild(KernParams kp, const double* __r
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const long j = j0 + tx * 4 + b;
-                if (j < m) out[i * ldo + j] = accumulate ? out[i * ldo + j] + v[b] : v[b];
+                if (j < m) {
+                    const double w = mul ? v[b] * mul[i * ldo + j] : v[b];
+                    out[i * ldo + j] = accumulate ? out[i * ldo + j] + w : w;
+                }
             }
         }
     }
 }
 
 void launch_kbuild_sym(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, long npad, double* A,
-                       const double* noise, long noise_len, double jit, int lower_only, int add_diag, int accumulate) {
+                       const double* noise, long noise_len, double jit, int lower_only, int add_diag, int accumulate,
+                       const double* mul) {
     const int nt = (int)(npad / KT);
     hipLaunchKernelGGL((k_kbuild<true>), dim3((unsigned)((long)nt * nt)), dim3(256), 0, st, kp, Xt, ldx, n, Xt, ldx, n,
-                       A, npad, npad, noise, noise_len, jit, lower_only, add_diag, nt, accumulate, 0);
+                       A, npad, npad, noise, noise_len, jit, lower_only, add_diag, nt, accumulate, 0, mul);
 }
 
 void launch_kbuild_cross(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
-                         long ld2, long m, double* Kout, long ldk, int accumulate, int diag_same) {
+                         long ld2, long m, double* Kout, long ldk, int accumulate, int diag_same, const double* mul) {
     const int ntr = (int)((n + KT - 1) / KT), ntc = (int)((m + KT - 1) / KT);
     hipLaunchKernelGGL((k_kbuild<false>), dim3((unsigned)((long)ntr * ntc)), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2,
-                       ld2, m, Kout, ldk, n, nullptr, 0, 0.0, 0, 0, ntc, accumulate, diag_same);
+                       ld2, m, Kout, ldk, n, nullptr, 0, 0.0, 0, 0, ntc, accumulate, diag_same, mul);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -206,7 +213,8 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                                               const double* __restrict__ alpha, int Dy, int q_off,
                                               long ntiles, int ntc, double* __restrict__ partials,
                                               double* __restrict__ Hout = nullptr, long ldh = 0, int diag_same = 0,
-                                              const double* __restrict__ aa_scale = nullptr) {
+                                              const double* __restrict__ aa_scale = nullptr,
+                                              const double* __restrict__ Mul = nullptr, long ldm = 0) {
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
     __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
     __shared__ double red[256];
@@ -267,6 +275,8 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                     } else {
                         g = G[i * ldg + j];
                     }
+                    // factor of a product kernel: dL_dK times the other factors' covariances (prod.py:86-99)
+                    if (Mul) g *= Mul[i * ldm + j];
                 }
                 const CovVal c = cov_all(kp.kind, kp.variance, r2[a][b], (FUSED || diag_same) && i == j);
                 a_var = fma(g, c.k, a_var);
@@ -351,19 +361,20 @@ int grad_generic_num_blocks(long n, long m) {
 
 // one launch per group of 32 lengthscale dimensions (ARD); partials for group gidx at partials + gidx*nblocks*GP_STRIDE
 void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, const double* W,
-                       long ldw, const double* alpha, int Dy, double* partials, int stride, const double* aa_scale) {
+                       long ldw, const double* alpha, int Dy, double* partials, int stride, const double* aa_scale,
+                       const double* Mul, long ldm) {
     (void)stride;
     const long nt = (n + KT - 1) / KT;
     const long ntiles = nt * (nt + 1) / 2;
     const int nb = pick_grad_blocks(ntiles);
     if (!kp.ard) {
         hipLaunchKernelGGL((k_grad<true, false>), dim3(nb), dim3(256), 0, st, kp, Xt, ldx, n, Xt, ldx, n, W, ldw,
-                           alpha, Dy, 0, ntiles, (int)nt, partials, nullptr, 0, 0, aa_scale);
+                           alpha, Dy, 0, ntiles, (int)nt, partials, nullptr, 0, 0, aa_scale, Mul, ldm);
     } else {
         for (int q_off = 0, gidx = 0; q_off < kp.D; q_off += KDC, ++gidx)
             hipLaunchKernelGGL((k_grad<true, true>), dim3(nb), dim3(256), 0, st, kp, Xt, ldx, n, Xt, ldx, n, W, ldw,
                                alpha, Dy, q_off, ntiles, (int)nt, partials + (long)gidx * nb * GP_STRIDE, nullptr, 0, 0,
-                               aa_scale);
+                               aa_scale, Mul, ldm);
     }
 }
 

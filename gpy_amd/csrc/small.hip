@@ -33,16 +33,28 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// value of lane (row*16 + j) for every lane of each 16-lane row: one v_mov_b64_dpp row_newbcast (no SGPR round trip,
+// no readlane->VALU hazard nops).  j is a compile-time constant after unrolling; the switch folds.
+#define BC16_CASE(J) case J: return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true);
+__device__ __forceinline__ double bcast16(double v, int j) {
+    switch (j) {
+        BC16_CASE(0) BC16_CASE(1) BC16_CASE(2) BC16_CASE(3) BC16_CASE(4) BC16_CASE(5) BC16_CASE(6) BC16_CASE(7)
+        BC16_CASE(8) BC16_CASE(9) BC16_CASE(10) BC16_CASE(11) BC16_CASE(12) BC16_CASE(13) BC16_CASE(14)
+        default: return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + 15, 0xf, 0xf, true);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
-// 16x16 Cholesky + inverse of the factor in the registers of one wave.  Lane l works on row i = l & 15
-// (lanes 16..63 mirror lanes 0..15): a[c] = A[i][c], x[c] = (running right-hand side I -> L^-1)[i][c].
-// Right-looking; every cross-row value is a compile-time-lane v_readlane (no LDS round trips).
-// Returns 0 or the 1-based index of the first non-positive pivot.
-__device__ __forceinline__ int potf2_inv_16(double (&a)[16], double (&x)[16], int lane) {
-    const int i = lane & 15;
+// 16x16 Cholesky + inverse of the factor in the registers of one wave.  Lane l works on row i = l & 15.
+// a[c] = A[i][c] is mirrored in the four 16-lane rows of the wave (the factorisation itself is replicated);
+// the running right-hand side I -> L^-1 is SPLIT over them: lane group g = l >> 4 keeps columns 4k+g in xs[k],
+// so the inverse costs a quarter of the instructions.  Right-looking; every cross-row value is a DPP row
+// broadcast.  Returns 0 or the 1-based index of the first non-positive pivot.
+__device__ __forceinline__ int potf2_inv_16(double (&a)[16], double (&xs)[4], int lane) {
+    const int i = lane & 15, g = lane >> 4;
     int fail = 0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) x[c] = (c == i) ? 1.0 : 0.0;
+    for (int k = 0; k < 4; ++k) xs[k] = (4 * k + g == i) ? 1.0 : 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         double piv = readlane_d(a[j], j);
@@ -55,16 +67,21 @@ __device__ __forceinline__ int potf2_inv_16(double (&a)[16], double (&x)[16], in
         const double lm = (i > j) ? a[j] : 0.0;  // L[i][j] on the rows that still change, 0 elsewhere
         const double sc = (i == j) ? rd : 1.0;   // row j of the right-hand side becomes row j of L^-1
 #pragma unroll
-        for (int c = j + 1; c < 16; ++c) a[c] = fma(-lm, readlane_d(a[j], c), a[c]);
+        for (int c = j + 1; c < 16; ++c) a[c] = fma(-lm, bcast16(a[j], c), a[c]);
+        // columns 4k+g <= j change; a column 4k+g > j in the last slot has a zero in row j, so it passes through unchanged
 #pragma unroll
-        for (int c = 0; c <= j; ++c) {
-            x[c] *= sc;
-            x[c] = fma(-lm, readlane_d(x[c], j), x[c]);
+        for (int k = 0; k <= (j >> 2); ++k) {
+            xs[k] *= sc;
+            xs[k] = fma(-lm, bcast16(xs[k], j), xs[k]);
         }
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        if (c > i) { a[c] = 0.0; x[c] = 0.0; }
+        if (c > i) a[c] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (4 * k + g > i) xs[k] = 0.0;
     }
     return fail;
 }
@@ -120,18 +137,19 @@ __global__ __launch_bounds__(256) void k_diag128(double* __restrict__ A, long ld
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             double* Td = Tt + tix(jb, jb) * TSZ;
-            double a[16], x[16];
+            double a[16], xs[4];
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = Td[fi * TS + c];
-            const int fail = potf2_inv_16(a, x, lane);
+            const int fail = potf2_inv_16(a, xs, lane);
             if (fail != 0 && lane == 0) atomicCAS(info, 0, (int)(c0 + jb * 16 + fail));
             if (lane < 16) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    Td[fi * TS + c] = a[c];
-                    Dv[fi * TS + c] = x[c];
-                    dinv[jb * 256 + fi * 16 + c] = x[c];
-                }
+                for (int c = 0; c < 16; ++c) Td[fi * TS + c] = a[c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {              // lane group fk holds columns 4k+fk of the inverse
+                Dv[fi * TS + 4 * k + fk] = xs[k];
+                dinv[jb * 256 + fi * 16 + 4 * k + fk] = xs[k];
             }
         } else if (jb > 0) {
             // remaining tiles of step jb-1's trailing update: (ib,kb), jb <= kb <= ib <= 7, except (jb,jb)

@@ -12,7 +12,7 @@ the same `numpy.linalg.LinAlgError` messages.
 import numpy as np
 
 from . import _lib
-from .kern import Add, Stationary
+from .kern import CombinationKernel, Stationary
 from .lazy import DeviceResult, kernel_signature
 from .likelihoods import Gaussian
 from .posterior import PosteriorExact
@@ -42,14 +42,14 @@ class _DeviceState(object):
         return self.ctx.fetch(which, fortran_order=fortran_order)
 
     def covariance_between_points(self, kern, X1, X2):
-        if isinstance(kern, Add):
+        if isinstance(kern, CombinationKernel):
             return self.ctx.covariance_between_points(kern.part_specs(), _lib.f64(X1), _lib.f64(X2))
         # a single kernel's active_dims were applied when X was uploaded: slice the new points the same way
         return self.ctx.covariance_between_points([(kern.kind, kern.ARD, kern._theta(), None)], kern._slice_X(X1),
                                                   kern._slice_X(X2))
 
     def predict(self, kern, Xnew, full_cov=False):
-        if isinstance(kern, Add):
+        if isinstance(kern, CombinationKernel):
             return self.ctx.predict_sum(kern.part_specs(), _lib.f64(Xnew), full_cov=full_cov)
         return self.ctx.predict(kern.kind, kern.ARD, kern._theta(), kern._slice_X(Xnew), full_cov=full_cov)
 
@@ -119,7 +119,7 @@ class ExactGaussianInference(object):
         noise = np.atleast_1d(np.asarray(variance, dtype=np.float64)).ravel()
         R = _lib.f64(Y - m)
         n = X.shape[0]
-        is_sum = isinstance(kern, Add)
+        is_sum = isinstance(kern, CombinationKernel)
         fused = K is None and (isinstance(kern, Stationary) or is_sum)
         Xdev = kern._slice_X(X) if fused else _lib.f64(X)
         if self._state is None:
@@ -136,7 +136,7 @@ class ExactGaussianInference(object):
         if fused:
             if is_sum:
                 specs = kern.part_specs()
-                diagA = sum(float(sp[2][0]) for sp in specs) + noise + 1e-8
+                diagA = kern.diag_variance() + noise + 1e-8
 
                 def attempt(extra):
                     return st.ctx.exact_inference_sum(specs, noise, jitter=1e-8, extra_jitter=extra, want_alpha=True,
@@ -210,13 +210,13 @@ class ExactStudentTInference(object):
 
     def inference(self, kern, X, Y, nu, mean_function=None, K=None):
         from scipy.special import digamma
-        if K is not None or not isinstance(kern, (Stationary, Add)):
+        if K is not None or not isinstance(kern, (Stationary, CombinationKernel)):
             raise NotImplementedError("the MI355X Student-t path evaluates gpy_amd kernels on the device")
         X = np.asarray(X)
         Y = np.asarray(Y, dtype=np.float64)
         m = 0 if mean_function is None else mean_function.f(X)
         R = _lib.f64(Y - m)
-        is_sum = isinstance(kern, Add)
+        is_sum = isinstance(kern, CombinationKernel)
         Xdev = kern._slice_X(X)
         specs = kern.part_specs() if is_sum else [(kern.kind, kern.ARD, kern._theta(), None)]
         if self._state is None:
@@ -232,7 +232,7 @@ class ExactStudentTInference(object):
                 break
             if tries >= self.maxtries:
                 raise LinAlgError("not positive definite, even with jitter.")
-            extra = sum(float(sp[2][0]) for sp in specs) * 1e-6 * 10 ** tries
+            extra = (kern.diag_variance() if is_sum else float(specs[0][2][0])) * 1e-6 * 10 ** tries
             tries += 1
         N, beta = Y.shape[0], r["beta"]
         dL_dnu = -N / (nu - 2.0) + digamma(0.5 * (nu + N)) - digamma(0.5 * nu)

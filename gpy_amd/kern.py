@@ -112,6 +112,9 @@ class Stationary(Parameterized):
     def __add__(self, other):
         return Add([self, other])
 
+    def __mul__(self, other):
+        return Prod([self, other])
+
     def reset_gradients(self):
         self.variance.gradient = 0.
         self.lengthscale.gradient = np.zeros(self.input_dim) if self.ARD else 0.
@@ -233,6 +236,9 @@ class Static(Parameterized):
     def __add__(self, other):
         return Add([self, other])
 
+    def __mul__(self, other):
+        return Prod([self, other])
+
 
 class White(Static):
     """(reference `static.py:63-98`): variance on the diagonal of K(X), zero cross-covariance."""
@@ -260,33 +266,74 @@ class Bias(Static):
         self.variance.gradient = np.sum(np.asarray(dL_dK))
 
 
-class Add(Parameterized):
-    """Sum of kernels (reference `GPy/kern/src/add.py:12-100`).  With `gpy_amd.ExactGaussianInference` the sum is
-    assembled and differentiated on the device in the same fused call as a single kernel (C-ABI
-    `mi355gp_exact_inference_sum`); parameter / gradient order = the parts' link order."""
+class CombinationKernel(Parameterized):
+    """Common part of `Add` and `Prod` (reference `GPy/kern/src/kern.py:327-390`): owns the parts, spans their input
+    columns, and describes itself to the C-ABI as a list of parts with term ids (`mi355gp_part`)."""
 
-    def __init__(self, parts, name="sum"):
-        super(Add, self).__init__(name)
-        flat = []
-        for p in parts:
-            flat.extend(p.parts if isinstance(p, Add) else [p])          # add.py:24-33 flattens nested sums
-        assert all(isinstance(p, (Stationary, Static)) for p in flat), "Add supports stationary, White and Bias parts"
-        self.parts = flat
-        self.input_dim = max(int(p.active_dims.max()) + 1 for p in flat)
+    def __init__(self, parts, name):
+        super(CombinationKernel, self).__init__(name)
+        self.parts = parts
+        self.input_dim = max(int(p.active_dims.max()) + 1 for p in parts)
         self.active_dims = np.arange(self.input_dim)
-        self.device = flat[0].device
-        for p in flat:
+        self.device = parts[0].device
+        for p in parts:
             self.link_parameter(p)
+
+    def leaves(self):
+        """the stationary / static kernels of the expression in link (= parameter, = gradient) order"""
+        out = []
+        for p in self.parts:
+            out.extend(p.leaves() if isinstance(p, CombinationKernel) else [p])
+        return out
+
+    def _slice_X(self, X):
+        return _lib.f64(np.asarray(X))
 
     def __add__(self, other):
         return Add([self, other])
 
-    def part_specs(self):
-        """[(kind, ARD, theta, active_dims)] for the C-ABI (active_dims index the columns of the model's X)."""
-        return [(p.kind, p.ARD, p._theta(), p.active_dims) for p in self.parts]
+    def __mul__(self, other):
+        return Prod([self, other])
 
-    def _slice_X(self, X):
-        return _lib.f64(np.asarray(X))
+    def _install_fused(self, g):
+        i = 0
+        for p in self.leaves():
+            k = p._theta().size
+            p._install_gradients(g[i:i + k])
+            i += k
+
+    def update_gradients_diag(self, dL_dKdiag, X):
+        raise NotImplementedError
+
+    def diag_variance(self):
+        """Kdiag of the expression (a constant for stationary / static leaves)"""
+        return float(self.Kdiag(np.zeros((1, self.input_dim)))[0])
+
+
+class Add(CombinationKernel):
+    """Sum of kernels (reference `GPy/kern/src/add.py:12-100`).  With `gpy_amd.ExactGaussianInference` the sum is
+    assembled and differentiated on the device in the same fused call as a single kernel (C-ABI
+    `mi355gp_exact_inference_sum`); parameter / gradient order = the parts' link order.  Parts may be `Prod`s."""
+
+    def __init__(self, parts, name="sum"):
+        flat = []
+        for p in parts:
+            flat.extend(p.parts if isinstance(p, Add) else [p])          # add.py:24-33 flattens nested sums
+        assert all(isinstance(p, (Stationary, Static, Prod)) for p in flat), \
+            "Add supports stationary, White, Bias and Prod parts"
+        super(Add, self).__init__(flat, name)
+
+    def part_specs(self):
+        """[(kind, ARD, theta, active_dims, term)] for the C-ABI (active_dims index the columns of the model's X);
+        the factors of a `Prod` part share a non-zero term id."""
+        specs, term = [], 0
+        for p in self.parts:
+            if isinstance(p, Prod):
+                term += 1
+                specs.extend((f.kind, f.ARD, f._theta(), f.active_dims, term) for f in p.parts)
+            else:
+                specs.append((p.kind, p.ARD, p._theta(), p.active_dims, 0))
+        return specs
 
     def K(self, X, X2=None):
         out = None
@@ -301,11 +348,7 @@ class Add(Parameterized):
     def update_gradients_full(self, dL_dK, X, X2=None):
         """(reference `add.py:81-82`).  A device-resident dL_dK of the fused sum call carries every part's gradient."""
         if isinstance(dL_dK, DeviceResult) and X2 is None and dL_dK.matches_kernel(self):
-            g, i = dL_dK.fused_dtheta, 0
-            for p in self.parts:
-                k = p._theta().size
-                p._install_gradients(g[i:i + k])
-                i += k
+            self._install_fused(dL_dK.fused_dtheta)
             return
         G = np.asarray(dL_dK)
         for p in self.parts:
@@ -321,6 +364,74 @@ class Add(Parameterized):
 
     def to_dict(self):
         return {"class": "GPy.kern.Add", "name": self.name, "parts": [p.to_dict() for p in self.parts]}
+
+
+class Prod(CombinationKernel):
+    """Product of kernels (reference `GPy/kern/src/prod.py:24-99`; nested products are flattened, `:33-41`).  Fused on the
+    device like `Add`: the factors share a term id of `mi355gp_part`, K is multiplied up factor by factor in the
+    K-build kernel and each factor's gradient pass weights dL_dK by the other factors' covariances."""
+
+    def __init__(self, kernels, name="mul"):
+        flat = []
+        for k in kernels:
+            flat.extend(k.parts if isinstance(k, Prod) else [k])
+        assert all(isinstance(k, (Stationary, Static)) for k in flat), "Prod supports stationary, White and Bias factors"
+        super(Prod, self).__init__(flat, name)
+
+    def part_specs(self):
+        return [(f.kind, f.ARD, f._theta(), f.active_dims, 1) for f in self.parts]
+
+    def K(self, X, X2=None):                                                     # prod.py:58-65
+        out = None
+        for p in self.parts:
+            Kp = p.K(X, X2)
+            out = Kp if out is None else out * Kp
+        return out
+
+    def Kdiag(self, X):                                                          # prod.py:67-71
+        out = None
+        for p in self.parts:
+            d = p.Kdiag(X)
+            out = d if out is None else out * d
+        return out
+
+    def update_gradients_full(self, dL_dK, X, X2=None):
+        """(reference `prod.py:86-99`): every factor sees dL_dK times the product of the other factors."""
+        if isinstance(dL_dK, DeviceResult) and X2 is None and dL_dK.matches_kernel(self):
+            self._install_fused(dL_dK.fused_dtheta)
+            return
+        G = np.asarray(dL_dK)
+        Ks = [p.K(X, X2) for p in self.parts]
+        for i, p in enumerate(self.parts):
+            W = G
+            for j, Kj in enumerate(Ks):
+                if j != i:
+                    W = W * Kj
+            p.update_gradients_full(W, X, X2)
+
+    def update_gradients_diag(self, dL_dKdiag, X):                               # prod.py:101-111
+        ds = [p.Kdiag(X) for p in self.parts]
+        for i, p in enumerate(self.parts):
+            w = np.asarray(dL_dKdiag, dtype=float)
+            for j, d in enumerate(ds):
+                if j != i:
+                    w = w * d
+            p.update_gradients_diag(w, X)
+
+    def gradients_X(self, dL_dK, X, X2=None):                                    # prod.py:113-121
+        G = np.asarray(dL_dK)
+        Ks = [p.K(X, X2) for p in self.parts]
+        out = 0.
+        for i, p in enumerate(self.parts):
+            W = G
+            for j, Kj in enumerate(Ks):
+                if j != i:
+                    W = W * Kj
+            out = out + p.gradients_X(W, X, X2)
+        return out
+
+    def to_dict(self):
+        return {"class": "GPy.kern.Prod", "name": self.name, "parts": [p.to_dict() for p in self.parts]}
 
 
 KERNEL_CLASSES = {"rbf": RBF, "matern52": Matern52, "matern32": Matern32, "exponential": Exponential,

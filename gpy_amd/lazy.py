@@ -86,5 +86,5 @@ def kernel_signature(kern):
     """Identity of a kernel evaluation: class, ARD flag, active dims and the exact parameter bits (per part for sums)."""
     parts = getattr(kern, "parts", None)
     if parts is not None:
-        return ("sum",) + tuple(kernel_signature(p) for p in parts)
+        return (type(kern).__name__,) + tuple(kernel_signature(p) for p in parts)
     return (kern.kind, bool(kern.ARD), tuple(int(i) for i in kern.active_dims), kern._theta().tobytes())

@@ -27,15 +27,18 @@ typedef struct mi355gp_ctx mi355gp_ctx;
 enum { MI355GP_RBF = 0, MI355GP_MATERN52 = 1, MI355GP_MATERN32 = 2, MI355GP_EXPONENTIAL = 3,
        MI355GP_WHITE = 4, MI355GP_BIAS = 5 /* static kernels, only as parts of a sum (kern/src/static.py:63-98,151-173) */ };
 
-/* One term of a sum kernel (GPy.kern.Add, kern/src/add.py:58-84).  theta = [variance, lengthscale (1, or n_active if ard)]
- * (static kinds: [variance]); active_dims: the input columns this term acts on (kern/src/kern.py:49-53,112-117),
- * NULL / n_active == 0 = all columns. */
+/* One part of a sum-of-products kernel expression (GPy.kern.Add, kern/src/add.py:58-84; GPy.kern.Prod,
+ * kern/src/prod.py:58-99).  theta = [variance, lengthscale (1, or n_active if ard)] (static kinds: [variance]);
+ * active_dims: the input columns this part acts on (kern/src/kern.py:49-53,112-117), NULL / n_active == 0 = all columns.
+ * term: 0 = the part is a summand of its own; parts sharing the same NONZERO term id are multiplied element-wise and
+ * their product is one summand: K = sum_t prod_{f in t} k_f.  Gradients come back per part, in part order. */
 typedef struct {
     int kind;
     int ard;
     int n_active;
     const int* active_dims;
     const double* theta;
+    int term;
 } mi355gp_part;
 
 /* which device-resident matrix mi355gp_fetch() materialises on the host (all N x N) */

@@ -305,47 +305,85 @@ def default_theta(D, ARD):
 
 
 # ----------------------------------------------------------------------------- sum kernels (GPy.kern.Add)
+def _part_K(part, X, X2=None):
+    """K of one part = (kind, ARD, variance, lengthscale, active_dims[, term]); 'white' / 'bias' follow
+    `kern/src/static.py:77-81,165-167`; `active_dims` slices X (`kern.py:112-117`)."""
+    kind, ARD, var, ls, dims = part[:5]
+    n, m = X.shape[0], (X if X2 is None else X2).shape[0]
+    if kind == "white":
+        return np.eye(n) * var if X2 is None else np.zeros((n, m))
+    if kind == "bias":
+        return np.full((n, m), float(var))
+    return kern_K(kind, X[:, dims], None if X2 is None else X2[:, dims], var, ls, ARD)
+
+
+def _terms(parts):
+    """[[part indices]] per summand: term id 0 (or a 5-tuple) = a summand of its own, parts sharing a non-zero
+    term id are the factors of one `Prod` (the grouping of include/mi355gp.h `mi355gp_part.term`)."""
+    groups, ids = [], []
+    for i, p in enumerate(parts):
+        t = p[5] if len(p) > 5 else 0
+        if t != 0 and t in ids:
+            groups[ids.index(t)].append(i)
+        else:
+            ids.append(t if t != 0 else None)
+            groups.append([i])
+    return groups
+
+
 def sum_kern_K(parts, X, X2=None):
-    """`Add.K` (reference `kern/src/add.py:58-72`) over parts = [(kind, ARD, variance, lengthscale, active_dims)];
-    kinds 'white' / 'bias' follow `kern/src/static.py:77-81,165-167`; `active_dims` slices X (`kern.py:112-117`)."""
+    """`Add.K` (reference `kern/src/add.py:58-72`) over summands that are single parts or `Prod`s of parts
+    (`kern/src/prod.py:58-65`: element-wise product of the factors' K)."""
     n, m = X.shape[0], (X if X2 is None else X2).shape[0]
     K = np.zeros((n, m))
-    for kind, ARD, var, ls, dims in parts:
-        if kind == "white":
-            if X2 is None:
-                K[np.arange(n), np.arange(n)] += var
-        elif kind == "bias":
-            K += var
-        else:
-            Xs = X[:, dims]
-            K += kern_K(kind, Xs, None if X2 is None else X2[:, dims], var, ls, ARD)
+    for g in _terms(parts):
+        T = _part_K(parts[g[0]], X, X2)
+        for i in g[1:]:
+            T = T * _part_K(parts[i], X, X2)
+        K += T
     return K
 
 
+def _part_grads(part, G, X):
+    """`update_gradients_full(G, X)` of one part (White: trace, Bias: sum, `static.py:89-93,169-170`)."""
+    kind, ARD, var, ls, dims = part[:5]
+    if kind == "white":
+        return np.array([np.trace(G)])
+    if kind == "bias":
+        return np.array([np.sum(G)])
+    dv, dl = update_gradients_full(kind, G, X[:, dims], None, var, ls, ARD)
+    return np.concatenate([[dv], np.atleast_1d(dl)])
+
+
 def sum_parameters_changed(parts, X, Y, noise):
-    """One `GP.parameters_changed` with a sum kernel: inference on K = sum of parts, then every part's
-    `update_gradients_full(dL_dK, X)` (`add.py:81-82`; White: trace, Bias: sum, `static.py:89-93,169-170`)."""
+    """One `GP.parameters_changed` with a sum(-of-products) kernel: inference on K, then every part's
+    `update_gradients_full` (`add.py:81-82`); a factor of a `Prod` receives dL_dK times the product of the other
+    factors' K (`prod.py:377-385`).  dtheta is concatenated in part order."""
     K = sum_kern_K(parts, X)
     res = exact_inference(K, Y, noise)
-    grads = []
-    for kind, ARD, var, ls, dims in parts:
-        if kind == "white":
-            grads.append(np.array([np.trace(res["dL_dK"])]))
-        elif kind == "bias":
-            grads.append(np.array([np.sum(res["dL_dK"])]))
-        else:
-            dv, dl = update_gradients_full(kind, res["dL_dK"], X[:, dims], None, var, ls, ARD)
-            grads.append(np.concatenate([[dv], np.atleast_1d(dl)]))
+    grads = [None] * len(parts)
+    for g in _terms(parts):
+        for i in g:
+            G = res["dL_dK"]
+            for j in g:
+                if j != i:
+                    G = G * _part_K(parts[j], X)
+            grads[i] = _part_grads(parts[i], G, X)
     res.update(K=K, dtheta=np.concatenate(grads))
     return res
 
 
+def sum_kdiag(parts):
+    """Kdiag of the expression: sum over summands of the product of variances (`add.py:74-79`, `prod.py:67-71`)."""
+    return sum(float(np.prod([parts[i][2] for i in g])) for g in _terms(parts))
+
+
 def sum_predict(parts, X, Xs, L, alpha):
-    """`PosteriorExact._raw_predict` (posterior.py:273-302) with a sum kernel."""
+    """`PosteriorExact._raw_predict` (posterior.py:273-302) with a sum(-of-products) kernel."""
     Kx = sum_kern_K(parts, X, Xs)
     mu = Kx.T @ alpha
     tmp = lapack.dtrtrs(np.asfortranarray(L), np.asfortranarray(Kx), lower=1)[0]
-    kdiag = sum(p[2] for p in parts)
+    kdiag = sum_kdiag(parts)
     var = (kdiag - np.sum(tmp * tmp, 0))[:, None]
     cov = sum_kern_K(parts, Xs) - tmp.T @ tmp
     return mu, var, cov

@@ -110,7 +110,7 @@ def load(cython_build_dir=None):
 
 
 def load_sum_kernels(ns):
-    """Adds the reference's `Add`, `White`, `Bias` (GPy/kern/src/add.py, static.py) to the namespace.  `Add.__init__` does
+    """Adds the reference's `Add`, `Prod`, `White`, `Bias` (GPy/kern/src/add.py, prod.py, static.py) to the namespace.  `Add.__init__` does
     `from .. import RBF, Linear, Bias, White` (add.py:34), so those names are put on the stub `GPy.kern` package."""
     if hasattr(ns, "Add"):
         return ns
@@ -123,6 +123,7 @@ def load_sum_kernels(ns):
         K.Linear = type("Linear", (), {})                 # only used in isinstance checks of the psi-statistics path
     add = importlib.import_module("GPy.kern.src.add")
     ns.Add, ns.White, ns.Bias = add.Add, st.White, st.Bias
+    ns.Prod = importlib.import_module("GPy.kern.src.prod").Prod
     return ns
 
 

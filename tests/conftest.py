@@ -18,8 +18,8 @@ def pytest_configure(config):
 
 def golden_names():
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    # sparse_* fixtures: tests/test_oracle_sparse.py; sum_*: tests/test_oracle_sum.py
-    return [n for n in names if not n.startswith(("sparse_", "sum_", "studentt_"))]
+    # sparse_* fixtures: tests/test_oracle_sparse.py; sum_* / prod_*: tests/test_oracle_sum.py
+    return [n for n in names if not n.startswith(("sparse_", "sum_", "studentt_", "prod_"))]
 
 
 def load_golden(name):

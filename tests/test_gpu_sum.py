@@ -15,9 +15,9 @@ TOL_LML, TOL_ALPHA, TOL_GRAD = 1e-10, 1e-9, 1e-8
 
 def _specs(g):
     out = []
-    for kind, ARD, var, ls, dims in g["parts"]:
+    for kind, ARD, var, ls, dims, term in g["parts"]:
         th = np.array([var]) if ls is None else np.concatenate([[var], np.atleast_1d(ls)])
-        out.append((kind, ARD, th, dims))
+        out.append((kind, ARD, th, dims, term))
     return out
 
 
@@ -58,7 +58,7 @@ def test_add_kernel_host_classes_in_gpregression():
     k.update_gradients_full(A, g["X"])
     parts = g["parts"]
     ref = []
-    for kind, ARD, var_, ls, dims in parts:
+    for kind, ARD, var_, ls, dims, _term in parts:
         if kind == "white":
             ref.append([np.trace(A)])
         elif kind == "bias":
@@ -68,6 +68,39 @@ def test_add_kernel_host_classes_in_gpregression():
             ref.append(np.concatenate([[dv], np.atleast_1d(dl)]))
     ref = np.concatenate(ref)
     assert np.abs(k.gradient - ref).max() <= TOL_GRAD * np.abs(ref).max()
+    f0 = m.objective_function()
+    m.optimize(max_iters=5)
+    assert m.objective_function() < f0
+
+
+def test_prod_kernel_host_classes_in_gpregression():
+    """`Prod` / `Add` of `Prod` through the host classes: fused device path vs the reference's golden vectors, and the
+    generic (foreign dL_dK) path of Prod.update_gradients_full (prod.py:377-385) vs the oracle."""
+    g = load_sum_golden("prod_n230_three_factors_plus_rbf_dy2")
+    k = (gpy_amd.RBF(1, variance=0.9, lengthscale=1.2, active_dims=[0])
+         * gpy_amd.Exponential(1, variance=1.2, lengthscale=2.5, active_dims=[1]) * gpy_amd.Bias(3, 0.6)
+         + gpy_amd.RBF(3, variance=0.5, lengthscale=[0.8, 1.0, 1.7], ARD=True))
+    assert isinstance(k, gpy_amd.Add) and isinstance(k.parts[0], gpy_amd.Prod) and len(k.parts[0].parts) == 3
+    m = gpy_amd.GPRegression(g["X"], g["Y"], k, noise_var=g["noise"])
+    assert abs(m.log_likelihood() - g["lml"]) <= TOL_LML * abs(g["lml"])
+    gref = np.concatenate([g["dtheta"], [g["dnoise"]]])
+    assert np.abs(m.gradient - gref).max() <= TOL_GRAD * np.abs(gref).max()
+    mu, var = m.predict_noiseless(g["Xs"])
+    assert np.abs(mu - g["pred_mu"]).max() <= 1e-9 and np.abs(var - g["pred_var"]).max() <= 1e-9
+    n = g["X"].shape[0]
+    A = np.random.default_rng(1).standard_normal((n, n))
+    k.update_gradients_full(A, g["X"])
+    ref, parts = [], g["parts"]
+    for grp in O._terms(parts):
+        for i in grp:
+            W = A
+            for j in grp:
+                if j != i:
+                    W = W * O._part_K(parts[j], g["X"])
+            ref.append((i, O._part_grads(parts[i], W, g["X"])))
+    ref = np.concatenate([r for _, r in sorted(ref, key=lambda t: t[0])])
+    assert np.abs(k.gradient - ref).max() <= TOL_GRAD * np.abs(ref).max()
+    assert np.abs(k.K(g["X"])[0] - g["K_row0"]).max() <= 1e-13
     f0 = m.objective_function()
     m.optimize(max_iters=5)
     assert m.objective_function() < f0

@@ -1,5 +1,5 @@
-"""CPU: the oracle's sum-kernel restatement (gp_oracle.sum_*) against golden vectors produced by the reference's own
-`GPy.kern.Add` / `White` / `Bias` code (oracle/make_golden_sum.py)."""
+"""CPU: the oracle's sum / product kernel restatement (gp_oracle.sum_*) against golden vectors produced by the reference's
+own `GPy.kern.Add` / `Prod` / `White` / `Bias` code (oracle/make_golden_sum.py, oracle/make_golden_prod.py)."""
 import glob
 import json
 import os
@@ -12,7 +12,8 @@ from oracle import gp_oracle as O
 
 
 def sum_golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "sum_*.npz")))
+    return sorted(os.path.splitext(os.path.basename(p))[0] for pat in ("sum_*.npz", "prod_*.npz")
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, pat)))
 
 
 def load_sum_golden(name):
@@ -20,9 +21,10 @@ def load_sum_golden(name):
     d["noise"] = float(d["noise"])
     D = d["X"].shape[1]
     parts = []
-    for kind, ARD, var, ls, dims in json.loads(str(d["specs"])):
+    for spec in json.loads(str(d["specs"])):          # prod_* fixtures carry a 6th entry: the term id
+        kind, ARD, var, ls, dims = spec[:5]
         parts.append((kind, ARD, var, None if ls is None else np.array(ls),
-                      np.arange(D) if dims is None else np.array(dims)))
+                      np.arange(D) if dims is None else np.array(dims), spec[5] if len(spec) > 5 else 0))
     d["parts"] = parts
     return d
 

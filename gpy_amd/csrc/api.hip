@@ -294,6 +294,11 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
         HIP_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[6]));
         stage_ms[MI355GP_T_TOTAL] = ms;
     }
+    if (info[0] < 0) {
+        c->have_factor = false;
+        mi355gp_set_error("panel factorisation: workgroup hand-off timed out (k_panel_fused)");
+        return -7;
+    }
     if (info[0] > 0) {
         c->have_factor = false;
         if (info[0] > n) info[0] = (int)n;
@@ -726,6 +731,10 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
         HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
         *ms = t;
     }
+    if (info < 0) {
+        mi355gp_set_error("panel factorisation: workgroup hand-off timed out (k_panel_fused)");
+        return -7;
+    }
     if (info == 0) {
         if (L_out) {
             launch_extract(0, A, np, N, 0, nullptr, 0, tmp, 0);
@@ -985,6 +994,10 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
     (void)hipStreamDestroy(st);
     factor_ws_free(&ws);
     HIP_CHECK(hipGetLastError());
+    if (info < 0) {
+        mi355gp_set_error("panel factorisation: workgroup hand-off timed out (k_panel_fused)");
+        return -7;
+    }
     return info > 0 ? info : 0;
 }
 

@@ -8,7 +8,12 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define NB 128            // base block: diagonal blocks, GEMM tiles and padding granule
 #define NBO 512           // outer panel width of the two-level right-looking Cholesky
-#define FACTOR_DEFAULT_RESERVE_CUS 0   // CUs (a multiple of 8: the same count per XCD) kept free of trailing-update workgroups; measured: no gain
+#define FACTOR_DEFAULT_RESERVE_CUS 0
+#define FACTOR_DEFAULT_TRSM_LDS 1       // k_trsm128 stages L_cc and its inverted diagonal tiles in LDS (0: operands straight from L2)
+#define FACTOR_DEFAULT_DIAG_SERVER 0    // 1: diagonal blocks factored by a resident single-workgroup server on a CU of its own
+#define FACTOR_DEFAULT_PANEL_FUSED_MAX_NRB 100000
+#define FACTOR_DEFAULT_PANEL_FUSED_MIN_NRB 0
+#define FACTOR_DEFAULT_PANEL_FUSED 0   // 1: k_panel_fused (one launch per outer panel, flag hand-offs between workgroups)   // CUs (a multiple of 8: the same count per XCD) kept free of trailing-update workgroups; measured: no gain
 #define GEMM_DEFAULT_NW 4        // wave arrangement of the 128x128 tile kernels (see gemm_tile.h); env MI355GP_GEMM_NW
 #define GEMM_DEFAULT_REVERSE_K 0 // lauum / trtri stage 1 walk k downwards (common end point); env MI355GP_REVERSE_K
 #define GEMM_DEFAULT_UPDATE_V2 0 // trailing update on the v2 tile pipeline (BK = 8, fragments prefetched across the barrier)

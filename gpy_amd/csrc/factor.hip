@@ -81,6 +81,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
             }
         }
         HIP_CHECK(hipEventCreateWithFlags(&ws->ev_bulk, hipEventDisableTiming));
+        const char* enve = getenv("MI355GP_DIAG_EXCL");
+        if (enve && *enve) ws->diag_excl_opt = atoi(enve) ? 1 : 0;
     }
     {
         const char* envs = getenv("MI355GP_PANEL_SPLIT");
@@ -96,6 +98,34 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     if (envw && *envw) ws->part2_wgs = atoi(envw);
     const char* envt = getenv("MI355GP_PART2_TILES");
     if (envt && *envt) ws->part2_tiles = atol(envt);
+    const char* envf = getenv("MI355GP_PANEL_FUSED");
+    if (envf && *envf) ws->panel_fused = atoi(envf) ? 1 : 0;
+    {
+        const char* envs2 = getenv("MI355GP_DIAG_SERVER");
+        if (envs2 && *envs2) ws->diag_server = atoi(envs2) ? 1 : 0;
+        HIP_CHECK(hipMalloc(&ws->diag_flags, sizeof(int) * 2 * ws->nblk));
+        HIP_CHECK(hipMemset(ws->diag_flags, 0, sizeof(int) * 2 * ws->nblk));
+        HIP_CHECK(hipStreamCreateWithPriority(&ws->st_diag, hipStreamNonBlocking, greatest));
+        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_diag, hipEventDisableTiming));
+    }
+    const char* envt2 = getenv("MI355GP_TRSM_LDS");
+    if (envt2 && *envt2) ws->trsm_lds = atoi(envt2) ? 1 : 0;
+    const char* envn = getenv("MI355GP_PANEL_FUSED_MAX_NRB");
+    if (envn && *envn) ws->panel_fused_max_nrb = atoi(envn);
+    const char* envm = getenv("MI355GP_PANEL_FUSED_MIN_NRB");
+    if (envm && *envm) ws->panel_fused_min_nrb = atoi(envm);
+    const char* envg = getenv("MI355GP_PANEL_WGS");
+    if (envg && *envg) ws->panel_max_wgs = atoi(envg);
+    {
+        const char* envd = getenv("MI355GP_PANEL_DBG");
+        if (envd && atoi(envd)) {
+            HIP_CHECK(hipMalloc(&ws->panel_dbg, sizeof(long long) * 256 * 16));
+            HIP_CHECK(hipMemset(ws->panel_dbg, 0, sizeof(long long) * 256 * 16));
+        }
+    }
+    HIP_CHECK(hipMalloc(&ws->panel_flags, sizeof(int) * 32));
+    HIP_CHECK(hipMemset(ws->panel_flags, 0, sizeof(int) * 32));
+    ws->panel_gen = 0;
     const char* envp = getenv("MI355GP_PANEL_INV");
     if (envp && *envp) ws->panel_inv = atoi(envp) ? 1 : 0;
     const char* env = getenv("MI355GP_UPD_STREAMS");
@@ -148,6 +178,14 @@ void factor_ws_free(FactorWs* ws) {
     ws->ev_rest = nullptr;
     if (ws->st_bulk) (void)hipStreamDestroy(ws->st_bulk);
     ws->st_bulk = nullptr;
+    if (ws->panel_flags) (void)hipFree(ws->panel_flags);
+    ws->panel_flags = nullptr;
+    if (ws->diag_flags) (void)hipFree(ws->diag_flags);
+    ws->diag_flags = nullptr;
+    if (ws->st_diag) (void)hipStreamDestroy(ws->st_diag);
+    ws->st_diag = nullptr;
+    if (ws->ev_diag) (void)hipEventDestroy(ws->ev_diag);
+    ws->ev_diag = nullptr;
     if (ws->ev_bulk) (void)hipEventDestroy(ws->ev_bulk);
     ws->ev_bulk = nullptr;
     ws->prof.destroy();
@@ -171,16 +209,45 @@ static void factor_panel(hipStream_t s, double* A, long npad, long K0, long W, F
         return;
     }
     const long ld = npad;
+    if (ws->panel_fused && ws->panel_flags && W <= 4 * NB && (npad - K0) / NB <= ws->panel_fused_max_nrb &&
+        (npad - K0) / NB >= ws->panel_fused_min_nrb) {
+        const int ns = (int)(W / NB), nrb = (int)((npad - K0) / NB);
+        ws->prof.begin(s, PF_DIAG, (double)ns * NB * NB * NB / 3.0);
+        const int rc = launch_panel_fused(s, A, ld, K0, ns, nrb, ws->dinv + (K0 / NB) * 8 * 256, ws->logsum + K0 / NB,
+                                          ws->info, ws->panel_flags, ++ws->panel_gen, ws->panel_max_wgs,
+                                          K0 == 0 ? ws->panel_dbg : nullptr);
+        ws->prof.end(s);
+        if (rc == 0 && K0 == 0 && ws->panel_dbg) {          // diagnostics: print the hand-off timeline of the first panel
+            (void)hipStreamSynchronize(s);
+            const int G = nrb < ws->panel_max_wgs ? nrb : ws->panel_max_wgs;
+            std::vector<long long> h((size_t)G * 16);
+            (void)hipMemcpy(h.data(), ws->panel_dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+            long long t0 = h[0];
+            for (int g = 0; g < G; ++g) t0 = (h[(size_t)g * 16] && h[(size_t)g * 16] < t0) ? h[(size_t)g * 16] : t0;
+            for (int g = 0; g < G; g += (g < 6 ? 1 : (G / 6 > 0 ? G / 6 : 1))) {
+                fprintf(stderr, "[panel dbg] npad=%ld wg %3d:", npad, g);
+                for (int k = 0; k < ns; ++k) {
+                    fprintf(stderr, " |");
+                    for (int i = 0; i < 4; ++i) fprintf(stderr, " %7.1f", (double)(h[((size_t)g * 4 + k) * 4 + i] - t0) / 100.0);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+        if (rc == 0) return;
+    }
     for (long j = 0; j < W; j += NB) {
         const long c = K0 + j, blk = c / NB;
         double* dv = ws->dinv + blk * 8 * 256;
         ws->prof.begin(s, PF_DIAG, (double)NB * NB * NB / 3.0);
-        launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info);
+        if (ws->diag_server_on)
+            launch_diag_call(s, ws->diag_flags, ws->diag_flags + ws->nblk, (int)blk, ws->diag_gen, ws->info);
+        else
+            launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info, ws->diag_excl);
         ws->prof.end(s);
         const long below = npad - (c + NB);
         if (below <= 0) continue;
         ws->prof.begin(s, PF_TRSM, (double)below * NB * NB);
-        launch_trsm128(s, A, ld, c, c + NB, below, dv);
+        launch_trsm128(s, A, ld, c, c + NB, below, dv, ws->trsm_lds);
         ws->prof.end(s);
         const long ncols = K0 + W - (c + NB);
         if (ncols > 0) {
@@ -206,12 +273,12 @@ static void factor_panel_inv(hipStream_t s, double* A, long npad, long K0, long 
         const long c = K0 + j, blk = c / NB;
         double* dv = ws->dinv + blk * 8 * 256;
         ws->prof.begin(s, PF_DIAG, (double)NB * NB * NB / 3.0);
-        launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info);
+        launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info, ws->diag_excl);
         ws->prof.end(s);
         const long below = end - (c + NB);                      // rows of the diagonal block still to do
         if (below <= 0) continue;
         ws->prof.begin(s, PF_TRSM, (double)below * NB * NB);
-        launch_trsm128(s, A, ld, c, c + NB, below, dv);
+        launch_trsm128(s, A, ld, c, c + NB, below, dv, ws->trsm_lds);
         ws->prof.end(s);
         double* C = A + (c + NB) * ld + (c + NB);
         const double* P = A + (c + NB) * ld + c;
@@ -255,7 +322,7 @@ static void factor_panel_split(hipStream_t s, double* A, long npad, long K0, lon
         const long c = K0 + j, blk = c / NB;
         double* dv = ws->dinv + blk * 8 * 256;
         ws->prof.begin(s, PF_DIAG, (double)NB * NB * NB / 3.0);
-        launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info);
+        launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info, ws->diag_excl);
         ws->prof.end(s);
         const long in_block = end - (c + NB);                  // rows of the diagonal block below this step
         if (rows_below > 0) {
@@ -265,7 +332,7 @@ static void factor_panel_split(hipStream_t s, double* A, long npad, long K0, lon
         }
         if (in_block <= 0) continue;
         ws->prof.begin(s, PF_TRSM, (double)in_block * NB * NB);
-        launch_trsm128(s, A, ld, c, c + NB, in_block, dv);
+        launch_trsm128(s, A, ld, c, c + NB, in_block, dv, ws->trsm_lds);
         ws->prof.end(s);
         const double* Pd = A + (c + NB) * ld + c;               // freshly solved rows of the diagonal block
         if (rows_below > 0) {
@@ -368,9 +435,14 @@ static void potrf_chunked(hipStream_t st, double* A, long npad, FactorWs* ws) {
 // trailing updates stay in order on `st`: their launch durations are not inflated by overlapping each other.
 void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     if (ws->lookahead != 1) {
+        ws->diag_excl = 0;
+        ws->diag_server_on = 0;
         potrf_chunked(st, A, npad, ws);                          // 0: serial reference schedule, 2: chunk streams
         return;
     }
+    ws->diag_excl = (ws->st_bulk != nullptr && ws->diag_excl_opt) ? 1 : 0;
+    ws->diag_server_on = (ws->diag_server && ws->diag_flags && ws->st_diag && !ws->panel_inv && !ws->panel_split &&
+                          !ws->panel_fused && npad / NB == ws->nblk) ? 1 : 0;
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
     const long P = (npad + NBO - 1) / NBO;
     auto pcol = [&](long p) { return (p * NBO < npad) ? p * NBO : npad; };
@@ -378,6 +450,13 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     hipStream_t su = ws->st_bulk ? ws->st_bulk : st;            // trailing updates (CU-masked when an express lane is set)
     (void)hipEventRecord(ws->ev_fork, st);                      // panel 0 follows everything queued on st so far
     (void)hipStreamWaitEvent(sp, ws->ev_fork, 0);
+    if (ws->diag_server_on) {                                   // resident diagonal-block server for this factorisation
+        ++ws->diag_gen;
+        (void)hipStreamWaitEvent(ws->st_diag, ws->ev_fork, 0);
+        launch_diag_server(ws->st_diag, A, npad, (int)(npad / NB), ws->dinv, ws->logsum, ws->info, ws->diag_flags,
+                           ws->diag_flags + ws->nblk, ws->diag_gen);
+        (void)hipEventRecord(ws->ev_diag, ws->st_diag);
+    }
     if (su != st) (void)hipStreamWaitEvent(su, ws->ev_fork, 0);
     factor_panel(sp, A, npad, 0, pcol(1), ws);
     for (long p = 0; p + 1 < P; ++p) {
@@ -395,6 +474,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     }
     (void)hipEventRecord(ws->ev_panel[P], sp);
     (void)hipStreamWaitEvent(st, ws->ev_panel[P], 0);
+    if (ws->diag_server_on) (void)hipStreamWaitEvent(st, ws->ev_diag, 0);
     if (su != st) {
         (void)hipEventRecord(ws->ev_bulk, su);
         (void)hipStreamWaitEvent(st, ws->ev_bulk, 0);

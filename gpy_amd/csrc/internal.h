@@ -26,9 +26,16 @@ void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long 
 // ---- small.hip : single-CU MFMA kernels on 128x128 diagonal blocks -------------------------------
 // in-place Cholesky of the 128x128 block at A[c0,c0]; writes the 8 inverses of its 16x16 diagonal tiles
 // to dinv (8*256 doubles), sum(log diag) to logsum[0], first failing 1-based global column to *info.
-void launch_diag128(hipStream_t st, double* A, long ld, long c0, double* dinv, double* logsum, int* info);
+void launch_diag128(hipStream_t st, double* A, long ld, long c0, double* dinv, double* logsum, int* info,
+                    int exclusive = 0);
+void launch_diag_server(hipStream_t st, double* A, long ld, int nblk, double* dinv, double* logsum, int* info, int* ready,
+                        int* done, int gen);
+void launch_diag_call(hipStream_t st, int* ready, int* done, int blk, int gen, int* info);
+// whole outer panel (ns 128-column steps over nrb 128-row blocks) in one launch; returns -1 if the grid cannot hold it
+int launch_panel_fused(hipStream_t st, double* A, long ld, long c0, int ns, int nrb, double* dinv, double* logsum,
+                       int* info, int* flags, int gen, int max_wgs, long long* dbg = nullptr);
 // rows [r0, r0+mrows) of the 128-wide panel at column c0:  P <- P * L_cc^{-T}   (mrows % 16 == 0)
-void launch_trsm128(hipStream_t st, double* A, long ld, long c0, long r0, long mrows, const double* dinv);
+void launch_trsm128(hipStream_t st, double* A, long ld, long c0, long r0, long mrows, const double* dinv, int lds = 0);
 // X_cc = L_cc^{-1} for all nblk diagonal blocks (upper tiles of the diagonal blocks of X zeroed)
 void launch_inv128(hipStream_t st, const double* L, double* X, long ld, int nblk, const double* dinv_all);
 void launch_dbg_mfma(hipStream_t st, const double* a, const double* b, double* d);
@@ -75,6 +82,16 @@ struct FactorWs {
     int panel_split = 0;             // env MI355GP_PANEL_SPLIT: measured slower (cross-stream event waits cost more than they hide)
     hipStream_t st_bulk = nullptr;   // trailing updates of the look-ahead schedule: CU-masked so that `reserve_cus` CUs stay
     int reserve_cus = 0;             // free of MFMA-saturating workgroups and the latency-bound panel kernels run there
+    int panel_fused = FACTOR_DEFAULT_PANEL_FUSED, panel_gen = 0, panel_max_wgs = 192;
+    int panel_fused_max_nrb = FACTOR_DEFAULT_PANEL_FUSED_MAX_NRB, panel_fused_min_nrb = FACTOR_DEFAULT_PANEL_FUSED_MIN_NRB;   // panels taller than this many 128-row blocks use the launch-per-step path   // k_panel_fused: one launch per outer panel
+    int diag_server = FACTOR_DEFAULT_DIAG_SERVER, diag_server_on = 0, diag_gen = 0;   // resident diagonal-block server (k_diag_server)
+    int* diag_flags = nullptr;       // ready[nblk], done[nblk]
+    hipStream_t st_diag = nullptr;
+    hipEvent_t ev_diag = nullptr;
+    int trsm_lds = FACTOR_DEFAULT_TRSM_LDS;                // k_trsm128 with L_cc staged in LDS (MI355GP_TRSM_LDS)
+    long long* panel_dbg = nullptr;  // MI355GP_PANEL_DBG=1: per-workgroup timestamps of the first fused panel of a call
+    int* panel_flags = nullptr;      // [4 + 16] hand-off flags of k_panel_fused (hold the launch generation)
+    int diag_excl = 0, diag_excl_opt = 1;   // k_diag128 claims a CU without update workgroups (only with reserve_cus > 0)
     hipEvent_t ev_bulk = nullptr;
     int part2_wgs = 0;          // > 0: trailing updates that overlap a panel factorisation keep only this many workgroups
     long part2_tiles = 0;       //      resident (one per CU) once the update has fewer tiles than this

@@ -134,12 +134,13 @@ def lib():
     L.mi355gp_dbg_gemm.argtypes = [ci, ci, ci, i64, i64, i64, _dp, _dp, _dp, cd, cd, ci, _c_dp]
     L.mi355gp_dbg_peaks.argtypes = [ci, _dp]
     L.mi355gp_dbg_gemm_clock.argtypes = [_c_dp, _c_dp]
+    L.mi355gp_dbg_mask_probe.argtypes = [ci, ci, ci, _dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
                  "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "sparse_create",
                  "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm", "exact_inference_sum",
-                 "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum"):
+                 "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum", "dbg_mask_probe"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -155,7 +156,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_sparse_fetch", "mi355gp_gradients_X", "mi355gp_sparse_attach_comm",
             "mi355gp_exact_inference_sum", "mi355gp_predict_sum", "mi355gp_dbg_gemm_clock",
             "mi355gp_covariance_between_points", "mi355gp_exact_studentt_sum",
-            "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks")
+            "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe")
 
 
 def last_error():
@@ -491,6 +492,14 @@ def bench_factor(N, reps=3, device=0):
     fl = float(N) ** 3 / 3.0
     return {"potrf_ms": p.value, "trtri_ms": t.value, "lauum_ms": l.value,
             "potrf_tflops": fl / p.value / 1e9, "trtri_tflops": fl / t.value / 1e9, "lauum_tflops": fl / l.value / 1e9}
+
+
+def dbg_mask_probe(pct=75, order=0, device=0):
+    """ms of a 4096^3 GEMM on (plain, CU-masked, CU-masked again) streams: is the mask in force?"""
+    require_device(device)
+    out = np.zeros(3)
+    check(lib().mi355gp_dbg_mask_probe(device, pct, order, out), "mi355gp_dbg_mask_probe")
+    return out
 
 
 def dbg_mfma(a, b, device=0):

@@ -957,12 +957,12 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
     HIP_CHECK(hipMemcpy(dX, X.data(), sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dIl, il, sizeof(il), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dNoise, &noise, sizeof(double), hipMemcpyHostToDevice));
+    hipStream_t st;
+    HIP_CHECK(hipStreamCreate(&st));                            // before the workspace: see factor_ws_alloc on stream order
     FactorWs ws;
     if (factor_ws_alloc(&ws, np) != 0) return -3;
     ws.scratchX = B;
     ws.scratchT = C;
-    hipStream_t st;
-    HIP_CHECK(hipStreamCreate(&st));
     hipEvent_t e[4];
     for (auto& ev : e) HIP_CHECK(hipEventCreate(&ev));
     const KernParams kp{MI355GP_RBF, 0, D, 1.0};
@@ -1048,5 +1048,67 @@ int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_
 int mi355gp_dbg_peaks(int device, double* out4) { return run_peaks(device, out4); }
 
 int mi355gp_dbg_gemm_clock(double* mhz, double* cycles) { return gemm_last_clock(mhz, cycles); }
+
+// Diagnostics: is a CU mask in force on a stream created with hipExtStreamCreateWithCUMask?  Times the same 4096^3 GEMM
+// on a plain stream and on a stream masked to pct % of every XCD's CUs.  order: 0 = masked stream created first,
+// 1 = plain stream first, 2 = four plain + three high-priority streams first (what a context has when it builds its
+// factorisation workspace).  out: [ms plain, ms masked, ms masked again after use of both].
+int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3) {
+    ARG_CHECK(out3 && pct > 0 && pct <= 100, "mi355gp_dbg_mask_probe: bad arguments");
+    HIP_CHECK(hipSetDevice(device));
+    const long n = 4096;
+    DevBuf A, B, C;
+    HIP_CHECK(A.alloc(n * n));
+    HIP_CHECK(B.alloc(n * n));
+    HIP_CHECK(C.alloc(n * n));
+    HIP_CHECK(hipMemset(A, 0, sizeof(double) * n * n));
+    HIP_CHECK(hipMemset(B, 0, sizeof(double) * n * n));
+    HIP_CHECK(hipMemset(C, 0, sizeof(double) * n * n));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    const int ncu = prop.multiProcessorCount, nx = 8, per = ncu / nx, keep = (per * pct + 50) / 100;
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int cu = 0; cu < ncu; ++cu)
+        if (cu / nx < keep) mask[cu / 32] |= 1u << (cu % 32);
+    int least = 0, greatest = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t plain = nullptr, masked = nullptr, extra[7] = {};
+    auto mk_masked = [&]() { return hipExtStreamCreateWithCUMask(&masked, (uint32_t)mask.size(), mask.data()); };
+    if (order == 0) {
+        HIP_CHECK(mk_masked());
+        HIP_CHECK(hipStreamCreate(&plain));
+    } else {
+        HIP_CHECK(hipStreamCreate(&plain));
+        if (order == 2) {
+            for (int i = 0; i < 4; ++i) HIP_CHECK(hipStreamCreateWithFlags(&extra[i], hipStreamNonBlocking));
+            for (int i = 4; i < 7; ++i) HIP_CHECK(hipStreamCreateWithPriority(&extra[i], hipStreamNonBlocking, greatest));
+        }
+        if (order >= 1) launch_gemm(plain, 0, 1, n, n, n, A, n, B, n, C, n, 1.0, 0.0);   // the plain queue exists and has run
+        HIP_CHECK(hipStreamSynchronize(plain));
+        HIP_CHECK(mk_masked());
+    }
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    hipStream_t order_s[3] = {plain, masked, masked};
+    for (int i = 0; i < 3; ++i) {
+        launch_gemm(order_s[i], 0, 1, n, n, n, A, n, B, n, C, n, 1.0, 0.0);
+        HIP_CHECK(hipEventRecord(e0, order_s[i]));
+        for (int r = 0; r < 3; ++r) launch_gemm(order_s[i], 0, 1, n, n, n, A, n, B, n, C, n, 1.0, 0.0);
+        HIP_CHECK(hipEventRecord(e1, order_s[i]));
+        HIP_CHECK(hipStreamSynchronize(order_s[i]));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        out3[i] = ms / 3.0;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(plain);
+    (void)hipStreamDestroy(masked);
+    for (auto x : extra)
+        if (x) (void)hipStreamDestroy(x);
+    return 0;
+}
+
 
 }  // extern "C"

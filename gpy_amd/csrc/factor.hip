@@ -54,7 +54,43 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     HIP_CHECK(hipMalloc(&ws->info, sizeof(int) * 4));
     int least = 0, greatest = 0;
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // The three streams that carry concurrent heavy work -- the caller's main stream (created before this workspace), the
+    // panel chain and the early-inverse stream -- are created back to back and before every optional one: hardware queues
+    // are handed to the command processor's pipes in creation order, and two busy queues on one pipe take turns per
+    // dispatch (measured: the same schedule ran 35 or 45 ms of potrf depending on what had been created in between).
     HIP_CHECK(hipStreamCreateWithPriority(&ws->st_panel, hipStreamNonBlocking, greatest));
+    {
+        const char* envo = getenv("MI355GP_TRI_OVERLAP");
+        if (envo && *envo) ws->tri_overlap = atoi(envo) ? 1 : 0;
+        const char* envn2 = getenv("MI355GP_TRI_MIN_NT");
+        if (envn2 && *envn2) ws->tri_min_nt = atoi(envn2);
+        const char* envw2 = getenv("MI355GP_TRI_WGS");
+        if (envw2 && *envw2) ws->tri_wgs = atoi(envw2);
+        const char* envc = getenv("MI355GP_TRI_CU_PCT");
+        if (envc && *envc) ws->tri_cu_pct = atoi(envc);
+        hipDeviceProp_t prop;
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        const int ncu = prop.multiProcessorCount, nx = 8;
+        if (ws->tri_overlap && ws->tri_cu_pct > 0 && ws->tri_cu_pct < 100 && ncu % nx == 0) {
+            // XCD-balanced mask (logical CU i sits on XCD i % 8): the same share of every XCD's CUs
+            const int per = ncu / nx, keep = (per * ws->tri_cu_pct + 50) / 100;
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int cu = 0; cu < ncu; ++cu)
+                if (cu / nx < keep) mask[cu / 32] |= 1u << (cu % 32);
+            if (hipExtStreamCreateWithCUMask(&ws->st_tri, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                ws->st_tri = nullptr;
+            }
+        }
+        if (ws->tri_overlap && !ws->st_tri) HIP_CHECK(hipStreamCreateWithPriority(&ws->st_tri, hipStreamNonBlocking, least));
+        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_tri, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_tri_lead, hipEventDisableTiming));
+        HIP_CHECK(hipMalloc(&ws->tri_counter, sizeof(int) * 4));
+        const char* envh = getenv("MI355GP_TRI_H");
+        if (envh && *envh) ws->tri_h_override = atoi(envh);
+    }
     {
         // Express lane for the panel chain: the big trailing updates run on a stream whose CU mask leaves `reserve_cus`
         // CUs out, so k_diag128 (one workgroup, dependent fp64 VALU chain) never shares a CU with an fp64-MFMA-saturating
@@ -87,7 +123,7 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     {
         const char* envs = getenv("MI355GP_PANEL_SPLIT");
         if (envs && *envs) ws->panel_split = atoi(envs) ? 1 : 0;
-        HIP_CHECK(hipStreamCreateWithPriority(&ws->st_rest, hipStreamNonBlocking, greatest));
+        if (ws->panel_split) HIP_CHECK(hipStreamCreateWithPriority(&ws->st_rest, hipStreamNonBlocking, greatest));
         for (int i = 0; i < 4; ++i) {
             HIP_CHECK(hipEventCreateWithFlags(&ws->ev_d[i], hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&ws->ev_t[i], hipEventDisableTiming));
@@ -105,7 +141,7 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
         if (envs2 && *envs2) ws->diag_server = atoi(envs2) ? 1 : 0;
         HIP_CHECK(hipMalloc(&ws->diag_flags, sizeof(int) * 2 * ws->nblk));
         HIP_CHECK(hipMemset(ws->diag_flags, 0, sizeof(int) * 2 * ws->nblk));
-        HIP_CHECK(hipStreamCreateWithPriority(&ws->st_diag, hipStreamNonBlocking, greatest));
+        if (ws->diag_server) HIP_CHECK(hipStreamCreateWithPriority(&ws->st_diag, hipStreamNonBlocking, greatest));
         HIP_CHECK(hipEventCreateWithFlags(&ws->ev_diag, hipEventDisableTiming));
     }
     const char* envt2 = getenv("MI355GP_TRSM_LDS");
@@ -132,10 +168,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     if (env && *env) ws->n_upd = atoi(env);
     if (ws->n_upd < 1) ws->n_upd = 1;
     if (ws->n_upd > FactorWs::MAX_UPD) ws->n_upd = FactorWs::MAX_UPD;
-    for (int i = 0; i < ws->n_upd; ++i) {
-        HIP_CHECK(hipStreamCreateWithFlags(&ws->st_upd[i], hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_join[i], hipEventDisableTiming));
-    }
+    for (int i = 0; i < ws->n_upd; ++i) HIP_CHECK(hipEventCreateWithFlags(&ws->ev_join[i], hipEventDisableTiming));
+    // the chunk-update streams themselves are created by potrf_chunked on first use (option LOOKAHEAD = 2 only)
     HIP_CHECK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
     const size_t nouter = (size_t)(npad + NBO - 1) / NBO + 2;
     ws->ev_panel.resize(nouter);
@@ -182,6 +216,14 @@ void factor_ws_free(FactorWs* ws) {
     ws->panel_flags = nullptr;
     if (ws->diag_flags) (void)hipFree(ws->diag_flags);
     ws->diag_flags = nullptr;
+    if (ws->st_tri) (void)hipStreamDestroy(ws->st_tri);
+    ws->st_tri = nullptr;
+    if (ws->ev_tri) (void)hipEventDestroy(ws->ev_tri);
+    ws->ev_tri = nullptr;
+    if (ws->ev_tri_lead) (void)hipEventDestroy(ws->ev_tri_lead);
+    ws->ev_tri_lead = nullptr;
+    if (ws->tri_counter) (void)hipFree(ws->tri_counter);
+    ws->tri_counter = nullptr;
     if (ws->st_diag) (void)hipStreamDestroy(ws->st_diag);
     ws->st_diag = nullptr;
     if (ws->ev_diag) (void)hipEventDestroy(ws->ev_diag);
@@ -396,6 +438,8 @@ static void potrf_chunked(hipStream_t st, double* A, long npad, FactorWs* ws) {
         cb.push_back(P);
     }
     const int nchunk = (int)cb.size() - 1;
+    for (int i = 0; i < ws->n_upd; ++i)
+        if (!ws->st_upd[i]) (void)hipStreamCreateWithFlags(&ws->st_upd[i], hipStreamNonBlocking);
     auto chunk_stream = [&](int c) { return ws->st_upd[c % ws->n_upd]; };
     hipStream_t sp = ws->st_panel;
     (void)hipEventRecord(ws->ev_fork, st);                      // everything queued on st so far precedes the factorisation
@@ -459,9 +503,43 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     }
     if (su != st) (void)hipStreamWaitEvent(su, ws->ev_fork, 0);
     factor_panel(sp, A, npad, 0, pcol(1), ws);
+    // Inverse of a leading block early (trtri_device picks up from ws->ovl_h): h tiles, a power of two <= nt/2 or the
+    // largest power of two below nt, whichever still fits the time model: inverting the leading block (the part that
+    // has to run at the masked stream's CU share) must not take longer than potrf needs for the rest of the matrix.
+    const int ntl = (int)(npad / NB);
+    int ovl_h = 0;
+    if (ws->tri_overlap && ws->st_tri && ws->scratchX && ws->scratchT && ntl >= ws->tri_min_nt) {
+        int h = 1;
+        while (2 * h < ntl) h *= 2;
+        for (; h >= 8; h /= 2) {
+            const double lead = (double)h * NB, rest = (double)npad - lead;
+            const double t_lead = lead * lead * lead / 3.0 / 45e12;
+            const double t_tail = rest * rest * rest / 3.0 / 50e12 + rest / NBO * 0.45e-3;
+            if (t_lead <= t_tail) break;
+        }
+        if (ws->tri_h_override > 0) h = ws->tri_h_override;
+        if (h >= 8 && h < ntl && (h & (h - 1)) == 0) ovl_h = h;
+    }
+    ws->ovl_h = 0;
     for (long p = 0; p + 1 < P; ++p) {
         const long K0 = pcol(p), W = pcol(p + 1) - K0;
         (void)hipEventRecord(ws->ev_panel[p], sp);
+        if (ovl_h > 0 && pcol(p + 1) == (long)ovl_h * NB) {       // columns < 128 h are final: start on their inverse
+            hipStream_t sq = ws->st_tri;
+            (void)hipStreamWaitEvent(sq, ws->ev_panel[p], 0);
+            (void)hipMemsetAsync(ws->tri_counter, 0, sizeof(int) * 4, sq);
+            launch_inv128(sq, A, ws->scratchX, npad, ovl_h, ws->dinv);
+            int level = 0;
+            for (; (1 << level) < ovl_h; ++level) launch_trtri_level(sq, A, ws->scratchX, ws->scratchT, npad, ovl_h, level);
+            (void)hipEventRecord(ws->ev_tri_lead, sq);
+            // pair 0 of level log2(h): T21 = L21 X11 (rows h .. 2h of the finished columns), tile list shared with the
+            // machine-wide instance that trtri_device launches after potrf
+            const int nt_pair = ntl < 2 * ovl_h ? ntl : 2 * ovl_h;
+            launch_trtri_stage1_steal(sq, A, ws->scratchX, ws->scratchT, npad, nt_pair, level, ws->tri_counter,
+                                      ws->tri_wgs > 0 ? ws->tri_wgs : 512 * ws->tri_cu_pct / 100);
+            (void)hipEventRecord(ws->ev_tri, sq);
+            ws->ovl_h = ovl_h;
+        }
         (void)hipStreamWaitEvent(su, ws->ev_panel[p], 0);
         update_cols(su, A, npad, K0, W, pcol(p + 1), pcol(p + 2), ws);       // part 1: the next panel's columns
         (void)hipEventRecord(ws->ev_cols[p + 1], su);
@@ -481,12 +559,39 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     }
 }
 
-// X = L^-1: diagonal 128-blocks on single CUs (all blocks concurrently), then log2(nt) batched levels.
+// X = L^-1: diagonal 128-blocks on single CUs (all blocks concurrently), then log2(nt) batched levels.  If the preceding
+// potrf_device already put the leading ovl_h tiles and the top-level T21 on st_tri (same X / T buffers), only the
+// trailing block and the top-level X21 = -X22 T21 are left.
 void trtri_device(hipStream_t st, const double* L, double* X, double* T, long npad, FactorWs* ws) {
     const int nt = (int)(npad / NB);
     ws->prof.begin(st, PF_TRTRI, (double)npad * npad * npad / 3.0);
-    launch_inv128(st, L, X, npad, nt, ws->dinv);
-    for (int level = 0; (1 << level) < nt; ++level) launch_trtri_level(st, L, X, T, npad, nt, level);
+    const int h = ws->ovl_h;
+    ws->ovl_h = 0;
+    if (h > 0 && X == ws->scratchX && T == ws->scratchT && h < nt) {
+        int lev = 0;
+        while ((1 << lev) < h) ++lev;
+        // (a) tiles [h, nt): diagonal blocks and the levels below lev
+        const long off = (long)h * NB * npad + (long)h * NB;
+        launch_inv128(st, L + off, X + off, npad, nt - h, ws->dinv + (long)h * 8 * 256);
+        for (int level = 0; level < lev; ++level) launch_trtri_level(st, L + off, X + off, T + off, npad, nt - h, level);
+        // (b) level lev, pairs >= 1 (tiles from 2h on)
+        if (nt > 2 * h) {
+            const long off2 = (long)2 * h * NB * npad + (long)2 * h * NB;
+            launch_trtri_level(st, L + off2, X + off2, T + off2, npad, nt - 2 * h, lev);
+        }
+        // (c) level lev, pair 0: help drain the T21 tile list, then X21 = -X22 T21
+        const int nt_pair = nt < 2 * h ? nt : 2 * h;
+        (void)hipStreamWaitEvent(st, ws->ev_tri_lead, 0);
+        launch_trtri_stage1_steal(st, L, X, T, npad, nt_pair, lev, ws->tri_counter, 512);
+        (void)hipStreamWaitEvent(st, ws->ev_tri, 0);
+        launch_trtri_level(st, L, X, T, npad, nt_pair, lev, 2);
+        // (d) the levels above
+        for (int level = lev + 1; (1 << level) < nt; ++level) launch_trtri_level(st, L, X, T, npad, nt, level);
+    } else {
+        if (h > 0) (void)hipStreamWaitEvent(st, ws->ev_tri, 0);   // early work went to other buffers: let it drain, redo all
+        launch_inv128(st, L, X, npad, nt, ws->dinv);
+        for (int level = 0; (1 << level) < nt; ++level) launch_trtri_level(st, L, X, T, npad, nt, level);
+    }
     ws->prof.end(st);
 }
 

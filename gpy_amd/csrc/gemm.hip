@@ -137,12 +137,11 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
 // stage 1: T21 = L21 * X11   (X11 lower triangular -> k from tj to the end of the left block)
 // stage 2: X21 = -X22 * T21  (X22 lower triangular -> k from the start of the right block to ti)
 template <int STAGE, int NW>
-__global__ LB(NW) void k_trtri_stage(const double* __restrict__ L, double* __restrict__ X,
-                                                        double* __restrict__ T, long ld, int nt, int nbt, int rev) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void trtri_stage_tile(int bid, const double* __restrict__ L, double* __restrict__ X,
+                                                 double* __restrict__ T, long ld, int nt, int nbt, int rev, double* smem) {
     const int per = nbt * nbt;
-    const int p = blockIdx.x / per;
-    const int rem = blockIdx.x - p * per;
+    const int p = bid / per;
+    const int rem = bid - p * per;
     int ri, cj;
     if (STAGE == 1) {          // heavy tiles (small cj) first
         cj = rem / nbt;
@@ -169,23 +168,64 @@ __global__ LB(NW) void k_trtri_stage(const double* __restrict__ L, double* __res
     }
 }
 
+template <int STAGE, int NW>
+__global__ LB(NW) void k_trtri_stage(const double* __restrict__ L, double* __restrict__ X,
+                                                        double* __restrict__ T, long ld, int nt, int nbt, int rev) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    trtri_stage_tile<STAGE, NW>((int)blockIdx.x, L, X, T, ld, nt, nbt, rev, smem);
+}
+
+// Stage 1 with a shared tile counter: several launches of this kernel (on different streams, with different grids) drain
+// ONE tile list.  The look-ahead factorisation puts an instance with a bounded grid on a CU-masked stream while potrf
+// still runs and a second, machine-wide instance on the main stream afterwards: whatever the first one did not get to is
+// picked up at full speed, nothing is left behind on the masked stream.
+__global__ LB(4) void k_trtri_stage1_steal(const double* __restrict__ L, double* __restrict__ X, double* __restrict__ T,
+                                           long ld, int nt, int nbt, int rev, int* __restrict__ counter, int nblocks) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_bid;
+    for (;;) {
+        if (threadIdx.x == 0) s_bid = atomicAdd(counter, 1);
+        __syncthreads();
+        const int bid = s_bid;
+        __syncthreads();
+        if (bid >= nblocks) return;
+        trtri_stage_tile<1, 4>(bid, L, X, T, ld, nt, nbt, rev, smem);
+    }
+}
+
+void launch_trtri_stage1_steal(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level,
+                               int* counter, int grid) {
+    const int nbt = 1 << level;
+    if (nbt >= nt) return;
+    const int pairs = (nt + 2 * nbt - 1) / (2 * nbt);
+    const int nblocks = pairs * nbt * nbt;
+    static const int rev = env_int("MI355GP_REVERSE_K", GEMM_DEFAULT_REVERSE_K);
+    LDS_OPT_IN(k_trtri_stage1_steal);
+    if (grid > nblocks) grid = nblocks;
+    hipLaunchKernelGGL(k_trtri_stage1_steal, dim3((unsigned)grid), dim3(256), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev,
+                       counter, nblocks);
+}
+
 template <int NW>
 static void launch_trtri_level_t(hipStream_t st, long nblocks, const double* L, double* X, double* T, long ld, int nt,
-                                 int nbt) {
+                                 int nbt, int stages) {
     static const int rev = env_int("MI355GP_REVERSE_K", GEMM_DEFAULT_REVERSE_K);
     LDS_OPT_IN((k_trtri_stage<1, NW>));
     LDS_OPT_IN((k_trtri_stage<2, NW>));
-    hipLaunchKernelGGL((k_trtri_stage<1, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev);
-    hipLaunchKernelGGL((k_trtri_stage<2, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev);
+    if (stages & 1)
+        hipLaunchKernelGGL((k_trtri_stage<1, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev);
+    if (stages & 2)
+        hipLaunchKernelGGL((k_trtri_stage<2, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev);
 }
 
-void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level) {
+// stages: bit 0 = T21 = L21 X11, bit 1 = X21 = -X22 T21 (3 = the whole level)
+void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level, int stages) {
     const int nbt = 1 << level;
     if (nbt >= nt) return;
     const int pairs = (nt + 2 * nbt - 1) / (2 * nbt);
     const long nblocks = (long)pairs * nbt * nbt;
-    NW_DISPATCH((launch_trtri_level_t<4>(st, nblocks, L, X, T, ld, nt, nbt)),
-                (launch_trtri_level_t<8>(st, nblocks, L, X, T, ld, nt, nbt)));
+    NW_DISPATCH((launch_trtri_level_t<4>(st, nblocks, L, X, T, ld, nt, nbt, stages)),
+                (launch_trtri_level_t<8>(st, nblocks, L, X, T, ld, nt, nbt, stages)));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -10,7 +10,8 @@
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
                       int K, int ntr, int ntc, int row0t, int col0t, int max_wgs = 0);
 // one bottom-up level of the batched triangular inverse: X21 = -X22 * (L21 * X11) for every block pair
-void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level);
+void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level,
+                        int stages = 3);
 // W (lower tiles) = X^T X for lower-triangular X
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt);
 // rows-below-the-diagonal-block part of a panel: Out[ti, tj] = sum_{k < (tj+1)*128} R[ti, k] * XD[tj, k]  (= R * XD^T with XD
@@ -37,6 +38,9 @@ int launch_panel_fused(hipStream_t st, double* A, long ld, long c0, int ns, int 
 // rows [r0, r0+mrows) of the 128-wide panel at column c0:  P <- P * L_cc^{-T}   (mrows % 16 == 0)
 void launch_trsm128(hipStream_t st, double* A, long ld, long c0, long r0, long mrows, const double* dinv, int lds = 0);
 // X_cc = L_cc^{-1} for all nblk diagonal blocks (upper tiles of the diagonal blocks of X zeroed)
+// stage 1 of one level with a shared tile counter (zeroed by the caller): see k_trtri_stage1_steal
+void launch_trtri_stage1_steal(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level,
+                               int* counter, int grid);
 void launch_inv128(hipStream_t st, const double* L, double* X, long ld, int nblk, const double* dinv_all);
 void launch_dbg_mfma(hipStream_t st, const double* a, const double* b, double* d);
 
@@ -88,6 +92,13 @@ struct FactorWs {
     int* diag_flags = nullptr;       // ready[nblk], done[nblk]
     hipStream_t st_diag = nullptr;
     hipEvent_t ev_diag = nullptr;
+    // trtri of the finished leading block + the top-level T21 = L21 X11 run on st_tri while potrf's chain-bound second
+    // half leaves the GPU mostly idle (needs scratchX / scratchT = the X / T buffers of the trtri_device call that follows)
+    int tri_overlap = FACTOR_DEFAULT_TRI_OVERLAP, tri_cu_pct = 75, tri_min_nt = 48, tri_wgs = 0, ovl_h = 0;
+    hipStream_t st_tri = nullptr;
+    hipEvent_t ev_tri = nullptr, ev_tri_lead = nullptr;
+    int* tri_counter = nullptr;
+    int tri_h_override = 0;          // MI355GP_TRI_H: leading tiles inverted early (0 = time model)
     int trsm_lds = FACTOR_DEFAULT_TRSM_LDS;                // k_trsm128 with L_cc staged in LDS (MI355GP_TRSM_LDS)
     long long* panel_dbg = nullptr;  // MI355GP_PANEL_DBG=1: per-workgroup timestamps of the first fused panel of a call
     int* panel_flags = nullptr;      // [4 + 16] hand-off flags of k_panel_fused (hold the launch generation)

@@ -239,6 +239,8 @@ int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_
 int mi355gp_dbg_peaks(int device, double* out8);
 /* effective shader clock (MHz) and shader cycles of workgroup 0 of the last mi355gp_dbg_gemm launch */
 int mi355gp_dbg_gemm_clock(double* mhz, double* cycles);
+/* diagnostics: is a CU-masked stream really confined?  out3 = ms of a 4096^3 GEMM on [plain, masked, masked] streams */
+int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3);
 
 #ifdef __cplusplus
 }

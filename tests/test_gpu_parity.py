@@ -214,6 +214,48 @@ def test_results_are_bit_reproducible_and_independent_of_lookahead(ctx):
     assert outs[0] == outs[1] == outs[2]
 
 
+@pytest.mark.parametrize("env", [{"MI355GP_TRSM_LDS": "0"}, {"MI355GP_TRI_OVERLAP": "0"},
+                                 {"MI355GP_TRI_MIN_NT": "16", "MI355GP_TRI_H": "8"}, {"MI355GP_PANEL_FUSED": "1"},
+                                 {"MI355GP_PANEL_FUSED": "1", "MI355GP_PANEL_WGS": "6"}, {"MI355GP_DIAG_SERVER": "1"},
+                                 {"MI355GP_RESERVE_CUS": "8", "MI355GP_DIAG_EXCL": "1"}])
+def test_experimental_panel_schedules_give_the_same_factorisation(env):
+    """The schedule switches of DESIGN.md 6e (read when a context allocates its factorisation workspace) change how the
+    panel chain is launched, not what it computes: same LML / alpha / gradients as the default to rounding."""
+    import os
+    X, Y = O.synthetic(2900, 5, seed=7)
+    var, ls, noise = O.default_theta(5, True)
+    th = L.theta_vec(var, ls, True, 5)
+    c0 = L.Context(0)
+    try:
+        c0.set_data(X, Y)
+        _, ref = c0.exact_inference("rbf", True, th, noise)
+    finally:
+        c0.close()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = L.Context(0)
+        try:
+            c.set_data(X, Y)
+            for _ in range(2):                                   # second call: flags carry a new generation
+                info, r = c.exact_inference("rbf", True, th, noise)
+                assert info == 0
+                assert abs(r["lml"] - ref["lml"]) <= 1e-12 * abs(ref["lml"])
+                assert np.abs(r["alpha"] - ref["alpha"]).max() <= 1e-11 * np.abs(ref["alpha"]).max()
+                assert np.abs(r["dtheta"] - ref["dtheta"]).max() <= 1e-10 * np.abs(ref["dtheta"]).max()
+            c.set_option("lookahead", 0)                         # serial schedule: must not depend on the server / flags
+            info, r = c.exact_inference("rbf", True, th, noise)
+            assert info == 0 and abs(r["lml"] - ref["lml"]) <= 1e-12 * abs(ref["lml"])
+        finally:
+            c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("kind,ARD,N,D", [("rbf", False, 4096, 8), ("matern52", True, 16384, 32)])
 def test_size_independent_properties_at_baseline_sizes(kind, ARD, N, D, ctx):
     """BASELINE configs[1] and configs[2]: properties that need no O(N^3) CPU reference."""

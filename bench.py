@@ -175,7 +175,7 @@ def main():
     theta = L.theta_vec(var, ls, ARD, D)
     ctx = L.Context(comm.local_rank)
     ctx.set_data(X, Y)
-    ctx.set_option("profile", ("update_nt",))                 # hipEvent pairs around every k_update_nt launch
+    ctx.set_option("profile", ("update_nt", "lauum"))         # hipEvent pairs around every k_update_nt / k_lauum launch
     last = {}
 
     def step():
@@ -210,7 +210,14 @@ def main():
                          "traffic": profiled_traffic("k_update_nt") if (N, D, args.kind) == (16384, 32, "matern52")
                          else None,
                          "launches_per_step": upd_n, "avg_launch_ms": upd_ms / max(upd_n, 1),
-                         "algorithmic_flops_per_step": upd_flops},
+                         "algorithmic_flops_per_step": upd_flops,
+                         "note": "launch durations include the time k_update_nt shares the GPU with the overlapped inverse "
+                                 "of the leading block (MI355GP_TRI_OVERLAP=0: 0.57)"},
+            # the same tile-GEMM device routine in its single uncontended launch (W = X^T X, N^3/3 flops)
+            "roofline_k_lauum": {"achieved": pf["lauum"][1] / (pf["lauum"][0] * 1e-3) / 1e12 if pf["lauum"][0] > 0 else 0.0,
+                                 "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": (pf["lauum"][1] / (pf["lauum"][0] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS)
+                                 if pf["lauum"][0] > 0 else 0.0},
             "lml": r["lml"],
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

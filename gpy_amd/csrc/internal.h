@@ -152,9 +152,17 @@ void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx
                        const double* aa_scale = nullptr, const double* Mul = nullptr, long ldm = 0);
 void launch_studentt_scale(hipStream_t st, const double* scal, double nu, long n, double* out);
 // Hout (optional, may alias G): H = dL_dK * (dK/dr)/r, the weights of the gradients_X reductions
+// optional on-the-fly form of the weight matrix read by launch_grad_generic: g = gscale * G + beta * sum_d Y[i][d] V[j][d]
+struct RankTerm {
+    const double* Y;
+    const double* V;
+    int Dy;
+    double beta, gscale;
+};
 void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
                          long ld2, long m, int symmetric, const double* G, long ldg, double* partials,
-                         int stride, double* Hout = nullptr, long ldh = 0);
+                         int stride, double* Hout = nullptr, long ldh = 0,
+                         RankTerm rk = RankTerm{nullptr, nullptr, 0, 0.0, 1.0});
 // part[split][cols][nv] = sum over a row range of M[i][j] * V(i, c); V(i, c) = V[i*sr + c*sc] plus an optional
 // all-ones column; returns the number of row splits (sum them with launch_sum_splits)
 int launch_colreduce_multi(hipStream_t st, const double* M, long ld, long rows, long cols, const double* V, long sr,

@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                                               long ntiles, int ntc, double* __restrict__ partials,
                                               double* __restrict__ Hout = nullptr, long ldh = 0, int diag_same = 0,
                                               const double* __restrict__ aa_scale = nullptr,
-                                              const double* __restrict__ Mul = nullptr, long ldm = 0) {
+                                              const double* __restrict__ Mul = nullptr, long ldm = 0,
+                                              RankTerm rk = RankTerm{nullptr, nullptr, 0, 0.0, 1.0}) {
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
     __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
     __shared__ double red[256];
@@ -274,6 +275,11 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                         }
                     } else {
                         g = G[i * ldg + j];
+                        if (rk.Y) {   // dL_dKnm = gscale * G + beta * Y v^T formed on the fly (var_dtc.py:219,233)
+                            double yv = 0.0;
+                            for (int d = 0; d < rk.Dy; ++d) yv = fma(rk.Y[i * rk.Dy + d], rk.V[j * rk.Dy + d], yv);
+                            g = fma(rk.gscale, g, rk.beta * yv);
+                        }
                     }
                     // factor of a product kernel: dL_dK times the other factors' covariances (prod.py:86-99)
                     if (Mul) g *= Mul[i * ldm + j];
@@ -388,20 +394,20 @@ void launch_studentt_scale(hipStream_t st, const double* scal, double nu, long n
 
 void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
                          long ld2, long m, int symmetric, const double* G, long ldg, double* partials,
-                         int stride, double* Hout, long ldh) {
+                         int stride, double* Hout, long ldh, RankTerm rk) {
     (void)stride;
     const long ntr = (n + KT - 1) / KT, ntc = (m + KT - 1) / KT;
     const long ntiles = ntr * ntc;
     const int nb = pick_grad_blocks(ntiles);
     if (!kp.ard) {
         hipLaunchKernelGGL((k_grad<false, false>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg,
-                           nullptr, 0, 0, ntiles, (int)ntc, partials, Hout, ldh, symmetric);
+                           nullptr, 0, 0, ntiles, (int)ntc, partials, Hout, ldh, symmetric, nullptr, nullptr, 0, rk);
     } else {
         // Hout may alias G (in place): only the LAST group launch writes it, every launch reads G
         for (int q_off = 0, gidx = 0; q_off < kp.D; q_off += KDC, ++gidx)
             hipLaunchKernelGGL((k_grad<false, true>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg,
                                nullptr, 0, q_off, ntiles, (int)ntc, partials + (long)gidx * nb * GP_STRIDE,
-                               (q_off + KDC >= kp.D) ? Hout : nullptr, ldh, symmetric);
+                               (q_off + KDC >= kp.D) ? Hout : nullptr, ldh, symmetric, nullptr, nullptr, 0, rk);
     }
 }
 

@@ -413,10 +413,12 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
             launch_kbuild_cross(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, s->Kfu, mp);
         }
         launch_gemm(st, 0, 1, rcp, mp, mp, s->Kfu, mp, s->Q2, mp, s->T, mp, 1.0, 0.0);
-        hipLaunchKernelGGL(k_form_dLdKnm, dim3((unsigned)rcp, (unsigned)((mp + 255) / 256)), dim3(256), 0, st, s->T, mp, rc, rcp, m, s->dY + r0 * Dy,
-                           s->vvec, Dy, beta);
+        // dL_dKnm = 2 T + beta Y v^T is formed inside the gradient pass (no separate read-modify-write of the chunk); its
+        // H = dL_dKnm * (dK/dr)/r overwrites T in place.  Padding rows / columns of T are zero from the GEMM (zero padding
+        // of Kfu and Q2) and are never written.
         const int nbk = grad_generic_num_blocks(rc, m);
-        launch_grad_generic(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, 0, s->T, mp, s->gradPart, GP_STRIDE, s->T, mp);
+        launch_grad_generic(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, 0, s->T, mp, s->gradPart, GP_STRIDE, s->T, mp,
+                            RankTerm{s->dY + r0 * Dy, s->vvec, Dy, beta, 2.0});
         for (int g = 0; g < (kp.ard ? groups : 1); ++g)
             launch_reduce_partials(st, s->gradPart + (long)g * nbk * GP_STRIDE, nbk, GP_STRIDE,
                                    s->gradChunk + (long)g * GP_STRIDE);

@@ -37,18 +37,42 @@ static int gemm_variant_preload() {
             CALL4;                       \
         }                                \
     } while (0)
+static int device_cu_count() {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+}
+
 #define LB(NW) __launch_bounds__((NW) * 64, (NW) / 2)
 
 // ------------------------------------------------------------------------------------------------
 // Trailing update of the right-looking Cholesky (the dsyrk/dgemm inside LAPACK dpotrf, which GPy reaches
 // through GPy/util/linalg.py:58):  C[ti,tj] -= A[ti,:] * B[tj,:]^T.
 // `tri`: region is square on the diagonal -> enumerate the lower triangle only.
+// Start-up stagger: every tile of one launch has the same K, so all workgroup slots finish their tiles together and the
+// whole chip reads and writes its 128 KB C tiles in the same few microseconds, round after round, while the MFMA pipes
+// wait (the variable-K kernels k_lauum / k_trtri_stage do not have this: 70 vs 61 TF/s).  The workgroups of the FIRST
+// round wait for a fraction of one tile time that depends on where they landed (CU, wave slot, SE, XCD); later
+// workgroups inherit the phase of the slot they take over, so the C traffic of a launch is spread over the tile period.
+__device__ __forceinline__ void stagger_first_round(int stagger_ticks, int first_round) {
+    if (stagger_ticks <= 0 || (int)blockIdx.x >= first_round) return;
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);        // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);       // HW_REG_XCC_ID
+    const unsigned slot = hw & 15u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+    const unsigned phase = ((slot & 1u) * 8u + cu * 5u + sh * 3u + se * 7u + xcc * 11u) & 15u;   // 16 phases
+    const long long wait = (long long)stagger_ticks * phase / 16;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+}
+
 template <int NW, bool PRE>
 __global__ LB(NW) void k_update_nt(double* __restrict__ C, long ldc,
                                                       const double* __restrict__ A, long lda,
                                                       const double* __restrict__ B, long ldb, int K, int ntc,
-                                                      int row0t, int col0t, int tri, long ntiles) {
+                                                      int row0t, int col0t, int tri, long ntiles, int stagger_ticks,
+                                                      int first_round) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    stagger_first_round(stagger_ticks, first_round);
     // grid-stride over the tile list: gridDim.x == ntiles is the one-tile-per-workgroup launch; a smaller grid
     // (launch_update_nt `max_wgs`) keeps only that many workgroups resident so that the panel chain of the
     // look-ahead schedule finds free slots on every CU while a trailing update is running.
@@ -106,8 +130,12 @@ template <int NW, bool PRE>
 static void launch_update_nt_t(hipStream_t st, long nblocks, long grid, double* C, long ldc, const double* A, long lda,
                                const double* B, long ldb, int K, int ntc, int row0t, int col0t, int tri) {
     LDS_OPT_IN((k_update_nt<NW, PRE>));
+    // stagger only launches of several full rounds: one tile takes K/16 slabs x 2 waves per SIMD x 64 MFMAs x 64 cycles
+    static const int stag = env_int("MI355GP_UPDATE_STAGGER", GEMM_DEFAULT_UPDATE_STAGGER);
+    static const int slots = 2 * device_cu_count();
+    const int ticks = (stag && nblocks >= 4L * slots) ? (int)((long)K / 16 * 8192 / 24) * stag / 100 : 0;   // 100 MHz ticks at ~2.4 GHz
     hipLaunchKernelGGL((k_update_nt<NW, PRE>), dim3((unsigned)grid), dim3(NW * 64), GT_LDS_BYTES, st, C, ldc, A, lda,
-                       B, ldb, K, ntc, row0t, col0t, tri, nblocks);
+                       B, ldb, K, ntc, row0t, col0t, tri, nblocks, ticks, slots);
 }
 
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,

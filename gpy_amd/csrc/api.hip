@@ -127,7 +127,7 @@ int mi355gp_create(int device, mi355gp_ctx** out) {
     HIP_CHECK(hipSetDevice(device));
     mi355gp_ctx* c = new mi355gp_ctx();
     c->device = device;
-    HIP_CHECK(hipStreamCreate(&c->st));
+    if (factor_engine(device, &c->st, nullptr, nullptr) != 0) return -2;    // the device's shared main stream (factor.hip)
     for (auto& e : c->ev) HIP_CHECK(hipEventCreate(&e));
     *out = c;
     return 0;
@@ -140,7 +140,7 @@ int mi355gp_destroy(mi355gp_ctx* c) {
     free_data(c);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    if (c->st) (void)hipStreamDestroy(c->st);
+    if (c->st) (void)hipStreamSynchronize(c->st);                         // shared stream: never destroyed by a context
     delete c;
     return 0;
 }
@@ -229,9 +229,18 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
     HIP_CHECK(hipEventRecord(c->ev[2], st));
     trtri_device(st, c->A, c->B, c->C, np, &c->ws);
     HIP_CHECK(hipEventRecord(c->ev[3], st));
+    // alpha = X^T (X R) only needs X: the two bandwidth-bound triangular mat-vecs run on the side stream underneath the
+    // compute-bound W = X^T X instead of after it
+    hipStream_t side = (c->ws.st_tri && c->ws.solve_overlap) ? c->ws.st_tri : nullptr;
+    if (side) {
+        HIP_CHECK(hipStreamWaitEvent(side, c->ev[3], 0));
+        launch_tri_matvec(side, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
+        HIP_CHECK(hipEventRecord(c->ws.ev_tri, side));
+    }
     lauum_device(st, c->B, c->C, np, &c->ws);
     HIP_CHECK(hipEventRecord(c->ev[4], st));
-    launch_tri_matvec(st, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
+    if (side) HIP_CHECK(hipStreamWaitEvent(st, c->ws.ev_tri, 0));
+    else launch_tri_matvec(st, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
     launch_scalars(st, c->dAlpha, c->dR, c->C, np, n, c->Dy, c->ws.logsum, c->ws.nblk, c->dScal, c->dDiag);
     if (studentt_nu > 0.0) launch_studentt_scale(st, c->dScal, studentt_nu, n, c->dScal + 4);
     HIP_CHECK(hipEventRecord(c->ev[5], st));
@@ -958,7 +967,7 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
     HIP_CHECK(hipMemcpy(dIl, il, sizeof(il), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dNoise, &noise, sizeof(double), hipMemcpyHostToDevice));
     hipStream_t st;
-    HIP_CHECK(hipStreamCreate(&st));                            // before the workspace: see factor_ws_alloc on stream order
+    if (factor_engine(device, &st, nullptr, nullptr) != 0) return -2;
     FactorWs ws;
     if (factor_ws_alloc(&ws, np) != 0) return -3;
     ws.scratchX = B;
@@ -991,7 +1000,6 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
     *ms_trtri = acc[1] / reps;
     *ms_lauum = acc[2] / reps;
     for (auto& ev : e) (void)hipEventDestroy(ev);
-    (void)hipStreamDestroy(st);
     factor_ws_free(&ws);
     HIP_CHECK(hipGetLastError());
     if (info < 0) {

@@ -46,6 +46,54 @@ void KernelProf::destroy() {
     recs.clear();
 }
 
+// ---- process-wide stream engine ------------------------------------------------------------------------
+// The three streams that carry concurrent heavy work -- main (trailing updates, trtri, lauum, everything else), panel
+// (the high-priority panel chain) and tri (the CU-masked early-inverse stream) -- exist ONCE per device and process,
+// created back to back on first use, and are shared by every context / workspace on that device.  Hardware queues are
+// handed to the command processor's pipes in creation order, and two busy queues on one pipe take turns dispatch by
+// dispatch: the same schedule ran potrf in 35 or in 45 ms (and the overlapped inverse in 13 or 20 ms) depending on which
+// streams a process had created and destroyed before.  One fixed set makes the good case the only case; the calls of
+// different contexts are serialised on the main stream, which is what a saturated GPU does to them anyway.
+struct FactorEngine {
+    hipStream_t main = nullptr, panel = nullptr, tri = nullptr;
+    int tri_pct = 0;
+    bool ready = false;
+};
+static FactorEngine g_engine[16];
+
+int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t* tri) {
+    if (device < 0 || device >= 16) return -1;
+    FactorEngine& e = g_engine[device];
+    if (!e.ready) {
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithFlags(&e.main, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithPriority(&e.panel, hipStreamNonBlocking, greatest));
+        const char* envc = getenv("MI355GP_TRI_CU_PCT");
+        e.tri_pct = (envc && *envc) ? atoi(envc) : 75;
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount, nx = 8;
+        if (e.tri_pct > 0 && e.tri_pct < 100 && ncu % nx == 0) {
+            // XCD-balanced mask (logical CU i sits on XCD i % 8): the same share of every XCD's CUs
+            const int per = ncu / nx, keep = (per * e.tri_pct + 50) / 100;
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int cu = 0; cu < ncu; ++cu)
+                if (cu / nx < keep) mask[cu / 32] |= 1u << (cu % 32);
+            if (hipExtStreamCreateWithCUMask(&e.tri, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                e.tri = nullptr;
+            }
+        }
+        if (!e.tri) HIP_CHECK(hipStreamCreateWithPriority(&e.tri, hipStreamNonBlocking, least));
+        e.ready = true;
+    }
+    if (main) *main = e.main;
+    if (panel) *panel = e.panel;
+    if (tri) *tri = e.tri;
+    return 0;
+}
+
 // ---- workspace --------------------------------------------------------------------------------------
 int factor_ws_alloc(FactorWs* ws, long npad) {
     ws->nblk = npad / NB;
@@ -54,11 +102,9 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     HIP_CHECK(hipMalloc(&ws->info, sizeof(int) * 4));
     int least = 0, greatest = 0;
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    // The three streams that carry concurrent heavy work -- the caller's main stream (created before this workspace), the
-    // panel chain and the early-inverse stream -- are created back to back and before every optional one: hardware queues
-    // are handed to the command processor's pipes in creation order, and two busy queues on one pipe take turns per
-    // dispatch (measured: the same schedule ran 35 or 45 ms of potrf depending on what had been created in between).
-    HIP_CHECK(hipStreamCreateWithPriority(&ws->st_panel, hipStreamNonBlocking, greatest));
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (factor_engine(dev, nullptr, &ws->st_panel, &ws->st_tri) != 0) return -1;    // shared, never destroyed by a workspace
     {
         const char* envo = getenv("MI355GP_TRI_OVERLAP");
         if (envo && *envo) ws->tri_overlap = atoi(envo) ? 1 : 0;
@@ -66,25 +112,7 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
         if (envn2 && *envn2) ws->tri_min_nt = atoi(envn2);
         const char* envw2 = getenv("MI355GP_TRI_WGS");
         if (envw2 && *envw2) ws->tri_wgs = atoi(envw2);
-        const char* envc = getenv("MI355GP_TRI_CU_PCT");
-        if (envc && *envc) ws->tri_cu_pct = atoi(envc);
-        hipDeviceProp_t prop;
-        int dev = 0;
-        HIP_CHECK(hipGetDevice(&dev));
-        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        const int ncu = prop.multiProcessorCount, nx = 8;
-        if (ws->tri_overlap && ws->tri_cu_pct > 0 && ws->tri_cu_pct < 100 && ncu % nx == 0) {
-            // XCD-balanced mask (logical CU i sits on XCD i % 8): the same share of every XCD's CUs
-            const int per = ncu / nx, keep = (per * ws->tri_cu_pct + 50) / 100;
-            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-            for (int cu = 0; cu < ncu; ++cu)
-                if (cu / nx < keep) mask[cu / 32] |= 1u << (cu % 32);
-            if (hipExtStreamCreateWithCUMask(&ws->st_tri, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-                (void)hipGetLastError();
-                ws->st_tri = nullptr;
-            }
-        }
-        if (ws->tri_overlap && !ws->st_tri) HIP_CHECK(hipStreamCreateWithPriority(&ws->st_tri, hipStreamNonBlocking, least));
+        ws->tri_cu_pct = g_engine[dev].tri_pct > 0 && g_engine[dev].tri_pct <= 100 ? g_engine[dev].tri_pct : 75;
         HIP_CHECK(hipEventCreateWithFlags(&ws->ev_tri, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ws->ev_tri_lead, hipEventDisableTiming));
         HIP_CHECK(hipMalloc(&ws->tri_counter, sizeof(int) * 4));
@@ -146,6 +174,10 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     }
     const char* envt2 = getenv("MI355GP_TRSM_LDS");
     if (envt2 && *envt2) ws->trsm_lds = atoi(envt2) ? 1 : 0;
+    const char* envso = getenv("MI355GP_SOLVE_OVERLAP");
+    if (envso && *envso) ws->solve_overlap = atoi(envso) ? 1 : 0;
+    const char* envr = getenv("MI355GP_PANEL_REC");
+    if (envr && *envr) ws->panel_rec = atoi(envr) ? 1 : 0;
     const char* envn = getenv("MI355GP_PANEL_FUSED_MAX_NRB");
     if (envn && *envn) ws->panel_fused_max_nrb = atoi(envn);
     const char* envm = getenv("MI355GP_PANEL_FUSED_MIN_NRB");
@@ -199,7 +231,6 @@ void factor_ws_free(FactorWs* ws) {
         ws->ev_join[i] = nullptr;
         ws->st_upd[i] = nullptr;
     }
-    if (ws->st_panel) (void)hipStreamDestroy(ws->st_panel);
     ws->st_panel = nullptr;
     if (ws->st_rest) (void)hipStreamDestroy(ws->st_rest);
     ws->st_rest = nullptr;
@@ -216,7 +247,6 @@ void factor_ws_free(FactorWs* ws) {
     ws->panel_flags = nullptr;
     if (ws->diag_flags) (void)hipFree(ws->diag_flags);
     ws->diag_flags = nullptr;
-    if (ws->st_tri) (void)hipStreamDestroy(ws->st_tri);
     ws->st_tri = nullptr;
     if (ws->ev_tri) (void)hipEventDestroy(ws->ev_tri);
     ws->ev_tri = nullptr;
@@ -277,8 +307,9 @@ static void factor_panel(hipStream_t s, double* A, long npad, long K0, long W, F
         }
         if (rc == 0) return;
     }
-    for (long j = 0; j < W; j += NB) {
-        const long c = K0 + j, blk = c / NB;
+    // one 128-column step: diagonal block, then the rows below it
+    auto leaf = [&](long c) {
+        const long blk = c / NB;
         double* dv = ws->dinv + blk * 8 * 256;
         ws->prof.begin(s, PF_DIAG, (double)NB * NB * NB / 3.0);
         if (ws->diag_server_on)
@@ -287,20 +318,47 @@ static void factor_panel(hipStream_t s, double* A, long npad, long K0, long W, F
             launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info, ws->diag_excl);
         ws->prof.end(s);
         const long below = npad - (c + NB);
-        if (below <= 0) continue;
+        if (below <= 0) return;
         ws->prof.begin(s, PF_TRSM, (double)below * NB * NB);
         launch_trsm128(s, A, ld, c, c + NB, below, dv, ws->trsm_lds);
         ws->prof.end(s);
-        const long ncols = K0 + W - (c + NB);
-        if (ncols > 0) {
-            double* C = A + (c + NB) * ld + (c + NB);
-            const double* P = A + (c + NB) * ld + c;
-            ws->prof.begin(s, PF_UPDATE, syrk_flops((double)ncols, NB) + gemm_flops((double)(below - ncols), (double)ncols, NB));
-            launch_update_nt(s, C, ld, P, ld, P, ld, NB, (int)(below / NB), (int)(ncols / NB), (int)((c + NB) / NB),
-                             (int)((c + NB) / NB));
-            ws->prof.end(s);
+    };
+    // rank-K update of the panel's columns [cd, cend) (rows cd .. npad) with its columns [c0, cd)
+    auto inpanel_update = [&](long c0, long cd, long cend) {
+        const long below = npad - cd, ncols = cend - cd, K = cd - c0;
+        if (below <= 0 || ncols <= 0) return;
+        const double* P = A + cd * ld + c0;
+        ws->prof.begin(s, PF_UPDATE, syrk_flops((double)ncols, (double)K) + gemm_flops((double)(below - ncols), (double)ncols, (double)K));
+        launch_update_nt(s, A + cd * ld + cd, ld, P, ld, P, ld, (int)K, (int)(below / NB), (int)(ncols / NB), (int)(cd / NB),
+                         (int)(cd / NB));
+        ws->prof.end(s);
+    };
+    if (!ws->panel_rec) {                    // right-looking inside the panel: every step updates all remaining columns, K = 128
+        for (long j = 0; j < W; j += NB) {
+            leaf(K0 + j);
+            inpanel_update(K0 + j, K0 + j + NB, K0 + W);
         }
+        return;
     }
+    // Recursive inside the panel (default): [left half] -> update of the right half with K = width of the left half ->
+    // [right half].  Same launches and flops as the right-looking loop, but the K=128 read-modify-write passes over the
+    // panel's C tiles shrink from 384+256+128 to 128+256+128 columns (the 256-column one at K=256).
+    struct Rec {
+        decltype(leaf)& lf;
+        decltype(inpanel_update)& up;
+        void run(long c0, int ns) {
+            if (ns == 1) {
+                lf(c0);
+                return;
+            }
+            int h = 1;
+            while (2 * h < ns) h *= 2;
+            run(c0, h);
+            up(c0, c0 + (long)h * NB, c0 + (long)ns * NB);
+            run(c0 + (long)h * NB, ns - h);
+        }
+    } rec{leaf, inpanel_update};
+    rec.run(K0, (int)(W / NB));
 }
 
 // Inverse-based panel (needs ws->scratchX / scratchT): the chain kernels that must win workgroup slots against a

@@ -99,6 +99,8 @@ struct FactorWs {
     hipEvent_t ev_tri = nullptr, ev_tri_lead = nullptr;
     int* tri_counter = nullptr;
     int tri_h_override = 0;          // MI355GP_TRI_H: leading tiles inverted early (0 = time model)
+    int solve_overlap = 1;           // MI355GP_SOLVE_OVERLAP: alpha = X^T (X R) on st_tri underneath lauum
+    int panel_rec = FACTOR_DEFAULT_PANEL_REC;   // recursive (1) or right-looking (0) order inside an outer panel
     int trsm_lds = FACTOR_DEFAULT_TRSM_LDS;                // k_trsm128 with L_cc staged in LDS (MI355GP_TRSM_LDS)
     long long* panel_dbg = nullptr;  // MI355GP_PANEL_DBG=1: per-workgroup timestamps of the first fused panel of a call
     int* panel_flags = nullptr;      // [4 + 16] hand-off flags of k_panel_fused (hold the launch generation)
@@ -108,6 +110,8 @@ struct FactorWs {
     long part2_tiles = 0;       //      resident (one per CU) once the update has fewer tiles than this
     KernelProf prof;
 };
+// the process-wide main / panel / tri streams of a device (created on first use, shared, never destroyed)
+int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t* tri);
 int factor_ws_alloc(FactorWs* ws, long npad);
 void factor_ws_free(FactorWs* ws);
 // A (npad x npad, ld = npad, lower) -> L in place.  Asynchronous; on return all work is ordered before later work on `st`.

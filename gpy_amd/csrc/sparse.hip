@@ -234,7 +234,7 @@ int mi355gp_sparse_create(int device, mi355gp_sparse** out) {
     HIP_CHECK(hipSetDevice(device));
     mi355gp_sparse* s = new mi355gp_sparse();
     s->device = device;
-    HIP_CHECK(hipStreamCreate(&s->st));
+    if (factor_engine(device, &s->st, nullptr, nullptr) != 0) return -2;    // the device's shared main stream
     for (auto& e : s->ev) HIP_CHECK(hipEventCreate(&e));
     *out = s;
     return 0;
@@ -251,7 +251,7 @@ int mi355gp_sparse_destroy(mi355gp_sparse* s) {
     if (s->comm) rccl_comm_destroy(s->comm);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
-    if (s->st) (void)hipStreamDestroy(s->st);
+    if (s->st) (void)hipStreamSynchronize(s->st);
     delete s;
     return 0;
 }

@@ -4,6 +4,7 @@
 // Layout: one padded (npad x npad, npad % 128 == 0) row-major fp64 buffer per matrix, lower triangle
 // significant; padding rows/cols carry the identity, which factorises and inverts to itself.
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "internal.h"
@@ -60,9 +61,11 @@ struct FactorEngine {
     bool ready = false;
 };
 static FactorEngine g_engine[16];
+static std::mutex g_engine_mutex;
 
 int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t* tri) {
     if (device < 0 || device >= 16) return -1;
+    std::lock_guard<std::mutex> lock(g_engine_mutex);
     FactorEngine& e = g_engine[device];
     if (!e.ready) {
         int least = 0, greatest = 0;

@@ -18,6 +18,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define FACTOR_DEFAULT_PANEL_FUSED 0   // 1: k_panel_fused (one launch per outer panel, flag hand-offs between workgroups)   // CUs (a multiple of 8: the same count per XCD) kept free of trailing-update workgroups; measured: no gain
 #define GEMM_DEFAULT_NW 4        // wave arrangement of the 128x128 tile kernels (see gemm_tile.h); env MI355GP_GEMM_NW
 #define GEMM_DEFAULT_REVERSE_K 0
+#define GEMM_DEFAULT_UPDATE_SMALL_NW8 0  // 1: trailing-update launches of at most one tile per CU use 8-wave workgroups
 #define GEMM_DEFAULT_UPDATE_STAGGER 0   // percent of one tile time over which the first round of k_update_nt is spread (0 = off) // lauum / trtri stage 1 walk k downwards (common end point); env MI355GP_REVERSE_K
 #define GEMM_DEFAULT_UPDATE_V2 0 // trailing update on the v2 tile pipeline (BK = 8, fragments prefetched across the barrier)
 #define GEMM_DEFAULT_PRELOAD 1   // trailing update reads C before the k-loop; env MI355GP_PRELOAD_C

@@ -150,6 +150,16 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
                            row0t, col0t, tri, nblocks);
         return;
     }
+    // Few tiles (at most one per CU): the launch is the latency of ONE tile, so give every tile 8 waves (two per SIMD,
+    // 64x32 accumulators each) instead of 4 -- half the MFMA time per tile.  These are the in-panel K=128 updates and the
+    // late part-1 updates of the look-ahead chain.
+    static const int small8 = env_int("MI355GP_UPDATE_SMALL_NW8", GEMM_DEFAULT_UPDATE_SMALL_NW8);
+    static const int ncu = device_cu_count();
+    if (small8 && nblocks <= ncu && grid == nblocks) {
+        if (gemm_variant_preload()) launch_update_nt_t<8, true>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri);
+        else launch_update_nt_t<8, false>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri);
+        return;
+    }
     if (gemm_variant_preload())
         NW_DISPATCH((launch_update_nt_t<4, true>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)),
                     (launch_update_nt_t<8, true>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)));

@@ -256,6 +256,24 @@ def test_experimental_panel_schedules_give_the_same_factorisation(env):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("n", [6200])
+def test_pdinv_with_overlapped_leading_inverse_at_ragged_sizes(n):
+    """N >= 6144 takes the schedule that inverts the leading block underneath potrf's second half; tile
+    count that is not a power of two (49) exercises the sub-range merge levels.  Size-independent checks:
+    A Ainv v = v, L L^T v = A v, log det against LAPACK."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, 4))
+    s = (X * X).sum(1)
+    A = np.exp(-0.125 * np.maximum(s[:, None] + s[None, :] - 2.0 * X @ X.T, 0.0)) + 0.1 * np.eye(n)
+    Ai, Lc, logdet, info, _ = L.pdinv(A)
+    assert info == 0
+    V = rng.standard_normal((n, 3))
+    assert np.abs(A @ (Ai @ V) - V).max() <= 1e-9
+    assert np.abs(Lc @ (Lc.T @ V) - A @ V).max() <= 1e-12 * np.abs(A @ V).max()
+    assert abs(np.linalg.slogdet(A)[1] - logdet) <= 1e-9 * abs(logdet)
+    assert np.abs(Ai - Ai.T).max() == 0.0
+
+
 @pytest.mark.parametrize("kind,ARD,N,D", [("rbf", False, 4096, 8), ("matern52", True, 16384, 32)])
 def test_size_independent_properties_at_baseline_sizes(kind, ARD, N, D, ctx):
     """BASELINE configs[1] and configs[2]: properties that need no O(N^3) CPU reference."""

@@ -154,8 +154,6 @@ int grad_num_blocks(long n);
 void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, const double* W,
                        long ldw, const double* alpha, int Dy, double* partials, int stride,
                        const double* aa_scale = nullptr, const double* Mul = nullptr, long ldm = 0);
-void launch_studentt_scale(hipStream_t st, const double* scal, double nu, long n, double* out);
-// Hout (optional, may alias G): H = dL_dK * (dK/dr)/r, the weights of the gradients_X reductions
 // optional on-the-fly form of the weight matrix read by launch_grad_generic: g = gscale * G + beta * sum_d Y[i][d] V[j][d]
 struct RankTerm {
     const double* Y;
@@ -163,6 +161,12 @@ struct RankTerm {
     int Dy;
     double beta, gscale;
 };
+// sparse pass 2: theta partials + H^T [x~ | 1] column partials in one pass over the weights (k_grad_cols); 0 = not applicable
+int launch_grad_cols(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2, long ld2,
+                     long m, long mcols, const double* G, long ldg, RankTerm rk, double* partials, double* colpart,
+                     int* nblocks_out);
+void launch_studentt_scale(hipStream_t st, const double* scal, double nu, long n, double* out);
+// Hout (optional, may alias G): H = dL_dK * (dK/dr)/r, the weights of the gradients_X reductions
 void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
                          long ld2, long m, int symmetric, const double* G, long ldg, double* partials,
                          int stride, double* Hout = nullptr, long ldh = 0,

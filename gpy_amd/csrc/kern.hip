@@ -384,6 +384,169 @@ void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gradient pass of the sparse path with the column reductions fused in (D <= 16): besides the theta partials of k_grad,
+// every block accumulates  HX[j][c] = sum_i H[i][j] * x~[i][c]  (c < D) and the column sums of H (c = D) for its 64
+// columns over ITS range of row tiles -- H = dL_dKnm * (dK/dr)/r never goes to memory (the separate pass wrote and
+// re-read the 3.3 GB chunk).  Block = (column tile, row split); partial sums per split are combined in fixed order by
+// launch_sum_splits, so the result stays bit-reproducible.  G: n x m weights, optionally formed on the fly (RankTerm).
+template <bool ARD>
+__global__ __launch_bounds__(256) void k_grad_cols(KernParams kp, const double* __restrict__ Xt1, long ld1, long n,
+                                                   const double* __restrict__ Xt2, long ld2, long m,
+                                                   const double* __restrict__ G, long ldg, RankTerm rk, int ntc,
+                                                   int ntr, int tiles_per_split, double* __restrict__ partials,
+                                                   double* __restrict__ colpart, long mcols, int nv) {
+    constexpr int NVMAX = 17;
+    __shared__ __attribute__((aligned(16))) double si[KDC * KT];
+    __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
+    __shared__ double red[256];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int tj = blockIdx.x % ntc, split = blockIdx.x / ntc;
+    const long j0 = (long)tj * KT;
+    const int D = kp.D;                                   // <= 16: one staging pass holds every dimension
+    double a_var = 0.0, a_iso = 0.0;
+    double a_q[NVMAX - 1];
+    double hc[4][NVMAX];
+#pragma unroll
+    for (int q = 0; q < NVMAX - 1; ++q) a_q[q] = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c < NVMAX; ++c) hc[b][c] = 0.0;
+    const int ti_end = ((split + 1) * tiles_per_split < ntr) ? (split + 1) * tiles_per_split : ntr;
+    for (int ti = split * tiles_per_split; ti < ti_end; ++ti) {
+        const long i0 = (long)ti * KT;
+        double r2[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+        __syncthreads();
+        stage_x(Xt1, ld1, i0, 0, D, si, t);
+        stage_x(Xt2, ld2, j0, 0, D, sj, t);
+        __syncthreads();
+        accum_r2(si, sj, D, ty, tx, r2);
+        double gT[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long i = i0 + ty * 4 + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long j = j0 + tx * 4 + b;
+                double g = 0.0;
+                if (i < n && j < m) {
+                    g = G[i * ldg + j];
+                    if (rk.Y) {
+                        double yv = 0.0;
+                        for (int d = 0; d < rk.Dy; ++d) yv = fma(rk.Y[i * rk.Dy + d], rk.V[j * rk.Dy + d], yv);
+                        g = fma(rk.gscale, g, rk.beta * yv);
+                    }
+                }
+                const CovVal c = cov_all(kp.kind, kp.variance, r2[a][b], false);
+                a_var = fma(g, c.k, a_var);
+                if (!ARD) a_iso = fma(g, c.dk_r, a_iso);
+                gT[a][b] = g * c.dk_or;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NVMAX - 1; ++q) {
+            if (q < D) {
+                const d4 xi = *reinterpret_cast<const d4*>(si + q * KT + ty * 4);
+                if (ARD) {
+                    const d4 xj = *reinterpret_cast<const d4*>(sj + q * KT + tx * 4);
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const double d = xi[a] - xj[b];
+                            sacc = fma(gT[a][b], d * d, sacc);
+                        }
+                    a_q[q] += sacc;
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) hc[b][q] = fma(gT[a][b], xi[a], hc[b][q]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) hc[b][NVMAX - 1] += gT[a][b];     // column sums (the "ones" column, stored at c = D)
+    }
+    // theta partials of this block
+    double* out = partials + (long)blockIdx.x * GP_STRIDE;
+    auto block_sum = [&](double v) -> double {
+        __syncthreads();
+        red[t] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (t < s) red[t] += red[t + s];
+            __syncthreads();
+        }
+        return red[0];
+    };
+    const double sv = block_sum(a_var);
+    if (t == 0) out[0] = sv;
+    if (!ARD) {
+        const double sl = block_sum(a_iso);
+        if (t == 0) out[1] = sl;
+    } else {
+#pragma unroll
+        for (int q = 0; q < NVMAX - 1; ++q) {
+            if (q < D) {
+                const double sq = block_sum(a_q[q]);
+                if (t == 0) out[2 + q] = sq;
+            }
+        }
+    }
+    // column partials: sum over the 16 row groups (ty) in fixed order, one (b, c) pair at a time
+    double* cp = colpart + (long)split * mcols * nv;
+#pragma unroll
+    for (int c = 0; c < NVMAX; ++c) {
+        const int cdst = (c == NVMAX - 1) ? D : c;
+        if (c < D || c == NVMAX - 1) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                __syncthreads();
+                red[ty * 16 + tx] = hc[b][c];
+                __syncthreads();
+                if (ty == 0) {
+                    double sacc = 0.0;
+                    for (int r = 0; r < 16; ++r) sacc += red[r * 16 + tx];
+                    const long j = j0 + tx * 4 + b;
+                    if (j < mcols) cp[j * nv + cdst] = (j < m) ? sacc : 0.0;
+                }
+            }
+        }
+    }
+}
+
+// returns the number of row splits (colpart holds nsplit * mcols * (D+1) doubles, partials ntc*nsplit blocks); 0 if the
+// fused form does not apply (D > 16)
+int launch_grad_cols(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2, long ld2,
+                     long m, long mcols, const double* G, long ldg, RankTerm rk, double* partials, double* colpart,
+                     int* nblocks_out) {
+    if (kp.D > 16) return 0;
+    const int ntr = (int)((n + KT - 1) / KT), ntc = (int)((mcols + KT - 1) / KT);
+    int nsplit = 2048 / ntc;
+    if (nsplit > 64) nsplit = 64;
+    if (nsplit > ntr) nsplit = ntr;
+    if (nsplit < 1) nsplit = 1;
+    const int tps = (ntr + nsplit - 1) / nsplit;
+    nsplit = (ntr + tps - 1) / tps;
+    const int nb = ntc * nsplit;
+    if (kp.ard)
+        hipLaunchKernelGGL((k_grad_cols<true>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg, rk, ntc, ntr,
+                           tps, partials, colpart, mcols, kp.D + 1);
+    else
+        hipLaunchKernelGGL((k_grad_cols<false>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg, rk, ntc, ntr,
+                           tps, partials, colpart, mcols, kp.D + 1);
+    *nblocks_out = nb;
+    return nsplit;
+}
+
 // out[0] = (nu + n) / (nu + beta - 2) with beta = scal[0] = sum(alpha * R)   (exact_studentt_inference.py:46,51)
 __global__ void k_studentt_scale(const double* __restrict__ scal, double nu, double n, double* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (nu + n) / (nu + scal[0] - 2.0);

@@ -124,6 +124,7 @@ __global__ void k_vec_axpy(double* __restrict__ dst, const double* __restrict__ 
 static dim3 grid2d(long cols, long rows) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows); }
 
 struct mi355gp_sparse {
+    int fuse_cols = 1;            // MI355GP_SPARSE_FUSE_COLS: k_grad_cols (gradient pass + column reductions in one)
     int device = 0;
     hipStream_t st = nullptr;
     long n = 0, chunk = 0;
@@ -235,6 +236,10 @@ int mi355gp_sparse_create(int device, mi355gp_sparse** out) {
     mi355gp_sparse* s = new mi355gp_sparse();
     s->device = device;
     if (factor_engine(device, &s->st, nullptr, nullptr) != 0) return -2;    // the device's shared main stream
+    {
+        const char* e = getenv("MI355GP_SPARSE_FUSE_COLS");
+        if (e && *e) s->fuse_cols = atoi(e) ? 1 : 0;
+    }
     for (auto& e : s->ev) HIP_CHECK(hipEventCreate(&e));
     *out = s;
     return 0;
@@ -413,17 +418,22 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
             launch_kbuild_cross(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, s->Kfu, mp);
         }
         launch_gemm(st, 0, 1, rcp, mp, mp, s->Kfu, mp, s->Q2, mp, s->T, mp, 1.0, 0.0);
-        // dL_dKnm = 2 T + beta Y v^T is formed inside the gradient pass (no separate read-modify-write of the chunk); its
-        // H = dL_dKnm * (dK/dr)/r overwrites T in place.  Padding rows / columns of T are zero from the GEMM (zero padding
-        // of Kfu and Q2) and are never written.
-        const int nbk = grad_generic_num_blocks(rc, m);
-        launch_grad_generic(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, 0, s->T, mp, s->gradPart, GP_STRIDE, s->T, mp,
-                            RankTerm{s->dY + r0 * Dy, s->vvec, Dy, beta, 2.0});
+        // dL_dKnm = 2 T + beta Y v^T is formed inside the gradient pass (no separate read-modify-write of the chunk).
+        // D <= 16: the same pass also accumulates H^T [X~ | 1] (H = dL_dKnm * (dK/dr)/r stays on chip); otherwise H
+        // overwrites T in place and a second pass reduces it.  Padding rows / columns of T are zero from the GEMM.
+        const RankTerm rk{s->dY + r0 * Dy, s->vvec, Dy, beta, 2.0};
+        int nbk = 0;
+        int ns = s->fuse_cols ? launch_grad_cols(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, mp, s->T, mp, rk, s->gradPart,
+                                                 s->colPart, &nbk) : 0;
+        if (ns == 0) {
+            nbk = grad_generic_num_blocks(rc, m);
+            launch_grad_generic(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, 0, s->T, mp, s->gradPart, GP_STRIDE, s->T, mp, rk);
+            ns = launch_colreduce_multi(st, s->T, mp, rc, mp, s->XtC, 1, chunk, D, 1, s->colPart);
+        }
         for (int g = 0; g < (kp.ard ? groups : 1); ++g)
             launch_reduce_partials(st, s->gradPart + (long)g * nbk * GP_STRIDE, nbk, GP_STRIDE,
                                    s->gradChunk + (long)g * GP_STRIDE);
         hipLaunchKernelGGL(k_vec_axpy, dim3(1), dim3(256), 0, st, s->gradNM, s->gradChunk, (long)groups * GP_STRIDE, 1.0);
-        const int ns = launch_colreduce_multi(st, s->T, mp, rc, mp, s->XtC, 1, chunk, D, 1, s->colPart);
         launch_sum_splits(st, s->colPart, mp * (D + 1), ns, 1, s->HX);
     }
     if (s->comm) {                                              // the one exchange step of pass 2

@@ -211,8 +211,10 @@ def main():
                          else None,
                          "launches_per_step": upd_n, "avg_launch_ms": upd_ms / max(upd_n, 1),
                          "algorithmic_flops_per_step": upd_flops,
-                         "note": "launch durations include the time k_update_nt shares the GPU with the overlapped inverse "
-                                 "of the leading block (MI355GP_TRI_OVERLAP=0: 0.57)"},
+                         "note": ("launch durations include the time k_update_nt shares the GPU with the overlapped "
+                                  "inverse of the leading block" +
+                                  (" (MI355GP_TRI_OVERLAP=0: 0.57)" if (N, D, args.kind) == (16384, 32, "matern52") else ""))
+                         if N >= 6144 else None},
             # the same tile-GEMM device routine in its single uncontended launch (W = X^T X, N^3/3 flops)
             "roofline_k_lauum": {"achieved": pf["lauum"][1] / (pf["lauum"][0] * 1e-3) / 1e12 if pf["lauum"][0] > 0 else 0.0,
                                  "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",

@@ -151,3 +151,35 @@ def test_standardize_normalizer_matches_reference_formulas():
     const = Standardize()
     const.scale_by(np.ones((5, 1)))
     assert const.std[0] == 1.0                      # zero standard deviation resets to 1 (normalizer.py:94-97)
+
+
+def test_combination_kernels_flatten_and_describe_themselves_to_the_c_abi():
+    """`Add` / `Prod` follow the reference's flattening (add.py:24-33, prod.py:33-41); `part_specs()` is the
+    `mi355gp_part` list: factors of a product share a non-zero term id, plain summands carry term 0; parameter /
+    gradient order is the leaves' link order."""
+    import ctypes
+    from gpy_amd import _lib as L
+    r1 = gpy_amd.RBF(2, variance=1.5, lengthscale=0.7, active_dims=[0, 1])
+    m32 = gpy_amd.Matern32(1, variance=0.4, lengthscale=2.0, active_dims=[2])
+    b = gpy_amd.Bias(3, 0.3)
+    w = gpy_amd.White(3, 0.05)
+    r2 = gpy_amd.RBF(3, variance=0.9, lengthscale=[1.0, 2.0, 3.0], ARD=True)
+    k = (r1 * m32) * b + w + (r2 + gpy_amd.Bias(3, 0.1))
+    assert isinstance(k, gpy_amd.Add) and [type(p).__name__ for p in k.parts] == ["Prod", "White", "RBF", "Bias"]
+    assert [type(p).__name__ for p in k.parts[0].parts] == ["RBF", "Matern32", "Bias"]          # nested Prod flattened
+    specs = k.part_specs()
+    assert [s[0] for s in specs] == ["rbf", "matern32", "bias", "white", "rbf", "bias"]
+    assert [s[4] for s in specs] == [1, 1, 1, 0, 0, 0]
+    assert [p.name for p in k.leaves()] == ["rbf", "Mat32", "bias", "white", "rbf", "bias"]
+    # Kdiag of the expression: sum over summands of the product of variances
+    assert abs(k.diag_variance() - (1.5 * 0.4 * 0.3 + 0.05 + 0.9 + 0.1)) < 1e-15
+    arr, keep, ntheta = L.make_parts(specs)
+    assert ntheta == 2 + 2 + 1 + 1 + 4 + 1 and [arr[i].term for i in range(6)] == [1, 1, 1, 0, 0, 0]
+    assert arr[1].n_active == 1 and arr[1].active_dims[0] == 2 and arr[4].ard == 1
+    assert ctypes.sizeof(L.Part) == 40                            # int, int, int, (pad), ptr, ptr, int, (pad): include/mi355gp.h
+    d = k.to_dict()
+    assert d["class"] == "GPy.kern.Add" and d["parts"][0]["class"] == "GPy.kern.Prod"
+    # two products in one sum get distinct term ids
+    k2 = r1 * m32 + r2 * b
+    assert [s[4] for s in k2.part_specs()] == [1, 1, 2, 2]
+    assert gpy_amd.lazy.kernel_signature(k2) != gpy_amd.lazy.kernel_signature(r1 * m32 + r2 + b)

@@ -14,9 +14,13 @@ def analyze(path, verbose=False):
     ev.sort()
     idx=[i for i,e in enumerate(ev) if e[2]=='k_kbuild']
     s=idx[-1]
-    e_end=[i for i,e in enumerate(ev) if e[2]=='k_inv128' and i>s][0]
-    seg=ev[s+1:e_end]
+    e_end=[i for i,e in enumerate(ev) if e[2]=='k_diag128' and i>s][-1]+3     # last diagonal block (+ its solve) of this evaluation
+    seg=[e for e in ev[s+1:e_end] if e[2] in ('k_update_nt','k_diag128','k_trsm128','k_panel_fused')]
     print(path, "potrf span ms %.2f"%((seg[-1][1]-ev[s][1])/1e6))
+    oth={}
+    for e in ev[s+1:e_end]:
+        if e[2] not in ('k_update_nt','k_diag128','k_trsm128'): oth[e[2]]=oth.get(e[2],0)+(e[1]-e[0])/1e3
+    if oth: print(" other kernels running during potrf (us):", {k:round(v) for k,v in oth.items()})
     upd=[e for e in seg if e[2]=='k_update_nt' and e[4]>=400 or (e[2]=='k_update_nt' and e[3]==seg[0][3] and False)]
     # classify queues: chain queue = queue of k_diag128
     qd=[e[3] for e in seg if e[2]=='k_diag128'][0]

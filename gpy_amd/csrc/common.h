@@ -10,6 +10,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define NBO 512           // outer panel width of the two-level right-looking Cholesky
 #define FACTOR_DEFAULT_RESERVE_CUS 0
 #define FACTOR_DEFAULT_TRI_OVERLAP 1    // 1: inverse of the leading block overlapped with the second half of potrf
+#define FACTOR_DEFAULT_DIAG_EXCL_FIRST 1   // small factorisations only (N < 6144): from N = 8192 on it measured slower
 #define FACTOR_DEFAULT_PANEL_REC 0
 #define FACTOR_DEFAULT_TRSM_LDS 1       // k_trsm128 stages L_cc and its inverted diagonal tiles in LDS (0: operands straight from L2)
 #define FACTOR_DEFAULT_DIAG_SERVER 0    // 1: diagonal blocks factored by a resident single-workgroup server on a CU of its own

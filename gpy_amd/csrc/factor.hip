@@ -179,6 +179,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     if (envt2 && *envt2) ws->trsm_lds = atoi(envt2) ? 1 : 0;
     const char* envso = getenv("MI355GP_SOLVE_OVERLAP");
     if (envso && *envso) ws->solve_overlap = atoi(envso) ? 1 : 0;
+    const char* envx = getenv("MI355GP_DIAG_EXCL_FIRST");
+    if (envx && *envx) ws->diag_excl_first = atoi(envx) ? 1 : 0;
     const char* envr = getenv("MI355GP_PANEL_REC");
     if (envr && *envr) ws->panel_rec = atoi(envr) ? 1 : 0;
     const char* envn = getenv("MI355GP_PANEL_FUSED_MAX_NRB");
@@ -318,7 +320,8 @@ static void factor_panel(hipStream_t s, double* A, long npad, long K0, long W, F
         if (ws->diag_server_on)
             launch_diag_call(s, ws->diag_flags, ws->diag_flags + ws->nblk, (int)blk, ws->diag_gen, ws->info);
         else
-            launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info, ws->diag_excl);
+            launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info,
+                           ws->diag_excl || (ws->diag_excl_first && c == K0 && ws->lookahead == 1 && ws->excl_first_ok));
         ws->prof.end(s);
         const long below = npad - (c + NB);
         if (below <= 0) return;
@@ -582,6 +585,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
         if (h >= 8 && h < ntl && (h & (h - 1)) == 0) ovl_h = h;
     }
     ws->ovl_h = 0;
+    ws->excl_first_ok = (ovl_h == 0 && ntl < ws->tri_min_nt) ? 1 : 0;   // small factorisations only (measured: N >= 8192 loses)
     for (long p = 0; p + 1 < P; ++p) {
         const long K0 = pcol(p), W = pcol(p + 1) - K0;
         (void)hipEventRecord(ws->ev_panel[p], sp);

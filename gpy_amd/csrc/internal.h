@@ -99,6 +99,9 @@ struct FactorWs {
     hipEvent_t ev_tri = nullptr, ev_tri_lead = nullptr;
     int* tri_counter = nullptr;
     int tri_h_override = 0;          // MI355GP_TRI_H: leading tiles inverted early (0 = time model)
+    // the first k_diag128 of a panel starts when part 1 has just drained the GPU: with the exclusive LDS request it takes a
+    // CU that no part-2 workgroup can join afterwards (27 us instead of 85-250 us next to one)
+    int diag_excl_first = FACTOR_DEFAULT_DIAG_EXCL_FIRST, excl_first_ok = 0;
     int solve_overlap = 1;           // MI355GP_SOLVE_OVERLAP: alpha = X^T (X R) on st_tri underneath lauum
     int panel_rec = FACTOR_DEFAULT_PANEL_REC;   // recursive (1) or right-looking (0) order inside an outer panel
     int trsm_lds = FACTOR_DEFAULT_TRSM_LDS;                // k_trsm128 with L_cc staged in LDS (MI355GP_TRSM_LDS)

@@ -106,6 +106,32 @@ def test_prod_kernel_host_classes_in_gpregression():
     assert m.objective_function() < f0
 
 
+def test_covariance_between_points_and_full_cov_prediction_with_a_sum_of_products():
+    """Posterior.covariance_between_points (posterior.py:109-130) and the full-covariance prediction for an `Add` of a
+    `Prod` and plain parts, against the oracle's expression evaluation (cross-covariances: White contributes nothing)."""
+    from scipy.linalg import solve_triangular
+    g = load_sum_golden("prod_n260_rbfard_x_m52_plus_white")
+    parts, X = g["parts"], g["X"]
+    r = O.sum_parameters_changed(parts, X, g["Y"], g["noise"])
+    rng = np.random.default_rng(11)
+    X1, X2 = rng.standard_normal((23, X.shape[1])), rng.standard_normal((140, X.shape[1]))
+    t1 = solve_triangular(r["L"], O.sum_kern_K(parts, X, X1), lower=True)
+    t2 = solve_triangular(r["L"], O.sum_kern_K(parts, X, X2), lower=True)
+    expect = O.sum_kern_K(parts, X1, X2) - t1.T @ t2
+    c = L.Context(0)
+    try:
+        c.set_data(X, g["Y"])
+        info, _ = c.exact_inference_sum(_specs(g), g["noise"])
+        assert info == 0
+        got = c.covariance_between_points(_specs(g), X1, X2)
+        assert got.shape == (23, 140) and np.abs(got - expect).max() <= 1e-10
+        mu, cov = c.predict_sum(_specs(g), X1, full_cov=True)
+        cov_ref = O.sum_kern_K(parts, X1) - t1.T @ t1                       # K(X1, X1): White on its diagonal (static.py:77-81)
+        assert np.abs(cov - cov_ref).max() <= 1e-10
+    finally:
+        c.close()
+
+
 def test_studentt_process_inference_matches_reference_golden():
     """ExactStudentTInference on the device (C-ABI mi355gp_exact_studentt_sum) vs the reference's own outputs.
     There is no noise term: Ky = K + 1e-8 I has cond ~ 1e9..1e10, so two correct fp64 factorisations differ by

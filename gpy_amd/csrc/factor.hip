@@ -176,7 +176,7 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
         HIP_CHECK(hipEventCreateWithFlags(&ws->ev_diag, hipEventDisableTiming));
     }
     const char* envt2 = getenv("MI355GP_TRSM_LDS");
-    if (envt2 && *envt2) ws->trsm_lds = atoi(envt2) ? 1 : 0;
+    if (envt2 && *envt2) ws->trsm_lds = atoi(envt2);           // 0: operands from L2, 1: LDS-staged, 2: LDS-staged, two strips per wave
     const char* envso = getenv("MI355GP_SOLVE_OVERLAP");
     if (envso && *envso) ws->solve_overlap = atoi(envso) ? 1 : 0;
     const char* envx = getenv("MI355GP_DIAG_EXCL_FIRST");

@@ -343,6 +343,66 @@ __global__ __launch_bounds__(256) void k_trsm128_g(double* __restrict__ A, long 
     trsm_strip_g(A, ld, c0, prow0, dinv, lane);
 }
 
+// Two strips per wave, interleaved: the two dependent MFMA chains fill each other's latency and share every L / Dinv
+// fragment read, so a workgroup covers 128 panel rows in about the time it needs for 64 -- half as many workgroups hold
+// a CU slot (and keep a 74 KB trailing-update workgroup out of it) while the chain runs under a busy GPU.
+__device__ __forceinline__ void trsm_strip2(double* __restrict__ A, long ld, long c0, long prow0, long prow1, const double* sm,
+                                            int lane) {
+    const int fi = lane & 15, fk = lane >> 4;
+    double* P0 = A + (prow0 + fi) * ld + c0;
+    double* P1 = A + (prow1 + fi) * ld + c0;
+    const double* Ls = sm + fi * TS + fk;
+    const double* Ds = sm + 28 * TSZ + fi * TS + fk;
+    d4 Y0[8], Y1[8];
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        d4 a0, a1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a0[r] = P0[jb * 16 + fk + 4 * r];
+            a1[r] = P1[jb * 16 + fk + 4 * r];
+        }
+#pragma unroll
+        for (int k = 0; k < jb; ++k) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double a = -Ls[tix_sl(jb, k) * TSZ + 4 * s];
+                a0 = mfma_f64(a, Y0[k][s], a0);
+                a1 = mfma_f64(a, Y1[k][s], a1);
+            }
+        }
+        d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double d = Ds[jb * TSZ + 4 * s];
+            y0 = mfma_f64(d, a0[s], y0);
+            y1 = mfma_f64(d, a1[s], y1);
+        }
+        Y0[jb] = y0;
+        Y1[jb] = y1;
+    }
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            P0[jb * 16 + fk + 4 * r] = Y0[jb][r];
+            P1[jb * 16 + fk + 4 * r] = Y1[jb][r];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_trsm128x2(double* __restrict__ A, long ld, long c0, long r0, long mrows,
+                                                   const double* __restrict__ dinv) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    trsm_stage_L(A, ld, c0, dinv, sm);
+    __syncthreads();
+    const long base = r0 + (long)blockIdx.x * 128 + w * 16;          // strips w and w + 4 of this workgroup's 128 rows
+    const long end = r0 + mrows;
+    if (base >= end) return;
+    if (base + 64 < end) trsm_strip2(A, ld, c0, base, base + 64, sm, lane);
+    else trsm_strip<false>(A, ld, c0, base, sm, lane);
+}
+
 __global__ __launch_bounds__(256) void k_trsm128(double* __restrict__ A, long ld, long c0, long r0, long mrows,
                                                  const double* __restrict__ dinv) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -368,6 +428,17 @@ void launch_trsm128(hipStream_t st, double* A, long ld, long c0, long r0, long m
         opted = true;
     }
     const long nwaves = mrows / 16;
+    if (lds == 2) {
+        static bool opted2 = false;
+        if (!opted2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm128x2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      TRSM_LDS_BYTES);
+            opted2 = true;
+        }
+        hipLaunchKernelGGL(k_trsm128x2, dim3((unsigned)((mrows + 127) / 128)), dim3(256), TRSM_LDS_BYTES, st, A, ld, c0, r0,
+                           mrows, dinv);
+        return;
+    }
     hipLaunchKernelGGL(k_trsm128, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), TRSM_LDS_BYTES, st, A, ld, c0, r0, mrows,
                        dinv);
 }

@@ -219,6 +219,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
 }
 
 void factor_ws_free(FactorWs* ws) {
+    if (ws->panel_dbg) (void)hipFree(ws->panel_dbg);
+    ws->panel_dbg = nullptr;
     if (ws->dinv) (void)hipFree(ws->dinv);
     if (ws->logsum) (void)hipFree(ws->logsum);
     if (ws->info) (void)hipFree(ws->info);

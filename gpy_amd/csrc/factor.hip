@@ -81,8 +81,15 @@ int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t
             // XCD-balanced mask (logical CU i sits on XCD i % 8): the same share of every XCD's CUs
             const int per = ncu / nx, keep = (per * e.tri_pct + 50) / 100;
             std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-            for (int cu = 0; cu < ncu; ++cu)
-                if (cu / nx < keep) mask[cu / 32] |= 1u << (cu % 32);
+            const char* envm = getenv("MI355GP_TRI_MASK_MODE");
+            const int mode = (envm && *envm) ? atoi(envm) : 0;
+            for (int cu = 0; cu < ncu; ++cu) {
+                const int idx = cu / nx;                       // CU index inside its XCD
+                bool on = idx < keep;                          // mode 0: the first `keep` CUs of every XCD
+                if (mode == 1) on = (idx % 4) != 3;            // mode 1: three of every four (75 %), interleaved
+                if (mode == 2) on = idx >= per - keep;         // mode 2: the last `keep`
+                if (on) mask[cu / 32] |= 1u << (cu % 32);
+            }
             if (hipExtStreamCreateWithCUMask(&e.tri, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
                 (void)hipGetLastError();
                 e.tri = nullptr;

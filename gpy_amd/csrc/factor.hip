@@ -56,14 +56,14 @@ void KernelProf::destroy() {
 // streams a process had created and destroyed before.  One fixed set makes the good case the only case; the calls of
 // different contexts are serialised on the main stream, which is what a saturated GPU does to them anyway.
 struct FactorEngine {
-    hipStream_t main = nullptr, panel = nullptr, tri = nullptr;
+    hipStream_t main = nullptr, panel = nullptr, tri = nullptr, tri_half = nullptr;
     int tri_pct = 0;
     bool ready = false;
 };
 static FactorEngine g_engine[16];
 static std::mutex g_engine_mutex;
 
-int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t* tri) {
+int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t* tri, hipStream_t* tri_half) {
     if (device < 0 || device >= 16) return -1;
     std::lock_guard<std::mutex> lock(g_engine_mutex);
     FactorEngine& e = g_engine[device];
@@ -96,11 +96,24 @@ int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t
             }
         }
         if (!e.tri) HIP_CHECK(hipStreamCreateWithPriority(&e.tri, hipStreamNonBlocking, least));
+        // fourth queue (fourth pipe): the same side stream on two of the four shader engines of every XCD, for
+        // factorisations whose early-inverse work is small next to what potrf still has to do
+        if (ncu % nx == 0) {
+            const int per = ncu / nx, keep = per / 2;
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int cu = 0; cu < ncu; ++cu)
+                if (cu / nx < keep) mask[cu / 32] |= 1u << (cu % 32);
+            if (hipExtStreamCreateWithCUMask(&e.tri_half, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                e.tri_half = nullptr;
+            }
+        }
         e.ready = true;
     }
     if (main) *main = e.main;
     if (panel) *panel = e.panel;
     if (tri) *tri = e.tri;
+    if (tri_half) *tri_half = e.tri_half;
     return 0;
 }
 
@@ -114,7 +127,7 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    if (factor_engine(dev, nullptr, &ws->st_panel, &ws->st_tri) != 0) return -1;    // shared, never destroyed by a workspace
+    if (factor_engine(dev, nullptr, &ws->st_panel, &ws->st_tri, &ws->st_tri_half) != 0) return -1;    // shared, never destroyed by a workspace
     {
         const char* envo = getenv("MI355GP_TRI_OVERLAP");
         if (envo && *envo) ws->tri_overlap = atoi(envo) ? 1 : 0;
@@ -186,6 +199,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     if (envt2 && *envt2) ws->trsm_lds = atoi(envt2);           // 0: operands from L2, 1: LDS-staged, 2: LDS-staged, two strips per wave
     const char* envso = getenv("MI355GP_SOLVE_OVERLAP");
     if (envso && *envso) ws->solve_overlap = atoi(envso) ? 1 : 0;
+    const char* envth = getenv("MI355GP_TRI_HALF");
+    if (envth && *envth) ws->tri_half_ok = atoi(envth) ? 1 : 0;
     const char* envx = getenv("MI355GP_DIAG_EXCL_FIRST");
     if (envx && *envx) ws->diag_excl_first = atoi(envx) ? 1 : 0;
     const char* envr = getenv("MI355GP_PANEL_REC");
@@ -262,6 +277,7 @@ void factor_ws_free(FactorWs* ws) {
     if (ws->diag_flags) (void)hipFree(ws->diag_flags);
     ws->diag_flags = nullptr;
     ws->st_tri = nullptr;
+    ws->st_tri_half = ws->st_tri_cur = nullptr;
     if (ws->ev_tri) (void)hipEventDestroy(ws->ev_tri);
     ws->ev_tri = nullptr;
     if (ws->ev_tri_lead) (void)hipEventDestroy(ws->ev_tri_lead);
@@ -592,6 +608,16 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
         }
         if (ws->tri_h_override > 0) h = ws->tri_h_override;
         if (h >= 8 && h < ntl && (h & (h - 1)) == 0) ovl_h = h;
+        // which side stream: three shader engines per XCD when the early work (leading inverse + top-level L21 X11) is
+        // about as long as the rest of potrf, two when it is much shorter (potrf is disturbed less; N=8192 -2 %,
+        // N=20480 -2 %, but N=16384 +1.6 % with two)
+        if (ovl_h > 0) {
+            const double lead = (double)ovl_h * NB, rest = (double)npad - lead, right = rest < lead ? rest : lead;
+            const double t_early = (lead * lead * lead / 3.0 + lead * lead * right) / 60e12;
+            const double t_tail = rest * rest * rest / 3.0 / 50e12 + rest / NBO * 0.45e-3;
+            ws->st_tri_cur = (ws->st_tri_half && ws->tri_half_ok && t_early < 0.8 * t_tail) ? ws->st_tri_half : ws->st_tri;
+            ws->tri_cur_pct = (ws->st_tri_cur == ws->st_tri_half) ? 50 : ws->tri_cu_pct;
+        }
     }
     ws->ovl_h = 0;
     ws->excl_first_ok = (ovl_h == 0 && ntl < ws->tri_min_nt) ? 1 : 0;   // small factorisations only (measured: N >= 8192 loses)
@@ -599,7 +625,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
         const long K0 = pcol(p), W = pcol(p + 1) - K0;
         (void)hipEventRecord(ws->ev_panel[p], sp);
         if (ovl_h > 0 && pcol(p + 1) == (long)ovl_h * NB) {       // columns < 128 h are final: start on their inverse
-            hipStream_t sq = ws->st_tri;
+            hipStream_t sq = ws->st_tri_cur ? ws->st_tri_cur : ws->st_tri;
             (void)hipStreamWaitEvent(sq, ws->ev_panel[p], 0);
             (void)hipMemsetAsync(ws->tri_counter, 0, sizeof(int) * 4, sq);
             launch_inv128(sq, A, ws->scratchX, npad, ovl_h, ws->dinv);
@@ -610,7 +636,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
             // machine-wide instance that trtri_device launches after potrf
             const int nt_pair = ntl < 2 * ovl_h ? ntl : 2 * ovl_h;
             launch_trtri_stage1_steal(sq, A, ws->scratchX, ws->scratchT, npad, nt_pair, level, ws->tri_counter,
-                                      ws->tri_wgs > 0 ? ws->tri_wgs : 512 * ws->tri_cu_pct / 100);
+                                      ws->tri_wgs > 0 ? ws->tri_wgs : 512 * ws->tri_cur_pct / 100);
             (void)hipEventRecord(ws->ev_tri, sq);
             ws->ovl_h = ovl_h;
         }

@@ -95,7 +95,8 @@ struct FactorWs {
     // trtri of the finished leading block + the top-level T21 = L21 X11 run on st_tri while potrf's chain-bound second
     // half leaves the GPU mostly idle (needs scratchX / scratchT = the X / T buffers of the trtri_device call that follows)
     int tri_overlap = FACTOR_DEFAULT_TRI_OVERLAP, tri_cu_pct = 75, tri_min_nt = 48, tri_wgs = 0, ovl_h = 0;
-    hipStream_t st_tri = nullptr;
+    hipStream_t st_tri = nullptr, st_tri_half = nullptr, st_tri_cur = nullptr;   // 75 % / 50 % of every XCD / the one in use
+    int tri_half_ok = 1, tri_cur_pct = 75;
     hipEvent_t ev_tri = nullptr, ev_tri_lead = nullptr;
     int* tri_counter = nullptr;
     int tri_h_override = 0;          // MI355GP_TRI_H: leading tiles inverted early (0 = time model)
@@ -114,7 +115,7 @@ struct FactorWs {
     KernelProf prof;
 };
 // the process-wide main / panel / tri streams of a device (created on first use, shared, never destroyed)
-int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t* tri);
+int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t* tri, hipStream_t* tri_half = nullptr);
 int factor_ws_alloc(FactorWs* ws, long npad);
 void factor_ws_free(FactorWs* ws);
 // A (npad x npad, ld = npad, lower) -> L in place.  Asynchronous; on return all work is ordered before later work on `st`.

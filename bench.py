@@ -92,33 +92,79 @@ def timed_region(comm, step_fn, steps, warmup):
     return comm.max_over_ranks(dt)
 
 
-def cpu_baseline(kind, ARD, D, n_sample, n_full):
-    """The oracle (NumPy/SciPy restatement of GPy's CPU path, oracle/gp_oracle.py) on the host cores, on a bounded
-    sample: one full iteration at N = n_sample, scaled to N = n_full by (n_full/n_sample)^3."""
+def _cpu_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def _oracle_seconds(kind, ARD, D, n):
+    from oracle import gp_oracle as O
+    X, Y = O.synthetic(n, D, seed=0)
+    var, ls, noise = O.default_theta(D, ARD)
+    t0 = time.perf_counter()
+    O.parameters_changed(kind, X, Y, var, ls, ARD, noise, cached=True)
+    return time.perf_counter() - t0
+
+
+def committed_cpu_record(kind, ARD, D, n_full):
+    """profiles/*cpu_baseline*.json: full-size measurements committed from earlier runs (direct N = n_full timing of the
+    port on a GPU box host; the reference's own code vs the port on the build container).  None if none matches."""
+    import glob
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cpu_baseline*.json"))):
+        try:
+            for rec in json.load(open(f)).get("records", []):
+                if (rec.get("kind"), bool(rec.get("ARD")), rec.get("D"), rec.get("N")) == (kind, bool(ARD), D, n_full):
+                    out.append(dict(rec, file=os.path.basename(f)))
+        except Exception:
+            pass
+    return out or None
+
+
+def cpu_baseline(kind, ARD, D, n_small, n_full, full=False):
+    """The oracle (NumPy/SciPy restatement of GPy's CPU path, oracle/gp_oracle.py; kind "port") on the host cores.
+    Default: a bounded sample -- one full iteration at TWO sizes (n_small, 2 n_small), the model t(N) = a N^2 + b N^3
+    fitted through both (the path is ~N^2 at these sizes: a dozen single-threaded N x N NumPy passes and the serial ARD
+    gradient loop; only dpotrf / dtrtri / dpotri are N^3 and multi-threaded) and evaluated at n_full.
+    full=True times n_full directly (minutes)."""
     from oracle import gp_oracle as O
     try:
         import subprocess
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
     except Exception:
         pass
-    X, Y = O.synthetic(n_sample, D, seed=0)
-    var, ls, noise = O.default_theta(D, ARD)
-    O.parameters_changed(kind, X[:512], Y[:512], var, ls, ARD, noise)        # warm BLAS threads
-    t0 = time.perf_counter()
-    O.parameters_changed(kind, X, Y, var, ls, ARD, noise, cached=True)
-    dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    scale = (float(n_full) / n_sample) ** 3
-    return {"value": 1.0 / (dt * scale), "unit": "iters/s", "cores": int(threads), "kind": "port",
-            "sample": "one full iteration of the NumPy/SciPy oracle (GPy's CPU algorithm, paramz-style K/r caching) at "
-                      "N=%d D=%d measured %.2f s on %d BLAS threads (host has %d cores; the ARD gradient loop is "
-                      "single-threaded as in GPy), scaled by (%d/%d)^3 to N=%d" % (
-                          n_sample, D, dt, threads, os.cpu_count() or 1, n_full, n_sample, n_full),
-            "measured_seconds": dt, "sample_N": n_sample}
+    _oracle_seconds(kind, ARD, D, 512)                                         # warm BLAS threads
+    threads = _cpu_threads()
+    rec = {"unit": "iters/s", "cores": int(threads), "kind": "port", "host_cores": os.cpu_count() or 1}
+    if full or 2 * n_small >= n_full:
+        dt = _oracle_seconds(kind, ARD, D, n_full)
+        rec.update(value=1.0 / dt, measured_seconds=dt, sample_N=n_full,
+                   sample="one full iteration of the NumPy/SciPy oracle (GPy's CPU algorithm, paramz-style K/r caching) "
+                          "timed directly at N=%d D=%d: %.1f s on %d BLAS threads" % (n_full, D, dt, threads))
+    else:
+        n1, n2 = n_small, 2 * n_small
+        t1, t2 = _oracle_seconds(kind, ARD, D, n1), _oracle_seconds(kind, ARD, D, n2)
+        # t = a N^2 + b N^3 through (n1, t1), (n2, t2)
+        b = (t2 / n2 ** 2 - t1 / n1 ** 2) / (n2 - n1)
+        a = t1 / n1 ** 2 - b * n1
+        if b < 0.0:                      # noise at tiny sizes: fall back to the pure N^2 law through the larger sample
+            a, b = t2 / n2 ** 2, 0.0
+        if a < 0.0:
+            a, b = 0.0, t2 / n2 ** 3
+        est = a * n_full ** 2 + b * n_full ** 3
+        rec.update(value=1.0 / est, estimated_seconds=est, fit={"a_N2": a, "b_N3": b, "n": [n1, n2], "seconds": [t1, t2]},
+                   sample="one full iteration of the NumPy/SciPy oracle (GPy's CPU algorithm, paramz-style K/r caching) "
+                          "at N=%d (%.2f s) and N=%d (%.2f s), D=%d, on %d BLAS threads of %d host cores; "
+                          "t = a N^2 + b N^3 fitted through both and evaluated at N=%d (%.0f s); the ARD gradient "
+                          "loop and the N x N NumPy passes are single-threaded as in GPy" % (
+                              n1, t1, n2, t2, D, threads, os.cpu_count() or 1, n_full, est))
+    committed = committed_cpu_record(kind, ARD, D, n_full)
+    if committed:
+        rec["committed_full_size"] = committed
+    return rec
 
 
 def profiled_traffic(kernel_prefix):
@@ -139,6 +185,80 @@ def profiled_traffic(kernel_prefix):
     return None
 
 
+def parity_gate(kind, ARD, D, device):
+    """no timing counts before parity.  A small same-kernel evaluation through the drop-in classes against
+    the CPU oracle (N = 2048, the bench's own D / kernel / ARD).  Returns the observed errors; raises on a miss."""
+    import gpy_amd
+    from oracle import gp_oracle as O
+    n = 2048
+    X, Y = O.synthetic(n, D, seed=3)
+    var, ls, noise = O.default_theta(D, ARD)
+    ref = O.parameters_changed(kind, X, Y, var, ls, ARD, noise)
+    cls = gpy_amd.kern.KERNEL_CLASSES[kind]
+    m = gpy_amd.GPRegression(X, Y, cls(D, variance=var, lengthscale=ls, ARD=ARD, device=device), noise_var=noise,
+                             device=device)
+    gref = np.concatenate([[ref["dvar"]], ref["dlen"], [ref["dL_dnoise"]]])
+    err = {"n": n, "lml_rel": abs(m.log_likelihood() - ref["lml"]) / abs(ref["lml"]),
+           "alpha_rel": float(np.linalg.norm(m.posterior.woodbury_vector - ref["alpha"]) / np.linalg.norm(ref["alpha"])),
+           "grad_rel": float(np.abs(m.gradient - gref).max() / np.abs(gref).max()), "against": "oracle (port)"}
+    m.inference_method._state.ctx.close()
+    if not (err["lml_rel"] <= 1e-10 and err["alpha_rel"] <= 1e-9 and err["grad_rel"] <= 1e-8):
+        raise SystemExit("bench.py: parity gate failed before timing: %r" % (err,))
+    return err
+
+
+def golden_check(kind, ARD, N, D, seed, lml, alpha, grad):
+    """If tests/golden holds the REFERENCE's outputs for exactly this workload (oracle/make_golden_baseline.py), compare
+    the timed configuration's own results with them.  None when there is no such fixture."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "tests", "golden", "baseline_c*.npz")):
+        g = np.load(f, allow_pickle=False)
+        if "M" in g.files or (str(g["kind"]), bool(g["ARD"]), int(g["N"]), int(g["D"]), int(g["seed"])) != (
+                kind, bool(ARD), N, D, seed):
+            continue
+        gref = np.concatenate([g["dvar"], g["dlen"], g["dnoise"]])
+        err = {"fixture": os.path.basename(f), "against": str(g["source"]),
+               "lml_rel": abs(lml - float(g["lml"])) / abs(float(g["lml"])),
+               "alpha_rel": float(np.linalg.norm(alpha - g["alpha"]) / np.linalg.norm(g["alpha"])),
+               "grad_rel": float(np.abs(grad - gref).max() / np.abs(gref).max())}
+        if not (err["lml_rel"] <= 1e-10 and err["alpha_rel"] <= 1e-9 and err["grad_rel"] <= 1e-8):
+            raise SystemExit("bench.py: the timed configuration disagrees with the reference golden: %r" % (err,))
+        return err
+    return None
+
+
+def grid_leg(comm, args, timeout=420.0):
+    """BASELINE configs[3] (RBF, N=32768, D=8) on the 2D block-cyclic grid over ALL ranks of this launch
+    (grid_shape(world); loopback transport when there is one process), run in CHILD processes with a timeout so that a
+    fault of the never-before-timed multi-GPU path cannot take the headline line down.  Returns the sub-record (rank 0)."""
+    import subprocess
+    from gpy_amd import grid as G
+    Pr, Pc = G.grid_shape(comm.world)
+    out_path = os.path.join(ROOT, "gpurun_out", "grid_leg_%s_%d.json" % (os.environ.get("MASTER_PORT", "0"), os.getpid()))
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    env = dict(os.environ, MI355GP_GRID_LEG_OUT=out_path if comm.rank == 0 else "",
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--grid", "%dx%d" % (Pr, Pc), "--n", str(args.grid_n), "--d", "8",
+           "--kind", "rbf", "--iso", "--steps", "3", "--warmup", "1", "--nb", str(args.nb), "--grid-child"]
+    rec = {"workload": "RBF iso exact GP N=%d D=8, one parameters_changed on a %dx%d block-cyclic grid" % (
+        args.grid_n, Pr, Pc)}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        ok = r.returncode == 0
+        err = (r.stderr or r.stdout)[-400:]
+    except subprocess.TimeoutExpired:
+        ok, err = False, "timed out after %.0f s" % timeout
+    if comm.rank != 0:
+        return None
+    if ok and os.path.exists(out_path):
+        rec.update(json.load(open(out_path)))
+        os.unlink(out_path)
+    else:
+        rec["error"] = err
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,8 +268,14 @@ def main():
     ap.add_argument("--d", type=int, default=WORKLOAD["D"])
     ap.add_argument("--kind", default=WORKLOAD["kind"])
     ap.add_argument("--iso", action="store_true", help="single lengthscale instead of ARD")
-    ap.add_argument("--cpu-sample-n", type=int, default=4096)
+    ap.add_argument("--cpu-sample-n", type=int, default=3072, help="the CPU baseline is timed at this N and at twice it")
+    ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline directly at the full N (minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true")
+    ap.add_argument("--no-grid-leg", action="store_true", help="skip the block-cyclic sub-record (configs[3])")
+    ap.add_argument("--grid-n", type=int, default=32768)
+    ap.add_argument("--grid-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--abi-only", action="store_true", help="time the bare C-ABI call instead of the drop-in classes")
     ap.add_argument("--grid", default="", help="PrxPc: ONE problem on a 2D block-cyclic process grid (RCCL panel "
                     "broadcasts, strong scaling) instead of the default independent replicas; with one process the "
                     "logical ranks share the GPU (loopback transport)")
@@ -165,30 +291,46 @@ def main():
 
     comm = Comm()
     assert comm.world == max(1, args.gpus) or comm.world == 1, "launch with torch.distributed.run for --gpus > 1"
+    import gpy_amd
     from gpy_amd import _lib as L
     from gpy_amd.datasets import default_theta, synthetic
 
     ARD = not args.iso
     N, D = args.n, args.d
+    parity = None
+    if not args.no_parity_gate:
+        parity = parity_gate(args.kind, ARD, D, comm.local_rank)       # every rank gates its own device
     X, Y = synthetic(N, D, seed=comm.rank)                    # every replica gets its own data set
     var, ls, noise = default_theta(D, ARD)
     theta = L.theta_vec(var, ls, ARD, D)
-    ctx = L.Context(comm.local_rank)
-    ctx.set_data(X, Y)
+    # ---- the drop-in path: GPRegression.parameters_changed through the reference's three call signatures ------------
+    kern = gpy_amd.kern.KERNEL_CLASSES[args.kind](D, variance=var, lengthscale=ls, ARD=ARD, device=comm.local_rank)
+    m = gpy_amd.GPRegression(X, Y, kern, noise_var=noise, device=comm.local_rank)
+    m.inference_method.collect_stage_ms = True
+    ctx = m.inference_method._state.ctx
     ctx.set_option("profile", ("update_nt", "lauum"))         # hipEvent pairs around every k_update_nt / k_lauum launch
+    x0 = m.param_array.copy()
     last = {}
 
-    def step():
+    def step_model():
+        # what an optimiser does: write the parameter vector, which runs parameters_changed (log_likelihood + all gradients)
+        m.param_array = x0
+        last["lml"], last["grad"] = m.log_likelihood(), m.gradient
+
+    def step_abi():
         info, r = ctx.exact_inference(args.kind, ARD, theta, noise, want_alpha=False, want_stage_ms=True)
         assert info == 0
         last["r"] = r
 
-    dt = timed_region(comm, step, args.steps, args.warmup)
+    dt = timed_region(comm, step_abi if args.abi_only else step_model, args.steps, args.warmup)
     n_gpus = comm.world
     its = n_gpus * args.steps / dt
+    out = None
     if comm.rank == 0:
-        r = last["r"]
-        st = r["stage_ms"]
+        if args.abi_only:
+            st, lml = last["r"]["stage_ms"], last["r"]["lml"]
+        else:
+            st, lml = m.inference_method.last_stage_ms, last["lml"]
         pf = ctx.get_profile()                                # last timed step
         upd_ms, upd_flops, upd_n = pf["update_nt"]
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
@@ -196,9 +338,11 @@ def main():
             "metric": "exact-GP log_lik+grad iters/sec", "value": its, "unit": "iters/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s %s exact GP, one parameters_changed (K build + Cholesky + alpha + LML + Ky^-1 + "
-                                   "all gradients), N=%d D=%d Dy=1 per GPU" % (args.kind, "ARD" if ARD else "iso", N, D),
-                       "N": N, "D": D, "kernel": args.kind, "ARD": ARD, "parallelism": "replicas x%d" % n_gpus},
+            "config": {"workload": "%s %s exact GP, one GPRegression parameters_changed (K build + Cholesky + alpha + LML + "
+                                   "Ky^-1 + all gradients), N=%d D=%d Dy=1 per GPU" % (args.kind, "ARD" if ARD else "iso", N, D),
+                       "N": N, "D": D, "kernel": args.kind, "ARD": ARD, "parallelism": "replicas x%d" % n_gpus,
+                       "path": "C-ABI only" if args.abi_only else "drop-in classes (gpy_amd.GPRegression: param_array "
+                               "write -> parameters_changed -> log_likelihood + gradient)"},
             "cholesky_gflops": (N ** 3 / 3.0) / (st["potrf"] * 1e-3) / 1e9,
             "cholesky_frac_of_fp64_peak": (N ** 3 / 3.0) / (st["potrf"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
             "iteration_tflops": float(N) ** 3 / (st["total"] * 1e-3) / 1e12,
@@ -210,22 +354,43 @@ def main():
                          "traffic": profiled_traffic("k_update_nt") if (N, D, args.kind) == (16384, 32, "matern52")
                          else None,
                          "launches_per_step": upd_n, "avg_launch_ms": upd_ms / max(upd_n, 1),
-                         "algorithmic_flops_per_step": upd_flops,
-                         "note": ("launch durations include the time k_update_nt shares the GPU with the overlapped "
-                                  "inverse of the leading block" +
-                                  (" (MI355GP_TRI_OVERLAP=0: 0.57)" if (N, D, args.kind) == (16384, 32, "matern52") else ""))
-                         if N >= 6144 else None},
+                         "algorithmic_flops_per_step": upd_flops},
             # the same tile-GEMM device routine in its single uncontended launch (W = X^T X, N^3/3 flops)
             "roofline_k_lauum": {"achieved": pf["lauum"][1] / (pf["lauum"][0] * 1e-3) / 1e12 if pf["lauum"][0] > 0 else 0.0,
                                  "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                                  "frac": (pf["lauum"][1] / (pf["lauum"][0] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS)
                                  if pf["lauum"][0] > 0 else 0.0},
-            "lml": r["lml"],
+            "lml": lml,
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.kind, ARD, D, min(args.cpu_sample_n, N), N)
-        print(json.dumps(out), flush=True)
+        if not args.abi_only:
+            # host overhead of the drop-in classes: the same evaluation through the bare C-ABI, same context, same data
+            k2 = max(3, min(args.steps, 10))
+            step_abi()
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                step_abi()
+            abi_ms = 1e3 * (time.perf_counter() - t0) / k2
+            out["host_path"] = {"drop_in_ms_per_step": out["ms_per_step"], "abi_ms_per_step": abi_ms,
+                                "overhead_frac": out["ms_per_step"] / abi_ms - 1.0, "abi_steps": k2}
+            step_model()
+        out["parity_checked"] = parity is not None
+        if parity is not None:
+            out["parity"] = {"gate": parity}
+            if not args.abi_only:
+                g = golden_check(args.kind, ARD, N, D, 0, last["lml"], m.posterior.woodbury_vector, last["grad"])
+                if g is not None:
+                    out["parity"]["timed_config_vs_reference"] = g
     ctx.close()
+    del m
+    if not args.no_grid_leg:
+        comm.barrier()
+        rec = grid_leg(comm, args)
+        if out is not None:
+            out["grid"] = rec
+    if comm.rank == 0:
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.kind, ARD, D, min(args.cpu_sample_n, N // 2), N, full=args.cpu_full)
+        print(json.dumps(out), flush=True)
     comm.close()
 
 
@@ -319,6 +484,18 @@ def main_grid(args):
             "stage_ms": {k: round(float(v), 4) for k, v in r["stage_ms"].items()},
             "comm_bytes_per_step": traffic, "lml": r["lml"],
         }
+        gc = golden_check(args.kind, ARD, N, D, 0, r["lml"], r["alpha"],
+                          np.concatenate([r["dtheta"], [r["dnoise"]]]))
+        if gc is not None:
+            out["parity_vs_golden"] = gc
+        leg = os.environ.get("MI355GP_GRID_LEG_OUT", "")
+        if leg:                                               # child of the default bench: hand the sub-record back
+            keep = ("ms_per_step", "value", "n_gpus", "scaling", "iteration_tflops", "iteration_frac_of_fp64_peak",
+                    "stage_ms", "comm_bytes_per_step", "lml", "parity_vs_golden", "steps", "warmup")
+            sub = {k: out[k] for k in keep if k in out}
+            sub.update(grid="%dx%d" % (Pr, Pc), nb=args.nb, transport="loopback" if g.is_loopback else "RCCL", N=N)
+            with open(leg, "w") as f:
+                json.dump(sub, f)
         print(json.dumps(out), flush=True)
     g.close()
     comm.close()

@@ -9,11 +9,11 @@ HIP kernel in gpy_amd/csrc.  No PyTorch, no NumPy fallback: without an MI355X th
 from . import _lib
 from ._lib import MI355GPError, build, device_count
 from .inference import ExactGaussianInference, ExactStudentTInference
-from .kern import RBF, Add, Prod, Bias, Exponential, Matern32, Matern52, Stationary, White
-from .likelihoods import Gaussian
+from .kern import RBF, Add, Prod, Bias, ExpQuad, Exponential, Matern32, Matern52, Stationary, White
+from .likelihoods import Gaussian, HeteroscedasticGaussian
 from .models import GP, GPRegression
-from .posterior import PosteriorExact
+from .posterior import PosteriorExact, StudentTPosterior
 from .sparse import SparseGP, SparseGPRegression, VarDTC
 
-__all__ = ["RBF", "Matern52", "Matern32", "Exponential", "Stationary", "White", "Bias", "Add", "Prod", "Gaussian", "ExactGaussianInference", "ExactStudentTInference",
+__all__ = ["RBF", "ExpQuad", "HeteroscedasticGaussian", "StudentTPosterior", "Matern52", "Matern32", "Exponential", "Stationary", "White", "Bias", "Add", "Prod", "Gaussian", "ExactGaussianInference", "ExactStudentTInference",
            "PosteriorExact", "GP", "GPRegression", "VarDTC", "SparseGP", "SparseGPRegression", "MI355GPError", "build", "device_count"]

@@ -62,6 +62,7 @@ struct mi355gp_ctx {
     hipEvent_t ev[8] = {};
     // state of the last inference call (for fetch / predict)
     bool have_factor = false, have_kernel = false;
+    bool studentt = false;              // the last call was a Student-t process: dL_dK's alpha alpha^T term is scaled by dScal[4]
     KernParams kp = {0, 0, 0, 1.0};
     std::vector<double> theta;
     // The covariance function of the last fused call as a SUM of parts (GPy/kern/src/add.py; one part = plain kernel).
@@ -314,6 +315,7 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
         return info[0];
     }
     c->have_factor = true;
+    c->studentt = studentt_nu > 0.0;
     const double datafit = scal[0], alpha2 = scal[1], trw = scal[2], logdet = scal[3];
     const double Dy = (double)c->Dy;
     for (int i = 0; i < MI355GP_NUM_OUT; ++i) out_scalars[i] = 0.0;
@@ -556,7 +558,7 @@ int mi355gp_fetch(mi355gp_ctx* c, int which, double* out, int fortran_order) {
     } else if (which == MI355GP_FETCH_KINV) {
         launch_extract(st, c->C, np, n, 1, nullptr, 0, tmp, 0);
     } else if (which == MI355GP_FETCH_DLDK) {
-        launch_extract(st, c->C, np, n, 2, c->dAlpha, c->Dy, tmp, 0);
+        launch_extract(st, c->C, np, n, 2, c->dAlpha, c->Dy, tmp, 0, c->studentt ? c->dScal + 4 : nullptr);
     } else {
         mi355gp_set_error("mi355gp_fetch: unknown matrix id %d", which);
         rc = -1;

@@ -8,6 +8,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define NB 128            // base block: diagonal blocks, GEMM tiles and padding granule
 #define NBO 512           // outer panel width of the two-level right-looking Cholesky
+#define FACTOR_NBO_SMALL_N 0      // npad up to which the outer panels are FACTOR_NBO_SMALL wide (0: never)
+#define FACTOR_NBO_SMALL 256
 #define FACTOR_DEFAULT_RESERVE_CUS 0
 #define FACTOR_DEFAULT_TRI_OVERLAP 1    // 1: inverse of the leading block overlapped with the second half of potrf
 #define FACTOR_DEFAULT_DIAG_EXCL_FIRST 1   // small factorisations only (N < 6144): from N = 8192 on it measured slower

@@ -181,6 +181,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
         }
         HIP_CHECK(hipEventCreateWithFlags(&ws->ev_rest, hipEventDisableTiming));
     }
+    const char* envnbo = getenv("MI355GP_NBO");
+    if (envnbo && *envnbo) ws->nbo_override = atoi(envnbo);
     const char* envw = getenv("MI355GP_PART2_WGS");
     if (envw && *envw) ws->part2_wgs = atoi(envw);
     const char* envt = getenv("MI355GP_PART2_TILES");
@@ -230,7 +232,7 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     for (int i = 0; i < ws->n_upd; ++i) HIP_CHECK(hipEventCreateWithFlags(&ws->ev_join[i], hipEventDisableTiming));
     // the chunk-update streams themselves are created by potrf_chunked on first use (option LOOKAHEAD = 2 only)
     HIP_CHECK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
-    const size_t nouter = (size_t)(npad + NBO - 1) / NBO + 2;
+    const size_t nouter = (size_t)(npad + NB - 1) / NB + 2;      // enough for the narrowest outer panel (nbo = 128)
     ws->ev_panel.resize(nouter);
     ws->ev_cols.resize(nouter);
     for (size_t i = 0; i < nouter; ++i) {
@@ -504,8 +506,9 @@ static void update_cols(hipStream_t s, double* A, long npad, long K0, long W, lo
 //     the latency-bound diag/trsm chain hides behind MFMA-bound work.
 static void potrf_chunked(hipStream_t st, double* A, long npad, FactorWs* ws) {
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
-    const long P = (npad + NBO - 1) / NBO;                       // outer panels
-    auto pcol = [&](long p) { return (p * NBO < npad) ? p * NBO : npad; };
+    const long nbo = ws->nbo_for(npad);
+    const long P = (npad + nbo - 1) / nbo;                       // outer panels
+    auto pcol = [&](long p) { return (p * nbo < npad) ? p * nbo : npad; };
     if (!ws->lookahead) {                                        // reference schedule: everything in order on st
         for (long p = 0; p < P; ++p) {
             factor_panel(st, A, npad, pcol(p), pcol(p + 1) - pcol(p), ws);
@@ -577,8 +580,9 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     ws->diag_server_on = (ws->diag_server && ws->diag_flags && ws->st_diag && !ws->panel_inv && !ws->panel_split &&
                           !ws->panel_fused && npad / NB == ws->nblk) ? 1 : 0;
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
-    const long P = (npad + NBO - 1) / NBO;
-    auto pcol = [&](long p) { return (p * NBO < npad) ? p * NBO : npad; };
+    const long nbo = ws->nbo_for(npad);
+    const long P = (npad + nbo - 1) / nbo;
+    auto pcol = [&](long p) { return (p * nbo < npad) ? p * nbo : npad; };
     hipStream_t sp = ws->st_panel;
     hipStream_t su = ws->st_bulk ? ws->st_bulk : st;            // trailing updates (CU-masked when an express lane is set)
     (void)hipEventRecord(ws->ev_fork, st);                      // panel 0 follows everything queued on st so far
@@ -603,7 +607,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
         for (; h >= 8; h /= 2) {
             const double lead = (double)h * NB, rest = (double)npad - lead;
             const double t_lead = lead * lead * lead / 3.0 / 45e12;
-            const double t_tail = rest * rest * rest / 3.0 / 50e12 + rest / NBO * 0.45e-3;
+            const double t_tail = rest * rest * rest / 3.0 / 50e12 + rest / (double)nbo * 0.45e-3 * ((double)nbo / NBO);
             if (t_lead <= t_tail) break;
         }
         if (ws->tri_h_override > 0) h = ws->tri_h_override;
@@ -614,7 +618,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
         if (ovl_h > 0) {
             const double lead = (double)ovl_h * NB, rest = (double)npad - lead, right = rest < lead ? rest : lead;
             const double t_early = (lead * lead * lead / 3.0 + lead * lead * right) / 60e12;
-            const double t_tail = rest * rest * rest / 3.0 / 50e12 + rest / NBO * 0.45e-3;
+            const double t_tail = rest * rest * rest / 3.0 / 50e12 + rest / (double)nbo * 0.45e-3 * ((double)nbo / NBO);
             ws->st_tri_cur = (ws->st_tri_half && ws->tri_half_ok && t_early < 0.8 * t_tail) ? ws->st_tri_half : ws->st_tri;
             ws->tri_cur_pct = (ws->st_tri_cur == ws->st_tri_half) ? 50 : ws->tri_cu_pct;
         }

@@ -75,6 +75,15 @@ struct FactorWs {
     std::vector<hipEvent_t> ev_cols;         // [p]: every update of panel p's columns has been issued (-> its factorisation)
     hipEvent_t ev_fork = nullptr, ev_join[MAX_UPD] = {};
     int lookahead = 1;
+    // outer panel width of the two-level right-looking Cholesky: NBO (512) keeps the big trailing update at 64 flop per
+    // byte of C traffic; small factorisations are bound by the panel chain and the K = nbo "part 1" update on it, so
+    // they take narrower outer panels (MI355GP_NBO overrides; a multiple of 128)
+    int nbo_override = 0;
+    long nbo_for(long npad) const {
+        long w = nbo_override > 0 ? nbo_override : (npad <= FACTOR_NBO_SMALL_N ? FACTOR_NBO_SMALL : NBO);
+        w = (w / NB) * NB;
+        return w < NB ? NB : w;
+    }
     // Optional scratch for the inverse-based panel solve (factor.hip: factor_panel_inv): two npad x npad buffers with the
     // same leading dimension as A that are free during the factorisation (the context's X = L^-1 and W buffers).
     // nullptr -> the trsm128-based panel path.
@@ -199,9 +208,9 @@ void launch_scalars(hipStream_t st, const double* alpha, const double* R, const 
                     int Dy, const double* logsum, long nblk, double* out4, double* diag_out);
 // dense n x n host-shaped outputs from padded device matrices
 //   mode 0: lower triangle of A, strict upper zero;  1: symmetric mirror of lower(A);
-//   2: 0.5*(alpha alpha^T - Dy * sym(A));  transpose != 0 writes the transpose (Fortran order)
+//   2: 0.5*(s * alpha alpha^T - Dy * sym(A)), s = aa_scale[0] (device) or 1;  transpose != 0 writes the transpose
 void launch_extract(hipStream_t st, const double* A, long ld, long n, int mode, const double* alpha, int Dy,
-                    double* out, int transpose);
+                    double* out, int transpose, const double* aa_scale = nullptr);
 void launch_pad_from_dense(hipStream_t st, const double* src, long n, double* A, long npad, const double* noise,
                            long noise_len, double jit);
 // column reductions over a (rows x ld) matrix: mode 0: out[j*Dy+d] = sum_i M[i][j]*v[i*Dy+d]; mode 1: out[j] = c0 - sum_i M[i][j]^2

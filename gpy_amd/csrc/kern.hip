@@ -790,7 +790,7 @@ void launch_scalars(hipStream_t st, const double* alpha, const double* R, const 
 // ------------------------------------------------------------------------------------------------
 // dense host-shaped views of padded device matrices (lazy fetch path; PCIe-bound, not on the hot loop)
 __global__ void k_extract(const double* __restrict__ A, long ld, long n, int mode, const double* __restrict__ alpha,
-                          int Dy, double* __restrict__ out, int transpose) {
+                          int Dy, double* __restrict__ out, int transpose, const double* __restrict__ aa_scale) {
     const long nbx = (n + 255) / 256;
     const long i = blockIdx.x / nbx;
     const long j = (blockIdx.x - i * nbx) * 256 + threadIdx.x;
@@ -804,16 +804,17 @@ __global__ void k_extract(const double* __restrict__ A, long ld, long n, int mod
         if (mode == 2) {
             double aa = 0.0;
             for (int d = 0; d < Dy; ++d) aa = fma(alpha[i * Dy + d], alpha[j * Dy + d], aa);
-            v = 0.5 * (aa - (double)Dy * v);
+            // Student-t process: the alpha alpha^T term carries (nu+N)/(nu+beta-2) (exact_studentt_inference.py:46)
+            v = 0.5 * ((aa_scale ? aa_scale[0] : 1.0) * aa - (double)Dy * v);
         }
     }
     if (transpose) out[j * n + i] = v; else out[i * n + j] = v;
 }
 
 void launch_extract(hipStream_t st, const double* A, long ld, long n, int mode, const double* alpha, int Dy,
-                    double* out, int transpose) {
+                    double* out, int transpose, const double* aa_scale) {
     hipLaunchKernelGGL(k_extract, dim3((unsigned)(((n + 255) / 256) * n)), dim3(256), 0, st, A, ld, n, mode, alpha, Dy,
-                       out, transpose);
+                       out, transpose, aa_scale);
 }
 
 // A (npad x npad) <- dense src (n x n) + diag(noise + jit); identity in the padding

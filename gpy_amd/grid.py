@@ -23,6 +23,19 @@ FETCH_L, FETCH_LINV = 0, 100
 ID_BYTES = 128
 
 
+def _process_start():
+    """Wall-clock start of this process (an id file older than this belongs to an earlier job)."""
+    import time
+    try:
+        import psutil
+        return psutil.Process().create_time()
+    except Exception:
+        return time.time()
+
+
+_PROCESS_START = _process_start()
+
+
 # ---- 2D block-cyclic index algebra (mirrors csrc/grid.hip) ----------------------------------------------------
 def grid_shape(world):
     """Most square Pr x Pc with Pr <= Pc and Pr*Pc == world (8 -> 2 x 4)."""
@@ -94,20 +107,46 @@ def exchange_id_torch(id_bytes, rank):
     return bytes(t.cpu().tolist())
 
 
-def exchange_id_file(id_bytes, rank, path, timeout=120.0):
-    """Rank 0 writes the id to `path` (atomically); the others poll for it."""
+def exchange_id_file(id_bytes, rank, path, timeout=120.0, world=None):
+    """Rank 0 writes the id to `path` (atomically, mode 0600); the others poll for it.  A file is only accepted if it was
+    written no earlier than 30 s before this process started (a left-over of an earlier, crashed job is ignored); with `world` given,
+    every reader drops an acknowledgement next to it and rank 0 removes the files once all have read."""
     import time
+    t_start = _PROCESS_START
     if rank == 0:
+        for old in (path,):
+            try:
+                os.unlink(old)
+            except OSError:
+                pass
         tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(id_bytes)
         os.replace(tmp, path)
+        if world:
+            t0 = time.time()
+            acks = [path + ".ack%d" % r for r in range(1, world)]
+            while time.time() - t0 < timeout and not all(os.path.exists(a) for a in acks):
+                time.sleep(0.02)
+            for a in acks + [path]:
+                try:
+                    os.unlink(a)
+                except OSError:
+                    pass
         return id_bytes
     t0 = time.time()
     while time.time() - t0 < timeout:
-        if os.path.exists(path) and os.path.getsize(path) == ID_BYTES:
-            with open(path, "rb") as f:
-                return f.read()
+        try:
+            st = os.stat(path)
+            if st.st_size == ID_BYTES and st.st_mtime >= t_start - 30.0:
+                with open(path, "rb") as f:
+                    data = f.read()
+                if world:
+                    open(path + ".ack%d" % rank, "wb").close()
+                return data
+        except OSError:
+            pass
         time.sleep(0.05)
     raise _lib.MI355GPError("timed out waiting for the RCCL id at %s" % path)
 
@@ -154,9 +193,13 @@ class GridContext(object):
                 if use_torch:
                     idb = exchange_id_torch(idb, rank)
                 else:
-                    d = os.environ.get("MI355GP_ID_DIR", "/tmp")
-                    tag = os.environ.get("MASTER_PORT", "0")
-                    idb = exchange_id_file(idb, rank, os.path.join(d, "mi355gp_id_%s" % tag))
+                    # per-user private directory; the file name carries the launcher's job identity (torchrun exports
+                    # TORCHELASTIC_RUN_ID; MASTER_PORT otherwise) so concurrent jobs never read each other's id
+                    d = os.environ.get("MI355GP_ID_DIR") or os.path.join(
+                        os.environ.get("XDG_RUNTIME_DIR") or os.path.expanduser("~"), ".mi355gp")
+                    os.makedirs(d, mode=0o700, exist_ok=True)
+                    tag = "%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "job"), os.environ.get("MASTER_PORT", "0"))
+                    idb = exchange_id_file(idb, rank, os.path.join(d, "mi355gp_id_%s" % tag), world=world)
             else:
                 idb = exchange(idb, rank)
         return cls(local, rank, world, Pr, Pc, nb, idb)

@@ -15,7 +15,7 @@ from . import _lib
 from .kern import CombinationKernel, Stationary
 from .lazy import DeviceResult, kernel_signature
 from .likelihoods import Gaussian
-from .posterior import PosteriorExact
+from .posterior import PosteriorExact, StudentTPosterior
 
 LinAlgError = np.linalg.LinAlgError
 
@@ -27,16 +27,33 @@ class _DeviceState(object):
         self.ctx = _lib.Context(device)
         self.X = None
         self.R = None
+        self._tokX = self._tokR = None
         self.call_token = 0
         self.kern = None
 
+    def __getstate__(self):              # the HBM buffers and the ctypes handle never travel
+        return {"X": None, "R": None, "_tokX": None, "_tokR": None, "call_token": self.call_token, "kern": None,
+                "ctx": None}
+
+    @staticmethod
+    def _token(a):
+        """O(1) identity token of a host array: the object, its buffer address / shape / strides and 64 strided samples.
+        GPy hands the SAME immutable `ObsAr` X (and the same Y) to every iteration of an optimisation
+        (reference `core/gp.py:44-60`), so the per-iteration check must not cost O(N D) like `np.array_equal` does."""
+        flat = a.reshape(-1)
+        step = max(1, flat.size // 64)
+        return (id(a), a.__array_interface__["data"][0], a.shape, a.strides, flat[::step][:64].tobytes())
+
     def ensure_data(self, X, R):
-        if self.X is None or self.X.shape != X.shape or self.R.shape != R.shape or not np.array_equal(self.X, X):
+        tx, tr = self._token(X), self._token(R)
+        same_x = self.X is not None and (tx == self._tokX or (self.X.shape == X.shape and np.array_equal(self.X, X)))
+        if not same_x or self.R.shape != R.shape:
             self.ctx.set_data(X, R)
             self.X, self.R = X.copy(), R.copy()
-        elif not np.array_equal(self.R, R):
+        elif not (tr == self._tokR or np.array_equal(self.R, R)):
             self.ctx.set_targets(R)
             self.R = R.copy()
+        self._tokX, self._tokR = tx, tr
 
     def fetch(self, which, fortran_order=False):
         return self.ctx.fetch(which, fortran_order=fortran_order)
@@ -77,6 +94,7 @@ class ExactGaussianInference(object):
     def __getstate__(self):          # device handles never travel (cf. reference rbf.py:313-318)
         d = dict(self.__dict__)
         d["_state"] = None
+        d["_last"] = None            # holds the device state of the last call
         return d
 
     def LOO(self, kern, X, Y, likelihood, posterior, Y_metadata=None, K=None):
@@ -113,11 +131,11 @@ class ExactGaussianInference(object):
                   Z_tilde=None):
         X = np.asarray(X)
         Y = np.asarray(Y, dtype=np.float64)
-        m = 0 if mean_function is None else mean_function.f(X)
         if variance is None:
             variance = likelihood.gaussian_variance(Y_metadata)
         noise = np.atleast_1d(np.asarray(variance, dtype=np.float64)).ravel()
-        R = _lib.f64(Y - m)
+        # (reference :42-50) R = Y - m; without a mean function R IS Y (same object every iteration: O(1) data check)
+        R = _lib.f64(Y) if mean_function is None else _lib.f64(Y - mean_function.f(X))
         n = X.shape[0]
         is_sum = isinstance(kern, CombinationKernel)
         fused = K is None and (isinstance(kern, Stationary) or is_sum)
@@ -241,8 +259,10 @@ class ExactStudentTInference(object):
         dL_dnu *= 0.5
         sig = kernel_signature(kern)
         dL_dK = DeviceResult(st, _lib.FETCH_DLDK, N, st.call_token, kernel_sig=sig, fused_dtheta=r["dtheta"])
-        post = PosteriorExact(woodbury_chol=DeviceResult(st, _lib.FETCH_L, N, st.call_token, fortran_order=True),
-                              woodbury_vector=r["alpha"], K=DeviceResult(st, _lib.FETCH_K, N, st.call_token),
-                              woodbury_inv=DeviceResult(st, _lib.FETCH_KINV, N, st.call_token), state=st)
-        post.nu = nu
+        # beta of the reference's StudentTPosterior is sum(alpha * K alpha) = sum(alpha * R) - jitter |alpha|^2 (posterior.py:345)
+        beta_post = beta - (1e-8 + extra) * float(np.sum(r["alpha"] ** 2))
+        post = StudentTPosterior(deg_free=nu, beta=beta_post,
+                                 woodbury_chol=DeviceResult(st, _lib.FETCH_L, N, st.call_token, fortran_order=True),
+                                 woodbury_vector=r["alpha"], K=DeviceResult(st, _lib.FETCH_K, N, st.call_token),
+                                 woodbury_inv=DeviceResult(st, _lib.FETCH_KINV, N, st.call_token), state=st)
         return post, r["lml"], {"dL_dK": dL_dK, "dL_dnu": dL_dnu, "dL_dm": r["scale"] * r["alpha"]}

@@ -15,6 +15,42 @@ from .lazy import DeviceResult
 from .param import Param, Parameterized
 
 
+class _KCache(object):
+    """`@Cache_this(limit=3)` of the reference's `Stationary.K` (`stationary.py:96-105`, paramz `Cacher`): the last
+    `limit` results keyed by the identity of (X, X2) and the exact parameter bits, so the K that the inference step
+    evaluated is not recomputed (upload + build + download) when the gradient / prediction step asks for it again.
+    paramz invalidates through `ObsAr` observers; here an entry carries an O(1) fingerprint of its inputs (buffer
+    address, shape, strides and 64 strided samples) that is re-checked on every hit."""
+
+    def __init__(self, limit=3):
+        self.limit = limit
+        self.entries = []            # [(key, value)], most recent last
+
+    @staticmethod
+    def _fp(a):
+        if a is None:
+            return None
+        flat = a.reshape(-1)
+        step = max(1, flat.size // 64)
+        return (id(a), a.__array_interface__["data"][0], a.shape, a.strides, flat[::step][:64].tobytes())
+
+    def get(self, X, X2, theta, compute):
+        key = (self._fp(X), self._fp(X2), theta.tobytes())
+        for i, (k, v) in enumerate(self.entries):
+            if k == key:
+                self.entries.append(self.entries.pop(i))
+                return v
+        v = compute()
+        v.setflags(write=False)      # shared between callers, like paramz's cached arrays
+        self.entries.append((key, v))
+        if len(self.entries) > self.limit:
+            self.entries.pop(0)
+        return v
+
+    def clear(self):
+        self.entries = []
+
+
 class Stationary(Parameterized):
     kind = None                # name understood by the C-ABI
     _gpy_class = None          # "class" string for to_dict (resolvable by GPy's loader)
@@ -50,6 +86,12 @@ class Stationary(Parameterized):
         self.lengthscale = Param("lengthscale", lengthscale)
         assert self.variance.size == 1
         self.link_parameters(self.variance, self.lengthscale)
+        self._K_cache = _KCache(limit=3)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_K_cache"] = _KCache(limit=3)
+        return d
 
     # ---- helpers ---------------------------------------------------------------------------------
     def _slice_X(self, X):
@@ -65,10 +107,16 @@ class Stationary(Parameterized):
 
     # ---- the hot-path interface -----------------------------------------------------------------------
     def K(self, X, X2=None):
-        """Covariance matrix K(X, X2) (reference `stationary.py:105-115`)."""
-        Xs = self._slice_X(X)
-        X2s = None if X2 is None else self._slice_X(X2)
-        return _lib.kern_K(self.kind, self.ARD, self._theta(), Xs, X2s, device=self.device)
+        """Covariance matrix K(X, X2) (reference `stationary.py:105-115`, `@Cache_this(limit=3)` :105)."""
+        X = np.asarray(X)
+        X2 = None if X2 is None else np.asarray(X2)
+        theta = self._theta()
+
+        def compute():
+            Xs = self._slice_X(X)
+            X2s = None if X2 is None else self._slice_X(X2)
+            return _lib.kern_K(self.kind, self.ARD, theta, Xs, X2s, device=self.device)
+        return self._K_cache.get(X, X2, theta, compute)
 
     def Kdiag(self, X):
         """(reference `stationary.py:170-173`)"""
@@ -170,6 +218,16 @@ class RBF(Stationary):
         d = super(RBF, self).to_dict()
         d["inv_l"] = self.use_invLengthscale
         return d
+
+
+class ExpQuad(Stationary):
+    """The exponentiated quadratic k(r) = variance * exp(-r^2/2) (reference `stationary.py:623-662`): the same
+    function as `RBF` without the psi-statistics / `inv_l` extras; serialises as "GPy.kern.ExpQuad"."""
+    kind = "rbf"
+    _gpy_class = "GPy.kern.ExpQuad"
+
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="ExpQuad", **kw):
+        super(ExpQuad, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name, **kw)
 
 
 class Matern52(Stationary):
@@ -434,5 +492,5 @@ class Prod(CombinationKernel):
         return {"class": "GPy.kern.Prod", "name": self.name, "parts": [p.to_dict() for p in self.parts]}
 
 
-KERNEL_CLASSES = {"rbf": RBF, "matern52": Matern52, "matern32": Matern32, "exponential": Exponential,
+KERNEL_CLASSES = {"rbf": RBF, "expquad": ExpQuad, "matern52": Matern52, "matern32": Matern32, "exponential": Exponential,
                   "white": White, "bias": Bias}

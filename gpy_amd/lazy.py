@@ -29,11 +29,24 @@ class DeviceResult(object):
     dtype = np.dtype(np.float64)
     size = property(lambda self: self._n * self._n)
 
+    def __getstate__(self):
+        """Pickling materialises the host copy (while the device still holds it) and drops the device handle."""
+        d = dict(self.__dict__)
+        if d["_host"] is None and d["_ctx"] is not None:
+            try:
+                d["_host"] = self.fetch()
+            except Exception:
+                d["_host"] = None
+        d["_ctx"] = None
+        return d
+
     def matches_kernel(self, kern):
         return self.fused_dtheta is not None and self._kernel_sig == kernel_signature(kern)
 
     def fetch(self):
         if self._host is None:
+            if self._ctx is None:
+                raise RuntimeError("this result was detached from its device context (unpickled) before being fetched")
             if self._ctx.call_token != self._token:
                 raise RuntimeError("this device-resident result was overwritten by a later inference call; "
                                    "materialise it (np.asarray) before re-running inference")

@@ -29,3 +29,32 @@ class Gaussian(Parameterized):
 
     def to_dict(self):
         return {"class": "GPy.likelihoods.Gaussian", "name": self.name, "variance": self.variance.values.tolist()}
+
+
+class HeteroscedasticGaussian(Gaussian):
+    """One noise variance per data point (reference `GPy/likelihoods/gaussian.py:347-371`): `variance` has as many entries
+    as `Y_metadata['output_index']`, `gaussian_variance` hands the length-N vector to the inference call (the device adds it
+    to the diagonal of K) and the noise gradients are the matching entries of diag(dL_dK), which the device returns as an
+    N-vector (`mi355gp_exact_inference(..., diag_dLdK_out)`)."""
+
+    def __init__(self, Y_metadata, variance=1., name="het_Gauss"):
+        n = np.asarray(Y_metadata["output_index"]).shape
+        Parameterized.__init__(self, name)
+        self.variance = Param("variance", np.ones(n).ravel() * variance)
+        self.link_parameter(self.variance)
+
+    def gaussian_variance(self, Y_metadata=None):
+        return self.variance.values[np.asarray(Y_metadata["output_index"]).flatten()]
+
+    def exact_inference_gradients(self, dL_dKdiag, Y_metadata=None):
+        return np.asarray(dL_dKdiag)[np.asarray(Y_metadata["output_index"]).flatten()]
+
+    def predictive_values(self, mu, var, full_cov=False, Y_metadata=None):
+        s = self.variance.values[np.asarray(Y_metadata["output_index"]).flatten()]
+        if full_cov:
+            return mu, var + np.eye(var.shape[0]) * s
+        return mu, var + s[:, None]
+
+    def to_dict(self):
+        return {"class": "GPy.likelihoods.HeteroscedasticGaussian", "name": self.name,
+                "variance": self.variance.values.tolist()}

@@ -15,6 +15,11 @@ class PosteriorExact(object):
         self._prior_mean = prior_mean
         self._mean = None
 
+    def __getstate__(self):          # device handles never travel; the lazy members materialise themselves
+        d = dict(self.__dict__)
+        d["_state"] = None
+        return d
+
     @property
     def woodbury_chol(self):
         return self._woodbury_chol
@@ -49,3 +54,19 @@ class PosteriorExact(object):
         if self._state is None:
             raise RuntimeError("this posterior is not attached to a device context")
         return self._state.covariance_between_points(kern, X1, X2)
+
+
+class StudentTPosterior(PosteriorExact):
+    """Posterior of a Student-t PROCESS (reference `posterior.py:338-349`): the Gaussian predictive (co)variance scaled by
+    (nu + beta - 2) / (nu + N - 2), beta = sum(alpha * R)."""
+
+    def __init__(self, deg_free, beta=None, **kwargs):
+        super(StudentTPosterior, self).__init__(**kwargs)
+        self.nu = deg_free
+        self._beta = beta            # sum(woodbury_vector * mean) as reduced on the device; None -> recompute on the host
+
+    def _raw_predict(self, kern, Xnew, pred_var, full_cov=False):
+        mu, var = super(StudentTPosterior, self)._raw_predict(kern, Xnew, pred_var, full_cov)
+        beta = self._beta if self._beta is not None else float(np.sum(self.woodbury_vector * self.mean))
+        N = self.woodbury_vector.shape[0]
+        return mu, (self.nu + beta - 2.0) / (self.nu + N - 2.0) * var

@@ -73,6 +73,7 @@ class SparsePosterior(object):
             var = kern.K(Xnew) - np.dot(Kx.T, np.dot(Wi, Kx))
         else:
             var = (kern.Kdiag(Xnew) - np.sum(np.dot(Wi.T, Kx) * Kx, 0))[:, None]
+            var = np.clip(var, 1e-15, np.inf)                        # posterior.py:248
         return mu, var
 
 

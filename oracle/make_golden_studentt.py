@@ -24,9 +24,16 @@ def case(ns, mod, name, kind, N, D, ARD, nu, Dy=1, seed=0):
     k = ref_loader.make_kernel(ns, kind, D, var, ls if ARD else float(np.atleast_1d(ls)[0]), ARD)
     post, lml, gd = mod.ExactStudentTInference().inference(k, X, Y, nu)
     k.update_gradients_full(gd["dL_dK"], X)
+    # StudentTPosterior._raw_predict (posterior.py:338-349): Gaussian predictive variance scaled by (nu+beta-2)/(nu+N-2)
+    Xs = np.random.default_rng(seed + 50).standard_normal((23, D))
+    pred_mu, pred_var = post._raw_predict(k, Xs, X, full_cov=False)
+    _, pred_cov = post._raw_predict(k, Xs, X, full_cov=True)
+    rows = np.sort(np.random.default_rng(seed + 51).choice(N, 8, replace=False))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), kind=kind, ARD=ARD, X=X, Y=Y, variance=var,
                         lengthscale=np.atleast_1d(ls), nu=nu, lml=float(lml), alpha=np.asarray(post.woodbury_vector),
-                        dL_dnu=float(gd["dL_dnu"]), dL_dm=np.asarray(gd["dL_dm"]),
+                        dL_dnu=float(gd["dL_dnu"]), dL_dm=np.asarray(gd["dL_dm"]), Xs=Xs, pred_mu=np.asarray(pred_mu),
+                        pred_var=np.asarray(pred_var), pred_cov=np.asarray(pred_cov), rows=rows,
+                        dL_dK_rows=np.asarray(gd["dL_dK"])[rows],
                         dtheta=np.concatenate([np.atleast_1d(np.asarray(k.variance.gradient, float)),
                                                np.atleast_1d(np.asarray(k.lengthscale.gradient, float))]))
     print("%-34s lml=% .12e" % (name, lml))

@@ -19,7 +19,8 @@ def pytest_configure(config):
 def golden_names():
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
     # sparse_* fixtures: tests/test_oracle_sparse.py; sum_* / prod_*: tests/test_oracle_sum.py
-    return [n for n in names if not n.startswith(("sparse_", "sum_", "studentt_", "prod_"))]
+    # baseline_* (full BASELINE.json sizes, inputs regenerated from the seed): tests/test_gpu_baseline.py
+    return [n for n in names if not n.startswith(("sparse_", "sum_", "studentt_", "prod_", "baseline_"))]
 
 
 def load_golden(name):
@@ -41,3 +42,21 @@ def oracle_native_built():
     import subprocess
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
     return True
+
+
+def baseline_golden(name):
+    """tests/golden/baseline_*.npz (oracle/make_golden_baseline.py): outputs of the REFERENCE at the full BASELINE.json
+    sizes; the inputs are regenerated from the stored seed."""
+    p = os.path.join(GOLDEN_DIR, name + ".npz")
+    if not os.path.exists(p):
+        pytest.skip("golden fixture %s not generated" % name)
+    d = dict(np.load(p, allow_pickle=False))
+    for k in ("kind", "source"):
+        d[k] = str(d[k])
+    d["ARD"] = bool(d["ARD"])
+    for k in ("N", "D", "seed", "M"):
+        if k in d:
+            d[k] = int(d[k])
+    for k in ("variance", "noise", "lml"):
+        d[k] = float(d[k])
+    return d

@@ -373,3 +373,108 @@ def test_bench_factor_entry_point_reports_sane_rates():
     r = L.bench_factor(2048, reps=2)
     assert all(r[k] > 0 for k in ("potrf_ms", "trtri_ms", "lauum_ms"))
     assert 0.5 < r["lauum_tflops"] < 78.6 and 0.5 < r["potrf_tflops"] < 78.6
+
+
+def test_integration_stub_against_the_real_library():
+    """integration/gpy_mi355x.py (the reference-side ctypes binding of INTEGRATION.md) bound to the real libmi355gp.so, with
+    gpy_amd's paramz-free classes standing in for GPy's (the CPU suite runs the same file against the reference's own
+    classes with the library mocked by the oracle: tests/test_integration_stub.py)."""
+    import os
+    import sys
+    import types
+    import gpy_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "integration"))
+    import gpy_mi355x
+    ns = types.SimpleNamespace(RBF=gpy_amd.RBF, Matern52=gpy_amd.Matern52, Matern32=gpy_amd.Matern32,
+                               Exponential=gpy_amd.Exponential, PosteriorExact=gpy_amd.PosteriorExact,
+                               LatentFunctionInference=object)
+    C = gpy_mi355x.make_classes(gpy_mi355x.bind(L.LIB_PATH), ns)
+    X, Y = O.synthetic(700, 4, seed=12, Dy=2)
+    var, ls, noise = O.default_theta(4, True)
+    ref = O.parameters_changed("matern52", X, Y, var, ls, True, noise)
+    k = C.Matern52(4, variance=var, lengthscale=ls, ARD=True)
+    lik = gpy_amd.Gaussian(variance=noise)
+    post, lml, gd = C.ExactGaussianInference().inference(k, X, lik, Y)
+    lik.update_gradients(gd["dL_dthetaL"])
+    k.update_gradients_full(gd["dL_dK"], X)
+    gref = np.concatenate([[ref["dvar"]], ref["dlen"], [ref["dL_dnoise"]]])
+    got = np.concatenate([k.variance.gradient, k.lengthscale.gradient, lik.variance.gradient])
+    assert abs(lml - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+    assert np.linalg.norm(post.woodbury_vector - ref["alpha"]) <= TOL_ALPHA * np.linalg.norm(ref["alpha"])
+    assert np.abs(got - gref).max() <= TOL_GRAD * np.abs(gref).max()
+    assert np.abs(np.asarray(post.woodbury_chol) - ref["L"]).max() <= 1e-11
+    assert np.abs(np.asarray(gd["dL_dK"]) - ref["dL_dK"]).max() <= 1e-9 * np.abs(ref["dL_dK"]).max()
+    assert np.abs(k.K(X) - ref["K"]).max() <= TOL_K * var
+
+
+def test_mean_function_Z_tilde_set_targets_and_pickling():
+    """The branches of ExactGaussianInference.inference that the golden cases do not reach: `mean_function`
+    (exact_gaussian_inference.py:42-50, core/gp.py:281-282), `Z_tilde` (:64-68), new targets on unchanged inputs
+    (mi355gp_set_targets), and pickling after an inference call (device handles are dropped, lazy results materialise)."""
+    import pickle
+    import gpy_amd
+
+    class Linear(object):                                        # a mean function in GPy's shape: f(X), update_gradients
+        def __init__(self, w):
+            self.w, self.grad = w, None
+
+        def f(self, X):
+            return X @ self.w
+
+        def update_gradients(self, dL_dm, X):
+            self.grad = X.T @ dL_dm
+
+    X, Y = O.synthetic(500, 3, seed=13)
+    w = np.array([[0.3], [-0.2], [0.1]])
+    var, ls, noise = O.default_theta(3, False)
+    K = O.kern_K("rbf", X, None, var, ls, False)
+    ref = O.exact_inference(K, Y, noise, mean=X @ w, Z_tilde=-2.5)
+    mf = Linear(w)
+    k = gpy_amd.RBF(3, variance=var, lengthscale=ls)
+    inf = gpy_amd.ExactGaussianInference()
+    post, lml, gd = inf.inference(k, X, gpy_amd.Gaussian(noise), Y, mean_function=mf, Z_tilde=-2.5)
+    assert abs(lml - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+    assert np.linalg.norm(gd["dL_dm"] - ref["alpha"]) <= TOL_ALPHA * np.linalg.norm(ref["alpha"])
+    m = gpy_amd.GP(X, Y, k, gpy_amd.Gaussian(noise), mean_function=mf)
+    assert np.abs(mf.grad - X.T @ ref["alpha"]).max() <= 1e-8 * np.abs(X.T @ ref["alpha"]).max()
+    mu, _ = m.predict(X[:5])
+    assert np.abs(mu - (K[:5] @ ref["alpha"] + X[:5] @ w)).max() <= 1e-9
+    # same X, new Y: only the targets are re-uploaded (mi355gp_set_targets)
+    st = inf._state
+    Y2 = Y + 0.5
+    ref2 = O.exact_inference(K, Y2, noise)
+    _, lml2, _ = inf.inference(k, X, gpy_amd.Gaussian(noise), Y2)
+    assert inf._state is st and abs(lml2 - ref2["lml"]) <= TOL_LML * abs(ref2["lml"])
+    # pickling after a call (ADVICE r1): the inference object, the posterior and a lazy N x N result
+    inf2 = pickle.loads(pickle.dumps(inf))
+    assert inf2._state is None and inf2._last is None
+    post2, lml3, gd3 = inf.inference(k, X, gpy_amd.Gaussian(noise), Y2)
+    postp = pickle.loads(pickle.dumps(post2))
+    assert postp._state is None and np.abs(np.asarray(postp.woodbury_chol) - ref2["L"]).max() <= 1e-11
+    Gp = pickle.loads(pickle.dumps(gd3["dL_dK"]))
+    assert np.abs(np.asarray(Gp) - ref2["dL_dK"]).max() <= 1e-9 * np.abs(ref2["dL_dK"]).max()
+    mp = pickle.loads(pickle.dumps(m))
+    assert abs(mp.log_likelihood() - m.log_likelihood()) == 0.0
+    _, lml4, _ = inf2.inference(k, X, gpy_amd.Gaussian(noise), Y2)           # the unpickled object builds a fresh context
+    assert abs(lml4 - ref2["lml"]) <= TOL_LML * abs(ref2["lml"])
+
+
+def test_expquad_kernel_cache_and_heteroscedastic_likelihood():
+    import gpy_amd
+    X, Y = O.synthetic(300, 2, seed=14)
+    k = gpy_amd.ExpQuad(2, variance=1.1, lengthscale=0.9)                    # stationary.py:623-662: RBF's function
+    assert k.to_dict()["class"] == "GPy.kern.ExpQuad"
+    K1 = k.K(X)
+    assert np.abs(K1 - O.kern_K("rbf", X, None, 1.1, 0.9, False)).max() <= TOL_K * 1.1
+    assert k.K(X) is K1                                                      # Cache_this(limit=3) on K (stationary.py:105)
+    k.lengthscale[:] = 1.0
+    K2 = k.K(X)
+    assert K2 is not K1 and np.abs(K2 - O.kern_K("rbf", X, None, 1.1, 1.0, False)).max() <= TOL_K * 1.1
+    # per-point noise through the likelihood class (likelihoods/gaussian.py:347-362)
+    meta = {"output_index": np.arange(300)[:, None]}
+    lik = gpy_amd.HeteroscedasticGaussian(meta, variance=0.1)
+    lik.variance[:] = 0.05 + 0.1 * np.random.default_rng(1).random(300)
+    m = gpy_amd.GP(X, Y, k, lik, Y_metadata=meta)
+    ref = O.exact_inference(O.kern_K("rbf", X, None, 1.1, 1.0, False), Y, lik.variance.values)
+    assert abs(m.log_likelihood() - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+    assert np.abs(lik.variance.gradient - ref["diag_dL_dK"]).max() <= TOL_GRAD * np.abs(ref["diag_dL_dK"]).max()

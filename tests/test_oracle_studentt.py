@@ -33,3 +33,12 @@ def test_studentt_oracle_matches_reference_golden(name):
     dv, dl = O.update_gradients_full(g["kind"], r["dL_dK"], g["X"], None, g["variance"], g["ls"], g["ARD"])
     got = np.concatenate([[dv], np.atleast_1d(dl)])
     assert np.abs(got - g["dtheta"]).max() <= 1e-7 * np.abs(g["dtheta"]).max()
+    # StudentTPosterior._raw_predict (posterior.py:338-349): Gaussian prediction, variance scaled by (nu+beta-2)/(nu+N-2)
+    mu, var = O.predict(g["kind"], g["X"], g["Xs"], r["L"], r["alpha"], g["variance"], g["ls"], g["ARD"])
+    _, cov = O.predict(g["kind"], g["X"], g["Xs"], r["L"], r["alpha"], g["variance"], g["ls"], g["ARD"], full_cov=True)
+    N = g["X"].shape[0]
+    scale = (g["nu"] + float(np.sum(r["alpha"] * (K @ r["alpha"]))) - 2.0) / (g["nu"] + N - 2.0)
+    assert np.abs(mu - g["pred_mu"]).max() <= 1e-6 * np.abs(g["pred_mu"]).max()
+    assert np.abs(scale * var - g["pred_var"]).max() <= 1e-6 * np.abs(g["pred_var"]).max()
+    assert np.abs(scale * cov - g["pred_cov"]).max() <= 1e-6 * np.abs(g["pred_cov"]).max()
+    assert np.abs(r["dL_dK"][g["rows"]] - g["dL_dK_rows"]).max() <= 1e-6 * np.abs(g["dL_dK_rows"]).max()

@@ -19,6 +19,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define FACTOR_DEFAULT_PANEL_FUSED_MAX_NRB 100000
 #define FACTOR_DEFAULT_PANEL_FUSED_MIN_NRB 0
 #define FACTOR_DEFAULT_PANEL_FUSED 0   // 1: k_panel_fused (one launch per outer panel, flag hand-offs between workgroups)   // CUs (a multiple of 8: the same count per XCD) kept free of trailing-update workgroups; measured: no gain
+#define GEMM_DEFAULT_TRI64_MAX 512    // levels of the triangular inverse with at most this many 128-tiles per stage run as 64 x 64 quadrants
+#define GEMM_DEFAULT_LAUUM64_MAX 528  // X^T X of at most this many lower 128-tiles (nt <= 32) runs as 64 x 64 quadrants
+#define GEMM_DEFAULT_UPD64_MAX 128  // trailing-update launches of at most this many 128-tiles run as 64 x 64 quadrants (0 = never)
 #define GEMM_DEFAULT_NW 4        // wave arrangement of the 128x128 tile kernels (see gemm_tile.h); env MI355GP_GEMM_NW
 #define GEMM_DEFAULT_REVERSE_K 0
 #define GEMM_DEFAULT_UPDATE_SMALL_NW8 0  // 1: trailing-update launches of at most one tile per CU use 8-wave workgroups

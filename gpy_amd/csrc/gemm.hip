@@ -126,6 +126,34 @@ __global__ __launch_bounds__(256, 2) void k_update_nt_v2(double* __restrict__ C,
     }
 }
 
+// The same update cut into 64 x 64 quadrants (gemm_tile.h, "64 x 64 output tiles"): for launches with fewer 128-tiles than
+// CUs -- the K = nbo "part 1" and the K = 128 in-panel updates on the panel chain.  Workgroup b: 128-tile b >> 2, quadrant
+// b & 3.  Reads C first, accumulates -A*B on it, stores: the arithmetic of k_update_nt<4, true>, bit for bit.
+__global__ __launch_bounds__(256) void k_update_nt64(double* __restrict__ C, long ldc, const double* __restrict__ A, long lda,
+                                                     const double* __restrict__ B, long ldb, int K, int ntc, int row0t,
+                                                     int col0t, int tri) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const long bid = blockIdx.x >> 2;
+    const int qi = (blockIdx.x >> 1) & 1, qj = blockIdx.x & 1;
+    int ti, tj;
+    if (tri) {
+        ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+        while ((long)ti * (ti + 1) / 2 > bid) --ti;
+        while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+        tj = (int)(bid - (long)ti * (ti + 1) / 2);
+    } else {
+        ti = (int)(bid / ntc);
+        tj = (int)(bid - (long)ti * ntc);
+        if (col0t + tj > row0t + ti) return;
+    }
+    d4 acc[2][2];
+    double* Ct = C + ((long)ti * NB + qi * 64) * ldc + (long)tj * NB + qj * 64;
+    gt64_load(Ct, ldc, acc);
+    gemm_tile_64_v3<true, true, true>(A + ((long)ti * NB + qi * 64) * lda, lda, B + ((long)tj * NB + qj * 64) * ldb, ldb, K,
+                                      acc, smem);
+    gt64_store<0>(Ct, ldc, acc);
+}
+
 template <int NW, bool PRE>
 static void launch_update_nt_t(hipStream_t st, long nblocks, long grid, double* C, long ldc, const double* A, long lda,
                                const double* B, long ldb, int K, int ntc, int row0t, int col0t, int tri) {
@@ -148,6 +176,13 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
     if (v2) {
         hipLaunchKernelGGL(k_update_nt_v2, dim3((unsigned)grid), dim3(256), GT2_LDS_BYTES, st, C, ldc, A, lda, B, ldb, K, ntc,
                            row0t, col0t, tri, nblocks);
+        return;
+    }
+    // Few tiles: the launch is the latency of ONE tile on ONE CU -> four times as many 64 x 64 tiles (bit-identical result)
+    static const int upd64_max = env_int("MI355GP_UPD64_MAX", GEMM_DEFAULT_UPD64_MAX);
+    if (nblocks <= upd64_max && grid == nblocks && gemm_variant_preload() && gemm_variant_nw() == 4) {
+        hipLaunchKernelGGL(k_update_nt64, dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, C, ldc, A, lda, B, ldb,
+                           K, ntc, row0t, col0t, tri);
         return;
     }
     // Few tiles (at most one per CU): the launch is the latency of ONE tile, so give every tile 8 waves (two per SIMD,
@@ -203,6 +238,40 @@ __device__ __forceinline__ void trtri_stage_tile(int bid, const double* __restri
         gemm_tile_128<true, false, NW>(X + (long)ti * NB * ld + (long)right0 * NB, ld,
                                    T + (long)right0 * NB * ld + (long)tj * NB, ld, K, acc, smem);
         gt_store<1, NW>(X + (long)ti * NB * ld + (long)tj * NB, ld, acc);
+    }
+}
+
+// 64 x 64 quadrants of the same tiles (launches with few tiles: the low levels of every inverse, every level of a small one)
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_trtri_stage64(const double* __restrict__ L, double* __restrict__ X,
+                                                       double* __restrict__ T, long ld, int nt, int nbt) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int bid = blockIdx.x >> 2, qi = (blockIdx.x >> 1) & 1, qj = blockIdx.x & 1;
+    const int per = nbt * nbt;
+    const int p = bid / per;
+    const int rem = bid - p * per;
+    int ri, cj;
+    if (STAGE == 1) {
+        cj = rem / nbt;
+        ri = rem - cj * nbt;
+    } else {
+        ri = nbt - 1 - rem / nbt;
+        cj = rem % nbt;
+    }
+    const int left0 = 2 * p * nbt, right0 = left0 + nbt;
+    const int ti = right0 + ri, tj = left0 + cj;
+    if (ti >= nt) return;
+    d4 acc[2][2];
+    gt64_zero(acc);
+    const long r0 = (long)ti * NB + qi * 64, c0 = (long)tj * NB + qj * 64;
+    if (STAGE == 1) {
+        const int K = (right0 - tj) * NB;
+        gemm_tile_64_v3<true, false>(L + r0 * ld + (long)tj * NB, ld, X + (long)tj * NB * ld + c0, ld, K, acc, smem);
+        gt64_store<0>(T + r0 * ld + c0, ld, acc);
+    } else {
+        const int K = (ti - right0 + 1) * NB;
+        gemm_tile_64_v3<true, false>(X + r0 * ld + (long)right0 * NB, ld, T + (long)right0 * NB * ld + c0, ld, K, acc, smem);
+        gt64_store<1>(X + r0 * ld + c0, ld, acc);
     }
 }
 
@@ -262,6 +331,14 @@ void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, l
     if (nbt >= nt) return;
     const int pairs = (nt + 2 * nbt - 1) / (2 * nbt);
     const long nblocks = (long)pairs * nbt * nbt;
+    static const int tri64_max = env_int("MI355GP_TRI64_MAX", GEMM_DEFAULT_TRI64_MAX);
+    if (nblocks <= tri64_max && gemm_variant_nw() == 4) {
+        if (stages & 1)
+            hipLaunchKernelGGL((k_trtri_stage64<1>), dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, L, X, T, ld, nt, nbt);
+        if (stages & 2)
+            hipLaunchKernelGGL((k_trtri_stage64<2>), dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, L, X, T, ld, nt, nbt);
+        return;
+    }
     NW_DISPATCH((launch_trtri_level_t<4>(st, nblocks, L, X, T, ld, nt, nbt, stages)),
                 (launch_trtri_level_t<8>(st, nblocks, L, X, T, ld, nt, nbt, stages)));
 }
@@ -285,6 +362,21 @@ __global__ LB(NW) void k_lauum(const double* __restrict__ X, double* __restrict_
     gt_store<0, NW>(W + (long)ti * NB * ld + (long)tj * NB, ld, acc);
 }
 
+__global__ __launch_bounds__(256) void k_lauum64(const double* __restrict__ X, double* __restrict__ W, long ld, int nt) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int bid = blockIdx.x >> 2, qi = (blockIdx.x >> 1) & 1, qj = blockIdx.x & 1;
+    int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+    while ((long)ti * (ti + 1) / 2 > bid) --ti;
+    while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+    const int tj = bid - (int)((long)ti * (ti + 1) / 2);
+    d4 acc[2][2];
+    gt64_zero(acc);
+    const int K = (nt - ti) * NB;
+    const long r0 = (long)ti * NB + qi * 64, c0 = (long)tj * NB + qj * 64;
+    gemm_tile_64_v3<false, false>(X + (long)ti * NB * ld + r0, ld, X + (long)ti * NB * ld + c0, ld, K, acc, smem);
+    gt64_store<0>(W + r0 * ld + c0, ld, acc);
+}
+
 template <int NW>
 static void launch_lauum_t(hipStream_t st, long nblocks, const double* X, double* W, long ld, int nt) {
     static const int rev = env_int("MI355GP_REVERSE_K", GEMM_DEFAULT_REVERSE_K);
@@ -294,6 +386,11 @@ static void launch_lauum_t(hipStream_t st, long nblocks, const double* X, double
 
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt) {
     const long nblocks = (long)nt * (nt + 1) / 2;
+    static const int lauum64_max = env_int("MI355GP_LAUUM64_MAX", GEMM_DEFAULT_LAUUM64_MAX);
+    if (nblocks <= lauum64_max && gemm_variant_nw() == 4) {
+        hipLaunchKernelGGL(k_lauum64, dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, X, W, ld, nt);
+        return;
+    }
     NW_DISPATCH((launch_lauum_t<4>(st, nblocks, X, W, ld, nt)), (launch_lauum_t<8>(st, nblocks, X, W, ld, nt)));
 }
 

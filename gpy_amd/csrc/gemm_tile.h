@@ -541,3 +541,138 @@ __device__ __forceinline__ void gemm_tile_128_v4(const double* __restrict__ A, l
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }
+
+// =====================================================================================================================
+// 64 x 64 output tiles on the v3 (LDS-DMA) pipeline, for launches with FEWER 128-tiles than the chip has CUs.
+// fp64 MFMA peak is per CU (4 SIMDs x one 16x16x4 MFMA per 64 cycles = 0.31 TFLOP/s): a 128x128 tile confined to one
+// workgroup = one CU needs >= 55 us for K = 512 and >= 14 us for K = 128 however empty the rest of the GPU is.  The
+// latency-bound kernels of the panel chain (the K = 512 "part 1" update of the next panel's columns, the K = 128 in-panel
+// updates) have 10 .. 120 such tiles; cut into 64 x 64 quadrants they occupy four times as many CUs and finish in about a
+// third of the time.  Same slab size (16), same k -> MFMA-slice assignment (physical k = 4 kq + s) and the same
+// accumulation order as gemm_tile_128_v3: results are bit-identical, whichever of the two a launch takes.
+//   waves 2 x 2, each a 32 x 32 sub-tile = 2 x 2 accumulators (32 VGPRs)
+//   k-contiguous operand : [64][16], 8 DMAs of 8 rows per slab (two per wave), source-side granule swizzle gt3_h
+//   m/n-contiguous       : 16 k-rows of 64 doubles, one DMA moves the PAIR (2i, 2i+1) (lanes 0-31 / 32-63); pairs are 136
+//                          doubles apart (136 = 8 mod 16 puts the kq = 0 / 1 halves of a 32-lane ds_read_b64 group 32
+//                          banks apart)
+// LDS: 2 stages x 2 operands x 1088 doubles = 34,816 B.
+#define GT64_OP 1088
+#define GT64_PAIR 136
+#define GT64_LDS_BYTES (2 * 2 * GT64_OP * 8)
+
+template <bool KC>
+__device__ __forceinline__ void gt64_src_offsets(long ld, int lane, int w, int (&voff)[2]) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * w + ii;
+        if (KC) {
+            const int row = 8 * i + (lane >> 3), g = (lane & 7) ^ gt3_h(row);
+            voff[ii] = (int)((row * ld + 2 * g) * 8);
+        } else {
+            voff[ii] = (int)(((2 * i + (lane >> 5)) * ld + 2 * (lane & 31)) * 8);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void gt64_issue(__amdgpu_buffer_rsrc_t rs, const int (&voff)[2], double* sdst, int w) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * w + ii;
+        double* d = KC ? sdst + i * 128 : sdst + i * GT64_PAIR;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, d, 16, voff[ii], 0, 0, 0);
+    }
+}
+
+// acc[mi][ni] += sum_{k<K} opA(i,k) * opB(k,j) for this wave's 32 x 32 part of a 64 x 64 tile (A, B as in gemm_tile_128)
+template <bool AK, bool BK, bool NEGA = false>
+__device__ __forceinline__ void gemm_tile_64_v3(const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                                long ldb, int K, d4 (&acc)[2][2], double* smem) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+    const int nk = K / 16;
+    const int arow = wr * 32 + (lane & 15), bcol = wc * 32 + (lane & 15), kq = lane >> 4;
+    auto rsrc = [](const double* p) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000);
+    };
+    int va[2], vb[2];
+    gt64_src_offsets<AK>(lda, lane, w, va);
+    gt64_src_offsets<BK>(ldb, lane, w, vb);
+    const long sa = AK ? 16 : 16 * lda, sb = BK ? 16 : 16 * ldb;
+    int fa0[2], fb0[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r = arow + mi * 16, c = bcol + mi * 16;
+        fa0[mi] = AK ? r * 16 : r;
+        fb0[mi] = BK ? c * 16 : c;
+    }
+    const int ha = gt3_h(arow), hb = gt3_h(bcol);
+    gt64_issue<AK>(rsrc(A), va, smem, w);
+    gt64_issue<BK>(rsrc(B), vb, smem + GT64_OP, w);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            double* nxt = smem + (cur ^ 1) * 2 * GT64_OP;
+            gt64_issue<AK>(rsrc(A + (kt + 1) * sa), va, nxt, w);
+            gt64_issue<BK>(rsrc(B + (kt + 1) * sb), vb, nxt + GT64_OP, w);
+        }
+        const double* a_s = smem + cur * 2 * GT64_OP;
+        const double* b_s = a_s + GT64_OP;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                        // slices 2e, 2e+1
+            d2 af[2], bf[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                if (AK) af[mi] = *reinterpret_cast<const d2*>(a_s + fa0[mi] + 2 * ((2 * kq + e) ^ ha));
+                else af[mi] = (d2){a_s[(2 * kq + e) * GT64_PAIR + fa0[mi]], a_s[(2 * kq + e) * GT64_PAIR + 64 + fa0[mi]]};
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if (BK) bf[ni] = *reinterpret_cast<const d2*>(b_s + fb0[ni] + 2 * ((2 * kq + e) ^ hb));
+                else bf[ni] = (d2){b_s[(2 * kq + e) * GT64_PAIR + fb0[ni]], b_s[(2 * kq + e) * GT64_PAIR + 64 + fb0[ni]]};
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = mfma_f64(NEGA ? -af[mi][s] : af[mi][s], bf[ni][s], acc[mi][ni]);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void gt64_zero(d4 (&acc)[2][2]) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+}
+
+// element (mi, ni, r) of this lane lives at C[(wr*32 + mi*16 + 4r + lane>>4) * ldc + wc*32 + ni*16 + (lane & 15)]
+__device__ __forceinline__ void gt64_load(const double* __restrict__ C, long ldc, d4 (&acc)[2][2]) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+    const double* base = C + (long)(wr * 32 + (lane >> 4)) * ldc + wc * 32 + (lane & 15);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = base[(long)(mi * 16 + 4 * r) * ldc + ni * 16];
+}
+
+// MODE 0: C = acc;  1: C = -acc
+template <int MODE>
+__device__ __forceinline__ void gt64_store(double* __restrict__ C, long ldc, const d4 (&acc)[2][2]) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+    double* base = C + (long)(wr * 32 + (lane >> 4)) * ldc + wc * 32 + (lane & 15);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[(long)(mi * 16 + 4 * r) * ldc + ni * 16] = (MODE == 1) ? -acc[mi][ni][r] : acc[mi][ni][r];
+}

@@ -13,10 +13,10 @@ Inputs are NOT stored: tests regenerate them from the seed with oracle.gp_oracle
 default_rng stream is stable and the GPU box runs the same image).  Stored: LML, logdet, alpha, all gradients,
 diag(dL_dK), a few rows of Ky^-1 / L -- < 2 MB in total.
 
-The lean oracle (`lean_exact`) makes the same LAPACK calls the reference makes for this path
-(dpotrf / dpotrs / dpotri: util/linalg.py:58,125,142) in place on ONE N x N buffer, skips the dtrtri whose result
-the reference never uses (util/linalg.py:204), and evaluates the gradient sums of stationary.py:199,212-213 row block
-by row block.  tests/test_oracle_baseline.py pins it against oracle.gp_oracle (itself pinned against the reference)
+The lean oracle (`lean_exact`) makes the LAPACK calls the reference makes for this path (dpotrf / dtrtrs / dtrtri /
+dpotri: util/linalg.py:58,114,125,142,227) on the blocks of a 2 x 2 partition of Ky (a monolithic dpotrf of a
+32768 x 32768 matrix segfaults in this SciPy/OpenBLAS build -- the reference's own jitchol would too) and evaluates the
+gradient sums of stationary.py:199,212-213 row block by row block.  tests/test_oracle_baseline.py pins it against oracle.gp_oracle (itself pinned against the reference)
 at a size both can run.
 """
 import importlib
@@ -65,60 +65,100 @@ def exact_from_reference(ns, kind, N, D, ARD, seed=0):
     return out
 
 
-def lean_exact(kind, X, Y, variance, lengthscale, noise, block=2048):
-    """Isotropic stationary kernel, Dy columns; returns dict(lml, logdet, alpha, dvar, dlen, dnoise, diag_dL_dK, A)
-    where A holds Ky^-1 in its lower triangle (row-major)."""
+def lean_exact(kind, X, Y, variance, lengthscale, noise, block=2048, n1=None):
+    """Isotropic stationary kernel, Dy columns; returns dict(lml, logdet, alpha, dvar, dlen, dnoise, diag_dL_dK, rows, Wi_rows,
+    L_rows).  The matrix is held as the 2 x 2 block partition [[A11, .], [A21, A22]] (n1 = N // 2 rows in the first block)
+    and factorised / inverted block-wise with the LAPACK calls of the reference's path on the blocks -- what LAPACK's own
+    blocked dpotrf / dpotri do internally, one level up.  (A monolithic lapack.dpotrf segfaults at N = 32768 in this
+    SciPy/OpenBLAS build -- the reference's own jitchol would as well -- and the 2 x 2 form keeps every call below 2^29
+    elements.)"""
     N, D = X.shape
     Dy = Y.shape[1]
     ell = float(np.atleast_1d(lengthscale)[0])
     variance = float(variance)
     s = np.sum(np.square(X), 1)
+    n1 = N // 2 if n1 is None else n1
+    n2 = N - n1
 
-    def r_block(i0, i1):                                       # stationary.py:130-168 (iso: divide r by l afterwards)
-        r2 = -2.0 * (X[i0:i1] @ X.T) + (s[i0:i1, None] + s[None, :])
-        r2[np.arange(i1 - i0), np.arange(i0, i1)] = 0.0
+    def r_block(i0, i1, j0=0, j1=None):                        # stationary.py:130-168 (iso: divide r by l afterwards)
+        j1 = N if j1 is None else j1
+        r2 = -2.0 * (X[i0:i1] @ X[j0:j1].T) + (s[i0:i1, None] + s[None, j0:j1])
+        lo, hi = max(i0, j0), min(i1, j1)
+        if hi > lo:
+            r2[np.arange(lo, hi) - i0, np.arange(lo, hi) - j0] = 0.0
         np.clip(r2, 0, np.inf, out=r2)
         return np.sqrt(r2) / ell
 
-    A = np.empty((N, N))                                       # K -> Ky -> L -> Ky^-1, all in this one buffer
-    for i0 in range(0, N, block):
-        i1 = min(N, i0 + block)
-        A[i0:i1] = O.K_of_r(kind, r_block(i0, i1), variance)
-    A[np.arange(N), np.arange(N)] += noise + 1e-8              # exact_gaussian_inference.py:55-56
-    # A is symmetric, so its transpose view is the F-ordered matrix LAPACK wants: no N x N copy
-    c, info = lapack.dpotrf(A.T, lower=1, overwrite_a=1, clean=1)          # util/linalg.py:58
-    assert info == 0 and np.shares_memory(c, A)
-    # c = A.T holds L (lower, column-major)  <=>  A holds L^T (upper, row-major)
-    logdet = 2.0 * np.sum(np.log(np.diag(A)))
-    alpha = lapack.dpotrs(c, Y, lower=1)[0]                    # util/linalg.py:116-125
-    L_rows_idx = sample_rows(N)
-    L_rows = np.ascontiguousarray(c[L_rows_idx])               # rows of L
-    ci, info = lapack.dpotri(c, lower=1, overwrite_c=1)        # util/linalg.py:127-145 -> lower triangle of Ky^-1 (F-order)
-    assert info == 0 and np.shares_memory(ci, A)
-    # ci lower (F) = A upper (C): Wi[i, j] for j >= i is A[i, j]
+    def build(i0, i1, j0, j1):                                 # F-ordered block of Ky
+        B = np.empty((i1 - i0, j1 - j0), order="F")
+        for a in range(i0, i1, block):
+            b = min(i1, a + block)
+            B[a - i0:b - i0] = O.K_of_r(kind, r_block(a, b, j0, j1), variance)
+        if i0 == j0:
+            B[np.arange(i1 - i0), np.arange(i1 - i0)] += noise + 1e-8          # exact_gaussian_inference.py:55-56
+        return B
+
+    A11, A21, A22 = build(0, n1, 0, n1), build(n1, N, 0, n1), build(n1, N, n1, N)
+    L11, info = lapack.dpotrf(A11, lower=1, overwrite_a=1, clean=1)            # util/linalg.py:58
+    assert info == 0
+    del A11
+    # L21 = A21 L11^-T  (dtrsm, side R, trans T): solve X L11^T = A21
+    from scipy.linalg import blas
+    L21 = blas.dtrsm(1.0, L11, A21, side=1, lower=1, trans_a=1, overwrite_b=1)
+    del A21
+    A22 = blas.dsyrk(-1.0, L21, beta=1.0, c=A22, lower=1, overwrite_c=1)       # S = A22 - L21 L21^T (lower)
+    L22, info = lapack.dpotrf(A22, lower=1, overwrite_a=1, clean=1)
+    assert info == 0
+    del A22
+    logdet = 2.0 * (np.sum(np.log(np.diag(L11))) + np.sum(np.log(np.diag(L22))))
+    # alpha = Ky^-1 Y by forward / back substitution through the blocks (dpotrs, util/linalg.py:116-125)
+    y1 = lapack.dtrtrs(L11, Y[:n1], lower=1)[0]
+    y2 = lapack.dtrtrs(L22, Y[n1:] - L21 @ y1, lower=1)[0]
+    a2 = lapack.dtrtrs(L22, y2, lower=1, trans=1)[0]
+    a1 = lapack.dtrtrs(L11, y1 - L21.T @ a2, lower=1, trans=1)[0]
+    alpha = np.vstack([a1, a2])
+    rows = sample_rows(N)
+    L_rows = np.zeros((ROWS, N))
+    for k, ri in enumerate(rows):
+        if ri < n1:
+            L_rows[k, :n1] = L11[ri]
+        else:
+            L_rows[k, :n1], L_rows[k, n1:] = L21[ri - n1], L22[ri - n1]
+    # Ky^-1 = W^T W with W = L^-1 = [[W11, 0], [W21, W22]], W21 = -W22 L21 W11   (dpotri, util/linalg.py:127-145)
+    W11 = lapack.dtrtri(L11, lower=1)[0]
+    W22 = lapack.dtrtri(L22, lower=1)[0]
+    W21 = blas.dtrmm(-1.0, W22, blas.dtrmm(1.0, W11, L21, side=1, lower=1), side=0, lower=1)
+    del L21
+    K22 = lapack.dpotri(L22, lower=1, overwrite_c=1)[0]       # W22^T W22 (lower)
+    K21 = blas.dtrmm(1.0, W22, W21, side=0, lower=1, trans_a=1)                # W22^T W21
+    del W22, L22
+    K11 = lapack.dpotri(L11, lower=1, overwrite_c=1)[0]       # W11^T W11 (lower)
+    K11 = blas.dsyrk(1.0, W21, beta=1.0, c=K11, trans=1, lower=1, overwrite_c=1)   # + W21^T W21
+    del W11, W21, L11
+    O.symmetrify(K11)
+    O.symmetrify(K22)
     lml = 0.5 * (-Y.size * O.LOG_2_PI - Dy * logdet - np.sum(alpha * Y))
     dvar = dlr = 0.0
     diagG = np.empty(N)
     Wi_rows = np.empty((ROWS, N))
-    for i0 in range(0, N, block):
-        i1 = min(N, i0 + block)
+    edges = sorted(set(range(0, N, block)) | {n1, N})           # row blocks never straddle the block-row boundary n1
+    for i0, i1 in zip(edges[:-1], edges[1:]):
         Wi = np.empty((i1 - i0, N))
-        Wi[:, i0:] = A[i0:i1, i0:]                             # j >= i0: upper part as stored (fix the in-block lower below)
-        Wi[:, :i0] = A[:i0, i0:i1].T
-        blk = Wi[:, i0:i1]
-        iu = np.triu_indices(i1 - i0, 1)
-        blk.T[iu] = blk[iu]                                    # mirror the diagonal block's upper triangle down
+        if i0 < n1:
+            Wi[:, :n1], Wi[:, n1:] = K11[i0:i1], K21[:, i0:i1].T
+        else:
+            Wi[:, :n1], Wi[:, n1:] = K21[i0 - n1:i1 - n1], K22[i0 - n1:i1 - n1]
         G = 0.5 * (alpha[i0:i1] @ alpha.T - Dy * Wi)           # exact_gaussian_inference.py:70
         r = r_block(i0, i1)
         K = O.K_of_r(kind, r, variance)
         dvar += np.sum(K * G) / variance                       # stationary.py:199
         dlr += np.sum(O.dK_dr(kind, r, variance) * G * r)      # stationary.py:202,212-213
         diagG[i0:i1] = G[np.arange(i1 - i0), np.arange(i0, i1)]
-        for k, ri in enumerate(L_rows_idx):
+        for k, ri in enumerate(rows):
             if i0 <= ri < i1:
                 Wi_rows[k] = Wi[ri - i0]
     return dict(lml=float(lml), logdet=float(logdet), alpha=alpha, dvar=np.array([dvar]), dlen=np.array([-dlr / ell]),
-                dnoise=np.array([np.sum(diagG)]), diag_dL_dK=diagG, rows=L_rows_idx, Wi_rows=Wi_rows, L_rows=L_rows)
+                dnoise=np.array([np.sum(diagG)]), diag_dL_dK=diagG, rows=rows, Wi_rows=Wi_rows, L_rows=L_rows)
 
 
 def exact_lean(kind, N, D, seed=0):
@@ -127,7 +167,7 @@ def exact_lean(kind, N, D, seed=0):
     t0 = time.time()
     r = lean_exact(kind, X, Y, var, ls, noise)
     r.update(kind=kind, ARD=False, N=N, D=D, seed=seed, variance=var, lengthscale=ls, noise=noise,
-             source="lean oracle (dpotrf/dpotrs/dpotri in place)", seconds=time.time() - t0)
+             source="lean oracle (2x2-blocked dpotrf/dtrtri/dpotri)", seconds=time.time() - t0)
     return r
 
 

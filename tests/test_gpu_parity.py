@@ -407,23 +407,24 @@ def test_integration_stub_against_the_real_library():
     assert np.abs(k.K(X) - ref["K"]).max() <= TOL_K * var
 
 
+class _LinearMean(object):                                       # a mean function in GPy's shape: f(X), update_gradients
+    def __init__(self, w):
+        self.w, self.grad = w, None
+
+    def f(self, X):
+        return X @ self.w
+
+    def update_gradients(self, dL_dm, X):
+        self.grad = X.T @ dL_dm
+
+
 def test_mean_function_Z_tilde_set_targets_and_pickling():
     """The branches of ExactGaussianInference.inference that the golden cases do not reach: `mean_function`
     (exact_gaussian_inference.py:42-50, core/gp.py:281-282), `Z_tilde` (:64-68), new targets on unchanged inputs
     (mi355gp_set_targets), and pickling after an inference call (device handles are dropped, lazy results materialise)."""
     import pickle
     import gpy_amd
-
-    class Linear(object):                                        # a mean function in GPy's shape: f(X), update_gradients
-        def __init__(self, w):
-            self.w, self.grad = w, None
-
-        def f(self, X):
-            return X @ self.w
-
-        def update_gradients(self, dL_dm, X):
-            self.grad = X.T @ dL_dm
-
+    Linear = _LinearMean
     X, Y = O.synthetic(500, 3, seed=13)
     w = np.array([[0.3], [-0.2], [0.1]])
     var, ls, noise = O.default_theta(3, False)

@@ -21,6 +21,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -41,23 +42,22 @@
     } while (0)
 
 // ---------------------------------------------------------------------------------------------------
-// RCCL through dlopen (only the handful of entry points the grid needs; ABI of rccl.h / NCCL 2.27)
-typedef struct ncclComm* ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSuccess = 0 };
-enum { ncclFloat64 = 8 };   // ncclDataType_t
-enum { ncclSum = 0 };       // ncclRedOp_t
+// RCCL: types, enums and prototypes come from the installed <rccl/rccl.h>; the library itself is dlopen'ed (so the
+// single-GPU library has no link-time RCCL dependency) and every entry point is bound through decltype(&ncclXxx): a
+// signature change in RCCL is a compile error here, not silent ABI drift.
+#include <rccl/rccl.h>
+static_assert(sizeof(ncclUniqueId) == 128, "mi355gp_grid_unique_id hands out 128-byte ids");
 struct Rccl {
     void* h = nullptr;
-    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    int (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommSplit) CommSplit = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool load() {
         if (h) return true;
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -91,10 +91,10 @@ struct Rccl {
 static Rccl g_rccl;
 #define NCCL_CHECK(expr)                                                                                  \
     do {                                                                                                  \
-        int _r = (expr);                                                                                  \
+        ncclResult_t _r = (expr);                                                                         \
         if (_r != ncclSuccess) {                                                                          \
             mi355gp_set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
-            return -(2000 + _r);                                                                          \
+            return -(2000 + (int)_r);                                                                       \
         }                                                                                                 \
     } while (0)
 
@@ -279,7 +279,9 @@ struct GridRank {
     long LR = 0, LC = 0;             // allocated local rows / cols (uniform over ranks)
     long nvr = 0, nvc = 0;           // local rows / cols whose global index is < n (a prefix of the local order)
     double *A = nullptr, *X = nullptr, *W = nullptr;
-    double *RP = nullptr, *CP = nullptr, *XR = nullptr, *XRr = nullptr;
+    // panel buffers, double-buffered by step parity: step k+1's panels are produced on the communication stream while the
+    // bulk updates of step k still read step k's
+    double *RP2[2] = {nullptr, nullptr}, *CP2[2] = {nullptr, nullptr}, *XR2[2] = {nullptr, nullptr}, *XRr2[2] = {nullptr, nullptr};
     double *Dt = nullptr, *Dv = nullptr, *Ds = nullptr;
     double *XtR = nullptr, *XtC = nullptr, *XsR = nullptr, *XsC = nullptr;   // scaled dimension-major / raw row-major
     long *gR = nullptr, *gC = nullptr;                                       // global index of every local row / col
@@ -289,7 +291,8 @@ struct GridRank {
     double *scal = nullptr, *gradPart = nullptr, *gradOut = nullptr, *invls = nullptr, *noise = nullptr;
     int* info_g = nullptr;
     FactorWs ws;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;        // bulk updates and everything outside the factorisation loop
+    hipStream_t sc = nullptr;        // the critical path of a step: diagonal tile, panel solves, all panel broadcasts
 };
 
 struct mi355gp_grid {
@@ -299,6 +302,9 @@ struct mi355gp_grid {
     std::vector<GridRank> ranks;     // logical ranks hosted by this process (loopback: all, RCCL: one)
     ncclComm_t comm_world = nullptr, comm_row = nullptr, comm_col = nullptr;
     hipStream_t st = nullptr;        // loopback: shared by all logical ranks
+    hipStream_t sc = nullptr;        // second stream (high priority): panel factorisation + broadcasts, one step ahead
+    std::vector<hipEvent_t> ev_cr, ev_p1;   // [k]: panels of step k are in place / the part-1 updates of step k are done
+    int lookahead = 1;               // MI355GP_GRID_LOOKAHEAD=0: everything in order on one stream
     long n = 0, npad = 0, T = 0;
     int D = 0, Dy = 0;
     hipEvent_t ev[6] = {};
@@ -309,7 +315,7 @@ static int cnt_le(long k, int p, int P) { return (k >= p) ? (int)((k - p) / P + 
 static int cnt_lt(long k, int p, int P) { return (k > 0) ? cnt_le(k - 1, p, P) : 0; }
 
 static void free_rank(GridRank& r) {
-    void* ptrs[] = {r.A, r.X, r.W, r.RP, r.CP, r.XR, r.XRr, r.Dt, r.Dv, r.Ds, r.XtR, r.XtC, r.XsR, r.XsC, r.gR, r.gC,
+    void* ptrs[] = {r.A, r.X, r.W, r.RP2[0], r.RP2[1], r.CP2[0], r.CP2[1], r.XR2[0], r.XR2[1], r.XRr2[0], r.XRr2[1], r.Dt, r.Dv, r.Ds, r.XtR, r.XtC, r.XsR, r.XsC, r.gR, r.gC,
                     r.dl_r, r.dl_c, r.dg, r.vloc, r.gvec, r.gvec2, r.alpha, r.ybuf, r.Rg, r.scal, r.gradPart,
                     r.gradOut, r.invls, r.noise, r.info_g};
     for (void* p : ptrs)
@@ -327,6 +333,7 @@ typedef std::function<double*(GridRank&, bool)> BufFn;
 
 static int grid_bcast(mi355gp_grid* g, int group, int index, int root_coord, size_t count, const BufFn& buf) {
     if (count == 0) return 0;
+    hipStream_t lst = g->lookahead ? g->sc : g->st;            // every panel broadcast travels on the communication stream
     if (g->loopback) {
         GridRank* root = nullptr;
         for (GridRank& r : g->ranks) {
@@ -339,7 +346,7 @@ static int grid_bcast(mi355gp_grid* g, int group, int index, int root_coord, siz
             const bool in = (group == GROUP_ROW) ? (r.pr == index) : (r.pc == index);
             if (!in) continue;
             double* dst = buf(r, false);
-            if (dst != src) HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, g->st));
+            if (dst != src) HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, lst));
         }
         return 0;
     }
@@ -350,7 +357,7 @@ static int grid_bcast(mi355gp_grid* g, int group, int index, int root_coord, siz
     const bool is_root = coord == root_coord;
     const double* send = is_root ? buf(r, true) : buf(r, false);
     NCCL_CHECK(g_rccl.Broadcast(send, buf(r, false), count, ncclFloat64, root_coord,
-                                group == GROUP_ROW ? g->comm_row : g->comm_col, r.st));
+                                group == GROUP_ROW ? g->comm_row : g->comm_col, lst));
     return 0;
 }
 static int grid_group_start(mi355gp_grid* g) {
@@ -408,7 +415,14 @@ int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb,
     g->nb = nb;
     g->my_rank = rank;
     g->loopback = (id128 == nullptr);
-    HIP_CHECK(hipStreamCreate(&g->st));
+    HIP_CHECK(hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&g->sc, hipStreamNonBlocking, greatest));
+        const char* envl = getenv("MI355GP_GRID_LOOKAHEAD");
+        if (envl && *envl) g->lookahead = atoi(envl) ? 1 : 0;
+    }
     for (auto& e : g->ev) HIP_CHECK(hipEventCreate(&e));
     if (g->loopback) {
         g->ranks.resize((size_t)world);
@@ -417,6 +431,7 @@ int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb,
             g->ranks[r].pr = r / Pc;
             g->ranks[r].pc = r % Pc;
             g->ranks[r].st = g->st;
+            g->ranks[r].sc = g->sc;
         }
     } else {
         if (!g_rccl.load()) return -20;
@@ -426,6 +441,7 @@ int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb,
         r.pr = rank / Pc;
         r.pc = rank % Pc;
         r.st = g->st;
+        r.sc = g->sc;
         ncclUniqueId id;
         memcpy(&id, id128, sizeof(id));
         NCCL_CHECK(g_rccl.CommInitRank(&g->comm_world, world, id, rank));
@@ -446,6 +462,12 @@ int mi355gp_grid_destroy(mi355gp_grid* g) {
     if (g->comm_world) g_rccl.CommDestroy(g->comm_world);
     for (auto& e : g->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : g->ev_cr) (void)hipEventDestroy(e);
+    for (auto& e : g->ev_p1) (void)hipEventDestroy(e);
+    if (g->sc) {
+        (void)hipStreamSynchronize(g->sc);
+        (void)hipStreamDestroy(g->sc);
+    }
     if (g->st) (void)hipStreamDestroy(g->st);
     delete g;
     return 0;
@@ -456,9 +478,17 @@ int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, co
     ARGCHK(g && X && R && N > 0 && D > 0 && Dy > 0, "mi355gp_grid_set_data: bad arguments");
     HIP_CHECK(hipSetDevice(g->device));
     HIP_CHECK(hipStreamSynchronize(g->st));
+    HIP_CHECK(hipStreamSynchronize(g->sc));
     const long nb = g->nb;
     g->n = N;
     g->T = (N + nb - 1) / nb;
+    while ((long)g->ev_cr.size() < g->T + 1) {
+        hipEvent_t e1, e2;
+        HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        g->ev_cr.push_back(e1);
+        g->ev_p1.push_back(e2);
+    }
     g->npad = g->T * nb;
     g->D = D;
     g->Dy = Dy;
@@ -467,9 +497,9 @@ int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, co
     const int groups = (D + 31) / 32;
     for (GridRank& r : g->ranks) {
         const int rank = r.rank, pr = r.pr, pc = r.pc;
-        hipStream_t st = r.st;
+        hipStream_t st = r.st, sc = r.sc;
         free_rank(r);
-        r.rank = rank; r.pr = pr; r.pc = pc; r.st = st;
+        r.rank = rank; r.pr = pr; r.pc = pc; r.st = st; r.sc = sc;
         r.TLr = cnt_le(T - 1, pr, g->Pr);
         r.TLc = cnt_le(T - 1, pc, g->Pc);
         r.LR = TLrM * nb;
@@ -478,10 +508,12 @@ int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, co
         HIP_CHECK(hipMalloc(&r.A, mat));
         HIP_CHECK(hipMalloc(&r.X, mat));
         HIP_CHECK(hipMalloc(&r.W, mat));
-        HIP_CHECK(hipMalloc(&r.RP, sizeof(double) * r.LR * nb));
-        HIP_CHECK(hipMalloc(&r.CP, sizeof(double) * r.LC * nb));
-        HIP_CHECK(hipMalloc(&r.XR, sizeof(double) * r.LC * nb));
-        HIP_CHECK(hipMalloc(&r.XRr, sizeof(double) * r.LR * nb));
+        for (int b = 0; b < 2; ++b) {
+            HIP_CHECK(hipMalloc(&r.RP2[b], sizeof(double) * r.LR * nb));
+            HIP_CHECK(hipMalloc(&r.CP2[b], sizeof(double) * r.LC * nb));
+            HIP_CHECK(hipMalloc(&r.XR2[b], sizeof(double) * r.LC * nb));
+            HIP_CHECK(hipMalloc(&r.XRr2[b], sizeof(double) * r.LR * nb));
+        }
         HIP_CHECK(hipMalloc(&r.Dt, sizeof(double) * nb * nb));
         HIP_CHECK(hipMalloc(&r.Dv, sizeof(double) * nb * nb));
         HIP_CHECK(hipMalloc(&r.Ds, sizeof(double) * nb * nb));
@@ -580,22 +612,38 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
     }
     HIP_CHECK(hipEventRecord(g->ev[1], g->st));
     // ---- the one-pass factorisation / inversion ------------------------------------------------------------
-    for (long k = 0; k < T; ++k) {
-        const int opr = (int)(k % Pr), opc = (int)(k % Pc);
+    // Two streams per rank, one step of look-ahead:
+    //   sc (high priority)  crit(k):  diagonal tile k, D = L_kk^-1, its broadcasts, the panel solves of step k and ALL panel
+    //                                 broadcasts (RCCL); panels land in the buffers of parity k & 1
+    //   st                  part1(k): the updates of step k that step k+1's critical path reads -- tile column k+1 of A,
+    //                                 tile row k+1 of B;  then bulk(k): the rest of the three rank-nb updates
+    // crit(k+1) starts after part1(k) and runs underneath bulk(k); bulk(k+1) waits for crit(k+1).  crit(k+1) reads and
+    // writes only column k+1 of A and row k+1 of X, which bulk(k) does not touch; crit(k+2) overwrites the parity-k panel
+    // buffers only after part1(k+1), which is behind bulk(k) on st.  Every rank enqueues the same sequence of
+    // collectives on sc, so their order is consistent across the grid.
+    const bool la = g->lookahead != 0;
+    hipStream_t scs = la ? g->sc : g->st;
+    if (la) {
+        HIP_CHECK(hipEventRecord(g->ev[5], g->st));          // the covariance tiles precede everything on sc
+        HIP_CHECK(hipStreamWaitEvent(g->sc, g->ev[5], 0));
+    }
+    auto crit = [&](long k) -> int {
+        const int opr = (int)(k % Pr), opc = (int)(k % Pc), pb = (int)(k & 1);
         const long lkr = k / Pr, lkc = k / Pc;
         // (a) diagonal tile: L_kk and D = L_kk^-1 on its owner
         for (GridRank& r : g->ranks) {
             if (r.pr != opr || r.pc != opc) continue;
+            hipStream_t s = la ? r.sc : r.st;
             double* At = r.A + lkr * nb * r.LC + lkc * nb;
             HIP_CHECK(hipMemcpy2DAsync(r.Dt, sizeof(double) * nb, At, sizeof(double) * r.LC, sizeof(double) * nb, nb,
-                                       hipMemcpyDeviceToDevice, r.st));
-            potrf_device(r.st, r.Dt, nb, &r.ws);
-            hipLaunchKernelGGL(k_grid_tile_stats, dim3(1), dim3(64), 0, r.st, r.ws.logsum, q, r.ws.info, k * nb, r.scal,
+                                       hipMemcpyDeviceToDevice, s));
+            potrf_device(s, r.Dt, nb, &r.ws);
+            hipLaunchKernelGGL(k_grid_tile_stats, dim3(1), dim3(64), 0, s, r.ws.logsum, q, r.ws.info, k * nb, r.scal,
                                r.info_g);
-            HIP_CHECK(hipMemsetAsync(r.Dv, 0, sizeof(double) * tile, r.st));
-            trtri_device(r.st, r.Dt, r.Dv, r.Ds, nb, &r.ws);
+            HIP_CHECK(hipMemsetAsync(r.Dv, 0, sizeof(double) * tile, s));
+            trtri_device(s, r.Dt, r.Dv, r.Ds, nb, &r.ws);
             HIP_CHECK(hipMemcpy2DAsync(At, sizeof(double) * r.LC, r.Dt, sizeof(double) * nb, sizeof(double) * nb, nb,
-                                       hipMemcpyDeviceToDevice, r.st));
+                                       hipMemcpyDeviceToDevice, s));
         }
         // (b) D to the panel owners (process column opc) and to the owners of row k of X (process row opr)
         if (int rc = grid_bcast(g, GROUP_COL, opc, opr, tile, [](GridRank& r, bool) { return r.Dv; })) return rc;
@@ -603,21 +651,22 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
         // (c) panel solve L_ik = A_ik D^T on process column opc
         for (GridRank& r : g->ranks) {
             if (r.pc != opc) continue;
+            hipStream_t s = la ? r.sc : r.st;
             const int lr0 = cnt_le(k, r.pr, Pr);
             const long rows = (long)(r.TLr - lr0) * nb;
             if (rows <= 0) continue;
             double* Acol = r.A + (long)lr0 * nb * r.LC + lkc * nb;
-            grid_gemm_t<true, true>(r.st, r.RP + (long)lr0 * tile, nb, 0, GOp{Acol, r.LC, 0}, GOp{r.Dv, nb, 0}, rows, nb,
+            grid_gemm_t<true, true>(s, r.RP2[pb] + (long)lr0 * tile, nb, 0, GOp{Acol, r.LC, 0}, GOp{r.Dv, nb, 0}, rows, nb,
                                     nb, nb, 0, nopred);
-            HIP_CHECK(hipMemcpy2DAsync(Acol, sizeof(double) * r.LC, r.RP + (long)lr0 * tile, sizeof(double) * nb,
-                                       sizeof(double) * nb, rows, hipMemcpyDeviceToDevice, r.st));
+            HIP_CHECK(hipMemcpy2DAsync(Acol, sizeof(double) * r.LC, r.RP2[pb] + (long)lr0 * tile, sizeof(double) * nb,
+                                       sizeof(double) * nb, rows, hipMemcpyDeviceToDevice, s));
         }
         // (d) row panel along every process row
         for (int pr = 0; pr < Pr; ++pr) {
             const int lr0 = cnt_le(k, pr, Pr), TLr = cnt_le(T - 1, pr, Pr);
             const size_t cnt = (size_t)(TLr - lr0) * tile;
             if (int rc = grid_bcast(g, GROUP_ROW, pr, opc, cnt,
-                                    [&](GridRank& r, bool) { return r.RP + (long)lr0 * tile; }))
+                                    [&](GridRank& r, bool) { return r.RP2[pb] + (long)lr0 * tile; }))
                 return rc;
         }
         // (e) column panel: L_jk for the local columns j > k comes from process row j % Pr
@@ -626,7 +675,7 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
             const int pc = (int)(j % Pc), root = (int)(j % Pr);
             const long lj = j / Pc, li = j / Pr;
             if (int rc = grid_bcast(g, GROUP_COL, pc, root, tile, [&](GridRank& r, bool is_root) {
-                    return is_root ? r.RP + li * tile : r.CP + lj * tile;
+                    return is_root ? r.RP2[pb] + li * tile : r.CP2[pb] + lj * tile;
                 }))
                 return rc;
         }
@@ -634,22 +683,23 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
         // (g) row k of X on process row opr: X_kj = D * B_kj (j < k), X_kk = D
         for (GridRank& r : g->ranks) {
             if (r.pr != opr) continue;
+            hipStream_t s = la ? r.sc : r.st;
             const int lcB = cnt_lt(k, r.pc, Pc);                      // local columns with J < k
             const double* Brow = r.X + lkr * nb * r.LC;
-            grid_gemm_t<true, false>(r.st, r.XR, nb, 1, GOp{r.Dv, nb, 0}, GOp{Brow, r.LC, 0}, nb, (long)lcB * nb, nb, nb,
+            grid_gemm_t<true, false>(s, r.XR2[pb], nb, 1, GOp{r.Dv, nb, 0}, GOp{Brow, r.LC, 0}, nb, (long)lcB * nb, nb, nb,
                                      0, nopred);
-            if (r.pc == opc) HIP_CHECK(hipMemcpyAsync(r.XR + (long)lcB * tile, r.Dv, sizeof(double) * tile,
-                                                      hipMemcpyDeviceToDevice, r.st));
+            if (r.pc == opc) HIP_CHECK(hipMemcpyAsync(r.XR2[pb] + (long)lcB * tile, r.Dv, sizeof(double) * tile,
+                                                      hipMemcpyDeviceToDevice, s));
             const int lc0 = cnt_le(k, r.pc, Pc);
             for (int lj = 0; lj < lc0; ++lj)                           // final X row block back into the local matrix
                 HIP_CHECK(hipMemcpy2DAsync(r.X + lkr * nb * r.LC + (long)lj * nb, sizeof(double) * r.LC,
-                                           r.XR + (long)lj * tile, sizeof(double) * nb, sizeof(double) * nb, nb,
-                                           hipMemcpyDeviceToDevice, r.st));
+                                           r.XR2[pb] + (long)lj * tile, sizeof(double) * nb, sizeof(double) * nb, nb,
+                                           hipMemcpyDeviceToDevice, s));
         }
         // (h) X row panel down every process column
         for (int pc = 0; pc < Pc; ++pc) {
             const size_t cnt = (size_t)cnt_le(k, pc, Pc) * tile;
-            if (int rc = grid_bcast(g, GROUP_COL, pc, opr, cnt, [](GridRank& r, bool) { return r.XR; })) return rc;
+            if (int rc = grid_bcast(g, GROUP_COL, pc, opr, cnt, [&](GridRank& r, bool) { return r.XR2[pb]; })) return rc;
         }
         // (i) X_ki for the local rows i <= k comes from process column i % Pc
         if (int rc = grid_group_start(g)) return rc;
@@ -657,26 +707,57 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
             const int pr = (int)(i % Pr), root = (int)(i % Pc);
             const long li = i / Pr, lj = i / Pc;
             if (int rc = grid_bcast(g, GROUP_ROW, pr, root, tile, [&](GridRank& r, bool is_root) {
-                    return is_root ? r.XR + lj * tile : r.XRr + li * tile;
+                    return is_root ? r.XR2[pb] + lj * tile : r.XRr2[pb] + li * tile;
                 }))
                 return rc;
         }
         if (int rc = grid_group_end(g)) return rc;
-        // (f) the three rank-nb updates on the local tiles
+        return 0;
+    };
+    if (int rc = crit(0)) return rc;
+    if (la) HIP_CHECK(hipEventRecord(g->ev_cr[0], scs));
+    for (long k = 0; k < T; ++k) {
+        const int pb = (int)(k & 1);
+        if (la) HIP_CHECK(hipStreamWaitEvent(g->st, g->ev_cr[k], 0));
+        // (f1) part 1: what crit(k+1) reads -- tile column k+1 of A (I >= k+1), tile row k+1 of B (J <= k)
+        const int npr = (int)((k + 1) % Pr), npc = (int)((k + 1) % Pc);
+        if (k + 1 < T) {
+            for (GridRank& r : g->ranks) {
+                const int lr0 = cnt_le(k, r.pr, Pr), lc0 = cnt_le(k, r.pc, Pc);
+                const long rows_hi = (long)(r.TLr - lr0) * nb;
+                if (r.pc == npc && rows_hi > 0) {        // local tile column lc0 is global column k+1
+                    const GridPred lower{1, Pr, r.pr, Pc, r.pc, lr0, lc0};
+                    grid_gemm_t<true, true>(r.st, r.A + (long)lr0 * nb * r.LC + (long)lc0 * nb, r.LC, 0,
+                                            GOp{r.RP2[pb] + (long)lr0 * tile, nb, 0}, GOp{r.CP2[pb] + (long)lc0 * tile, nb, 0},
+                                            rows_hi, nb, nb, nb, 2, lower);
+                }
+                if (r.pr == npr && lc0 > 0)              // local tile row lr0 is global row k+1
+                    grid_gemm_t<true, false>(r.st, r.X + (long)lr0 * nb * r.LC, r.LC, 0, GOp{r.RP2[pb] + (long)lr0 * tile, nb, 0},
+                                             GOp{r.XR2[pb], nb, 1}, nb, (long)lc0 * nb, nb, nb, 2, nopred);
+            }
+            if (la) {
+                HIP_CHECK(hipEventRecord(g->ev_p1[k], g->st));
+                HIP_CHECK(hipStreamWaitEvent(g->sc, g->ev_p1[k], 0));
+            }
+            if (int rc = crit(k + 1)) return rc;
+            if (la) HIP_CHECK(hipEventRecord(g->ev_cr[k + 1], scs));
+        }
+        // (f2) bulk: the rest of the three rank-nb updates on the local tiles
         for (GridRank& r : g->ranks) {
             const int lr0 = cnt_le(k, r.pr, Pr), lc0 = cnt_le(k, r.pc, Pc);
-            const long rows_hi = (long)(r.TLr - lr0) * nb, cols_hi = (long)(r.TLc - lc0) * nb;
+            const int lr1 = cnt_le(k + 1, r.pr, Pr), lc1 = cnt_le(k + 1, r.pc, Pc);     // first local tile with I, J > k+1
+            const long rows_hi1 = (long)(r.TLr - lr1) * nb, cols_hi1 = (long)(r.TLc - lc1) * nb;
             const long rows_lo = (long)lr0 * nb, cols_lo = (long)lc0 * nb;
-            const GridPred lower_hi{1, Pr, r.pr, Pc, r.pc, lr0, lc0}, lower_lo{1, Pr, r.pr, Pc, r.pc, 0, 0};
-            // A_ij -= L_ik L_jk^T,  i >= j > k
-            grid_gemm_t<true, true>(r.st, r.A + (long)lr0 * nb * r.LC + (long)lc0 * nb, r.LC, 0,
-                                    GOp{r.RP + (long)lr0 * tile, nb, 0}, GOp{r.CP + (long)lc0 * tile, nb, 0}, rows_hi,
-                                    cols_hi, nb, nb, 2, lower_hi);
-            // B_ij -= L_ik X_kj,    i > k >= j
-            grid_gemm_t<true, false>(r.st, r.X + (long)lr0 * nb * r.LC, r.LC, 0, GOp{r.RP + (long)lr0 * tile, nb, 0},
-                                     GOp{r.XR, nb, 1}, rows_hi, cols_lo, nb, nb, 2, nopred);
+            const GridPred lower_hi{1, Pr, r.pr, Pc, r.pc, lr1, lc1}, lower_lo{1, Pr, r.pr, Pc, r.pc, 0, 0};
+            // A_ij -= L_ik L_jk^T,  i >= j > k+1
+            grid_gemm_t<true, true>(r.st, r.A + (long)lr1 * nb * r.LC + (long)lc1 * nb, r.LC, 0,
+                                    GOp{r.RP2[pb] + (long)lr1 * tile, nb, 0}, GOp{r.CP2[pb] + (long)lc1 * tile, nb, 0}, rows_hi1,
+                                    cols_hi1, nb, nb, 2, lower_hi);
+            // B_ij -= L_ik X_kj,    i > k+1, k >= j
+            grid_gemm_t<true, false>(r.st, r.X + (long)lr1 * nb * r.LC, r.LC, 0, GOp{r.RP2[pb] + (long)lr1 * tile, nb, 0},
+                                     GOp{r.XR2[pb], nb, 1}, rows_hi1, cols_lo, nb, nb, 2, nopred);
             // W_ij += X_ki^T X_kj,  k >= i >= j
-            grid_gemm_t<false, false>(r.st, r.W, r.LC, 0, GOp{r.XRr, nb, 1}, GOp{r.XR, nb, 1}, rows_lo, cols_lo, nb, nb,
+            grid_gemm_t<false, false>(r.st, r.W, r.LC, 0, GOp{r.XRr2[pb], nb, 1}, GOp{r.XR2[pb], nb, 1}, rows_lo, cols_lo, nb, nb,
                                       1, lower_lo);
         }
     }

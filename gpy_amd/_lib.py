@@ -129,6 +129,11 @@ def lib():
     L.mi355gp_sparse_set_data.argtypes = [vp, _dp, i64, ci, _dp, ci]
     L.mi355gp_vardtc_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_sparse_fetch.argtypes = [vp, ci, _dp]
+    L.mi355gp_vardtc_inference_sum.argtypes = [vp, ci, ctypes.POINTER(Part), _dp, i64, _dp, i64, cd, _dp, _c_dp, _c_dp, _c_dp,
+                                               _c_dp, _c_dp, _c_dp]
+    L.mi355gp_sparse_predict.argtypes = [vp, ci, ctypes.POINTER(Part), _dp, i64, _c_dp, _c_dp, ci]
+    L.mi355gp_sparse_fetch_dLdKnm.argtypes = [vp, i64, i64, _dp]
+    L.mi355gp_sparse_attach_loopback.argtypes = [vp, ci, ci, ci]
     L.mi355gp_sparse_attach_comm.argtypes = [vp, ci, ci, ctypes.c_char_p]
     L.mi355gp_dbg_mfma.argtypes = [ci, _dp, _dp, _dp]
     L.mi355gp_dbg_gemm.argtypes = [ci, ci, ci, i64, i64, i64, _dp, _dp, _dp, cd, cd, ci, _c_dp]
@@ -140,7 +145,8 @@ def lib():
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
                  "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "sparse_create",
                  "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm", "exact_inference_sum",
-                 "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum", "dbg_mask_probe"):
+                 "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum", "dbg_mask_probe",
+                 "vardtc_inference_sum", "sparse_predict", "sparse_fetch_dLdKnm", "sparse_attach_loopback"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -155,7 +161,8 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_sparse_create", "mi355gp_sparse_destroy", "mi355gp_sparse_set_data", "mi355gp_vardtc_inference",
             "mi355gp_sparse_fetch", "mi355gp_gradients_X", "mi355gp_sparse_attach_comm",
             "mi355gp_exact_inference_sum", "mi355gp_predict_sum", "mi355gp_dbg_gemm_clock",
-            "mi355gp_covariance_between_points", "mi355gp_exact_studentt_sum",
+            "mi355gp_covariance_between_points", "mi355gp_exact_studentt_sum", "mi355gp_vardtc_inference_sum",
+            "mi355gp_sparse_predict", "mi355gp_sparse_fetch_dLdKnm", "mi355gp_sparse_attach_loopback",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe")
 
 
@@ -401,6 +408,54 @@ class SparseContext(object):
     def fetch(self, which):
         out = np.empty((self.M, self.M))
         check(lib().mi355gp_sparse_fetch(self._h, which, out), "mi355gp_sparse_fetch")
+        return out
+
+    def attach_loopback(self, rank, world, group_key):
+        """Row-sharded mode over the in-process loopback transport (one host thread per logical rank)."""
+        check(lib().mi355gp_sparse_attach_loopback(self._h, rank, world, int(group_key)), "mi355gp_sparse_attach_loopback")
+
+    def vardtc_sum(self, specs, Z, noise, extra_jitter=0.0, want_dL_dm=False, want_stage_ms=False):
+        """Sum-of-parts kernel (specs as for `Context.exact_inference_sum`), scalar or per-point noise variances.
+        (info, dict(lml, dnoise (scalar or N-vector), dtheta (concatenated), dZ, woodbury_vector[, dL_dm, stage_ms]))"""
+        arr, keep, ntheta = make_parts(specs)
+        Z = f64(Z)
+        self.M = Z.shape[0]
+        assert Z.shape[1] == self.D
+        noise = f64(np.atleast_1d(noise)).ravel()
+        het = noise.size > 1
+        out = np.zeros(NUM_OUT)
+        dtheta = np.zeros(ntheta)
+        dZ = np.zeros((self.M, self.D))
+        wv = np.zeros((self.M, self.Dy))
+        rows = np.zeros(self.N) if het else None
+        dm = np.zeros((self.N, self.Dy)) if want_dL_dm else None
+        ms = np.zeros(4) if want_stage_ms else None
+        rc = check(lib().mi355gp_vardtc_inference_sum(self._h, len(specs), arr, Z, self.M, noise, noise.size,
+                                                      float(extra_jitter), out, _opt(dtheta), _opt(dZ), _opt(wv), _opt(rows),
+                                                      _opt(dm), _opt(ms)), "mi355gp_vardtc_inference_sum")
+        res = dict(lml=out[0], dnoise=rows if het else out[1], trA=out[2], data_fit=out[3], dtheta=dtheta, dZ=dZ,
+                   woodbury_vector=wv, dL_dm=dm)
+        if ms is not None:
+            res["stage_ms"] = dict(pass1=ms[0], mxm=ms[1], pass2=ms[2], total=ms[3])
+        return rc, res
+
+    def predict(self, specs, Xnew, full_cov=False, want_var=True):
+        """(mu (M* x Dy), var (M* x 1) or cov) of the sparse posterior of the last call, on the device."""
+        arr, keep, _ = make_parts(specs)
+        Xnew = f64(Xnew)
+        Mn = Xnew.shape[0]
+        assert Xnew.shape[1] == self.D
+        mu = np.empty((Mn, self.Dy))
+        var = (np.empty((Mn, Mn)) if full_cov else np.empty(Mn)) if want_var else None
+        check(lib().mi355gp_sparse_predict(self._h, len(specs), arr, Xnew, Mn, mu.ctypes.data_as(_c_dp), _opt(var),
+                                           int(bool(full_cov))), "mi355gp_sparse_predict")
+        if var is not None and not full_cov:
+            var = var[:, None]
+        return mu, var
+
+    def fetch_dL_dKnm(self, row0, nrows):
+        out = np.empty((nrows, self.M))
+        check(lib().mi355gp_sparse_fetch_dLdKnm(self._h, int(row0), int(nrows), out), "mi355gp_sparse_fetch_dLdKnm")
         return out
 
 

@@ -167,12 +167,14 @@ int grad_num_blocks(long n);
 void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, const double* W,
                        long ldw, const double* alpha, int Dy, double* partials, int stride,
                        const double* aa_scale = nullptr, const double* Mul = nullptr, long ldm = 0);
-// optional on-the-fly form of the weight matrix read by launch_grad_generic: g = gscale * G + beta * sum_d Y[i][d] V[j][d]
+// optional on-the-fly form of the weight matrix read by launch_grad_generic:
+//   g = rowscale[i] * (gscale * G + beta * sum_d Y[i][d] V[j][d])        (rowscale == NULL: 1)
 struct RankTerm {
     const double* Y;
     const double* V;
     int Dy;
     double beta, gscale;
+    const double* rowscale = nullptr;
 };
 // sparse pass 2: theta partials + H^T [x~ | 1] column partials in one pass over the weights (k_grad_cols); 0 = not applicable
 int launch_grad_cols(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2, long ld2,
@@ -183,7 +185,7 @@ void launch_studentt_scale(hipStream_t st, const double* scal, double nu, long n
 void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
                          long ld2, long m, int symmetric, const double* G, long ldg, double* partials,
                          int stride, double* Hout = nullptr, long ldh = 0,
-                         RankTerm rk = RankTerm{nullptr, nullptr, 0, 0.0, 1.0});
+                         RankTerm rk = RankTerm{nullptr, nullptr, 0, 0.0, 1.0, nullptr});
 // part[split][cols][nv] = sum over a row range of M[i][j] * V(i, c); V(i, c) = V[i*sr + c*sc] plus an optional
 // all-ones column; returns the number of row splits (sum them with launch_sum_splits)
 int launch_colreduce_multi(hipStream_t st, const double* M, long ld, long rows, long cols, const double* V, long sr,
@@ -216,6 +218,12 @@ void launch_pad_from_dense(hipStream_t st, const double* src, long n, double* A,
 // column reductions over a (rows x ld) matrix: mode 0: out[j*Dy+d] = sum_i M[i][j]*v[i*Dy+d]; mode 1: out[j] = c0 - sum_i M[i][j]^2
 void launch_col_reduce(hipStream_t st, const double* M, long ld, long rows, long cols, const double* v, int Dy,
                        double c0, int mode, double* out);
+
+// out_s[i][d] = sum_j K[i][j] v[j][d]  and (t_out != NULL)  t_out[i] = sum_j K[i][j] T[i][j]   over j < m, one wave per row
+void launch_rowdots(hipStream_t st, const double* K, const double* T, long ld, long rows, long m, const double* v, int Dy,
+                    double* out_s, double* t_out);
+// M[i][j] *= sqrt(w[i]) into Out (may alias M), rows x cols (ld shared)
+void launch_rowscale_sqrt(hipStream_t st, const double* M, long ld, long rows, long cols, const double* w, double* Out);
 
 // ---- grid.hip : RCCL (dlopen'ed) world communicator for row-sharded paths ---------------------------------------
 int rccl_comm_create(int rank, int world, const void* id128, void** comm);

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                                               double* __restrict__ Hout = nullptr, long ldh = 0, int diag_same = 0,
                                               const double* __restrict__ aa_scale = nullptr,
                                               const double* __restrict__ Mul = nullptr, long ldm = 0,
-                                              RankTerm rk = RankTerm{nullptr, nullptr, 0, 0.0, 1.0}) {
+                                              RankTerm rk = RankTerm{nullptr, nullptr, 0, 0.0, 1.0, nullptr}) {
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
     __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
     __shared__ double red[256];
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                             double yv = 0.0;
                             for (int d = 0; d < rk.Dy; ++d) yv = fma(rk.Y[i * rk.Dy + d], rk.V[j * rk.Dy + d], yv);
                             g = fma(rk.gscale, g, rk.beta * yv);
+                            if (rk.rowscale) g *= rk.rowscale[i];   // per-point precision (var_dtc.py:224-226)
                         }
                     }
                     // factor of a product kernel: dL_dK times the other factors' covariances (prod.py:86-99)
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(256) void k_grad_cols(KernParams kp, const double* 
                         double yv = 0.0;
                         for (int d = 0; d < rk.Dy; ++d) yv = fma(rk.Y[i * rk.Dy + d], rk.V[j * rk.Dy + d], yv);
                         g = fma(rk.gscale, g, rk.beta * yv);
+                        if (rk.rowscale) g *= rk.rowscale[i];
                     }
                 }
                 const CovVal c = cov_all(kp.kind, kp.variance, r2[a][b], false);
@@ -887,4 +889,48 @@ void launch_trmv_lower_T(hipStream_t st, const double* X, long ld, long n, const
                            Dy, d0, partials);
     hipLaunchKernelGGL(k_trmv_finish, dim3((unsigned)((n * Dy + 255) / 256)), dim3(256), 0, st, partials, n, Dy,
                        nchunks, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row reductions of the sparse path over a resident chunk: s[i][d] = sum_j K[i][j] v[j][d] (= K(X, Z) woodbury_vector:
+// dL_dm = V - s, var_dtc.py:148) and t[i] = sum_j K[i][j] T[i][j] (the per-point noise gradient, var_dtc.py:240-256).
+__global__ __launch_bounds__(256) void k_rowdots(const double* __restrict__ K, const double* __restrict__ T, long ld,
+                                                 long rows, long m, const double* __restrict__ v, int Dy,
+                                                 double* __restrict__ out_s, double* __restrict__ t_out) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    const double* kr = K + i * ld;
+    double t = 0.0;
+    if (t_out) {
+        const double* tr = T + i * ld;
+        for (long j = lane; j < m; j += 64) t = fma(kr[j], tr[j], t);
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+        if (lane == 0) t_out[i] = t;
+    }
+    if (out_s) {
+        for (int d = 0; d < Dy; ++d) {
+            double a = 0.0;
+            for (long j = lane; j < m; j += 64) a = fma(kr[j], v[j * Dy + d], a);
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+            if (lane == 0) out_s[i * Dy + d] = a;
+        }
+    }
+}
+void launch_rowdots(hipStream_t st, const double* K, const double* T, long ld, long rows, long m, const double* v, int Dy,
+                    double* out_s, double* t_out) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_rowdots, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, K, T, ld, rows, m, v, Dy, out_s, t_out);
+}
+
+__global__ void k_rowscale_sqrt(const double* __restrict__ M, long ld, long rows, long cols, const double* __restrict__ w,
+                                double* __restrict__ Out) {
+    const long j = (long)blockIdx.y * blockDim.x + threadIdx.x, i = blockIdx.x;
+    if (j >= cols || i >= rows) return;
+    Out[i * ld + j] = M[i * ld + j] * sqrt(w[i]);
+}
+void launch_rowscale_sqrt(hipStream_t st, const double* M, long ld, long rows, long cols, const double* w, double* Out) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_rowscale_sqrt, dim3((unsigned)rows, (unsigned)((cols + 255) / 256)), dim3(256), 0, st, M, ld, rows,
+                       cols, w, Out);
 }

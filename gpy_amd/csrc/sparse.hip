@@ -103,25 +103,97 @@ __global__ __launch_bounds__(256) void k_sparse_scalars(const double* __restrict
     }
     if (t < 4) out[t] = red[t][0];
 }
-// G[i][j] = beta * sum_d Y[i][d] v[j][d] + 2 G[i][j] for i < rows, j < m; 0 in the padding
+// G[i][j] = beta_i * (sum_d R[i][d] v[j][d] + 2 G[i][j]) for i < rows, j < m; 0 in the padding   (dL_dKnm, var_dtc.py:219-233)
 __global__ void k_form_dLdKnm(double* __restrict__ G, long ld, long rows, long rows_pad, long m,
-                              const double* __restrict__ Y, const double* __restrict__ v, int Dy, double beta) {
+                              const double* __restrict__ Y, const double* __restrict__ v, int Dy,
+                              const double* __restrict__ beta) {
     const long j = (long)blockIdx.y * blockDim.x + threadIdx.x, i = blockIdx.x;   // rows on x: no 65535 limit
     if (j >= ld || i >= rows_pad) return;
     double g = 0.0;
     if (i < rows && j < m) {
         double yv = 0.0;
         for (int d = 0; d < Dy; ++d) yv = fma(Y[i * Dy + d], v[j * Dy + d], yv);
-        g = fma(2.0, G[i * ld + j], beta * yv);
+        g = beta[i] * fma(2.0, G[i * ld + j], yv);
     }
     G[i * ld + j] = g;
+}
+// out[j] = c0 - sum_i A[i][j] * B[i][j]   (64 columns per block, 4 row groups, fixed-order combine)
+__global__ __launch_bounds__(256) void k_col_dot(const double* __restrict__ A, const double* __restrict__ B, long ld,
+                                                 long rows, long cols, double c0, double* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + tx;
+    double acc = 0.0;
+    if (j < cols)
+        for (long i = g; i < rows; i += 4) acc = fma(A[i * ld + j], B[i * ld + j], acc);
+    red[g][tx] = acc;
+    __syncthreads();
+    if (g == 0 && j < cols) out[j] = c0 - ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
 }
 __global__ void k_vec_axpy(double* __restrict__ dst, const double* __restrict__ src, long cnt, double a) {
     const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (l < cnt) dst[l] = fma(a, src[l], dst[l]);
 }
 
+// out[i][d] = w[i] * in[i][d]
+__global__ void k_scale_rows(const double* __restrict__ in, const double* __restrict__ w, long cnt, int Dy,
+                             double* __restrict__ out) {
+    const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < cnt) out[l] = w[l / Dy] * in[l];
+}
+
 static dim3 grid2d(long cols, long rows) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows); }
+
+// ---- communicators of the row-sharded mode ------------------------------------------------------------------------
+// RCCL (one rank per process / GPU) or LOOPBACK: `world` contexts of ONE process on one device, driven by one host thread
+// each, meet at a process-local rendezvous and are summed in rank order -- the transport that lets the world > 1 logic
+// (global N, tr(YY^T), the two exchange steps, replicated M x M algebra) be parity-tested on a 1-GPU box.
+#include <condition_variable>
+#include <map>
+#include <mutex>
+struct LoopGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    int world = 0, arrived = 0;
+    long gen = 0;
+    std::vector<double*> bufs;
+};
+static std::map<int, LoopGroup*> g_loop_groups;
+static std::mutex g_loop_mu;
+
+__global__ void k_vec_add(double* __restrict__ dst, const double* __restrict__ src, long cnt) {
+    const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < cnt) dst[l] += src[l];
+}
+
+static int loop_allreduce(LoopGroup* G, int rank, double* buf, size_t count, hipStream_t st) {
+    HIP_CHECK(hipStreamSynchronize(st));                      // this rank's partial sums are complete
+    std::unique_lock<std::mutex> lk(G->mu);
+    G->bufs[(size_t)rank] = buf;
+    const long gen = G->gen;
+    if (++G->arrived == G->world) {                           // the last arrival reduces, in rank order, and redistributes
+        const unsigned nblk = (unsigned)((count + 255) / 256);
+        for (int r = 1; r < G->world; ++r)
+            hipLaunchKernelGGL(k_vec_add, dim3(nblk), dim3(256), 0, st, G->bufs[0], G->bufs[(size_t)r], (long)count);
+        for (int r = 1; r < G->world; ++r)
+            HIP_CHECK(hipMemcpyAsync(G->bufs[(size_t)r], G->bufs[0], count * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        G->arrived = 0;
+        ++G->gen;
+        G->cv.notify_all();
+    } else {
+        G->cv.wait(lk, [&] { return G->gen != gen; });
+    }
+    return 0;
+}
+
+struct SPart {
+    KernParams kp = {0, 0, 0, 1.0};
+    std::vector<double> theta, inv_ls;
+    std::vector<int> dims;
+    double *XtZ = nullptr, *XtC = nullptr, *HX = nullptr, *HZ = nullptr, *gradNM = nullptr, *gradMM = nullptr;
+    bool stationary() const { return kp.kind <= 3; }
+};
 
 struct mi355gp_sparse {
     int fuse_cols = 1;            // MI355GP_SPARSE_FUSE_COLS: k_grad_cols (gradient pass + column reductions in one)
@@ -130,33 +202,55 @@ struct mi355gp_sparse {
     long n = 0, chunk = 0;
     int D = 0, Dy = 0, splitk = 8;
     double trYYT = 0.0;
+    std::vector<double> rowYY;    // host: |R_n|^2 per row (heteroscedastic log likelihood)
     // row-sharded multi-GPU mode (the reference's MPI design: var_dtc_parallel.py:121-130,387-394):
     // this rank holds n of n_global rows; psi2 / psi1Y and the pass-2 sums are all-reduced, M x M algebra is replicated
-    void* comm = nullptr;
+    void* comm = nullptr;         // RCCL communicator
+    LoopGroup* loop = nullptr;    // or the loopback rendezvous
     int world = 1, rank = 0;
     long n_global = 0;
-    double *dX = nullptr, *dY = nullptr, *XtC = nullptr, *Kfu = nullptr, *T = nullptr;
+    double *dX = nullptr, *dY = nullptr, *dV = nullptr, *dBeta = nullptr, *dRowS = nullptr, *dRowT = nullptr, *Kfu = nullptr,
+           *T = nullptr;
     // M-dependent
     long m = 0, mp = 0;
-    double *dZ = nullptr, *XtZ = nullptr, *invls = nullptr, *zero1 = nullptr;
+    double *dZ = nullptr, *invls = nullptr, *zero1 = nullptr;
     double *Lm = nullptr, *Xm = nullptr, *Tm = nullptr, *psi2part = nullptr, *psi2 = nullptr, *Amat = nullptr,
            *LB = nullptr, *XB = nullptr, *Bi = nullptr, *P = nullptr, *E = nullptr, *T1 = nullptr, *Q2 = nullptr,
            *dLdKmm = nullptr, *Winv = nullptr;
     double *psi1Y = nullptr, *vecA = nullptr, *vecB = nullptr, *cvec = nullptr, *wvec = nullptr, *vvec = nullptr,
-           *trmvPart = nullptr, *colPart = nullptr, *HX = nullptr, *HZ = nullptr, *gradPart = nullptr,
-           *gradChunk = nullptr, *gradNM = nullptr, *gradMM = nullptr, *scal = nullptr;
+           *trmvPart = nullptr, *colPart = nullptr, *gradPart = nullptr, *gradChunk = nullptr, *scal = nullptr,
+           *redbuf = nullptr;
+    std::vector<SPart> parts;
     FactorWs ws;
-    bool ws_ok = false, have_result = false;
+    bool ws_ok = false, have_result = false, winv_ok = false;
     hipEvent_t ev[6] = {};
-    KernParams kp = {0, 0, 0, 1.0};
-    std::vector<double> theta;
+    double beta_scalar = 0.0;     // homoscedastic precision of the last call (0: per-point)
 };
 
+static int sparse_allreduce(mi355gp_sparse* s, double* buf, size_t count) {
+    if (s->comm) return rccl_allreduce_sum(s->comm, buf, count, s->st);
+    if (s->loop) return loop_allreduce(s->loop, s->rank, buf, count, s->st);
+    return 0;
+}
+static bool sharded(const mi355gp_sparse* s) { return s->comm != nullptr || s->loop != nullptr; }
+
+static void free_parts(mi355gp_sparse* s) {
+    for (SPart& p : s->parts) {
+        double** ptrs[] = {&p.XtZ, &p.XtC, &p.HX, &p.HZ, &p.gradNM, &p.gradMM};
+        for (auto q : ptrs) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
+    }
+    s->parts.clear();
+}
+
 static void free_m(mi355gp_sparse* s) {
-    double** ptrs[] = {&s->dZ, &s->XtZ, &s->invls, &s->zero1, &s->Lm, &s->Xm, &s->Tm, &s->psi2part, &s->psi2, &s->Amat,
+    free_parts(s);
+    double** ptrs[] = {&s->dZ, &s->invls, &s->zero1, &s->Lm, &s->Xm, &s->Tm, &s->psi2part, &s->psi2, &s->Amat,
                        &s->LB, &s->XB, &s->Bi, &s->P, &s->E, &s->T1, &s->Q2, &s->dLdKmm, &s->Winv, &s->psi1Y, &s->vecA,
-                       &s->vecB, &s->cvec, &s->wvec, &s->vvec, &s->trmvPart, &s->colPart, &s->HX, &s->HZ, &s->gradPart,
-                       &s->gradChunk, &s->gradNM, &s->gradMM, &s->scal, &s->Kfu, &s->T};
+                       &s->vecB, &s->cvec, &s->wvec, &s->vvec, &s->trmvPart, &s->colPart, &s->gradPart,
+                       &s->gradChunk, &s->scal, &s->redbuf, &s->Kfu, &s->T};
     for (auto p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -164,13 +258,11 @@ static void free_m(mi355gp_sparse* s) {
     if (s->ws_ok) factor_ws_free(&s->ws);
     s->ws_ok = false;
     s->m = s->mp = 0;
-    s->have_result = false;
+    s->have_result = s->winv_ok = false;
 }
 
 static int alloc_m(mi355gp_sparse* s, long M) {
     free_m(s);
-    if (s->XtC) (void)hipFree(s->XtC);
-    s->XtC = nullptr;
     s->m = M;
     s->mp = round_up(M, NB);
     {
@@ -190,12 +282,10 @@ static int alloc_m(mi355gp_sparse* s, long M) {
         const long nchunks = (s->n + cmax - 1) / cmax;        // balanced chunks: no nearly-empty last chunk
         s->chunk = round_up((s->n + nchunks - 1) / nchunks, gran);
     }
-    HIP_CHECK(hipMalloc(&s->XtC, sizeof(double) * s->D * s->chunk));
     const long mp = s->mp, D = s->D, Dy = s->Dy;
     const size_t mm = sizeof(double) * mp * mp;
     const int groups = (int)((D + 31) / 32);
     HIP_CHECK(hipMalloc(&s->dZ, sizeof(double) * M * D));
-    HIP_CHECK(hipMalloc(&s->XtZ, sizeof(double) * D * mp));
     HIP_CHECK(hipMalloc(&s->invls, sizeof(double) * D));
     HIP_CHECK(hipMalloc(&s->zero1, sizeof(double) * 8));
     HIP_CHECK(hipMemset(s->zero1, 0, sizeof(double) * 8));
@@ -211,16 +301,82 @@ static int alloc_m(mi355gp_sparse* s, long M) {
     HIP_CHECK(hipMalloc(&s->trmvPart, sizeof(double) * nchunks * mp * Dy));
     const long nvmax = (D + 1 > Dy ? D + 1 : Dy);
     HIP_CHECK(hipMalloc(&s->colPart, sizeof(double) * 64 * mp * nvmax));
-    HIP_CHECK(hipMalloc(&s->HX, sizeof(double) * mp * (D + 1)));
-    HIP_CHECK(hipMalloc(&s->HZ, sizeof(double) * mp * (D + 1)));
     HIP_CHECK(hipMalloc(&s->gradPart, sizeof(double) * groups * 2048 * GP_STRIDE));
     HIP_CHECK(hipMalloc(&s->gradChunk, sizeof(double) * groups * GP_STRIDE));
-    HIP_CHECK(hipMalloc(&s->gradNM, sizeof(double) * groups * GP_STRIDE));
-    HIP_CHECK(hipMalloc(&s->gradMM, sizeof(double) * groups * GP_STRIDE));
     HIP_CHECK(hipMalloc(&s->scal, sizeof(double) * 8));
     if (factor_ws_alloc(&s->ws, mp) != 0) return -3;
     s->ws_ok = true;
     return 0;
+}
+
+// (re)builds the part list of a call; the device buffers of a part are kept while the number of parts is unchanged
+static int prepare_sparse_parts(mi355gp_sparse* s, int nparts, const mi355gp_part* parts) {
+    ARGCHK(nparts >= 1 && nparts <= 16 && parts, "between 1 and 16 kernel parts");
+    const long mp = s->mp, D = s->D;
+    const int groups = (int)((D + 31) / 32);
+    if ((int)s->parts.size() != nparts) {
+        free_parts(s);
+        s->parts.resize((size_t)nparts);
+        if (s->redbuf) (void)hipFree(s->redbuf);
+        s->redbuf = nullptr;
+        HIP_CHECK(hipMalloc(&s->redbuf, sizeof(double) * nparts * ((size_t)groups * GP_STRIDE + (size_t)mp * (D + 1))));
+        for (SPart& p : s->parts) {
+            HIP_CHECK(hipMalloc(&p.XtZ, sizeof(double) * D * mp));
+            HIP_CHECK(hipMalloc(&p.XtC, sizeof(double) * D * s->chunk));
+            HIP_CHECK(hipMalloc(&p.HX, sizeof(double) * mp * (D + 1)));
+            HIP_CHECK(hipMalloc(&p.HZ, sizeof(double) * mp * (D + 1)));
+            HIP_CHECK(hipMalloc(&p.gradNM, sizeof(double) * groups * GP_STRIDE));
+            HIP_CHECK(hipMalloc(&p.gradMM, sizeof(double) * groups * GP_STRIDE));
+        }
+    }
+    for (int i = 0; i < nparts; ++i) {
+        const mi355gp_part& in = parts[i];
+        SPart& p = s->parts[(size_t)i];
+        ARGCHK(in.kind >= 0 && in.kind <= 5 && in.theta, "unknown covariance kind / NULL theta in a kernel part");
+        ARGCHK(in.term == 0, "the sparse path evaluates SUMS of kernels (GPy.kern.Add); product terms are not supported");
+        ARGCHK(in.theta[0] > 0.0, "variance must be positive");
+        p.dims.clear();
+        if (in.active_dims && in.n_active > 0) {
+            for (int a = 0; a < in.n_active; ++a) {
+                ARGCHK(in.active_dims[a] >= 0 && in.active_dims[a] < D, "active dimension out of range");
+                p.dims.push_back(in.active_dims[a]);
+            }
+        } else {
+            for (int q = 0; q < D; ++q) p.dims.push_back(q);
+        }
+        const int na = (int)p.dims.size();
+        const bool st = in.kind <= 3;
+        const int nl = st ? (in.ard ? na : 1) : 0;
+        p.kp = KernParams{in.kind, (st && in.ard) ? 1 : 0, (int)D, in.theta[0]};
+        p.theta.assign(in.theta, in.theta + 1 + nl);
+        p.inv_ls.assign((size_t)D, 0.0);
+        for (int a = 0; a < na && st; ++a) {
+            const double l = in.theta[1 + (in.ard ? a : 0)];
+            ARGCHK(l > 0.0, "lengthscales must be positive");
+            p.inv_ls[(size_t)p.dims[a]] = 1.0 / l;
+        }
+    }
+    return 0;
+}
+
+// scaled, dimension-major copies of `rows` points (row-major src) for every part
+static int scale_for_parts(mi355gp_sparse* s, const double* src, long rows, long ldt, bool inducing) {
+    for (SPart& p : s->parts) {
+        HIP_CHECK(hipMemcpyAsync(s->invls, p.inv_ls.data(), sizeof(double) * s->D, hipMemcpyHostToDevice, s->st));
+        launch_scale_inputs(s->st, src, rows, s->D, s->invls, 1, inducing ? p.XtZ : p.XtC, ldt);
+    }
+    return 0;
+}
+
+// Kfu chunk = sum over parts of K_p(X_chunk, Z)  (add.py:58-72; White contributes nothing off the diagonal, static.py:77-81)
+static void build_cross_chunk(mi355gp_sparse* s, long rc, double* out) {
+    bool first = true;
+    for (SPart& p : s->parts) {
+        if (p.kp.kind == 4) continue;
+        launch_kbuild_cross(s->st, p.kp, p.XtC, s->chunk, rc, p.XtZ, s->mp, s->m, out, s->mp, first ? 0 : 1);
+        first = false;
+    }
+    if (first) (void)hipMemsetAsync(out, 0, sizeof(double) * rc * s->mp, s->st);     // only White parts: K(X, Z) = 0
 }
 
 extern "C" {
@@ -250,9 +406,9 @@ int mi355gp_sparse_destroy(mi355gp_sparse* s) {
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->st);
     free_m(s);
-    if (s->dX) (void)hipFree(s->dX);
-    if (s->dY) (void)hipFree(s->dY);
-    if (s->XtC) (void)hipFree(s->XtC);
+    double** ptrs[] = {&s->dX, &s->dY, &s->dV, &s->dBeta, &s->dRowS, &s->dRowT};
+    for (auto p : ptrs)
+        if (*p) (void)hipFree(*p);
     if (s->comm) rccl_comm_destroy(s->comm);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
@@ -267,26 +423,37 @@ int mi355gp_sparse_set_data(mi355gp_sparse* s, const double* X, int64_t N, int D
     HIP_CHECK(hipSetDevice(s->device));
     HIP_CHECK(hipStreamSynchronize(s->st));
     free_m(s);
-    if (s->dX) (void)hipFree(s->dX);
-    if (s->dY) (void)hipFree(s->dY);
-    if (s->XtC) (void)hipFree(s->XtC);
+    double** ptrs[] = {&s->dX, &s->dY, &s->dV, &s->dBeta, &s->dRowS, &s->dRowT};
+    for (auto p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
     s->n = N;
     s->D = D;
     s->Dy = Dy;
     HIP_CHECK(hipMalloc(&s->dX, sizeof(double) * N * D));
     HIP_CHECK(hipMalloc(&s->dY, sizeof(double) * N * Dy));
-    s->XtC = nullptr;                                         // sized with the chunk (alloc_m)
+    HIP_CHECK(hipMalloc(&s->dV, sizeof(double) * N * Dy));
+    HIP_CHECK(hipMalloc(&s->dBeta, sizeof(double) * N));
+    HIP_CHECK(hipMalloc(&s->dRowS, sizeof(double) * N * Dy));
+    HIP_CHECK(hipMalloc(&s->dRowT, sizeof(double) * N));
     HIP_CHECK(hipMemcpy(s->dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(s->dY, Y, sizeof(double) * N * Dy, hipMemcpyHostToDevice));
     double t = 0.0;
-    for (int64_t i = 0; i < N * Dy; ++i) t += Y[i] * Y[i];     // get_trYYT (var_dtc.py:48-54)
+    s->rowYY.assign((size_t)N, 0.0);
+    for (int64_t i = 0; i < N; ++i) {
+        double r = 0.0;
+        for (int d = 0; d < Dy; ++d) r += Y[i * Dy + d] * Y[i * Dy + d];
+        s->rowYY[(size_t)i] = r;
+        t += r;                                                 // get_trYYT (var_dtc.py:48-54)
+    }
     s->trYYT = t;
     s->n_global = N;
-    if (s->comm) {                                             // global N and tr(Y Y^T) over the shards
+    if (sharded(s)) {                                          // global N and tr(Y Y^T) over the shards
         double h[2] = {(double)N, t}, *d = nullptr;
         HIP_CHECK(hipMalloc(&d, sizeof(h)));
         HIP_CHECK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
-        if (int rc = rccl_allreduce_sum(s->comm, d, 2, s->st)) return rc;
+        if (int rc = sparse_allreduce(s, d, 2)) return rc;
         HIP_CHECK(hipStreamSynchronize(s->st));
         HIP_CHECK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
         (void)hipFree(d);
@@ -303,77 +470,118 @@ int mi355gp_sparse_attach_comm(mi355gp_sparse* s, int rank, int world, const voi
     HIP_CHECK(hipSetDevice(s->device));
     if (s->comm) rccl_comm_destroy(s->comm);
     s->comm = nullptr;
+    s->loop = nullptr;
     if (int rc = rccl_comm_create(rank, world, id128, &s->comm)) return rc;
     s->rank = rank;
     s->world = world;
     return 0;
 }
 
-// out_scalars: [0] log marginal likelihood, [1] dL/d(noise variance) (= dL_dthetaL), [2] trace(A), [3] data_fit,
-//              [4] sum(log diag LB), [5] beta
-// dtheta_out: 1 + (ard ? D : 1) ; dZ_out: M x D ; wv_out (optional): woodbury_vector M x Dy
-// stage_ms (optional): [0] pass 1 (Kfu, psi2, psi1Y), [1] M x M algebra, [2] pass 2 (gradients), [3] total
-int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double* theta, const double* Z, int64_t M,
-                             double noise_var, double extra_jitter, double* out_scalars, double* dtheta_out,
-                             double* dZ_out, double* wv_out, double* stage_ms) {
-    ARGCHK(s && s->n > 0, "mi355gp_vardtc_inference: set_data first");
-    ARGCHK(theta && Z && M > 0 && out_scalars, "mi355gp_vardtc_inference: bad arguments");
-    ARGCHK(kind >= 0 && kind <= 3 && theta[0] > 0.0, "mi355gp_vardtc_inference: bad kernel parameters");
-    HIP_CHECK(hipSetDevice(s->device));
-    const int D = s->D, Dy = s->Dy, nl = ard ? D : 1;
-    std::vector<double> inv_ls((size_t)D, 0.0);
-    for (int q = 0; q < nl; ++q) {
-        ARGCHK(theta[1 + q] > 0.0, "lengthscales must be positive");
-        inv_ls[q] = 1.0 / theta[1 + q];
+// The same mode over the LOOPBACK transport: `world` contexts of this process (one host thread each, any devices... the
+// 1-GPU box: all on one) that name the same group_key meet at a process-local rendezvous for every exchange step.
+int mi355gp_sparse_attach_loopback(mi355gp_sparse* s, int rank, int world, int group_key) {
+    ARGCHK(s && world >= 1 && rank >= 0 && rank < world, "mi355gp_sparse_attach_loopback: bad arguments");
+    std::lock_guard<std::mutex> lk(g_loop_mu);
+    LoopGroup*& G = g_loop_groups[group_key];
+    if (!G) {
+        G = new LoopGroup();
+        G->world = world;
+        G->bufs.assign((size_t)world, nullptr);
     }
+    ARGCHK(G->world == world, "mi355gp_sparse_attach_loopback: the group exists with a different world size");
+    if (s->comm) rccl_comm_destroy(s->comm);
+    s->comm = nullptr;
+    s->loop = G;
+    s->rank = rank;
+    s->world = world;
+    return 0;
+}
+
+// One SparseGP.parameters_changed for a SUM of kernels, scalar or per-point noise and R = Y - mean (see mi355gp.h).
+// out_scalars: [0] log marginal likelihood, [1] dL/d(noise variance) (homoscedastic; 0 otherwise), [2] trace(A),
+//              [3] data_fit, [4] sum(log diag LB), [5] beta (homoscedastic)
+int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_part* parts, const double* Z, int64_t M,
+                                 const double* noise, int64_t noise_len, double extra_jitter, double* out_scalars,
+                                 double* dtheta_out, double* dZ_out, double* wv_out, double* dnoise_rows_out,
+                                 double* dLdm_out, double* stage_ms) {
+    ARGCHK(s && s->n > 0, "mi355gp_vardtc_inference: set_data first");
+    ARGCHK(parts && Z && M > 0 && out_scalars && noise, "mi355gp_vardtc_inference: bad arguments");
+    ARGCHK(noise_len == 1 || noise_len == s->n, "noise must have 1 or N entries");
+    const bool het = noise_len > 1;
+    ARGCHK(!het || s->Dy == 1, "per-point noise needs a single output column (the reference's dL_dR, var_dtc.py:240-256)");
+    ARGCHK(!het || dnoise_rows_out, "per-point noise: dnoise_rows_out (N) is required");
+    HIP_CHECK(hipSetDevice(s->device));
+    const int D = s->D, Dy = s->Dy;
     if (M != s->m)
         if (int rc = alloc_m(s, M)) return rc;
+    if (int rc = prepare_sparse_parts(s, nparts, parts)) return rc;
     hipStream_t st = s->st;
     const long n = s->n, m = s->m, mp = s->mp, chunk = s->chunk;
     const int groups = (D + 31) / 32;
-    const double beta = 1.0 / fmax(noise_var, 1e-8);                                    // var_dtc.py:78-80
-    KernParams kp{kind, ard ? 1 : 0, D, theta[0]};
-    s->kp = kp;
-    s->theta.assign(theta, theta + 1 + nl);
-    s->have_result = false;
-    HIP_CHECK(hipMemcpyAsync(s->invls, inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
+    const size_t gsz = (size_t)groups * GP_STRIDE, hsz = (size_t)mp * (D + 1);
+    // per-point precision beta_n = 1 / max(noise_n, 1e-8) (var_dtc.py:78-80), V = beta * R (:88)
+    std::vector<double> hbeta((size_t)n);
+    double sum_beta = 0.0, sum_logbeta = 0.0, sum_bYY = 0.0;
+    for (long i = 0; i < n; ++i) {
+        const double b = 1.0 / fmax(noise[het ? i : 0], 1e-8);
+        hbeta[(size_t)i] = b;
+        sum_beta += b;
+        sum_logbeta += log(b);
+        sum_bYY += b * s->rowYY[(size_t)i];
+    }
+    const double beta = het ? 0.0 : hbeta[0];
+    s->beta_scalar = beta;
+    s->have_result = s->winv_ok = false;
+    HIP_CHECK(hipMemcpyAsync(s->dBeta, hbeta.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(s->dZ, Z, sizeof(double) * m * D, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipEventRecord(s->ev[0], st));
-    launch_scale_inputs(st, s->dZ, m, D, s->invls, kp.ard, s->XtZ, mp);
-    // Kmm + 1e-8 I (var_dtc.py:93-94), Lm = chol (jitchol, :95), Xm = Lm^-1
-    launch_kbuild_sym(st, kp, s->XtZ, mp, m, mp, s->Lm, s->zero1, 1, 1e-8 + extra_jitter, /*lower_only=*/1, 1);
+    {   // V = beta * R
+        const long cnt = n * Dy;
+        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, s->dY, s->dBeta, cnt, Dy, s->dV);
+    }
+    if (int rc = scale_for_parts(s, s->dZ, m, mp, true)) return rc;
+    // Kmm + 1e-8 I (var_dtc.py:93-94) = sum of the parts' K(Z) (White on the diagonal), Lm = chol (jitchol, :95), Xm = Lm^-1
+    for (size_t i = 0; i < s->parts.size(); ++i)
+        launch_kbuild_sym(st, s->parts[i].kp, s->parts[i].XtZ, mp, m, mp, s->Lm, s->zero1, 1, 1e-8 + extra_jitter,
+                          /*lower_only=*/1, /*add_diag=*/i == 0, /*accumulate=*/i > 0);
     potrf_device(st, s->Lm, mp, &s->ws);
     int info_m = 0;
     HIP_CHECK(hipMemcpyAsync(&info_m, s->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemsetAsync(s->Xm, 0, sizeof(double) * mp * mp, st));
     trtri_device(st, s->Lm, s->Xm, s->Tm, mp, &s->ws);
-    // ---- pass 1: psi2 = Kuf Kfu, psi1Y = Kuf Y -----------------------------------------------------------
+    // ---- pass 1: psi2 = sum_n beta_n k_n k_n^T (heteroscedastic) or Kuf Kfu (then A carries beta), psi1V = Kuf V -------
     HIP_CHECK(hipMemsetAsync(s->psi1Y, 0, sizeof(double) * mp * Dy, st));
     int nch = 0;
     for (long r0 = 0; r0 < n; r0 += chunk, ++nch) {
         const long rc = (n - r0 < chunk) ? (n - r0) : chunk;
-        launch_scale_inputs(st, s->dX + r0 * D, rc, D, s->invls, kp.ard, s->XtC, chunk);
+        if (int e = scale_for_parts(s, s->dX + r0 * D, rc, chunk, false)) return e;
         // the cross-covariance kernel writes rows < rc, columns < m: zero only what it leaves out
         if (m < mp) {
             if (rc < chunk || nch == 0) HIP_CHECK(hipMemsetAsync(s->Kfu, 0, sizeof(double) * chunk * mp, st));
         } else if (rc < chunk) {
             HIP_CHECK(hipMemsetAsync(s->Kfu + rc * mp, 0, sizeof(double) * (chunk - rc) * mp, st));
         }
-        launch_kbuild_cross(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, s->Kfu, mp);
-        launch_gram_splitk(st, s->Kfu, mp, round_up(rc, 16L * s->splitk), mp, s->splitk, nch > 0, s->psi2part);   // rows >= rc are zero
-        const int ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, s->dY + r0 * Dy, Dy, 1, Dy, 0, s->colPart);
-        launch_sum_splits(st, s->colPart, mp * Dy, ns, 1, s->psi1Y);               // psi1Y += Kuf Y_chunk
+        build_cross_chunk(s, rc, s->Kfu);
+        const double* G = s->Kfu;
+        if (het) {                                            // rows scaled by sqrt(beta_n) (var_dtc.py:126-129) into T
+            HIP_CHECK(hipMemsetAsync(s->T + rc * mp, 0, sizeof(double) * (round_up(rc, 16L * s->splitk) - rc) * mp, st));
+            launch_rowscale_sqrt(st, s->Kfu, mp, rc, mp, s->dBeta + r0, s->T);
+            G = s->T;
+        }
+        launch_gram_splitk(st, G, mp, round_up(rc, 16L * s->splitk), mp, s->splitk, nch > 0, s->psi2part);   // rows >= rc are zero
+        const int ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, s->dV + r0 * Dy, Dy, 1, Dy, 0, s->colPart);
+        launch_sum_splits(st, s->colPart, mp * Dy, ns, 1, s->psi1Y);               // psi1V += Kuf V_chunk
     }
     hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->psi2part, mp, s->splitk, s->psi2);
-    if (s->comm) {                                              // the one exchange step of pass 1
-        if (int rc = rccl_allreduce_sum(s->comm, s->psi2, (size_t)mp * mp, st)) return rc;
-        if (int rc = rccl_allreduce_sum(s->comm, s->psi1Y, (size_t)mp * Dy, st)) return rc;
+    if (sharded(s)) {                                           // the one exchange step of pass 1
+        if (int rc = sparse_allreduce(s, s->psi2, (size_t)mp * mp)) return rc;
+        if (int rc = sparse_allreduce(s, s->psi1Y, (size_t)mp * Dy)) return rc;
     }
     HIP_CHECK(hipEventRecord(s->ev[1], st));
     // ---- M x M algebra ----------------------------------------------------------------------------------------
-    // A = beta * Lm^-1 psi2 Lm^-T (var_dtc.py:129-134), B = I + A (:137), LB = chol(B) (:138), XB = LB^-1
+    // A = Lm^-1 psi2_beta Lm^-T (var_dtc.py:129-134), B = I + A (:137), LB = chol(B) (:138), XB = LB^-1
     launch_gemm(st, 0, 1, mp, mp, mp, s->Xm, mp, s->psi2, mp, s->T1, mp, 1.0, 0.0);
-    launch_gemm(st, 0, 0, mp, mp, mp, s->T1, mp, s->Xm, mp, s->Amat, mp, beta, 0.0);
+    launch_gemm(st, 0, 0, mp, mp, mp, s->T1, mp, s->Xm, mp, s->Amat, mp, het ? 1.0 : beta, 0.0);
     hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->Amat, 1.0, (const double*)nullptr, 0.0, 1.0, mp,
                        s->LB);
     potrf_device(st, s->LB, mp, &s->ws);
@@ -381,9 +589,7 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
     HIP_CHECK(hipMemcpyAsync(&info_b, s->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemsetAsync(s->XB, 0, sizeof(double) * mp * mp, st));
     trtri_device(st, s->LB, s->XB, s->Tm, mp, &s->ws);
-    // c = LB^-1 Lm^-1 psi1 (beta Y) (:141-143), w = LB^-T c (:144), v = Lm^-T w = woodbury_vector (:145)
-    hipLaunchKernelGGL(k_vec_axpy, dim3((unsigned)((mp * Dy + 255) / 256)), dim3(256), 0, st, s->psi1Y, s->psi1Y, mp * Dy,
-                       beta - 1.0);                                                    // psi1Y *= beta
+    // c = LB^-1 Lm^-1 psi1 V (:141-143), w = LB^-T c (:144), v = Lm^-T w = woodbury_vector (:145)
     launch_trmv_lower(st, s->Xm, mp, mp, s->psi1Y, Dy, s->vecA);
     launch_trmv_lower(st, s->XB, mp, mp, s->vecA, Dy, s->cvec);
     launch_trmv_lower_T(st, s->XB, mp, mp, s->cvec, Dy, s->wvec, s->trmvPart);
@@ -395,73 +601,111 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
     hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->P, -0.5, s->Amat, -0.5 * Dy, 0.5 * Dy, mp, s->E);
     launch_gemm(st, 1, 1, mp, mp, mp, s->Xm, mp, s->E, mp, s->T1, mp, 1.0, 0.0);        // Xm^T E
     launch_gemm(st, 0, 1, mp, mp, mp, s->T1, mp, s->Xm, mp, s->dLdKmm, mp, 1.0, 0.0);   // (Xm^T E) Xm
-    // dL_dpsi2 = beta * 0.5 * Lm^-T (Dy I - P) Lm^-1 (:220,231)
-    hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->P, -0.5 * beta, (const double*)nullptr, 0.0,
-                       0.5 * beta * Dy, mp, s->E);
+    // Q2 = dL_dpsi2_beta = 0.5 Lm^-T (Dy I - P) Lm^-1 (:220); the precision enters per row in pass 2 (:224-226,231)
+    hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->P, -0.5, (const double*)nullptr, 0.0, 0.5 * Dy, mp,
+                       s->E);
     launch_gemm(st, 1, 1, mp, mp, mp, s->Xm, mp, s->E, mp, s->T1, mp, 1.0, 0.0);
     launch_gemm(st, 0, 1, mp, mp, mp, s->T1, mp, s->Xm, mp, s->Q2, mp, 1.0, 0.0);
     hipLaunchKernelGGL(k_sparse_scalars_rows, dim3((unsigned)m), dim3(256), 0, st, s->Amat, s->P, s->LB, s->cvec, Dy, mp, m,
                        s->colPart);
     hipLaunchKernelGGL(k_sparse_scalars, dim3(1), dim3(256), 0, st, s->colPart, m, s->scal);
     HIP_CHECK(hipEventRecord(s->ev[2], st));
-    // ---- pass 2: dL_dKnm = beta Y v^T + 2 Kfu dL_dpsi2 (:219,233), its theta reductions and H^T [X~ | 1] ---------
-    HIP_CHECK(hipMemsetAsync(s->gradNM, 0, sizeof(double) * groups * GP_STRIDE, st));
-    HIP_CHECK(hipMemsetAsync(s->HX, 0, sizeof(double) * mp * (D + 1), st));
+    // ---- pass 2: dL_dKnm = beta_n (R v^T + 2 Kfu Q2) (:219,224-226,233), its theta reductions and H^T [X~ | 1] per part --
+    for (SPart& p : s->parts) {
+        HIP_CHECK(hipMemsetAsync(p.gradNM, 0, sizeof(double) * gsz, st));
+        HIP_CHECK(hipMemsetAsync(p.HX, 0, sizeof(double) * hsz, st));
+    }
+    const bool want_rows = het || dLdm_out != nullptr;
     nch = 0;
     const int one_chunk = (n <= chunk);
     for (long r0 = 0; r0 < n; r0 += chunk, ++nch) {
         const long rc = (n - r0 < chunk) ? (n - r0) : chunk;
         const long rcp = round_up(rc, NB);
         if (!one_chunk) {                                    // a single chunk is still resident from pass 1
-            launch_scale_inputs(st, s->dX + r0 * D, rc, D, s->invls, kp.ard, s->XtC, chunk);
+            if (int e = scale_for_parts(s, s->dX + r0 * D, rc, chunk, false)) return e;
             if (rc < chunk) HIP_CHECK(hipMemsetAsync(s->Kfu + rc * mp, 0, sizeof(double) * (chunk - rc) * mp, st));
-            launch_kbuild_cross(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, s->Kfu, mp);
+            build_cross_chunk(s, rc, s->Kfu);
         }
         launch_gemm(st, 0, 1, rcp, mp, mp, s->Kfu, mp, s->Q2, mp, s->T, mp, 1.0, 0.0);
-        // dL_dKnm = 2 T + beta Y v^T is formed inside the gradient pass (no separate read-modify-write of the chunk).
-        // D <= 16: the same pass also accumulates H^T [X~ | 1] (H = dL_dKnm * (dK/dr)/r stays on chip); otherwise H
-        // overwrites T in place and a second pass reduces it.  Padding rows / columns of T are zero from the GEMM.
-        const RankTerm rk{s->dY + r0 * Dy, s->vvec, Dy, beta, 2.0};
-        int nbk = 0;
-        int ns = s->fuse_cols ? launch_grad_cols(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, mp, s->T, mp, rk, s->gradPart,
-                                                 s->colPart, &nbk) : 0;
-        if (ns == 0) {
-            nbk = grad_generic_num_blocks(rc, m);
-            launch_grad_generic(st, kp, s->XtC, chunk, rc, s->XtZ, mp, m, 0, s->T, mp, s->gradPart, GP_STRIDE, s->T, mp, rk);
-            ns = launch_colreduce_multi(st, s->T, mp, rc, mp, s->XtC, 1, chunk, D, 1, s->colPart);
+        // per-row reductions for dL_dm = V - Kfu v (:148) and the per-point noise gradient (t_n = sum_j T_nj Kfu_nj)
+        if (want_rows) launch_rowdots(st, s->Kfu, s->T, mp, rc, m, s->vvec, Dy, s->dRowS + r0 * Dy, het ? s->dRowT + r0 : nullptr);
+        // dL_dKnm is formed inside the gradient pass (no separate read-modify-write of the chunk).  D <= 16: the same pass
+        // also accumulates H^T [X~ | 1] (H = dL_dKnm * (dK/dr)/r stays on chip); otherwise H is written to the Kfu buffer
+        // (not needed any more for this chunk: the gradient kernels recompute the covariance from the inputs) and reduced
+        // by a second pass -- T itself must survive for the parts that follow.
+        const RankTerm rk{s->dY + r0 * Dy, s->vvec, Dy, 1.0, 2.0, s->dBeta + r0};
+        const size_t nstat = s->parts.size();
+        for (size_t pi = 0; pi < nstat; ++pi) {
+            SPart& p = s->parts[pi];
+            if (p.kp.kind == 4) continue;                    // White: K(X, Z) = 0, no contribution (static.py:89-93)
+            int nbk = 0, ns = 0;
+            if (p.stationary() && s->fuse_cols)
+                ns = launch_grad_cols(st, p.kp, p.XtC, chunk, rc, p.XtZ, mp, m, mp, s->T, mp, rk, s->gradPart, s->colPart, &nbk);
+            if (ns == 0) {
+                nbk = grad_generic_num_blocks(rc, m);
+                double* Hbuf = p.stationary() ? s->Kfu : nullptr;
+                launch_grad_generic(st, p.kp, p.XtC, chunk, rc, p.XtZ, mp, m, 0, s->T, mp, s->gradPart, GP_STRIDE, Hbuf, mp, rk);
+                if (p.stationary()) ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, p.XtC, 1, chunk, D, 1, s->colPart);
+            }
+            for (int g = 0; g < (p.kp.ard ? groups : 1); ++g)
+                launch_reduce_partials(st, s->gradPart + (long)g * nbk * GP_STRIDE, nbk, GP_STRIDE,
+                                       s->gradChunk + (long)g * GP_STRIDE);
+            hipLaunchKernelGGL(k_vec_axpy, dim3(1), dim3(256), 0, st, p.gradNM, s->gradChunk, (long)gsz, 1.0);
+            if (p.stationary()) launch_sum_splits(st, s->colPart, mp * (D + 1), ns, 1, p.HX);
         }
-        for (int g = 0; g < (kp.ard ? groups : 1); ++g)
-            launch_reduce_partials(st, s->gradPart + (long)g * nbk * GP_STRIDE, nbk, GP_STRIDE,
-                                   s->gradChunk + (long)g * GP_STRIDE);
-        hipLaunchKernelGGL(k_vec_axpy, dim3(1), dim3(256), 0, st, s->gradNM, s->gradChunk, (long)groups * GP_STRIDE, 1.0);
-        launch_sum_splits(st, s->colPart, mp * (D + 1), ns, 1, s->HX);
     }
-    if (s->comm) {                                              // the one exchange step of pass 2
-        if (int rc = rccl_allreduce_sum(s->comm, s->gradNM, (size_t)groups * GP_STRIDE, st)) return rc;
-        if (int rc = rccl_allreduce_sum(s->comm, s->HX, (size_t)mp * (D + 1), st)) return rc;
+    if (sharded(s)) {                                           // the one exchange step of pass 2 (one buffer, one all-reduce)
+        double* rb = s->redbuf;
+        for (SPart& p : s->parts) {
+            HIP_CHECK(hipMemcpyAsync(rb, p.gradNM, sizeof(double) * gsz, hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(rb + gsz, p.HX, sizeof(double) * hsz, hipMemcpyDeviceToDevice, st));
+            rb += gsz + hsz;
+        }
+        if (int rc = sparse_allreduce(s, s->redbuf, s->parts.size() * (gsz + hsz))) return rc;
+        rb = s->redbuf;
+        for (SPart& p : s->parts) {
+            HIP_CHECK(hipMemcpyAsync(p.gradNM, rb, sizeof(double) * gsz, hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(p.HX, rb + gsz, sizeof(double) * hsz, hipMemcpyDeviceToDevice, st));
+            rb += gsz + hsz;
+        }
     }
-    // the M x M part: update_gradients_full(dL_dKmm, Z) and gradients_X(dL_dKmm, Z) (sparse_gp.py:114-117)
-    {
+    // the M x M part: update_gradients_full(dL_dKmm, Z) and gradients_X(dL_dKmm, Z) (sparse_gp.py:114-117), per part
+    for (SPart& p : s->parts) {
         const int nbk = grad_generic_num_blocks(m, m);
-        launch_grad_generic(st, kp, s->XtZ, mp, m, s->XtZ, mp, m, 1, s->dLdKmm, mp, s->gradPart, GP_STRIDE, s->T1, mp);
-        for (int g = 0; g < (kp.ard ? groups : 1); ++g)
-            launch_reduce_partials(st, s->gradPart + (long)g * nbk * GP_STRIDE, nbk, GP_STRIDE,
-                                   s->gradMM + (long)g * GP_STRIDE);
-        const int ns = launch_colreduce_multi(st, s->T1, mp, m, mp, s->XtZ, 1, mp, D, 1, s->colPart);
-        launch_sum_splits(st, s->colPart, mp * (D + 1), ns, 0, s->HZ);
+        launch_grad_generic(st, p.kp, p.XtZ, mp, m, p.XtZ, mp, m, 1, s->dLdKmm, mp, s->gradPart, GP_STRIDE,
+                            p.stationary() ? s->T1 : nullptr, mp);
+        for (int g = 0; g < (p.kp.ard ? groups : 1); ++g)
+            launch_reduce_partials(st, s->gradPart + (long)g * nbk * GP_STRIDE, nbk, GP_STRIDE, p.gradMM + (long)g * GP_STRIDE);
+        if (p.stationary()) {
+            const int ns = launch_colreduce_multi(st, s->T1, mp, m, mp, p.XtZ, 1, mp, D, 1, s->colPart);
+            launch_sum_splits(st, s->colPart, mp * (D + 1), ns, 0, p.HZ);
+        }
     }
     HIP_CHECK(hipEventRecord(s->ev[3], st));
     // ---- small results to the host -------------------------------------------------------------------------------------
-    std::vector<double> gnm((size_t)groups * GP_STRIDE), gmm((size_t)groups * GP_STRIDE), HX((size_t)mp * (D + 1)),
-        HZ((size_t)mp * (D + 1)), Zs((size_t)D * mp);
+    const size_t np_ = s->parts.size();
+    std::vector<double> gnm(np_ * gsz), gmm(np_ * gsz), HX(np_ * hsz), HZ(np_ * hsz), Zs(np_ * (size_t)D * mp);
+    std::vector<double> rowS, rowT;
     double scal[8];
-    HIP_CHECK(hipMemcpyAsync(gnm.data(), s->gradNM, sizeof(double) * gnm.size(), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(gmm.data(), s->gradMM, sizeof(double) * gmm.size(), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(HX.data(), s->HX, sizeof(double) * HX.size(), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(HZ.data(), s->HZ, sizeof(double) * HZ.size(), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(Zs.data(), s->XtZ, sizeof(double) * Zs.size(), hipMemcpyDeviceToHost, st));
+    for (size_t i = 0; i < np_; ++i) {
+        SPart& p = s->parts[i];
+        HIP_CHECK(hipMemcpyAsync(gnm.data() + i * gsz, p.gradNM, sizeof(double) * gsz, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(gmm.data() + i * gsz, p.gradMM, sizeof(double) * gsz, hipMemcpyDeviceToHost, st));
+        if (!p.stationary()) continue;
+        HIP_CHECK(hipMemcpyAsync(HX.data() + i * hsz, p.HX, sizeof(double) * hsz, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(HZ.data() + i * hsz, p.HZ, sizeof(double) * hsz, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(Zs.data() + i * (size_t)D * mp, p.XtZ, sizeof(double) * D * mp, hipMemcpyDeviceToHost, st));
+    }
     HIP_CHECK(hipMemcpyAsync(scal, s->scal, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
     if (wv_out) HIP_CHECK(hipMemcpyAsync(wv_out, s->vvec, sizeof(double) * m * Dy, hipMemcpyDeviceToHost, st));
+    if (want_rows) {
+        rowS.resize((size_t)n * Dy);
+        HIP_CHECK(hipMemcpyAsync(rowS.data(), s->dRowS, sizeof(double) * n * Dy, hipMemcpyDeviceToHost, st));
+        if (het) {
+            rowT.resize((size_t)n);
+            HIP_CHECK(hipMemcpyAsync(rowT.data(), s->dRowT, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        }
+    }
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipGetLastError());
     if (stage_ms) {
@@ -479,51 +723,122 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
     }
     if (info_m > 0) return info_m > m ? (int)m : info_m;                 // Kmm not positive definite: caller adds jitter
     if (info_b > 0) return info_b > m ? (int)m : info_b;
+    // sums over ALL shards of the per-point quantities
+    double glob[3] = {sum_beta, sum_logbeta, sum_bYY};
+    if (sharded(s)) {
+        HIP_CHECK(hipMemcpy(s->scal + 4, glob, sizeof(glob), hipMemcpyHostToDevice));
+        if (int rc = sparse_allreduce(s, s->scal + 4, 3)) return rc;
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipMemcpy(glob, s->scal + 4, sizeof(glob), hipMemcpyDeviceToHost));
+    }
     const double trA = scal[0], sumAP = scal[1], logLB = scal[2], data_fit = scal[3];
-    const double ng = (double)s->n_global;                       // all shards
-    const double variance = theta[0], psi0sum = ng * variance, nd = ng * Dy;
+    const double ng = (double)s->n_global, nd = ng * Dy;
+    double kdiag = 0.0;                                          // psi0_n = Kdiag = sum of the parts' variances
+    for (const SPart& p : s->parts) kdiag += p.kp.variance;
     // _compute_log_marginal_likelihood (var_dtc.py:264-276)
-    const double lik_1 = -0.5 * nd * (log(2.0 * M_PI) - log(beta)) - 0.5 * beta * s->trYYT;
-    const double lik_2 = -0.5 * Dy * (beta * psi0sum - trA);
+    double lik_1, lik_2;
+    if (het) {
+        lik_1 = -0.5 * nd * log(2.0 * M_PI) + 0.5 * Dy * glob[1] - 0.5 * glob[2];
+        lik_2 = -0.5 * Dy * (glob[0] * kdiag - trA);
+    } else {
+        lik_1 = -0.5 * nd * (log(2.0 * M_PI) - log(beta)) - 0.5 * beta * s->trYYT;
+        lik_2 = -0.5 * Dy * (beta * ng * kdiag - trA);
+    }
     const double lik_3 = -(double)Dy * logLB;
-    // _compute_dL_dR (var_dtc.py:258-261)
-    double dL_dR = -0.5 * nd * beta + 0.5 * s->trYYT * beta * beta;
-    dL_dR += 0.5 * Dy * (psi0sum * beta * beta - trA * beta);
-    dL_dR += beta * (0.5 * sumAP - data_fit);
     for (int i = 0; i < MI355GP_NUM_OUT; ++i) out_scalars[i] = 0.0;
     out_scalars[0] = lik_1 + lik_2 + lik_3 + 0.5 * data_fit;
-    out_scalars[1] = dL_dR;
     out_scalars[2] = trA;
     out_scalars[3] = data_fit;
     out_scalars[4] = logLB;
     out_scalars[5] = beta;
+    if (!het) {                                                  // _compute_dL_dR (var_dtc.py:258-261)
+        double dL_dR = -0.5 * nd * beta + 0.5 * s->trYYT * beta * beta;
+        dL_dR += 0.5 * Dy * (ng * kdiag * beta * beta - trA * beta);
+        dL_dR += beta * (0.5 * sumAP - data_fit);
+        out_scalars[1] = dL_dR;
+    } else {
+        // per point (var_dtc.py:240-256 with s_n = k_n^T v and q_n - r_n = 2 t_n + s_n^2, Dy = 1):
+        //   dL_dR_n = -0.5 b + 0.5 (b R_n)^2 + 0.5 b^2 psi0 - b^2 t_n - s_n R_n b^2
+        std::vector<double> Rh((size_t)n);
+        HIP_CHECK(hipMemcpy(Rh.data(), s->dY, sizeof(double) * n, hipMemcpyDeviceToHost));
+        for (long i = 0; i < n; ++i) {
+            const double b = hbeta[(size_t)i], R = Rh[(size_t)i];
+            dnoise_rows_out[i] = -0.5 * b + 0.5 * b * b * R * R + 0.5 * b * b * kdiag - b * b * rowT[(size_t)i] -
+                                 rowS[(size_t)i] * R * b * b;
+        }
+    }
+    if (dLdm_out) {                                              // dL_dm = V - Kfu v (var_dtc.py:148)
+        std::vector<double> Rh((size_t)n * Dy);
+        HIP_CHECK(hipMemcpy(Rh.data(), s->dY, sizeof(double) * n * Dy, hipMemcpyDeviceToHost));
+        for (long i = 0; i < n; ++i)
+            for (int d = 0; d < Dy; ++d) dLdm_out[i * Dy + d] = hbeta[(size_t)i] * Rh[(size_t)i * Dy + d] - rowS[(size_t)i * Dy + d];
+    }
     if (dtheta_out) {
-        // update_gradients_diag(dL_dKdiag = -0.5 Dy beta) (sparse_gp.py:110, stationary.py:175-184): variance only
-        dtheta_out[0] = -0.5 * Dy * beta * ng + (gnm[0] + gmm[0]) / variance;
-        if (!kp.ard) dtheta_out[1] = -(gnm[1] + gmm[1]) / theta[1];
-        else
-            for (int q = 0; q < D; ++q) {
-                const int o = (q / 32) * GP_STRIDE + 2 + (q % 32);
-                dtheta_out[1 + q] = -(gnm[o] + gmm[o]) / theta[1 + q];
-            }
+        double* o = dtheta_out;
+        for (size_t i = 0; i < np_; ++i) {
+            const SPart& p = s->parts[i];
+            const double* a = gnm.data() + i * gsz;
+            const double* b = gmm.data() + i * gsz;
+            // update_gradients_diag(dL_dKdiag = -0.5 Dy beta_n) (sparse_gp.py:110, stationary.py:175-184, static.py:95-96)
+            *o++ = -0.5 * Dy * glob[0] + (a[0] + b[0]) / p.kp.variance;
+            if (!p.stationary()) continue;
+            if (!p.kp.ard) *o++ = -(a[1] + b[1]) / p.theta[1];
+            else
+                for (size_t k = 0; k < p.dims.size(); ++k) {
+                    const int q = p.dims[k], off = (q / 32) * GP_STRIDE + 2 + (q % 32);
+                    *o++ = -(a[off] + b[off]) / p.theta[1 + k];
+                }
+        }
     }
     if (dZ_out) {
-        // gradients_X(dL_dKnm^T, Z, X) + gradients_X(dL_dKmm, Z) (sparse_gp.py:116-118):
+        // gradients_X(dL_dKnm^T, Z, X) + gradients_X(dL_dKmm, Z) (sparse_gp.py:116-118), summed over the parts (add.py:84-88):
         //   sum_n H[n,m] (z~_mq - x~_nq) / l_q  +  2 sum_j Hmm[j,m] (z~_mq - z~_jq) / l_q
-        for (long j = 0; j < m; ++j)
-            for (int q = 0; q < D; ++q) {
-                const double zs = Zs[(size_t)q * mp + j], il = inv_ls[ard ? q : 0];
-                const double a = zs * HX[j * (D + 1) + D] - HX[j * (D + 1) + q];
-                const double b = zs * HZ[j * (D + 1) + D] - HZ[j * (D + 1) + q];
-                dZ_out[j * D + q] = (a + 2.0 * b) * il;
-            }
+        for (long j = 0; j < m * D; ++j) dZ_out[j] = 0.0;
+        for (size_t i = 0; i < np_; ++i) {
+            const SPart& p = s->parts[i];
+            if (!p.stationary()) continue;
+            const double* hx = HX.data() + i * hsz;
+            const double* hz = HZ.data() + i * hsz;
+            const double* zs = Zs.data() + i * (size_t)D * mp;
+            for (long j = 0; j < m; ++j)
+                for (int q = 0; q < D; ++q) {
+                    const double il = p.inv_ls[(size_t)q];
+                    if (il == 0.0) continue;
+                    const double z = zs[(size_t)q * mp + j];
+                    const double a = z * hx[j * (D + 1) + D] - hx[j * (D + 1) + q];
+                    const double b = z * hz[j * (D + 1) + D] - hz[j * (D + 1) + q];
+                    dZ_out[j * D + q] += (a + 2.0 * b) * il;
+                }
+        }
     }
     s->have_result = true;
     return 0;
 }
 
+int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double* theta, const double* Z, int64_t M,
+                             double noise_var, double extra_jitter, double* out_scalars, double* dtheta_out,
+                             double* dZ_out, double* wv_out, double* stage_ms) {
+    ARGCHK(kind >= 0 && kind <= 3 && theta, "mi355gp_vardtc_inference: bad kernel parameters");
+    const mi355gp_part part{kind, ard, 0, nullptr, theta, 0};
+    return mi355gp_vardtc_inference_sum(s, 1, &part, Z, M, &noise_var, 1, extra_jitter, out_scalars, dtheta_out, dZ_out, wv_out,
+                                        nullptr, nullptr, stage_ms);
+}
+
+// woodbury_inv = Lm^-T (I - B^-1) Lm^-1 (var_dtc.py:206-210) into s->Winv, once per inference call
+static int ensure_winv(mi355gp_sparse* s) {
+    if (s->winv_ok) return 0;
+    hipStream_t st = s->st;
+    const long mp = s->mp;
+    hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->Bi, mp, 1, s->E);
+    hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->E, -1.0, (const double*)nullptr, 0.0, 1.0, mp, s->E);
+    launch_gemm(st, 1, 1, mp, mp, mp, s->Xm, mp, s->E, mp, s->T1, mp, 1.0, 0.0);
+    launch_gemm(st, 0, 1, mp, mp, mp, s->T1, mp, s->Xm, mp, s->Winv, mp, 1.0, 0.0);
+    s->winv_ok = true;
+    return 0;
+}
+
 // M x M results of the last call: 0 = dL_dKmm, 1 = woodbury_inv = Lm^-T (I - B^-1) Lm^-1 (var_dtc.py:206-210),
-// 2 = Lm (lower, strict upper zero), 3 = Kmm (with the 1e-8 jitter), 4 = psi2
+// 2 = Lm (lower, strict upper zero), 3 = Kmm (with the 1e-8 jitter), 4 = psi2 (heteroscedastic: sum_n beta_n k_n k_n^T)
 int mi355gp_sparse_fetch(mi355gp_sparse* s, int which, double* out) {
     ARGCHK(s && out && s->have_result, "mi355gp_sparse_fetch: run mi355gp_vardtc_inference first");
     HIP_CHECK(hipSetDevice(s->device));
@@ -532,17 +847,14 @@ int mi355gp_sparse_fetch(mi355gp_sparse* s, int which, double* out) {
     const double* src = nullptr;
     if (which == 0) src = s->dLdKmm;
     else if (which == 1) {
-        hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->Bi, mp, 1, s->E);
-        hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->E, -1.0, (const double*)nullptr, 0.0, 1.0, mp,
-                           s->E);
-        launch_gemm(st, 1, 1, mp, mp, mp, s->Xm, mp, s->E, mp, s->T1, mp, 1.0, 0.0);
-        launch_gemm(st, 0, 1, mp, mp, mp, s->T1, mp, s->Xm, mp, s->Winv, mp, 1.0, 0.0);
+        if (int rc = ensure_winv(s)) return rc;
         src = s->Winv;
     } else if (which == 2) {
         launch_extract(st, s->Lm, mp, mp, 0, nullptr, 0, s->E, 0);
         src = s->E;
     } else if (which == 3) {
-        launch_kbuild_sym(st, s->kp, s->XtZ, mp, m, mp, s->E, s->zero1, 1, 1e-8, 0, 1);
+        for (size_t i = 0; i < s->parts.size(); ++i)
+            launch_kbuild_sym(st, s->parts[i].kp, s->parts[i].XtZ, mp, m, mp, s->E, s->zero1, 1, 1e-8, 0, i == 0, i > 0);
         src = s->E;
     } else if (which == 4) src = s->psi2;
     else {
@@ -552,6 +864,102 @@ int mi355gp_sparse_fetch(mi355gp_sparse* s, int which, double* out) {
     HIP_CHECK(hipMemcpy2DAsync(out, sizeof(double) * m, src, sizeof(double) * mp, sizeof(double) * m, m,
                                hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// Rows [row0, row0 + nrows) of dL_dKnm = beta_n (R_n v^T + 2 k_n^T dL_dpsi2_beta) (var_dtc.py:219-233), nrows x M row-major:
+// what SparseGP._update_gradients hands to a FOREIGN kernel's update_gradients_full / gradients_X (sparse_gp.py:108-118).
+// The N x M matrix is never resident: the caller walks it in row blocks (nrows <= the context's chunk size).
+int mi355gp_sparse_fetch_dLdKnm(mi355gp_sparse* s, int64_t row0, int64_t nrows, double* out) {
+    ARGCHK(s && out && s->have_result, "mi355gp_sparse_fetch_dLdKnm: run mi355gp_vardtc_inference first");
+    ARGCHK(row0 >= 0 && nrows > 0 && row0 + nrows <= s->n && nrows <= s->chunk, "mi355gp_sparse_fetch_dLdKnm: bad row range");
+    HIP_CHECK(hipSetDevice(s->device));
+    hipStream_t st = s->st;
+    const long m = s->m, mp = s->mp, rc = nrows, rcp = round_up(rc, NB);
+    if (int e = scale_for_parts(s, s->dX + row0 * s->D, rc, s->chunk, false)) return e;
+    HIP_CHECK(hipMemsetAsync(s->Kfu, 0, sizeof(double) * rcp * mp, st));
+    build_cross_chunk(s, rc, s->Kfu);
+    launch_gemm(st, 0, 1, rcp, mp, mp, s->Kfu, mp, s->Q2, mp, s->T, mp, 1.0, 0.0);
+    hipLaunchKernelGGL(k_form_dLdKnm, dim3((unsigned)rcp, (unsigned)((mp + 255) / 256)), dim3(256), 0, st, s->T, mp, rc, rcp, m,
+                       s->dY + row0 * s->Dy, s->vvec, s->Dy, s->dBeta + row0);
+    HIP_CHECK(hipMemcpy2DAsync(out, sizeof(double) * m, s->T, sizeof(double) * mp, sizeof(double) * m, rc,
+                               hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Sparse posterior prediction on the device (Posterior._raw_predict, posterior.py:198-262, for the woodbury_inv /
+// woodbury_vector representation VarDTC returns): mu = K(X*, Z) v; var = Kdiag - sum(Kx * (Winv Kx), 0) or the full
+// K(X*, X*) - Kx^T Winv Kx.  The kernel (parts) must be the one of the last inference call.
+int mi355gp_sparse_predict(mi355gp_sparse* s, int nparts, const mi355gp_part* parts, const double* Xnew, int64_t Mn,
+                           double* mu_out, double* var_out, int full_cov) {
+    ARGCHK(s && s->have_result, "mi355gp_sparse_predict: run mi355gp_vardtc_inference first");
+    ARGCHK(Xnew && Mn > 0 && mu_out, "mi355gp_sparse_predict: bad arguments");
+    HIP_CHECK(hipSetDevice(s->device));
+    if (int rc = prepare_sparse_parts(s, nparts, parts)) return rc;
+    hipStream_t st = s->st;
+    const long m = s->m, mp = s->mp, D = s->D, Dy = s->Dy, mnp = round_up(Mn, NB), ldn = round_up(Mn, 64);
+    if (int rc = scale_for_parts(s, s->dZ, m, mp, true)) return rc;
+    if (int rc = ensure_winv(s)) return rc;
+    double *dXn = nullptr, *dXt = nullptr, *Kx = nullptr, *Tmp = nullptr, *dMu = nullptr, *dVar = nullptr;
+    auto cleanup = [&]() {
+        double* ptrs[] = {dXn, dXt, Kx, Tmp, dMu, dVar};
+        for (double* p : ptrs)
+            if (p) (void)hipFree(p);
+    };
+    hipError_t e = hipMalloc(&dXn, sizeof(double) * Mn * D);
+    if (e == hipSuccess) e = hipMalloc(&dXt, sizeof(double) * D * ldn);
+    if (e == hipSuccess) e = hipMalloc(&Kx, sizeof(double) * mp * mnp);
+    if (e == hipSuccess) e = hipMalloc(&Tmp, sizeof(double) * mp * mnp);
+    if (e == hipSuccess) e = hipMalloc(&dMu, sizeof(double) * Mn * Dy);
+    if (e == hipSuccess) e = hipMalloc(&dVar, sizeof(double) * (full_cov ? mnp * mnp : Mn));
+    if (e != hipSuccess) {
+        cleanup();
+        mi355gp_set_error("mi355gp_sparse_predict: %s", hipGetErrorString(e));
+        return -(1000 + (int)e);
+    }
+    (void)hipMemcpyAsync(dXn, Xnew, sizeof(double) * Mn * D, hipMemcpyHostToDevice, st);
+    (void)hipMemsetAsync(Kx, 0, sizeof(double) * mp * mnp, st);
+    if (full_cov && var_out) (void)hipMemsetAsync(dVar, 0, sizeof(double) * mnp * mnp, st);
+    double kdiag = 0.0;
+    bool first = true, firstxx = true;
+    for (SPart& p : s->parts) {
+        kdiag += p.kp.variance;
+        (void)hipMemcpyAsync(s->invls, p.inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st);
+        launch_scale_inputs(st, dXn, Mn, (int)D, s->invls, 1, dXt, ldn);
+        if (p.kp.kind != 4) {                                                        // K(Z, X*): White contributes nothing
+            launch_kbuild_cross(st, p.kp, p.XtZ, mp, m, dXt, ldn, Mn, Kx, mnp, first ? 0 : 1);
+            first = false;
+        }
+        if (full_cov && var_out) {
+            launch_kbuild_cross(st, p.kp, dXt, ldn, Mn, dXt, ldn, Mn, dVar, mnp, firstxx ? 0 : 1, /*diag_same=*/1);
+            firstxx = false;
+        }
+    }
+    launch_col_reduce(st, Kx, mnp, m, Mn, s->vvec, (int)Dy, 0.0, 0, dMu);                              // mu = Kx^T v
+    if (var_out) {
+        launch_gemm(st, 0, 1, mp, mnp, mp, s->Winv, mp, Kx, mnp, Tmp, mnp, 1.0, 0.0);                 // Winv Kx
+        if (!full_cov)
+            hipLaunchKernelGGL(k_col_dot, dim3((unsigned)((Mn + 63) / 64)), dim3(256), 0, st, Kx, Tmp, mnp, m, (long)Mn, kdiag, dVar);
+        else
+            launch_gemm(st, 1, 1, mnp, mnp, mp, Kx, mnp, Tmp, mnp, dVar, mnp, -1.0, 1.0);             // K** - Kx^T Winv Kx
+    }
+    hipError_t e2 = hipMemcpyAsync(mu_out, dMu, sizeof(double) * Mn * Dy, hipMemcpyDeviceToHost, st);
+    if (var_out && e2 == hipSuccess) {
+        if (!full_cov) e2 = hipMemcpyAsync(var_out, dVar, sizeof(double) * Mn, hipMemcpyDeviceToHost, st);
+        else e2 = hipMemcpy2DAsync(var_out, sizeof(double) * Mn, dVar, sizeof(double) * mnp, sizeof(double) * Mn, Mn,
+                                   hipMemcpyDeviceToHost, st);
+    }
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+    if (e2 == hipSuccess) e2 = hipGetLastError();
+    cleanup();
+    if (e2 != hipSuccess) {
+        mi355gp_set_error("mi355gp_sparse_predict: %s", hipGetErrorString(e2));
+        return -(1000 + (int)e2);
+    }
+    if (var_out && !full_cov)
+        for (int64_t i = 0; i < Mn; ++i) var_out[i] = var_out[i] < 1e-15 ? 1e-15 : var_out[i];      // posterior.py:248
     return 0;
 }
 

@@ -47,7 +47,7 @@ class HeteroscedasticGaussian(Gaussian):
         return self.variance.values[np.asarray(Y_metadata["output_index"]).flatten()]
 
     def exact_inference_gradients(self, dL_dKdiag, Y_metadata=None):
-        return np.asarray(dL_dKdiag)[np.asarray(Y_metadata["output_index"]).flatten()]
+        return np.asarray(dL_dKdiag).reshape(-1)[np.asarray(Y_metadata["output_index"]).flatten()]
 
     def predictive_values(self, mu, var, full_cov=False, Y_metadata=None):
         s = self.variance.values[np.asarray(Y_metadata["output_index"]).flatten()]

@@ -4,9 +4,11 @@
 and a homoscedastic Gaussian likelihood (BASELINE config 5).
 
 `VarDTC.inference(kern, X, Z, likelihood, Y, ...)` returns `(Posterior, log_marginal, grad_dict)` with the reference's
-keys.  The N x M matrix `dL_dKnm` is never materialised: the kernel and inducing-input gradients that
-`SparseGP._update_gradients` derives from it are reduced on the device in the second streaming pass and travel in
-`grad_dict['fused']`; `dL_dKmm` is a lazy device view.  A foreign consumer that insists on `dL_dKnm` gets a clear error.
+keys, for gpy_amd's stationary kernels and sums (`Add`) of stationary / White / Bias parts, a scalar or per-point
+Gaussian noise variance and an optional mean function.  The N x M matrix `dL_dKnm` is never resident: the kernel and
+inducing-input gradients that `SparseGP._update_gradients` derives from it are reduced on the device in the second
+streaming pass and travel in `grad_dict['fused']`; `dL_dKmm` is a lazy device view and `dL_dKnm` a lazy object that a
+foreign consumer can materialise in row blocks (`mi355gp_sparse_fetch_dLdKnm`).
 """
 import numpy as np
 
@@ -49,24 +51,70 @@ class _LazyMM(object):
         return self.fetch().T
 
 
-class _NotMaterialised(object):
-    def __init__(self, what, shape):
-        self.what, self.shape = what, shape
+class _LazyNM(object):
+    """dL_dKnm (N x M) of the last VarDTC call.  It is never resident as a whole on the device (3.3 GB at N = 200000,
+    M = 2048): gpy_amd's own model driver uses the reductions the device made from it (`grad_dict['fused']`); a FOREIGN
+    consumer -- e.g. GPy's `SparseGP._update_gradients` handing it to `kern.update_gradients_full(dL_dKnm, X, Z)`
+    (reference `core/sparse_gp.py:108-119`) -- gets it materialised in row blocks (`blocks()`), or entirely (`np.asarray`)."""
+    __array_priority__ = 100.0
+    ndim = 2
+    dtype = np.dtype(np.float64)
+
+    def __init__(self, ctx, N, M, token, owner, block=8192):
+        self._ctx, self.shape, self._token, self._owner, self._block = ctx, (N, M), token, owner, block
+        self._host = None
+
+    def blocks(self, rows=None):
+        """yields (row0, row1, dL_dKnm[row0:row1]) over the whole matrix"""
+        if self._owner._token != self._token:
+            raise RuntimeError("device-resident result overwritten by a later inference call")
+        step = rows or self._block
+        for r0 in range(0, self.shape[0], step):
+            r1 = min(self.shape[0], r0 + step)
+            yield r0, r1, self._ctx.fetch_dL_dKnm(r0, r1 - r0)
+
+    def fetch(self):
+        if self._host is None:
+            out = np.empty(self.shape)
+            for r0, r1, B in self.blocks():
+                out[r0:r1] = B
+            self._host = out
+        return self._host
 
     def __array__(self, dtype=None, copy=None):
-        raise RuntimeError("%s (%d x %d) is never materialised by the MI355X sparse path; its reductions "
-                           "(kernel and inducing-input gradients) are in grad_dict['fused']" % ((self.what,) + self.shape))
+        a = self.fetch()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getitem__(self, idx):
+        return self.fetch()[idx]
+
+    @property
+    def T(self):
+        return self.fetch().T
 
 
 class SparsePosterior(object):
     """`Posterior(woodbury_inv, woodbury_vector, K=Kmm, K_chol=Lm)` of the reference (`var_dtc.py:213`,
-    `posterior.py:21-77`); prediction follows `Posterior._raw_predict` (`posterior.py:198-232`)."""
+    `posterior.py:21-77`); prediction follows `Posterior._raw_predict` (`posterior.py:198-262`) and runs on the device
+    (C-ABI `mi355gp_sparse_predict`) while the posterior is the context's latest result."""
 
-    def __init__(self, woodbury_inv, woodbury_vector, K, K_chol):
+    def __init__(self, woodbury_inv, woodbury_vector, K, K_chol, device=None):
         self.woodbury_inv, self.woodbury_vector, self.K, self.K_chol = woodbury_inv, woodbury_vector, K, K_chol
+        self._device = device            # (ctx, token, owner, kernel signature, specs builder)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_device"] = None
+        for k in ("woodbury_inv", "K", "K_chol"):
+            d[k] = np.asarray(d[k])
+        return d
 
     def _raw_predict(self, kern, Xnew, pred_var, full_cov=False):
-        Kx = kern.K(pred_var, Xnew)                                   # (M, N*)
+        dev = self._device
+        if dev is not None and dev["owner"]._token == dev["token"] and _kernel_sig(kern) == dev["sig"]:
+            Xn = kern._slice_X(np.asarray(Xnew)) if isinstance(kern, Stationary) else _lib.f64(Xnew)
+            return dev["ctx"].predict(_specs(kern), Xn, full_cov=full_cov)
+        Kx = kern.K(pred_var, Xnew)                                   # (M, N*): foreign kernel / stale device state
         mu = np.dot(Kx.T, self.woodbury_vector)
         Wi = np.asarray(self.woodbury_inv)
         if full_cov:
@@ -75,6 +123,19 @@ class SparsePosterior(object):
             var = (kern.Kdiag(Xnew) - np.sum(np.dot(Wi.T, Kx) * Kx, 0))[:, None]
             var = np.clip(var, 1e-15, np.inf)                        # posterior.py:248
         return mu, var
+
+
+def _specs(kern):
+    """[(kind, ARD, theta, active_dims, term)] of a stationary kernel (its own column slicing applied to X on upload) or
+    of an `Add` of stationary / White / Bias parts (active_dims index the model's X)"""
+    if isinstance(kern, Stationary):
+        return [(kern.kind, kern.ARD, kern._theta(), None, 0)]
+    return kern.part_specs()
+
+
+def _kernel_sig(kern):
+    from .lazy import kernel_signature
+    return kernel_signature(kern)
 
 
 class VarDTC(object):
@@ -113,27 +174,40 @@ class VarDTC(object):
 
     def inference(self, kern, X, Z, likelihood, Y, Y_metadata=None, mean_function=None, precision=None, Lm=None,
                   dL_dKmm=None, psi0=None, psi1=None, psi2=None, Z_tilde=None):
-        if not isinstance(kern, Stationary):
-            raise NotImplementedError("the MI355X sparse path covers the stationary kernels of gpy_amd.kern")
-        if any(a is not None for a in (precision, Lm, dL_dKmm, psi0, psi1, psi2)):
+        from .kern import Add, Prod
+        ok = isinstance(kern, Stationary) or (isinstance(kern, Add) and not any(isinstance(p, Prod) for p in kern.parts))
+        if not ok:
+            raise NotImplementedError("the MI355X sparse path covers gpy_amd's stationary kernels and sums (Add) of "
+                                      "stationary / White / Bias parts")
+        if any(a is not None for a in (Lm, dL_dKmm, psi0, psi1, psi2)):
             raise NotImplementedError("precomputed statistics are not accepted by the MI355X sparse path")
         Y = np.asarray(Y, dtype=np.float64)
+        if precision is None:                                          # var_dtc.py:78-80
+            noise = np.atleast_1d(np.asarray(likelihood.gaussian_variance(Y_metadata), dtype=np.float64)).ravel()
+        else:
+            noise = 1.0 / np.atleast_1d(np.asarray(precision, dtype=np.float64)).ravel()
+        het = noise.size > 1
+        if het and mean_function is not None:                          # var_dtc.py:85-86
+            raise ValueError("Mean function not implemented with uncertain inputs or heteroscedasticity")
+        if het and Y.shape[1] != 1:
+            raise NotImplementedError("per-point noise: one output column (the reference's dL_dR, var_dtc.py:240-256)")
         m = 0 if mean_function is None else mean_function.f(X)
-        noise = np.atleast_1d(np.asarray(likelihood.gaussian_variance(Y_metadata), dtype=np.float64)).ravel()
-        if noise.size != 1:
-            raise NotImplementedError("heteroscedastic noise is not supported by the MI355X sparse path")
-        Xs, Zs, R = kern._slice_X(X), kern._slice_X(np.asarray(Z)), _lib.f64(Y - m)
+        single = isinstance(kern, Stationary)
+        Xs = kern._slice_X(X) if single else _lib.f64(X)
+        Zs = kern._slice_X(np.asarray(Z)) if single else _lib.f64(Z)
+        R = _lib.f64(Y - m)
         self._ensure(Xs, R)
-        theta = kern._theta()
+        specs = _specs(kern)
+        kdiag = float(kern.variance.values[0]) if single else kern.diag_variance()
         extra, tries, info = 0.0, 0, 1
         while True:                                   # jitchol's ladder (util/linalg.py:56-75) for Kmm / B
-            info, r = self._ctx.vardtc(kern.kind, kern.ARD, theta, Zs, float(noise[0]), extra_jitter=extra,
-                                       want_stage_ms=self.collect_stage_ms)
+            info, r = self._ctx.vardtc_sum(specs, Zs, noise, extra_jitter=extra, want_dL_dm=mean_function is not None,
+                                           want_stage_ms=self.collect_stage_ms)
             if info == 0:
                 break
             if tries >= self.maxtries:
                 raise LinAlgError("not positive definite, even with jitter.")
-            extra = float(theta[0]) * 1e-6 * 10 ** tries
+            extra = kdiag * 1e-6 * 10 ** tries
             tries += 1
         self._token += 1
         self.last_stage_ms = r.get("stage_ms")
@@ -143,12 +217,15 @@ class VarDTC(object):
         post = SparsePosterior(woodbury_inv=_LazyMM(self._ctx, C.FETCH_WOODBURY_INV, M, self._token, self),
                                woodbury_vector=r["woodbury_vector"],
                                K=_LazyMM(self._ctx, C.FETCH_KMM, M, self._token, self),
-                               K_chol=_LazyMM(self._ctx, C.FETCH_LM, M, self._token, self))
-        beta = 1.0 / max(float(noise[0]), self.const_jitter)
+                               K_chol=_LazyMM(self._ctx, C.FETCH_LM, M, self._token, self),
+                               device={"ctx": self._ctx, "token": self._token, "owner": self, "sig": _kernel_sig(kern)})
+        beta = 1.0 / np.fmax(noise, self.const_jitter)
+        dL_dR = r["dnoise"][:, None] if het else r["dnoise"]
         grad_dict = {"dL_dKmm": _LazyMM(self._ctx, C.FETCH_DLDKMM, M, self._token, self),
-                     "dL_dKdiag": np.full(N, -0.5 * Y.shape[1] * beta),
-                     "dL_dKnm": _NotMaterialised("dL_dKnm", (N, M)),
-                     "dL_dthetaL": r["dnoise"],
+                     "dL_dKdiag": -0.5 * Y.shape[1] * (beta * np.ones(N)),            # var_dtc.py:218
+                     "dL_dKnm": _LazyNM(self._ctx, N, M, self._token, self),
+                     "dL_dthetaL": likelihood.exact_inference_gradients(dL_dR, Y_metadata),
+                     "dL_dm": r["dL_dm"],
                      "fused": {"dtheta": r["dtheta"], "dZ": r["dZ"]}}
         return post, lml, grad_dict
 
@@ -158,8 +235,10 @@ class SparseGP(Parameterized):
     Flat parameter order follows GPy's links: [Z, kern.variance, kern.lengthscale..., noise variance]
     (`sparse_gp.py:59`: Z is linked at index 0)."""
 
-    def __init__(self, X, Y, Z, kernel, likelihood, inference_method=None, name="sparse gp", device=0):
+    def __init__(self, X, Y, Z, kernel, likelihood, inference_method=None, name="sparse gp", device=0, mean_function=None,
+                 Y_metadata=None):
         super(SparseGP, self).__init__(name)
+        self.mean_function, self.Y_metadata = mean_function, Y_metadata
         self.X, self.Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
         self.Y_normalized = self.Y
         self.num_data, self.input_dim = self.X.shape
@@ -175,10 +254,16 @@ class SparseGP(Parameterized):
 
     def parameters_changed(self):
         self.posterior, self._log_marginal_likelihood, self.grad_dict = self.inference_method.inference(
-            self.kern, self.X, self.Z.values, self.likelihood, self.Y_normalized)
+            self.kern, self.X, self.Z.values, self.likelihood, self.Y_normalized, Y_metadata=self.Y_metadata,
+            mean_function=self.mean_function)
         self.likelihood.update_gradients(self.grad_dict["dL_dthetaL"])
+        if self.mean_function is not None:                                      # sparse_gp.py:84-85
+            self.mean_function.update_gradients(self.grad_dict["dL_dm"], self.X)
         fused = self.grad_dict["fused"]
-        self.kern._install_gradients(fused["dtheta"])
+        if isinstance(self.kern, Stationary):
+            self.kern._install_gradients(fused["dtheta"])
+        else:
+            self.kern._install_fused(fused["dtheta"])
         self.Z.gradient = fused["dZ"] if fused["dZ"].shape == self.Z.shape else self._scatter_dZ(fused["dZ"])
 
     def _scatter_dZ(self, dZ):
@@ -196,12 +281,15 @@ class SparseGP(Parameterized):
         return -self.gradient
 
     def _raw_predict(self, Xnew, full_cov=False):
-        return self.posterior._raw_predict(self.kern, np.asarray(Xnew), self.Z.values, full_cov=full_cov)
+        mu, var = self.posterior._raw_predict(self.kern, np.asarray(Xnew), self.Z.values, full_cov=full_cov)
+        if self.mean_function is not None:
+            mu = mu + self.mean_function.f(Xnew)
+        return mu, var
 
-    def predict(self, Xnew, full_cov=False, include_likelihood=True):
+    def predict(self, Xnew, full_cov=False, include_likelihood=True, Y_metadata=None):
         mu, var = self._raw_predict(Xnew, full_cov)
         if include_likelihood:
-            mu, var = self.likelihood.predictive_values(mu, var, full_cov=full_cov)
+            mu, var = self.likelihood.predictive_values(mu, var, full_cov=full_cov, Y_metadata=Y_metadata)
         return mu, var
 
     def optimize(self, max_iters=100, messages=False, gtol=1e-6):
@@ -231,7 +319,7 @@ class SparseGP(Parameterized):
 class SparseGPRegression(SparseGP):
     """(reference `GPy/models/sparse_gp_regression.py:20-60`): Z defaults to a random subset of X."""
 
-    def __init__(self, X, Y, kernel=None, Z=None, num_inducing=10, noise_var=1., device=0, seed=None):
+    def __init__(self, X, Y, kernel=None, Z=None, num_inducing=10, noise_var=1., device=0, seed=None, mean_function=None):
         X = np.asarray(X, dtype=np.float64)
         if kernel is None:
             kernel = RBF(X.shape[1], device=device)
@@ -239,4 +327,4 @@ class SparseGPRegression(SparseGP):
             i = np.random.default_rng(seed).permutation(X.shape[0])[:min(num_inducing, X.shape[0])]
             Z = X[i].copy()
         super(SparseGPRegression, self).__init__(X, Y, Z, kernel, Gaussian(variance=noise_var),
-                                                 name="sparse_gp", device=device)
+                                                 name="sparse_gp", device=device, mean_function=mean_function)

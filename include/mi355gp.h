@@ -219,10 +219,37 @@ int mi355gp_sparse_set_data(mi355gp_sparse* s, const double* X, int64_t N, int D
 int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double* theta, const double* Z, int64_t M,
                              double noise_var, double extra_jitter, double* out_scalars, double* dtheta_out,
                              double* dZ_out, double* wv_out, double* stage_ms);
+/* The same evaluation for a SUM of kernel parts (GPy.kern.Add of stationary / White / Bias kernels with active_dims,
+ * kern/src/add.py:58-88, static.py:63-98,151-173; product terms are not accepted here), scalar OR per-point noise
+ * variances (heteroscedastic precision: var_dtc.py:78-86,126-129,224-226,240-256,267-269; Dy == 1) and targets
+ * R = Y - mean_function.f(X) uploaded by mi355gp_sparse_set_data (var_dtc.py:73-76,88-89).
+ *   noise: noise_len == 1 or N (the rows of this context) noise VARIANCES
+ *   out_scalars: as above; [1] (dL/d noise variance) only for noise_len == 1
+ *   dtheta_out: concatenation over the parts, each [variance, lengthscale(s)] ([variance] for White / Bias)
+ *   dnoise_rows_out (N, required for noise_len == N): dL_dR per point = what likelihood.exact_inference_gradients receives
+ *   dLdm_out (optional, N x Dy): dL_dm = beta R - K(X, Z) woodbury_vector (var_dtc.py:148; SparseGP hands it to
+ *                                mean_function.update_gradients, sparse_gp.py:84-85) */
+int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_part* parts, const double* Z, int64_t M,
+                                 const double* noise, int64_t noise_len, double extra_jitter, double* out_scalars,
+                                 double* dtheta_out, double* dZ_out, double* wv_out, double* dnoise_rows_out,
+                                 double* dLdm_out, double* stage_ms);
+/* Sparse posterior prediction on the device (Posterior._raw_predict, inference/latent_function_inference/posterior.py:198-262,
+ * for the (woodbury_inv, woodbury_vector) posterior of var_dtc.py:213): mu (Mn x Dy) = K(X*, Z) woodbury_vector;
+ * full_cov == 0: var (Mn) = Kdiag - sum(Kx * (woodbury_inv Kx), 0), clipped at 1e-15 (posterior.py:248); else Mn x Mn.
+ * `parts` = the kernel of the last inference call. */
+int mi355gp_sparse_predict(mi355gp_sparse* s, int nparts, const mi355gp_part* parts, const double* Xnew, int64_t Mn,
+                           double* mu_out, double* var_out, int full_cov);
+/* Rows [row0, row0 + nrows) of dL_dKnm (nrows x M, row-major) of the last call -- the matrix SparseGP._update_gradients
+ * hands to a foreign kernel's update_gradients_full / gradients_X (core/sparse_gp.py:108-118).  It is never resident as a
+ * whole (3.3 GB at config 5): the caller walks it in row blocks. */
+int mi355gp_sparse_fetch_dLdKnm(mi355gp_sparse* s, int64_t row0, int64_t nrows, double* out);
 /* Row-sharded multi-GPU mode (the reference's MPI design, var_dtc_parallel.py:121-130,387-394): every rank holds a
  * slice of the rows of (X, Y); psi2/psi1Y after pass 1 and the gradient sums after pass 2 are all-reduced over RCCL,
  * the M x M algebra is replicated.  Call on every rank before set_data (id128: mi355gp_grid_unique_id on rank 0). */
 int mi355gp_sparse_attach_comm(mi355gp_sparse* s, int rank, int world, const void* id128);
+/* The same mode over the LOOPBACK transport: `world` contexts of ONE process (one host thread each) that name the same
+ * group_key rendezvous for every exchange step and are summed in rank order -- world > 1 on a single GPU (tests). */
+int mi355gp_sparse_attach_loopback(mi355gp_sparse* s, int rank, int world, int group_key);
 /* M x M results of the last call: 0 dL_dKmm, 1 woodbury_inv (var_dtc.py:206-210), 2 Lm, 3 Kmm (+1e-8 I), 4 psi2 */
 int mi355gp_sparse_fetch(mi355gp_sparse* s, int which, double* out);
 

@@ -109,6 +109,105 @@ def vardtc(kind, X, Z, Y, variance, lengthscale, ARD, noise_var):
                 psi2=psi1.T @ psi1, A=A, LB=LB, dL_dKnm=dL_dpsi1)
 
 
+def vardtc_general(parts, X, Z, R, noise):
+    """The same evaluation for a SUM of parts (`GPy.kern.Add` of stationary / White / Bias kernels, add.py:58-84;
+    parts = [(kind, ARD, variance, lengthscale, active_dims)] as in gp_oracle.sum_kern_K), per-point noise variances
+    (heteroscedastic precision, var_dtc.py:78-86,126-129,224-226,240-256,267-269; Dy = 1) and R = Y - mean_function.f(X)
+    (var_dtc.py:73-76,88-89).  Returns dict(lml, dtheta (concatenated in part order), dnoise (scalar, or the N-vector dL_dR),
+    dZ, woodbury_vector, woodbury_inv, dL_dKmm, dL_dKnm, dL_dm)."""
+    N, Dy = R.shape
+    M = Z.shape[0]
+    noise = np.atleast_1d(np.asarray(noise, dtype=float)).ravel()
+    het = noise.size > 1
+    assert not het or Dy == 1
+    beta = 1.0 / np.fmax(noise, CONST_JITTER)                                # (1,) or (N,)
+    bcol = beta[:, None] if het else beta[0]
+    VVT = bcol * R
+    Kmm = O.sum_kern_K(parts, Z).copy()
+    Kmm[np.arange(M), np.arange(M)] += CONST_JITTER
+    Lm = O.jitchol(Kmm)
+    psi0 = np.full(N, O.sum_kdiag(parts))
+    psi1 = O.sum_kern_K(parts, X, Z)
+    tmp = _dtrtrs(Lm, (psi1 * np.sqrt(bcol)).T)
+    A = tmp @ tmp.T
+    B = np.eye(M) + A
+    LB = O.jitchol(B)
+    LBi_Lmi_psi1 = _dtrtrs(LB, _dtrtrs(Lm, psi1.T))
+    c = LBi_Lmi_psi1 @ VVT
+    Cpsi1Vf = _dtrtrs(Lm, _dtrtrs(LB, c, trans=1), trans=1)
+    dL_dm = -LBi_Lmi_psi1.T @ c + VVT                                        # var_dtc.py:148
+    delit = c @ c.T
+    data_fit = float(np.trace(delit))
+    P = backsub_both_sides(LB, Dy * np.eye(M) + delit)
+    dL_dKmm = backsub_both_sides(Lm, -0.5 * P - 0.5 * B * Dy + Dy * np.eye(M))
+    dL_dpsi0 = -0.5 * Dy * (beta * np.ones(N))
+    dL_dpsi1 = VVT @ Cpsi1Vf.T
+    dL_dpsi2_beta = 0.5 * backsub_both_sides(Lm, Dy * np.eye(M) - P)
+    dL_dpsi1 = dL_dpsi1 + 2.0 * (psi1 * bcol) @ dL_dpsi2_beta                # :224-226 / :229-233
+    if het:                                                                  # :267-269
+        lik_1 = -0.5 * N * Dy * np.log(2 * np.pi) + 0.5 * Dy * np.sum(np.log(beta)) - 0.5 * np.sum(beta * np.square(R).sum(-1))
+        lik_2 = -0.5 * Dy * (np.sum(beta * psi0) - np.trace(A))
+    else:
+        lik_1 = -0.5 * N * Dy * (np.log(2.0 * np.pi) - np.log(beta[0])) - 0.5 * beta[0] * float(np.sum(np.square(R)))
+        lik_2 = -0.5 * Dy * (np.sum(beta[0] * psi0) - np.trace(A))
+    lml = lik_1 + lik_2 - Dy * np.sum(np.log(np.diag(LB))) + 0.5 * data_fit
+    if het:                                                                  # :240-256
+        LBi = _dtrtrs(LB, np.eye(M))
+        Lmi_psi1 = _dtrtrs(Lm, psi1.T)
+        b2 = beta[:, None] ** 2
+        dL_dR = -0.5 * beta[:, None] + 0.5 * VVT ** 2
+        dL_dR += 0.5 * Dy * (psi0 - np.sum(Lmi_psi1 ** 2, 0))[:, None] * b2
+        dL_dR += 0.5 * np.sum((LBi.T @ LBi @ Lmi_psi1) * Lmi_psi1, 0)[:, None] * b2
+        dL_dR += -(c.T @ LBi_Lmi_psi1).T * R * b2
+        dL_dR += 0.5 * (c.T @ LBi_Lmi_psi1).T ** 2 * b2
+        dnoise = dL_dR[:, 0]
+    else:
+        b = beta[0]
+        trYYT = float(np.sum(np.square(R)))
+        dnoise = -0.5 * N * Dy * b + 0.5 * trYYT * b ** 2 + 0.5 * Dy * (psi0.sum() * b ** 2 - np.trace(A) * b)
+        dnoise += b * (0.5 * np.sum(A * P) - data_fit)
+        dnoise = float(dnoise)
+    Bi = -lapack.dpotri(np.asfortranarray(LB), lower=1)[0]
+    Bi = np.tril(Bi) + np.tril(Bi, -1).T
+    Bi[np.arange(M), np.arange(M)] += 1.0
+    woodbury_inv = backsub_both_sides(Lm, Bi)
+    # SparseGP._update_gradients (sparse_gp.py:108-118) part by part (add.py:81-84: every part sees the same dL_dK)
+    grads, dZ = [], np.zeros(Z.shape)
+    for part in parts:
+        kind, ARD, var, ls, dims = part[:5]
+        if kind in ("white", "bias"):
+            g = float(np.sum(dL_dpsi0))                                      # update_gradients_diag (static.py:95-96,172-173)
+            if kind == "bias":
+                g += float(np.sum(dL_dpsi1)) + float(np.sum(dL_dKmm))        # static.py:169-170
+            else:
+                g += float(np.trace(dL_dKmm))                                # White: K(X, Z) = 0, trace for the symmetric call
+            grads.append(np.array([g]))
+            continue
+        Xp, Zp = X[:, dims], Z[:, dims]
+        dv = float(np.sum(dL_dpsi0))
+        dl = 0.0
+        for G_, A_, B_ in ((dL_dpsi1, Xp, Zp), (dL_dKmm, Zp, None)):
+            a, b_ = O.update_gradients_full(kind, G_, A_, B_, var, ls, ARD)
+            dv += float(a)
+            dl = dl + np.atleast_1d(np.asarray(b_, float))
+        grads.append(np.concatenate([[dv], dl]))
+        gz = gradients_X(kind, dL_dKmm, Zp, None, var, ls, ARD) + gradients_X(kind, dL_dpsi1.T, Zp, Xp, var, ls, ARD)
+        dZ[:, dims] += gz
+    return dict(lml=float(lml), dtheta=np.concatenate(grads), dnoise=dnoise, dZ=dZ, woodbury_vector=Cpsi1Vf,
+                woodbury_inv=woodbury_inv, dL_dKmm=dL_dKmm, dL_dKnm=dL_dpsi1, dL_dm=dL_dm, Kmm=Kmm, Lm=Lm)
+
+
+def sparse_predict(parts, Z, Xnew, woodbury_vector, woodbury_inv, full_cov=False):
+    """`Posterior._raw_predict` of the sparse posterior (reference posterior.py:220-262): mu = Kx^T wv,
+    var = Kxx - Kx^T Winv Kx (diagonal clipped at 1e-15, :248)."""
+    Kx = O.sum_kern_K(parts, Z, Xnew)
+    mu = Kx.T @ woodbury_vector
+    if full_cov:
+        return mu, O.sum_kern_K(parts, Xnew) - Kx.T @ (woodbury_inv @ Kx)
+    var = O.sum_kdiag(parts) - np.sum((woodbury_inv.T @ Kx) * Kx, 0)
+    return mu, np.clip(var, 1e-15, np.inf)[:, None]
+
+
 def synthetic_Z(X, M, seed=0):
     """Z = X[perm[:M]] (reference models/sparse_gp_regression.py:41-43)"""
     rng = np.random.default_rng(seed + 77)

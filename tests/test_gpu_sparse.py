@@ -116,3 +116,188 @@ def test_row_sharded_mode_rccl_world_one(sctx):
         check_sparse(r, ref)
     finally:
         c.close()
+
+
+# ---- sum kernels, per-point noise, mean function, device prediction, dL_dKnm blocks --------------------------
+from test_oracle_sparse import check_sparse2, load_sparse2_golden, sparse2_golden_names  # noqa: E402
+
+
+def _specs_of(g):
+    return [(k, a, L.theta_vec(v, ls, a, len(d)) if ls is not None else np.array([v]), np.asarray(d, np.int32), 0)
+            for k, a, v, ls, d in g["parts"]]
+
+
+@pytest.mark.parametrize("name", sparse2_golden_names())
+def test_sparse_sum_hetero_meanfn_golden_through_the_c_abi(name, sctx):
+    """`mi355gp_vardtc_inference_sum` / `mi355gp_sparse_predict` / `mi355gp_sparse_fetch_dLdKnm` against outputs of the
+    reference's own VarDTC + SparseGP._update_gradients + Posterior._raw_predict (oracle/make_golden_sparse2.py)."""
+    g = load_sparse2_golden(name)
+    specs = _specs_of(g)
+    sctx.set_data(g["X"], g["R"])
+    info, r = sctx.vardtc_sum(specs, g["Z"], g["noise"], want_dL_dm=True)
+    assert info == 0
+    check_sparse2(r, g)
+    assert np.abs(r["dL_dm"] - g["dL_dm"]).max() <= 1e-6 * np.abs(g["dL_dm"]).max()
+    rows = g["rows"]
+    B = sctx.fetch_dL_dKnm(int(rows[0]), int(rows[-1] - rows[0] + 1))
+    assert np.abs(B[rows - rows[0]] - g["dL_dKnm_rows"]).max() <= 1e-6 * np.abs(g["dL_dKnm_rows"]).max()
+    dK = sctx.fetch(L.SparseContext.FETCH_DLDKMM)
+    assert np.abs(dK - g["dL_dKmm"]).max() <= 1e-4 * np.abs(g["dL_dKmm"]).max()
+    mu, var = sctx.predict(specs, g["Xs"])
+    _, cov = sctx.predict(specs, g["Xs"], full_cov=True)
+    assert np.abs(mu - g["pred_mu"]).max() <= 1e-6 * np.abs(g["pred_mu"]).max()
+    assert np.abs(var - g["pred_var"]).max() <= 1e-5 * np.abs(g["pred_var"]).max()
+    assert np.abs(cov - g["pred_cov"]).max() <= 1e-5 * np.abs(g["pred_cov"]).max()
+
+
+def test_sparse_host_classes_with_add_kernel_hetero_noise_and_mean_function():
+    import gpy_amd
+    X, Y = O.synthetic(500, 3, seed=21)
+    Z = S.synthetic_Z(X, 28, 3)
+    # RBF + White, homoscedastic, linear mean function
+    w = np.array([[0.2], [-0.1], [0.05]])
+
+    class Mean(object):
+        grad = None
+
+        def f(self, Xq):
+            return Xq @ w
+
+        def update_gradients(self, dL_dm, Xq):
+            Mean.grad = Xq.T @ dL_dm
+
+    k = gpy_amd.RBF(3, variance=1.2, lengthscale=0.9) + gpy_amd.White(3, variance=0.04)
+    m = gpy_amd.SparseGP(X, Y, Z, k, gpy_amd.Gaussian(0.12), mean_function=Mean())
+    parts = [("rbf", False, 1.2, np.array([0.9]), [0, 1, 2]), ("white", False, 0.04, None, [0, 1, 2])]
+    ref = S.vardtc_general(parts, X, Z, Y - X @ w, 0.12)
+    assert abs(m.log_likelihood() - ref["lml"]) <= 1e-9 * abs(ref["lml"])
+    gref = np.concatenate([ref["dZ"].ravel(), ref["dtheta"], [ref["dnoise"]]])
+    assert np.abs(m.gradient - gref).max() <= 1e-6 * np.abs(gref).max()
+    assert np.abs(Mean.grad - X.T @ ref["dL_dm"]).max() <= 1e-6 * np.abs(X.T @ ref["dL_dm"]).max()
+    Xs = np.random.default_rng(2).standard_normal((40, 3))
+    mu, var = m.predict(Xs, include_likelihood=False)
+    mur, varr = S.sparse_predict(parts, Z, Xs, ref["woodbury_vector"], ref["woodbury_inv"])
+    assert np.abs(mu - (mur + Xs @ w)).max() <= 1e-6 * np.abs(mur).max() and np.abs(var - varr).max() <= 1e-5 * np.abs(varr).max()
+    # a foreign consumer materialises dL_dKnm block by block
+    G = np.asarray(m.grad_dict["dL_dKnm"])
+    assert G.shape == (500, 28) and np.abs(G - ref["dL_dKnm"]).max() <= 1e-6 * np.abs(ref["dL_dKnm"]).max()
+    # per-point noise through HeteroscedasticGaussian
+    meta = {"output_index": np.arange(500)[:, None]}
+    lik = gpy_amd.HeteroscedasticGaussian(meta, variance=0.1)
+    lik.variance[:] = 0.05 + 0.1 * np.random.default_rng(3).random(500)
+    k2 = gpy_amd.Matern52(3, variance=0.9, lengthscale=[0.8, 1.1, 1.5], ARD=True)
+    m2 = gpy_amd.SparseGP(X, Y, Z, k2, lik, Y_metadata=meta)
+    ref2 = S.vardtc_general([("matern52", True, 0.9, np.array([0.8, 1.1, 1.5]), [0, 1, 2])], X, Z, Y, lik.variance.values)
+    assert abs(m2.log_likelihood() - ref2["lml"]) <= 1e-9 * abs(ref2["lml"])
+    assert np.abs(lik.variance.gradient - ref2["dnoise"]).max() <= 1e-6 * np.abs(ref2["dnoise"]).max()
+    assert np.abs(k2.gradient - ref2["dtheta"]).max() <= 1e-6 * np.abs(ref2["dtheta"]).max()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_mode_over_the_loopback_transport(world):
+    """world > 1 on ONE GPU: `world` contexts, one host thread each, meet at the in-process rendezvous for both exchange
+    steps (mi355gp_sparse_attach_loopback).  Every rank must return the unsharded result -- incl. per-point noise, whose
+    log-likelihood sums need their own all-reduce."""
+    import threading
+    from gpy_amd import grid as G
+    N, M, D = 5000, 96, 4
+    X, Y = O.synthetic(N, D, seed=5)
+    Z = S.synthetic_Z(X, M, 0)
+    parts = [("rbf", True, 1.1, np.array([0.7, 1.0, 1.3, 1.6]), [0, 1, 2, 3]), ("bias", False, 0.2, None, [0, 1, 2, 3])]
+    specs = _specs_of({"parts": parts})
+    noise_het = 0.05 + 0.1 * np.random.default_rng(1).random(N)
+    for noise in (0.1, noise_het):
+        ref = S.vardtc_general(parts, X, Z, Y, noise)
+        out, errs = [None] * world, []
+
+        def work(rank):
+            try:
+                c = L.SparseContext(0)
+                try:
+                    lo, hi = G.shard_rows(N, rank, world)
+                    c.attach_loopback(rank, world, group_key=1000 + world * 10 + (1 if np.ndim(noise) else 0))
+                    c.set_data(X[lo:hi], Y[lo:hi])
+                    info, r = c.vardtc_sum(specs, Z, noise[lo:hi] if np.ndim(noise) else noise)
+                    assert info == 0
+                    out[rank] = (r, lo, hi)
+                finally:
+                    c.close()
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        [t.start() for t in ts]
+        [t.join(timeout=120) for t in ts]
+        assert not errs, errs
+        for r, lo, hi in out:
+            assert abs(r["lml"] - ref["lml"]) <= 1e-9 * abs(ref["lml"])
+            assert np.abs(r["dtheta"] - ref["dtheta"]).max() <= 1e-6 * np.abs(ref["dtheta"]).max()
+            assert np.abs(r["dZ"] - ref["dZ"]).max() <= 1e-6 * np.abs(ref["dZ"]).max()
+            if np.ndim(noise):
+                assert np.abs(r["dnoise"] - ref["dnoise"][lo:hi]).max() <= 1e-6 * np.abs(ref["dnoise"]).max()
+            else:
+                assert abs(r["dnoise"] - ref["dnoise"]) <= 1e-6 * abs(ref["dnoise"])
+        assert out[0][0]["dtheta"].tobytes() == out[-1][0]["dtheta"].tobytes()      # identical on every rank
+
+
+_RCCL_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np
+from gpy_amd import _lib as L, grid as G
+from oracle import gp_oracle as O, sparse_oracle as S
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+idb = G.unique_id() if rank == 0 else b"\0" * G.ID_BYTES
+idb = G.exchange_id_file(idb, rank, %(idfile)r, world=world)
+if %(mode)r == "sparse":
+    N, M, D = 40000, 256, 4
+    X, Y = O.synthetic(N, D, seed=5); Z = S.synthetic_Z(X, M, 0)
+    var, ls, noise = O.default_theta(D, True)
+    lo, hi = G.shard_rows(N, rank, world)
+    c = L.SparseContext(rank); c.attach_comm(rank, world, idb); c.set_data(X[lo:hi], Y[lo:hi])
+    info, r = c.vardtc("rbf", True, L.theta_vec(var, ls, True, D), Z, noise)
+    res = dict(info=info, lml=r["lml"], dtheta=r["dtheta"].tolist(), dZn=float(np.linalg.norm(r["dZ"])))
+else:
+    N, D = 6000, 5
+    X, Y = O.synthetic(N, D, seed=3)
+    var, ls, noise = O.default_theta(D, True)
+    g = G.GridContext(rank, rank, world, 1, 2, 256, idb); g.set_data(X, Y)
+    info, r = g.exact_inference("matern52", True, L.theta_vec(var, ls, True, D), noise)
+    res = dict(info=info, lml=r["lml"], dtheta=r["dtheta"].tolist(), an=float(np.linalg.norm(r["alpha"])))
+json.dump(res, open(%(out)r %% rank, "w"))
+"""
+
+
+@pytest.mark.parametrize("mode", ["grid", "sparse"])
+def test_two_process_rccl_over_xgmi(mode, tmp_path):
+    """e1 / e2 with TWO processes on TWO GPUs over RCCL (panel broadcasts of the 1 x 2 block-cyclic grid; the all-reduces of
+    the row-sharded sparse path).  Skips on a single-GPU box; the loopback transports cover the same logic there."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if L.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(_RCCL_WORKER % dict(root=root, idfile=str(tmp_path / "id.bin"), mode=mode, out=str(tmp_path / "r%d.json")))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2",
+                                                                     HSA_ENABLE_IPC_MODE_LEGACY="0"))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    res = [json.load(open(tmp_path / ("r%d.json" % r))) for r in range(2)]
+    assert res[0]["info"] == 0 and res[0]["lml"] == res[1]["lml"] and res[0]["dtheta"] == res[1]["dtheta"]
+    if mode == "sparse":
+        X, Y = O.synthetic(40000, 4, seed=5)
+        Z = S.synthetic_Z(X, 256, 0)
+        var, ls, noise = O.default_theta(4, True)
+        ref = S.vardtc("rbf", X, Z, Y, var, ls, True, noise)
+        assert abs(res[0]["lml"] - ref["lml"]) <= 1e-9 * abs(ref["lml"])
+        assert np.abs(np.array(res[0]["dtheta"]) - ref["dtheta"]).max() <= 1e-6 * np.abs(ref["dtheta"]).max()
+    else:
+        X, Y = O.synthetic(6000, 5, seed=3)
+        var, ls, noise = O.default_theta(5, True)
+        ref = O.parameters_changed("matern52", X, Y, var, ls, True, noise)
+        gref = np.concatenate([[ref["dvar"]], ref["dlen"]])
+        assert abs(res[0]["lml"] - ref["lml"]) <= 1e-10 * abs(ref["lml"])
+        assert np.abs(np.array(res[0]["dtheta"]) - gref).max() <= 1e-8 * np.abs(gref).max()

@@ -57,3 +57,42 @@ def test_sparse_oracle_gradients_by_finite_differences():
     Zp, Zm = Z.copy(), Z.copy()
     Zp[4, 1] += eps; Zm[4, 1] -= eps
     assert abs((f(var, ls, noise, Zp) - f(var, ls, noise, Zm)) / (2 * eps) - base["dZ"][4, 1]) < 1e-4
+
+
+# ---- sum kernels, heteroscedastic noise, mean function (tests/golden/sparse2_*.npz, oracle/make_golden_sparse2.py) ----------
+def sparse2_golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "sparse2_*.npz")))
+
+
+def load_sparse2_golden(name):
+    d = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+    parts = []
+    for i, kind in enumerate(d["kinds"]):
+        ls = d["ls%d" % i]
+        parts.append((str(kind), bool(d["ARDs"][i]), float(d["variances"][i]), ls if ls.size else None,
+                      [int(v) for v in d["dims%d" % i]]))
+    d["parts"] = parts
+    d["R"] = d["Y"] - (d["X"] @ d["mean_w"] if d["mean_w"].size else 0.0)
+    return d
+
+
+def check_sparse2(res, g, tol_lml=1e-9, tol_g=1e-6):
+    assert abs(res["lml"] - g["lml"]) <= tol_lml * abs(g["lml"])
+    assert np.abs(res["dtheta"] - g["dtheta"]).max() <= tol_g * np.abs(g["dtheta"]).max()
+    assert np.abs(np.atleast_1d(res["dnoise"]) - g["dnoise"]).max() <= tol_g * np.abs(g["dnoise"]).max()
+    assert np.abs(res["dZ"] - g["dZ"]).max() <= tol_g * np.abs(g["dZ"]).max()
+    assert np.linalg.norm(res["woodbury_vector"] - g["woodbury_vector"]) <= 1e-5 * np.linalg.norm(g["woodbury_vector"])
+
+
+@pytest.mark.parametrize("name", sparse2_golden_names())
+def test_general_sparse_oracle_matches_reference_golden(name):
+    g = load_sparse2_golden(name)
+    res = S.vardtc_general(g["parts"], g["X"], g["Z"], g["R"], g["noise"])
+    check_sparse2(res, g)
+    assert np.abs(res["dL_dm"] - g["dL_dm"]).max() <= 1e-7 * np.abs(g["dL_dm"]).max()
+    assert np.abs(res["dL_dKnm"][g["rows"]] - g["dL_dKnm_rows"]).max() <= 1e-6 * np.abs(g["dL_dKnm_rows"]).max()
+    mu, var = S.sparse_predict(g["parts"], g["Z"], g["Xs"], res["woodbury_vector"], res["woodbury_inv"])
+    _, cov = S.sparse_predict(g["parts"], g["Z"], g["Xs"], res["woodbury_vector"], res["woodbury_inv"], full_cov=True)
+    assert np.abs(mu - g["pred_mu"]).max() <= 1e-6 * np.abs(g["pred_mu"]).max()
+    assert np.abs(var - g["pred_var"]).max() <= 1e-5 * np.abs(g["pred_var"]).max()
+    assert np.abs(cov - g["pred_cov"]).max() <= 1e-5 * np.abs(g["pred_cov"]).max()

@@ -324,10 +324,10 @@ class Context(object):
         return rc, res
 
     def set_option(self, name, value):
-        """'lookahead': 0/1/2.  'panel': 0/1 (inverse-based panel solve).  'profile': 0 = off, 1 = every kernel family, or a tuple of family names."""
+        """'lookahead': 0/1.  'profile': 0 = off, 1 = every kernel family, or a tuple of family names."""
         if name == "profile" and not isinstance(value, (int, bool)):
             value = sum(1 << PROFILE_FAMILIES.index(f) for f in value) << 1
-        check(lib().mi355gp_set_option(self._h, {"profile": 0, "lookahead": 1, "panel": 2}[name], int(value)), "mi355gp_set_option")
+        check(lib().mi355gp_set_option(self._h, {"profile": 0, "lookahead": 1}[name], int(value)), "mi355gp_set_option")
 
     def get_profile(self):
         """{family: (ms, algorithmic flops, launches)} of the last inference call made with option 'profile' on."""

@@ -304,11 +304,6 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
         HIP_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[6]));
         stage_ms[MI355GP_T_TOTAL] = ms;
     }
-    if (info[0] < 0) {
-        c->have_factor = false;
-        mi355gp_set_error("panel factorisation: workgroup hand-off timed out (k_panel_fused)");
-        return -7;
-    }
     if (info[0] > 0) {
         c->have_factor = false;
         if (info[0] > n) info[0] = (int)n;
@@ -742,10 +737,6 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
         HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
         *ms = t;
     }
-    if (info < 0) {
-        mi355gp_set_error("panel factorisation: workgroup hand-off timed out (k_panel_fused)");
-        return -7;
-    }
     if (info == 0) {
         if (L_out) {
             launch_extract(0, A, np, N, 0, nullptr, 0, tmp, 0);
@@ -926,8 +917,7 @@ int mi355gp_predict(mi355gp_ctx* c, int kind, int ard, const double* theta, cons
 int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
     ARG_CHECK(c != nullptr, "mi355gp_set_option: NULL context");
     if (option == MI355GP_OPT_PROFILE) { c->ws.prof.on = (value != 0); c->ws.prof.mask = (value == 1) ? 0xffu : (unsigned)value >> 1; }
-    else if (option == MI355GP_OPT_LOOKAHEAD) c->ws.lookahead = (value < 0 || value > 2) ? 1 : value;
-    else if (option == MI355GP_OPT_PANEL) c->ws.panel_inv = (value != 0);
+    else if (option == MI355GP_OPT_LOOKAHEAD) c->ws.lookahead = (value == 0) ? 0 : 1;
     else { mi355gp_set_error("mi355gp_set_option: unknown option %d", option); return -1; }
     return 0;
 }
@@ -1004,10 +994,6 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
     for (auto& ev : e) (void)hipEventDestroy(ev);
     factor_ws_free(&ws);
     HIP_CHECK(hipGetLastError());
-    if (info < 0) {
-        mi355gp_set_error("panel factorisation: workgroup hand-off timed out (k_panel_fused)");
-        return -7;
-    }
     return info > 0 ? info : 0;
 }
 

@@ -10,24 +10,11 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define NBO 512           // outer panel width of the two-level right-looking Cholesky
 #define FACTOR_NBO_SMALL_N 0      // npad up to which the outer panels are FACTOR_NBO_SMALL wide (0: never)
 #define FACTOR_NBO_SMALL 256
-#define FACTOR_DEFAULT_RESERVE_CUS 0
 #define FACTOR_DEFAULT_TRI_OVERLAP 1    // 1: inverse of the leading block overlapped with the second half of potrf
 #define FACTOR_DEFAULT_DIAG_EXCL_FIRST 1   // small factorisations only (N < 6144): from N = 8192 on it measured slower
-#define FACTOR_DEFAULT_PANEL_REC 0
-#define FACTOR_DEFAULT_TRSM_LDS 1       // k_trsm128 stages L_cc and its inverted diagonal tiles in LDS (0: operands straight from L2)
-#define FACTOR_DEFAULT_DIAG_SERVER 0    // 1: diagonal blocks factored by a resident single-workgroup server on a CU of its own
-#define FACTOR_DEFAULT_PANEL_FUSED_MAX_NRB 100000
-#define FACTOR_DEFAULT_PANEL_FUSED_MIN_NRB 0
-#define FACTOR_DEFAULT_PANEL_FUSED 0   // 1: k_panel_fused (one launch per outer panel, flag hand-offs between workgroups)   // CUs (a multiple of 8: the same count per XCD) kept free of trailing-update workgroups; measured: no gain
 #define GEMM_DEFAULT_TRI64_MAX 512    // levels of the triangular inverse with at most this many 128-tiles per stage run as 64 x 64 quadrants
 #define GEMM_DEFAULT_LAUUM64_MAX 528  // X^T X of at most this many lower 128-tiles (nt <= 32) runs as 64 x 64 quadrants
 #define GEMM_DEFAULT_UPD64_MAX 128  // trailing-update launches of at most this many 128-tiles run as 64 x 64 quadrants (0 = never)
-#define GEMM_DEFAULT_NW 4        // wave arrangement of the 128x128 tile kernels (see gemm_tile.h); env MI355GP_GEMM_NW
-#define GEMM_DEFAULT_REVERSE_K 0
-#define GEMM_DEFAULT_UPDATE_SMALL_NW8 0  // 1: trailing-update launches of at most one tile per CU use 8-wave workgroups
-#define GEMM_DEFAULT_UPDATE_STAGGER 0   // percent of one tile time over which the first round of k_update_nt is spread (0 = off) // lauum / trtri stage 1 walk k downwards (common end point); env MI355GP_REVERSE_K
-#define GEMM_DEFAULT_UPDATE_V2 0 // trailing update on the v2 tile pipeline (BK = 8, fragments prefetched across the barrier)
-#define GEMM_DEFAULT_PRELOAD 1   // trailing update reads C before the k-loop; env MI355GP_PRELOAD_C
 
 // v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) * B(4x16) + C.  Per lane (l = 0..63):
 //   A operand: A[row = l & 15][k = l >> 4]        (one double)

@@ -142,95 +142,14 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
         const char* envh = getenv("MI355GP_TRI_H");
         if (envh && *envh) ws->tri_h_override = atoi(envh);
     }
-    {
-        // Express lane for the panel chain: the big trailing updates run on a stream whose CU mask leaves `reserve_cus`
-        // CUs out, so k_diag128 (one workgroup, dependent fp64 VALU chain) never shares a CU with an fp64-MFMA-saturating
-        // update workgroup (measured: 42 us alone, 125-300 us when co-resident).  MI355GP_RESERVE_CUS=0 disables it.
-        const char* envr = getenv("MI355GP_RESERVE_CUS");
-        ws->reserve_cus = (envr && *envr) ? atoi(envr) : FACTOR_DEFAULT_RESERVE_CUS;
-        hipDeviceProp_t prop;
-        int dev = 0;
-        HIP_CHECK(hipGetDevice(&dev));
-        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        const int ncu = prop.multiProcessorCount;
-        if (ws->reserve_cus > 0 && ws->reserve_cus < ncu / 2) {
-            // Workgroups are dealt round-robin to the 8 XCDs, so the mask must take the SAME number of CUs from every XCD
-            // (an XCD with fewer CUs becomes the straggler of every launch: measured 2x slower).  Logical CU i sits on
-            // XCD i % 8, so the first 8*r indices are r CUs per XCD.
-            const int nx = 8, r = (ws->reserve_cus + nx - 1) / nx;
-            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-            for (int cu = 0; cu < ncu; ++cu)
-                if (cu >= nx * r) mask[cu / 32] |= 1u << (cu % 32);
-            hipError_t e = hipExtStreamCreateWithCUMask(&ws->st_bulk, (uint32_t)mask.size(), mask.data());
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                ws->st_bulk = nullptr;
-            }
-        }
-        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_bulk, hipEventDisableTiming));
-        const char* enve = getenv("MI355GP_DIAG_EXCL");
-        if (enve && *enve) ws->diag_excl_opt = atoi(enve) ? 1 : 0;
-    }
-    {
-        const char* envs = getenv("MI355GP_PANEL_SPLIT");
-        if (envs && *envs) ws->panel_split = atoi(envs) ? 1 : 0;
-        if (ws->panel_split) HIP_CHECK(hipStreamCreateWithPriority(&ws->st_rest, hipStreamNonBlocking, greatest));
-        for (int i = 0; i < 4; ++i) {
-            HIP_CHECK(hipEventCreateWithFlags(&ws->ev_d[i], hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&ws->ev_t[i], hipEventDisableTiming));
-        }
-        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_rest, hipEventDisableTiming));
-    }
     const char* envnbo = getenv("MI355GP_NBO");
     if (envnbo && *envnbo) ws->nbo_override = atoi(envnbo);
-    const char* envw = getenv("MI355GP_PART2_WGS");
-    if (envw && *envw) ws->part2_wgs = atoi(envw);
-    const char* envt = getenv("MI355GP_PART2_TILES");
-    if (envt && *envt) ws->part2_tiles = atol(envt);
-    const char* envf = getenv("MI355GP_PANEL_FUSED");
-    if (envf && *envf) ws->panel_fused = atoi(envf) ? 1 : 0;
-    {
-        const char* envs2 = getenv("MI355GP_DIAG_SERVER");
-        if (envs2 && *envs2) ws->diag_server = atoi(envs2) ? 1 : 0;
-        HIP_CHECK(hipMalloc(&ws->diag_flags, sizeof(int) * 2 * ws->nblk));
-        HIP_CHECK(hipMemset(ws->diag_flags, 0, sizeof(int) * 2 * ws->nblk));
-        if (ws->diag_server) HIP_CHECK(hipStreamCreateWithPriority(&ws->st_diag, hipStreamNonBlocking, greatest));
-        HIP_CHECK(hipEventCreateWithFlags(&ws->ev_diag, hipEventDisableTiming));
-    }
-    const char* envt2 = getenv("MI355GP_TRSM_LDS");
-    if (envt2 && *envt2) ws->trsm_lds = atoi(envt2);           // 0: operands from L2, 1: LDS-staged, 2: LDS-staged, two strips per wave
     const char* envso = getenv("MI355GP_SOLVE_OVERLAP");
     if (envso && *envso) ws->solve_overlap = atoi(envso) ? 1 : 0;
     const char* envth = getenv("MI355GP_TRI_HALF");
     if (envth && *envth) ws->tri_half_ok = atoi(envth) ? 1 : 0;
     const char* envx = getenv("MI355GP_DIAG_EXCL_FIRST");
     if (envx && *envx) ws->diag_excl_first = atoi(envx) ? 1 : 0;
-    const char* envr = getenv("MI355GP_PANEL_REC");
-    if (envr && *envr) ws->panel_rec = atoi(envr) ? 1 : 0;
-    const char* envn = getenv("MI355GP_PANEL_FUSED_MAX_NRB");
-    if (envn && *envn) ws->panel_fused_max_nrb = atoi(envn);
-    const char* envm = getenv("MI355GP_PANEL_FUSED_MIN_NRB");
-    if (envm && *envm) ws->panel_fused_min_nrb = atoi(envm);
-    const char* envg = getenv("MI355GP_PANEL_WGS");
-    if (envg && *envg) ws->panel_max_wgs = atoi(envg);
-    {
-        const char* envd = getenv("MI355GP_PANEL_DBG");
-        if (envd && atoi(envd)) {
-            HIP_CHECK(hipMalloc(&ws->panel_dbg, sizeof(long long) * 256 * 16));
-            HIP_CHECK(hipMemset(ws->panel_dbg, 0, sizeof(long long) * 256 * 16));
-        }
-    }
-    HIP_CHECK(hipMalloc(&ws->panel_flags, sizeof(int) * 32));
-    HIP_CHECK(hipMemset(ws->panel_flags, 0, sizeof(int) * 32));
-    ws->panel_gen = 0;
-    const char* envp = getenv("MI355GP_PANEL_INV");
-    if (envp && *envp) ws->panel_inv = atoi(envp) ? 1 : 0;
-    const char* env = getenv("MI355GP_UPD_STREAMS");
-    if (env && *env) ws->n_upd = atoi(env);
-    if (ws->n_upd < 1) ws->n_upd = 1;
-    if (ws->n_upd > FactorWs::MAX_UPD) ws->n_upd = FactorWs::MAX_UPD;
-    for (int i = 0; i < ws->n_upd; ++i) HIP_CHECK(hipEventCreateWithFlags(&ws->ev_join[i], hipEventDisableTiming));
-    // the chunk-update streams themselves are created by potrf_chunked on first use (option LOOKAHEAD = 2 only)
     HIP_CHECK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
     const size_t nouter = (size_t)(npad + NB - 1) / NB + 2;      // enough for the narrowest outer panel (nbo = 128)
     ws->ev_panel.resize(nouter);
@@ -243,8 +162,6 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
 }
 
 void factor_ws_free(FactorWs* ws) {
-    if (ws->panel_dbg) (void)hipFree(ws->panel_dbg);
-    ws->panel_dbg = nullptr;
     if (ws->dinv) (void)hipFree(ws->dinv);
     if (ws->logsum) (void)hipFree(ws->logsum);
     if (ws->info) (void)hipFree(ws->info);
@@ -256,28 +173,7 @@ void factor_ws_free(FactorWs* ws) {
     ws->ev_cols.clear();
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
     ws->ev_fork = nullptr;
-    for (int i = 0; i < FactorWs::MAX_UPD; ++i) {
-        if (ws->ev_join[i]) (void)hipEventDestroy(ws->ev_join[i]);
-        if (ws->st_upd[i]) (void)hipStreamDestroy(ws->st_upd[i]);
-        ws->ev_join[i] = nullptr;
-        ws->st_upd[i] = nullptr;
-    }
-    ws->st_panel = nullptr;
-    if (ws->st_rest) (void)hipStreamDestroy(ws->st_rest);
-    ws->st_rest = nullptr;
-    for (int i = 0; i < 4; ++i) {
-        if (ws->ev_d[i]) (void)hipEventDestroy(ws->ev_d[i]);
-        if (ws->ev_t[i]) (void)hipEventDestroy(ws->ev_t[i]);
-        ws->ev_d[i] = ws->ev_t[i] = nullptr;
-    }
-    if (ws->ev_rest) (void)hipEventDestroy(ws->ev_rest);
-    ws->ev_rest = nullptr;
-    if (ws->st_bulk) (void)hipStreamDestroy(ws->st_bulk);
-    ws->st_bulk = nullptr;
-    if (ws->panel_flags) (void)hipFree(ws->panel_flags);
-    ws->panel_flags = nullptr;
-    if (ws->diag_flags) (void)hipFree(ws->diag_flags);
-    ws->diag_flags = nullptr;
+    ws->st_panel = nullptr;                       // engine streams are shared and never destroyed by a workspace
     ws->st_tri = nullptr;
     ws->st_tri_half = ws->st_tri_cur = nullptr;
     if (ws->ev_tri) (void)hipEventDestroy(ws->ev_tri);
@@ -286,12 +182,6 @@ void factor_ws_free(FactorWs* ws) {
     ws->ev_tri_lead = nullptr;
     if (ws->tri_counter) (void)hipFree(ws->tri_counter);
     ws->tri_counter = nullptr;
-    if (ws->st_diag) (void)hipStreamDestroy(ws->st_diag);
-    ws->st_diag = nullptr;
-    if (ws->ev_diag) (void)hipEventDestroy(ws->ev_diag);
-    ws->ev_diag = nullptr;
-    if (ws->ev_bulk) (void)hipEventDestroy(ws->ev_bulk);
-    ws->ev_bulk = nullptr;
     ws->prof.destroy();
 }
 
@@ -299,269 +189,56 @@ void factor_ws_free(FactorWs* ws) {
 static double syrk_flops(double n, double K) { return K * n * (n + 1.0); }
 static double gemm_flops(double m, double n, double K) { return 2.0 * m * n * K; }
 
-// One outer panel: columns [K0, K0+W), rows [K0, npad).  128-column steps:
+// One outer panel: columns [K0, K0+W), rows [K0, npad).  128-column steps, right-looking inside the panel:
 //   diag128 (one CU) -> trsm128 on the rows below -> rank-128 update of the remaining columns of the panel.
-static void factor_panel_inv(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws);
-static void factor_panel_split(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws);
+// (The alternatives that were built and measured -- inverse-based panel solve, split chain / wide streams, one fused launch
+//  per panel with flag hand-offs, a resident diagonal-block server, recursive order -- are written up in DESIGN.md 6e;
+//  none beat this path and their code is gone.)
 static void factor_panel(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws) {
-    if (ws->panel_inv && ws->scratchX && ws->scratchT) {
-        factor_panel_inv(s, A, npad, K0, W, ws);
-        return;
-    }
-    if (ws->panel_split && ws->st_rest && ws->lookahead == 1 && W <= 4 * NB) {
-        factor_panel_split(s, A, npad, K0, W, ws);
-        return;
-    }
     const long ld = npad;
-    if (ws->panel_fused && ws->panel_flags && W <= 4 * NB && (npad - K0) / NB <= ws->panel_fused_max_nrb &&
-        (npad - K0) / NB >= ws->panel_fused_min_nrb) {
-        const int ns = (int)(W / NB), nrb = (int)((npad - K0) / NB);
-        ws->prof.begin(s, PF_DIAG, (double)ns * NB * NB * NB / 3.0);
-        const int rc = launch_panel_fused(s, A, ld, K0, ns, nrb, ws->dinv + (K0 / NB) * 8 * 256, ws->logsum + K0 / NB,
-                                          ws->info, ws->panel_flags, ++ws->panel_gen, ws->panel_max_wgs,
-                                          K0 == 0 ? ws->panel_dbg : nullptr);
-        ws->prof.end(s);
-        if (rc == 0 && K0 == 0 && ws->panel_dbg) {          // diagnostics: print the hand-off timeline of the first panel
-            (void)hipStreamSynchronize(s);
-            const int G = nrb < ws->panel_max_wgs ? nrb : ws->panel_max_wgs;
-            std::vector<long long> h((size_t)G * 16);
-            (void)hipMemcpy(h.data(), ws->panel_dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-            long long t0 = h[0];
-            for (int g = 0; g < G; ++g) t0 = (h[(size_t)g * 16] && h[(size_t)g * 16] < t0) ? h[(size_t)g * 16] : t0;
-            for (int g = 0; g < G; g += (g < 6 ? 1 : (G / 6 > 0 ? G / 6 : 1))) {
-                fprintf(stderr, "[panel dbg] npad=%ld wg %3d:", npad, g);
-                for (int k = 0; k < ns; ++k) {
-                    fprintf(stderr, " |");
-                    for (int i = 0; i < 4; ++i) fprintf(stderr, " %7.1f", (double)(h[((size_t)g * 4 + k) * 4 + i] - t0) / 100.0);
-                }
-                fprintf(stderr, "\n");
-            }
-        }
-        if (rc == 0) return;
-    }
-    // one 128-column step: diagonal block, then the rows below it
-    auto leaf = [&](long c) {
-        const long blk = c / NB;
-        double* dv = ws->dinv + blk * 8 * 256;
-        ws->prof.begin(s, PF_DIAG, (double)NB * NB * NB / 3.0);
-        if (ws->diag_server_on)
-            launch_diag_call(s, ws->diag_flags, ws->diag_flags + ws->nblk, (int)blk, ws->diag_gen, ws->info);
-        else
-            launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info,
-                           ws->diag_excl || (ws->diag_excl_first && c == K0 && ws->lookahead == 1 && ws->excl_first_ok));
-        ws->prof.end(s);
-        const long below = npad - (c + NB);
-        if (below <= 0) return;
-        ws->prof.begin(s, PF_TRSM, (double)below * NB * NB);
-        launch_trsm128(s, A, ld, c, c + NB, below, dv, ws->trsm_lds);
-        ws->prof.end(s);
-    };
-    // rank-K update of the panel's columns [cd, cend) (rows cd .. npad) with its columns [c0, cd)
-    auto inpanel_update = [&](long c0, long cd, long cend) {
-        const long below = npad - cd, ncols = cend - cd, K = cd - c0;
-        if (below <= 0 || ncols <= 0) return;
-        const double* P = A + cd * ld + c0;
-        ws->prof.begin(s, PF_UPDATE, syrk_flops((double)ncols, (double)K) + gemm_flops((double)(below - ncols), (double)ncols, (double)K));
-        launch_update_nt(s, A + cd * ld + cd, ld, P, ld, P, ld, (int)K, (int)(below / NB), (int)(ncols / NB), (int)(cd / NB),
-                         (int)(cd / NB));
-        ws->prof.end(s);
-    };
-    if (!ws->panel_rec) {                    // right-looking inside the panel: every step updates all remaining columns, K = 128
-        for (long j = 0; j < W; j += NB) {
-            leaf(K0 + j);
-            inpanel_update(K0 + j, K0 + j + NB, K0 + W);
-        }
-        return;
-    }
-    // Recursive inside the panel (default): [left half] -> update of the right half with K = width of the left half ->
-    // [right half].  Same launches and flops as the right-looking loop, but the K=128 read-modify-write passes over the
-    // panel's C tiles shrink from 384+256+128 to 128+256+128 columns (the 256-column one at K=256).
-    struct Rec {
-        decltype(leaf)& lf;
-        decltype(inpanel_update)& up;
-        void run(long c0, int ns) {
-            if (ns == 1) {
-                lf(c0);
-                return;
-            }
-            int h = 1;
-            while (2 * h < ns) h *= 2;
-            run(c0, h);
-            up(c0, c0 + (long)h * NB, c0 + (long)ns * NB);
-            run(c0 + (long)h * NB, ns - h);
-        }
-    } rec{leaf, inpanel_update};
-    rec.run(K0, (int)(W / NB));
-}
-
-// Inverse-based panel (needs ws->scratchX / scratchT): the chain kernels that must win workgroup slots against a
-// machine-filling trailing update shrink from 4 x (trsm128 + in-panel update) over the whole panel height to ONE GEMM.
-//   D phase : the W x W diagonal block is factored with the 128-step loop restricted to its own rows (<= 6-tile kernels)
-//   I phase : XD = L_D^-1 (inv128 + log2(W/128) batched levels) into scratchX at the block's own position
-//   R phase : rows below:  L_R = R * XD^T  (k_panel_trmm) into scratchT, copied back into A
-// rocprof: the trsm128-based chain takes 0.75 ms per panel on an idle GPU but ~1.7 ms under a trailing update.
-static void factor_panel_inv(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws) {
-    const long ld = npad, end = K0 + W;
     for (long j = 0; j < W; j += NB) {
         const long c = K0 + j, blk = c / NB;
         double* dv = ws->dinv + blk * 8 * 256;
         ws->prof.begin(s, PF_DIAG, (double)NB * NB * NB / 3.0);
-        launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info, ws->diag_excl);
+        launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info,
+                       ws->diag_excl_first && c == K0 && ws->lookahead == 1 && ws->excl_first_ok);
         ws->prof.end(s);
-        const long below = end - (c + NB);                      // rows of the diagonal block still to do
+        const long below = npad - (c + NB);
         if (below <= 0) continue;
         ws->prof.begin(s, PF_TRSM, (double)below * NB * NB);
-        launch_trsm128(s, A, ld, c, c + NB, below, dv, ws->trsm_lds);
+        launch_trsm128(s, A, ld, c, c + NB, below, dv);
         ws->prof.end(s);
-        double* C = A + (c + NB) * ld + (c + NB);
-        const double* P = A + (c + NB) * ld + c;
-        ws->prof.begin(s, PF_UPDATE, syrk_flops((double)below, NB));
-        launch_update_nt(s, C, ld, P, ld, P, ld, NB, (int)(below / NB), (int)(below / NB), (int)((c + NB) / NB),
-                         (int)((c + NB) / NB));
+        // rank-128 update of the panel's remaining columns [c + NB, K0 + W) (rows c + NB .. npad)
+        const long cd = c + NB, ncols = K0 + W - cd;
+        if (ncols <= 0) continue;
+        const double* P = A + cd * ld + c;
+        ws->prof.begin(s, PF_UPDATE, syrk_flops((double)ncols, (double)NB) + gemm_flops((double)(below - ncols), (double)ncols, (double)NB));
+        launch_update_nt(s, A + cd * ld + cd, ld, P, ld, P, ld, NB, (int)(below / NB), (int)(ncols / NB), (int)(cd / NB), (int)(cd / NB));
         ws->prof.end(s);
-    }
-    const long rows = npad - end;
-    if (rows <= 0) return;
-    double* XD = ws->scratchX + K0 * ld + K0;
-    double* TD = ws->scratchT + K0 * ld + K0;
-    const int nt = (int)(W / NB);
-    (void)hipMemset2DAsync(XD, sizeof(double) * ld, 0, sizeof(double) * W, W, s);      // upper blocks of XD must be zero
-    ws->prof.begin(s, PF_TRTRI, (double)W * W * W / 3.0);
-    launch_inv128(s, A + K0 * ld + K0, XD, ld, nt, ws->dinv + (K0 / NB) * 8 * 256);
-    for (int level = 0; (1 << level) < nt; ++level) launch_trtri_level(s, A + K0 * ld + K0, XD, TD, ld, nt, level);
-    ws->prof.end(s);
-    double* R = A + end * ld + K0;
-    double* Rt = ws->scratchT + end * ld + K0;
-    ws->prof.begin(s, PF_TRSM, (double)rows * W * W);
-    launch_panel_trmm(s, R, XD, Rt, ld, (int)(rows / NB), nt);
-    ws->prof.end(s);
-    (void)hipMemcpy2DAsync(R, sizeof(double) * ld, Rt, sizeof(double) * ld, sizeof(double) * W, rows,
-                           hipMemcpyDeviceToDevice, s);
-}
-
-// Split panel (experiment, MI355GP_PANEL_SPLIT=1; measured slower: potrf 33.1 -> 33.6 ms at N=16384, 3.85 -> 4.19 ms at
-// N=4096, the cross-stream event waits cost more than the pipelining hides): the dependency chain of a panel only runs
-// through its W x W diagonal block
-//   chain stream `s` : for each 128-column step  diag128 -> trsm of the diagonal block's remaining rows -> K=128 update
-//                      of the diagonal block's remaining tiles          (kernels of <= 6 workgroups)
-//   rest stream      : trsm of all rows BELOW the diagonal block (after that step's diag128) -> K=128 update of those
-//                      rows' remaining panel columns (after that step's small trsm), pipelined behind the chain
-// so diag128(j+1) no longer waits for the wide kernels of step j.  `s` waits for the rest stream before returning.
-static void factor_panel_split(hipStream_t s, double* A, long npad, long K0, long W, FactorWs* ws) {
-    const long ld = npad, end = K0 + W, rows_below = npad - end;
-    hipStream_t sr = ws->st_rest;
-    int nsteps = 0;
-    for (long j = 0; j < W; j += NB, ++nsteps) {
-        const long c = K0 + j, blk = c / NB;
-        double* dv = ws->dinv + blk * 8 * 256;
-        ws->prof.begin(s, PF_DIAG, (double)NB * NB * NB / 3.0);
-        launch_diag128(s, A, ld, c, dv, ws->logsum + blk, ws->info, ws->diag_excl);
-        ws->prof.end(s);
-        const long in_block = end - (c + NB);                  // rows of the diagonal block below this step
-        if (rows_below > 0) {
-            (void)hipEventRecord(ws->ev_d[nsteps], s);
-            (void)hipStreamWaitEvent(sr, ws->ev_d[nsteps], 0);
-            launch_trsm128(sr, A, ld, c, end, rows_below, dv);
-        }
-        if (in_block <= 0) continue;
-        ws->prof.begin(s, PF_TRSM, (double)in_block * NB * NB);
-        launch_trsm128(s, A, ld, c, c + NB, in_block, dv, ws->trsm_lds);
-        ws->prof.end(s);
-        const double* Pd = A + (c + NB) * ld + c;               // freshly solved rows of the diagonal block
-        if (rows_below > 0) {
-            (void)hipEventRecord(ws->ev_t[nsteps], s);
-            (void)hipStreamWaitEvent(sr, ws->ev_t[nsteps], 0);
-            launch_update_nt(sr, A + end * ld + (c + NB), ld, A + end * ld + c, ld, Pd, ld, NB, (int)(rows_below / NB),
-                             (int)(in_block / NB), (int)(end / NB), (int)((c + NB) / NB));
-        }
-        ws->prof.begin(s, PF_UPDATE, syrk_flops((double)in_block, NB));
-        launch_update_nt(s, A + (c + NB) * ld + (c + NB), ld, Pd, ld, Pd, ld, NB, (int)(in_block / NB),
-                         (int)(in_block / NB), (int)((c + NB) / NB), (int)((c + NB) / NB));
-        ws->prof.end(s);
-    }
-    if (rows_below > 0) {
-        (void)hipEventRecord(ws->ev_rest, sr);
-        (void)hipStreamWaitEvent(s, ws->ev_rest, 0);
     }
 }
 
 // rank-W update of the trailing columns [c0, c1) (rows c0 .. npad) with the panel at columns [K0, K0+W)
-static void update_cols(hipStream_t s, double* A, long npad, long K0, long W, long c0, long c1, FactorWs* ws,
-                        int max_wgs = 0) {
+static void update_cols(hipStream_t s, double* A, long npad, long K0, long W, long c0, long c1, FactorWs* ws) {
     if (c1 <= c0) return;
     const long ld = npad, rows = npad - c0, cols = c1 - c0;
     const double* P = A + c0 * ld + K0;
     ws->prof.begin(s, PF_UPDATE, syrk_flops((double)cols, (double)W) + gemm_flops((double)(rows - cols), (double)cols, (double)W));
     launch_update_nt(s, A + c0 * ld + c0, ld, P, ld, P, ld, (int)W, (int)(rows / NB), (int)(cols / NB), (int)(c0 / NB),
-                     (int)(c0 / NB), max_wgs);
+                     (int)(c0 / NB));
     ws->prof.end(s);
 }
 
-// Alternative schedule (option LOOKAHEAD = 2; measured equal to the default on MI355X, kept as an experiment switch):
-// the true dependencies at column-chunk granularity instead of whole steps on one stream:
-//   - panel p is factored on a high-priority stream as soon as the updates of ITS columns are done (look-ahead);
-//   - the trailing columns are cut into chunks of ~512 tiles; chunk c is always updated on stream c % n_upd, so
-//     step p+1's update of a chunk only waits for panel p+1 and for the same chunk's step-p update.  The tail of
-//     one launch (fewer tiles left than CU slots) therefore overlaps the head of the next chunk's launch, and
-//     the latency-bound diag/trsm chain hides behind MFMA-bound work.
-static void potrf_chunked(hipStream_t st, double* A, long npad, FactorWs* ws) {
+// Reference schedule (option LOOKAHEAD = 0): everything in order on one stream
+static void potrf_serial(hipStream_t st, double* A, long npad, FactorWs* ws) {
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
     const long nbo = ws->nbo_for(npad);
-    const long P = (npad + nbo - 1) / nbo;                       // outer panels
+    const long P = (npad + nbo - 1) / nbo;
     auto pcol = [&](long p) { return (p * nbo < npad) ? p * nbo : npad; };
-    if (!ws->lookahead) {                                        // reference schedule: everything in order on st
-        for (long p = 0; p < P; ++p) {
-            factor_panel(st, A, npad, pcol(p), pcol(p + 1) - pcol(p), ws);
-            update_cols(st, A, npad, pcol(p), pcol(p + 1) - pcol(p), pcol(p + 1), npad, ws);
-        }
-        return;
-    }
-    // chunk boundaries (in panels): chunk i = panels [cb[i], cb[i+1]); at least ~448 tiles of 128x128 each
-    std::vector<long> cb;
-    {
-        const long nt = npad / NB;
-        long tiles = 0;
-        cb.push_back(1);
-        for (long p = 1; p < P; ++p) {
-            const long t0 = pcol(p) / NB, t1 = pcol(p + 1) / NB;
-            for (long t = t0; t < t1; ++t) tiles += nt - t;
-            if (tiles >= 448 && p + 1 < P) { cb.push_back(p + 1); tiles = 0; }
-        }
-        cb.push_back(P);
-    }
-    const int nchunk = (int)cb.size() - 1;
-    for (int i = 0; i < ws->n_upd; ++i)
-        if (!ws->st_upd[i]) (void)hipStreamCreateWithFlags(&ws->st_upd[i], hipStreamNonBlocking);
-    auto chunk_stream = [&](int c) { return ws->st_upd[c % ws->n_upd]; };
-    hipStream_t sp = ws->st_panel;
-    (void)hipEventRecord(ws->ev_fork, st);                      // everything queued on st so far precedes the factorisation
-    (void)hipStreamWaitEvent(sp, ws->ev_fork, 0);
-    for (int i = 0; i < ws->n_upd; ++i) (void)hipStreamWaitEvent(ws->st_upd[i], ws->ev_fork, 0);
     for (long p = 0; p < P; ++p) {
-        const long K0 = pcol(p), W = pcol(p + 1) - K0;
-        if (p > 0) (void)hipStreamWaitEvent(sp, ws->ev_cols[p], 0);
-        factor_panel(sp, A, npad, K0, W, ws);
-        if (p + 1 >= P) break;
-        (void)hipEventRecord(ws->ev_panel[p], sp);
-        for (int i = 0; i < ws->n_upd; ++i) (void)hipStreamWaitEvent(ws->st_upd[i], ws->ev_panel[p], 0);
-        for (int c = 0; c < nchunk; ++c) {
-            if (cb[c + 1] <= p + 1) continue;                   // chunk already factored
-            hipStream_t su = chunk_stream(c);
-            long first = (cb[c] > p + 1) ? cb[c] : p + 1;
-            if (first == p + 1) {                               // the next panel's columns first: they gate panel p+1
-                update_cols(su, A, npad, K0, W, pcol(p + 1), pcol(p + 2), ws);
-                (void)hipEventRecord(ws->ev_cols[p + 1], su);
-                first = p + 2;
-            }
-            update_cols(su, A, npad, K0, W, pcol(first), pcol(cb[c + 1]), ws);
-        }
+        factor_panel(st, A, npad, pcol(p), pcol(p + 1) - pcol(p), ws);
+        update_cols(st, A, npad, pcol(p), pcol(p + 1) - pcol(p), pcol(p + 1), npad, ws);
     }
-    for (int i = 0; i < ws->n_upd; ++i) {
-        (void)hipEventRecord(ws->ev_join[i], ws->st_upd[i]);
-        (void)hipStreamWaitEvent(st, ws->ev_join[i], 0);
-    }
-    (void)hipEventRecord(ws->ev_panel[P], sp);
-    (void)hipStreamWaitEvent(st, ws->ev_panel[P], 0);
 }
 
 // Two-level right-looking Cholesky with one panel of look-ahead (default).  Outer panels of NBO = 512 columns keep
@@ -571,30 +248,17 @@ static void potrf_chunked(hipStream_t st, double* A, long npad, FactorWs* ws) {
 // trailing updates stay in order on `st`: their launch durations are not inflated by overlapping each other.
 void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     if (ws->lookahead != 1) {
-        ws->diag_excl = 0;
-        ws->diag_server_on = 0;
-        potrf_chunked(st, A, npad, ws);                          // 0: serial reference schedule, 2: chunk streams
+        potrf_serial(st, A, npad, ws);
         return;
     }
-    ws->diag_excl = (ws->st_bulk != nullptr && ws->diag_excl_opt) ? 1 : 0;
-    ws->diag_server_on = (ws->diag_server && ws->diag_flags && ws->st_diag && !ws->panel_inv && !ws->panel_split &&
-                          !ws->panel_fused && npad / NB == ws->nblk) ? 1 : 0;
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
     const long nbo = ws->nbo_for(npad);
     const long P = (npad + nbo - 1) / nbo;
     auto pcol = [&](long p) { return (p * nbo < npad) ? p * nbo : npad; };
     hipStream_t sp = ws->st_panel;
-    hipStream_t su = ws->st_bulk ? ws->st_bulk : st;            // trailing updates (CU-masked when an express lane is set)
+    hipStream_t su = st;                                        // trailing updates stay in order on the caller's stream
     (void)hipEventRecord(ws->ev_fork, st);                      // panel 0 follows everything queued on st so far
     (void)hipStreamWaitEvent(sp, ws->ev_fork, 0);
-    if (ws->diag_server_on) {                                   // resident diagonal-block server for this factorisation
-        ++ws->diag_gen;
-        (void)hipStreamWaitEvent(ws->st_diag, ws->ev_fork, 0);
-        launch_diag_server(ws->st_diag, A, npad, (int)(npad / NB), ws->dinv, ws->logsum, ws->info, ws->diag_flags,
-                           ws->diag_flags + ws->nblk, ws->diag_gen);
-        (void)hipEventRecord(ws->ev_diag, ws->st_diag);
-    }
-    if (su != st) (void)hipStreamWaitEvent(su, ws->ev_fork, 0);
     factor_panel(sp, A, npad, 0, pcol(1), ws);
     // Inverse of a leading block early (trtri_device picks up from ws->ovl_h): h tiles, a power of two <= nt/2 or the
     // largest power of two below nt, whichever still fits the time model: inverting the leading block (the part that
@@ -649,18 +313,11 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
         (void)hipEventRecord(ws->ev_cols[p + 1], su);
         (void)hipStreamWaitEvent(sp, ws->ev_cols[p + 1], 0);
         factor_panel(sp, A, npad, pcol(p + 1), pcol(p + 2) - pcol(p + 1), ws);
-        // part 2: everything to the right (optionally with a bounded number of resident workgroups, see part2_wgs)
-        const long t2 = (npad - pcol(p + 2)) / NB, tiles2 = t2 * (t2 + 1) / 2;
-        update_cols(su, A, npad, K0, W, pcol(p + 2), npad, ws,
-                    (ws->part2_wgs > 0 && tiles2 < ws->part2_tiles) ? ws->part2_wgs : 0);
+        // part 2: everything to the right
+        update_cols(su, A, npad, K0, W, pcol(p + 2), npad, ws);
     }
     (void)hipEventRecord(ws->ev_panel[P], sp);
     (void)hipStreamWaitEvent(st, ws->ev_panel[P], 0);
-    if (ws->diag_server_on) (void)hipStreamWaitEvent(st, ws->ev_diag, 0);
-    if (su != st) {
-        (void)hipEventRecord(ws->ev_bulk, su);
-        (void)hipStreamWaitEvent(st, ws->ev_bulk, 0);
-    }
 }
 
 // X = L^-1: diagonal 128-blocks on single CUs (all blocks concurrently), then log2(nt) batched levels.  If the preceding

@@ -14,34 +14,17 @@
         }                                                                                               \
     } while (0)
 
-// Wave arrangement of the tile kernels (gemm_tile.h): MI355GP_GEMM_NW = 4 | 8, read once.  MI355GP_PRELOAD_C = 0 | 1
-// selects whether the trailing update reads its C tile before (1) or after (0) the k-loop.
 #include <cstdlib>
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
-int gemm_variant_nw() {
-    static const int nw = (env_int("MI355GP_GEMM_NW", GEMM_DEFAULT_NW) == 8) ? 8 : 4;
-    return nw;
-}
-static int gemm_variant_preload() {
-    static const int p = env_int("MI355GP_PRELOAD_C", GEMM_DEFAULT_PRELOAD) ? 1 : 0;
-    return p;
-}
-#define NW_DISPATCH(CALL4, CALL8)        \
-    do {                                 \
-        if (gemm_variant_nw() == 8) {    \
-            CALL8;                       \
-        } else {                         \
-            CALL4;                       \
-        }                                \
+// every tile kernel runs 4-wave workgroups on the LDS-DMA pipeline (the 8-wave arrangement measured within +-1 %)
+#define NW_DISPATCH(CALL4, CALL8) \
+    do {                          \
+        CALL4;                    \
     } while (0)
-static int device_cu_count() {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n;
-}
+static int gemm_variant_nw() { return 4; }
 
 #define LB(NW) __launch_bounds__((NW) * 64, (NW) / 2)
 
@@ -49,33 +32,12 @@ static int device_cu_count() {
 // Trailing update of the right-looking Cholesky (the dsyrk/dgemm inside LAPACK dpotrf, which GPy reaches
 // through GPy/util/linalg.py:58):  C[ti,tj] -= A[ti,:] * B[tj,:]^T.
 // `tri`: region is square on the diagonal -> enumerate the lower triangle only.
-// Start-up stagger: every tile of one launch has the same K, so all workgroup slots finish their tiles together and the
-// whole chip reads and writes its 128 KB C tiles in the same few microseconds, round after round, while the MFMA pipes
-// wait (the variable-K kernels k_lauum / k_trtri_stage do not have this: 70 vs 61 TF/s).  The workgroups of the FIRST
-// round wait for a fraction of one tile time that depends on where they landed (CU, wave slot, SE, XCD); later
-// workgroups inherit the phase of the slot they take over, so the C traffic of a launch is spread over the tile period.
-__device__ __forceinline__ void stagger_first_round(int stagger_ticks, int first_round) {
-    if (stagger_ticks <= 0 || (int)blockIdx.x >= first_round) return;
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);        // HW_REG_HW_ID
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);       // HW_REG_XCC_ID
-    const unsigned slot = hw & 15u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
-    const unsigned phase = ((slot & 1u) * 8u + cu * 5u + sh * 3u + se * 7u + xcc * 11u) & 15u;   // 16 phases
-    const long long wait = (long long)stagger_ticks * phase / 16;
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-}
-
 template <int NW, bool PRE>
 __global__ LB(NW) void k_update_nt(double* __restrict__ C, long ldc,
                                                       const double* __restrict__ A, long lda,
                                                       const double* __restrict__ B, long ldb, int K, int ntc,
-                                                      int row0t, int col0t, int tri, long ntiles, int stagger_ticks,
-                                                      int first_round) {
+                                                      int row0t, int col0t, int tri, long ntiles) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    stagger_first_round(stagger_ticks, first_round);
-    // grid-stride over the tile list: gridDim.x == ntiles is the one-tile-per-workgroup launch; a smaller grid
-    // (launch_update_nt `max_wgs`) keeps only that many workgroups resident so that the panel chain of the
-    // look-ahead schedule finds free slots on every CU while a trailing update is running.
     for (long bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
         int ti, tj;
         if (tri) {
@@ -99,30 +61,6 @@ __global__ LB(NW) void k_update_nt(double* __restrict__ C, long ldc,
             gemm_tile_128<true, true, NW>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
             gt_store<2, NW>(Ct, ldc, acc);
         }
-    }
-}
-
-// the same update on the v2 pipeline (gemm_tile.h): NT is the one layout where it measured faster (+4 %)
-__global__ __launch_bounds__(256, 2) void k_update_nt_v2(double* __restrict__ C, long ldc, const double* __restrict__ A,
-                                                         long lda, const double* __restrict__ B, long ldb, int K, int ntc,
-                                                         int row0t, int col0t, int tri, long ntiles) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    for (long bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
-        int ti, tj;
-        if (tri) {
-            ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
-            while ((long)ti * (ti + 1) / 2 > bid) --ti;
-            while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
-            tj = (int)(bid - (long)ti * (ti + 1) / 2);
-        } else {
-            ti = (int)(bid / ntc);
-            tj = (int)(bid - (long)ti * ntc);
-            if (col0t + tj > row0t + ti) continue;
-        }
-        d4 acc[4][4];
-        gt_zero<4>(acc);
-        gemm_tile_128_v2<true, true>(A + (long)ti * NB * lda, lda, B + (long)tj * NB * ldb, ldb, K, acc, smem);
-        gt_store<2, 4>(C + (long)ti * NB * ldc + (long)tj * NB, ldc, acc);
     }
 }
 
@@ -154,53 +92,23 @@ __global__ __launch_bounds__(256) void k_update_nt64(double* __restrict__ C, lon
     gt64_store<0>(Ct, ldc, acc);
 }
 
-template <int NW, bool PRE>
-static void launch_update_nt_t(hipStream_t st, long nblocks, long grid, double* C, long ldc, const double* A, long lda,
-                               const double* B, long ldb, int K, int ntc, int row0t, int col0t, int tri) {
-    LDS_OPT_IN((k_update_nt<NW, PRE>));
-    // stagger only launches of several full rounds: one tile takes K/16 slabs x 2 waves per SIMD x 64 MFMAs x 64 cycles
-    static const int stag = env_int("MI355GP_UPDATE_STAGGER", GEMM_DEFAULT_UPDATE_STAGGER);
-    static const int slots = 2 * device_cu_count();
-    const int ticks = (stag && nblocks >= 4L * slots) ? (int)((long)K / 16 * 8192 / 24) * stag / 100 : 0;   // 100 MHz ticks at ~2.4 GHz
-    hipLaunchKernelGGL((k_update_nt<NW, PRE>), dim3((unsigned)grid), dim3(NW * 64), GT_LDS_BYTES, st, C, ldc, A, lda,
-                       B, ldb, K, ntc, row0t, col0t, tri, nblocks, ticks, slots);
-}
-
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
-                      int K, int ntr, int ntc, int row0t, int col0t, int max_wgs) {
+                      int K, int ntr, int ntc, int row0t, int col0t) {
     if (ntr <= 0 || ntc <= 0) return;
     const int tri = (row0t == col0t && ntr == ntc) ? 1 : 0;
     const long nblocks = tri ? (long)ntr * (ntr + 1) / 2 : (long)ntr * ntc;
-    const long grid = (max_wgs > 0 && max_wgs < nblocks) ? max_wgs : nblocks;
-    static const int v2 = env_int("MI355GP_UPDATE_V2", GEMM_DEFAULT_UPDATE_V2);
-    if (v2) {
-        hipLaunchKernelGGL(k_update_nt_v2, dim3((unsigned)grid), dim3(256), GT2_LDS_BYTES, st, C, ldc, A, lda, B, ldb, K, ntc,
-                           row0t, col0t, tri, nblocks);
-        return;
-    }
     // Few tiles: the launch is the latency of ONE tile on ONE CU -> four times as many 64 x 64 tiles (bit-identical result)
     static const int upd64_max = env_int("MI355GP_UPD64_MAX", GEMM_DEFAULT_UPD64_MAX);
-    if (nblocks <= upd64_max && grid == nblocks && gemm_variant_preload() && gemm_variant_nw() == 4) {
+    if (nblocks <= upd64_max) {
         hipLaunchKernelGGL(k_update_nt64, dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, C, ldc, A, lda, B, ldb,
                            K, ntc, row0t, col0t, tri);
         return;
     }
-    // Few tiles (at most one per CU): the launch is the latency of ONE tile, so give every tile 8 waves (two per SIMD,
-    // 64x32 accumulators each) instead of 4 -- half the MFMA time per tile.  These are the in-panel K=128 updates and the
-    // late part-1 updates of the look-ahead chain.
-    static const int small8 = env_int("MI355GP_UPDATE_SMALL_NW8", GEMM_DEFAULT_UPDATE_SMALL_NW8);
-    static const int ncu = device_cu_count();
-    if (small8 && nblocks <= ncu && grid == nblocks) {
-        if (gemm_variant_preload()) launch_update_nt_t<8, true>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri);
-        else launch_update_nt_t<8, false>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri);
-        return;
-    }
-    if (gemm_variant_preload())
-        NW_DISPATCH((launch_update_nt_t<4, true>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)),
-                    (launch_update_nt_t<8, true>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)));
-    else
-        NW_DISPATCH((launch_update_nt_t<4, false>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)),
-                    (launch_update_nt_t<8, false>(st, nblocks, grid, C, ldc, A, lda, B, ldb, K, ntc, row0t, col0t, tri)));
+    // C is read through buffer loads BEFORE the k-loop, which then runs with negated A fragments, and stored plainly
+    // (potrf 33.0 -> 32.3 ms against read-modify-write after the loop)
+    LDS_OPT_IN((k_update_nt<4, true>));
+    hipLaunchKernelGGL((k_update_nt<4, true>), dim3((unsigned)nblocks), dim3(256), GT_LDS_BYTES, st, C, ldc, A, lda, B, ldb, K,
+                       ntc, row0t, col0t, tri, nblocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -306,7 +214,7 @@ void launch_trtri_stage1_steal(hipStream_t st, const double* L, double* X, doubl
     if (nbt >= nt) return;
     const int pairs = (nt + 2 * nbt - 1) / (2 * nbt);
     const int nblocks = pairs * nbt * nbt;
-    static const int rev = env_int("MI355GP_REVERSE_K", GEMM_DEFAULT_REVERSE_K);
+    const int rev = 0;
     LDS_OPT_IN(k_trtri_stage1_steal);
     if (grid > nblocks) grid = nblocks;
     hipLaunchKernelGGL(k_trtri_stage1_steal, dim3((unsigned)grid), dim3(256), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev,
@@ -316,7 +224,7 @@ void launch_trtri_stage1_steal(hipStream_t st, const double* L, double* X, doubl
 template <int NW>
 static void launch_trtri_level_t(hipStream_t st, long nblocks, const double* L, double* X, double* T, long ld, int nt,
                                  int nbt, int stages) {
-    static const int rev = env_int("MI355GP_REVERSE_K", GEMM_DEFAULT_REVERSE_K);
+    const int rev = 0;
     LDS_OPT_IN((k_trtri_stage<1, NW>));
     LDS_OPT_IN((k_trtri_stage<2, NW>));
     if (stages & 1)
@@ -379,7 +287,7 @@ __global__ __launch_bounds__(256) void k_lauum64(const double* __restrict__ X, d
 
 template <int NW>
 static void launch_lauum_t(hipStream_t st, long nblocks, const double* X, double* W, long ld, int nt) {
-    static const int rev = env_int("MI355GP_REVERSE_K", GEMM_DEFAULT_REVERSE_K);
+    const int rev = 0;
     LDS_OPT_IN((k_lauum<NW>));
     hipLaunchKernelGGL((k_lauum<NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, X, W, ld, nt, rev);
 }
@@ -421,26 +329,6 @@ void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* 
                        int ntr, int ntc) {
     NW_DISPATCH((launch_trmm_lower_t<4>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc)),
                 (launch_trmm_lower_t<8>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc)));
-}
-
-// ------------------------------------------------------------------------------------------------
-// Panel solve through the explicit inverse of the (<= 512 x 512) diagonal block: L_R = R * L_D^-T = R * XD^T.
-// One launch for the whole panel height instead of four trsm128 + three in-panel updates on the critical chain.
-template <int NW>
-__global__ LB(NW) void k_panel_trmm(const double* __restrict__ R, const double* __restrict__ XD,
-                                    double* __restrict__ Out, long ld, int ntc) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int ti = blockIdx.x / ntc, tj = ntc - 1 - (int)(blockIdx.x % ntc);      // long-K column tiles first
-    d4 acc[4][GTCfg<NW>::NI];
-    gt_zero<NW>(acc);
-    gemm_tile_128<true, true, NW>(R + (long)ti * NB * ld, ld, XD + (long)tj * NB * ld, ld, (tj + 1) * NB, acc, smem);
-    gt_store<0, NW>(Out + (long)ti * NB * ld + (long)tj * NB, ld, acc);
-}
-
-void launch_panel_trmm(hipStream_t st, const double* R, const double* XD, double* Out, long ld, int ntr, int ntc) {
-    if (ntr <= 0 || ntc <= 0) return;
-    LDS_OPT_IN((k_panel_trmm<4>));
-    hipLaunchKernelGGL((k_panel_trmm<4>), dim3((unsigned)(ntr * ntc)), dim3(256), GT_LDS_BYTES, st, R, XD, Out, ld, ntc);
 }
 
 // C (mpad x mpad, ldc) = alpha * A^T A + beta * C with A (K x mpad): the K** - tmp^T tmp of full_cov prediction
@@ -489,65 +377,6 @@ __global__ LB(NW) void k_gemm_full(const double* __restrict__ A, long lda,
 }
 
 template <bool AK, bool BK>
-__global__ __launch_bounds__(256, 2) void k_gemm_full_v2(const double* __restrict__ A, long lda,
-                                                         const double* __restrict__ B, long ldb,
-                                                         double* __restrict__ C, long ldc, int K, int ntc, double alpha,
-                                                         double beta) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
-    d4 acc[4][4];
-    gt_zero<4>(acc);
-    const double* Ap = AK ? A + (long)ti * NB * lda : A + (long)ti * NB;
-    const double* Bp = BK ? B + (long)tj * NB * ldb : B + (long)tj * NB;
-    const long long c0 = clock64(), w0 = wall_clock64();
-    gemm_tile_128_v2<AK, BK>(Ap, lda, Bp, ldb, K, acc, smem);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        g_gemm_clk[0] = clock64() - c0;
-        g_gemm_clk[1] = wall_clock64() - w0;
-    }
-    double* Ct = C + (long)ti * NB * ldc + (long)tj * NB;
-    if (beta == 0.0) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] *= alpha;
-        gt_store<0, 4>(Ct, ldc, acc);
-    } else {
-        gt_store<3, 4>(Ct, ldc, acc, alpha, beta);
-    }
-}
-
-template <bool AK, bool BK>
-__global__ __launch_bounds__(256, 2) void k_gemm_full_v3(const double* __restrict__ A, long lda,
-                                                         const double* __restrict__ B, long ldb,
-                                                         double* __restrict__ C, long ldc, int K, int ntc, double alpha,
-                                                         double beta) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
-    d4 acc[4][4];
-    gt_zero<4>(acc);
-    const double* Ap = AK ? A + (long)ti * NB * lda : A + (long)ti * NB;
-    const double* Bp = BK ? B + (long)tj * NB * ldb : B + (long)tj * NB;
-    const long long c0 = clock64(), w0 = wall_clock64();
-    if (K < 0) gemm_tile_128_v4<AK, BK>(Ap, lda, Bp, ldb, -K, acc, smem);     // K < 0 selects the v4 pipeline (diagnostics)
-    else gemm_tile_128_v3<AK, BK>(Ap, lda, Bp, ldb, K, acc, smem);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        g_gemm_clk[0] = clock64() - c0;
-        g_gemm_clk[1] = wall_clock64() - w0;
-    }
-    double* Ct = C + (long)ti * NB * ldc + (long)tj * NB;
-    if (beta == 0.0) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] *= alpha;
-        gt_store<0, 4>(Ct, ldc, acc);
-    } else {
-        gt_store<3, 4>(Ct, ldc, acc, alpha, beta);
-    }
-}
-
-template <bool AK, bool BK>
 static void launch_gemm_full(hipStream_t st, unsigned nblocks, const double* A, long lda, const double* B, long ldb,
                              double* C, long ldc, int K, int ntc, double alpha, double beta) {
     static const int dbg_ld0 = env_int("MI355GP_DBG_LD0", 0), dbg_swz = env_int("MI355GP_DBG_SWZ", 0);
@@ -556,20 +385,6 @@ static void launch_gemm_full(hipStream_t st, unsigned nblocks, const double* A, 
     // MI355GP_DBG_NOSYNC: 1 = no staging and no barrier in the k-loop, 2 = staging but no barrier (racy; timing only)
     const int swz = ((dbg_swz && (ntc % 8 == 0) && ((nblocks / ntc) % 8 == 0)) ? 1 : 0) | ((dbg_nosync & 3) << 1);
     const size_t lds = dbg_1wg ? 100 * 1024 : GT_LDS_BYTES;
-    static const int v2 = env_int("MI355GP_GEMM_V2", 0);
-    if (v2 == 3 || v2 == 4) {
-        if (v2 == 4) K = -K;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_full_v3<AK, BK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GT3_LDS_BYTES);
-        hipLaunchKernelGGL((k_gemm_full_v3<AK, BK>), dim3(nblocks), dim3(256), GT3_LDS_BYTES, st, A, lda, B, ldb, C, ldc, K,
-                           ntc, alpha, beta);
-        return;
-    }
-    if (v2) {
-        hipLaunchKernelGGL((k_gemm_full_v2<AK, BK>), dim3(nblocks), dim3(256), GT2_LDS_BYTES, st, A, lda, B, ldb, C, ldc, K,
-                           ntc, alpha, beta);
-        return;
-    }
     if (gemm_variant_nw() == 8) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_full<AK, BK, 8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -232,129 +232,7 @@ __device__ __forceinline__ void gt_store(double* __restrict__ C, long ldc, const
 }
 
 // =====================================================================================================================
-// v2 pipeline (experiment, NW = 4 only): K in slabs of 8, two LDS stages of 2 x 8 KB, and the NEXT slab's MFMA fragments
-// prefetched into registers while the current slab's 32 MFMAs issue:
-//     slab j:   global -> regs  (iteration j-3)   regs -> LDS (j-2)   LDS -> fragment regs (j-1)   MFMA (j)
-// After the barrier of iteration j-1 the MFMAs of slab j start from registers: no LDS latency is exposed at the
-// barrier (in v1 the first fragment reads of a slab can only be issued after the barrier).
-// Layouts: k-contiguous operands [128][8] unpadded, 16-byte granules XOR-swizzled (position row*4 + (g ^ F[(row>>2)&3]),
-// F = {0,3,2,1}) so that both the staging ds_write_b128 and the fragment ds_read_b128 are bank-conflict free; the logical
-// k-slice s of lane group kq is physical k = 2*kq + s (one b128 read serves both slices).  m/n-contiguous operands
-// [8][136] (stride = 8 mod 16: the kq = 0 / 1 halves of a 32-lane ds_read_b64 group land 32 banks apart).
-#define GT2_BK 8
-#define GT2_SMN 136
-#define GT2_KC_DOUBLES (128 * 8)            // 1024
-#define GT2_MN_DOUBLES (8 * GT2_SMN)        // 1088
-#define GT2_OP 1088                         // doubles reserved per operand per stage
-#define GT2_LDS_BYTES (2 * 2 * GT2_OP * 8)  // 34,816 B
-
-__device__ __forceinline__ int gt2_kc_pos(int row, int g) {            // granule position -> double offset
-    const int h = (0x1230 >> (((row >> 2) & 3) * 4)) & 3;              // F = {0,3,2,1} packed as nibbles
-    return (row * 4 + (g ^ h)) * 2;
-}
-
-template <bool KC>
-__device__ __forceinline__ void gt2_g2r(const double* __restrict__ P, long ld, int k0, d2 (&r)[2], int t) {
-    if (KC) {
-        const int row = t >> 2, g = t & 3;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) r[it] = *reinterpret_cast<const d2*>(P + (long)(row + 64 * it) * ld + k0 + 2 * g);
-    } else {
-        const int k = t >> 6, cp = (t & 63) * 2;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) r[it] = *reinterpret_cast<const d2*>(P + (long)(k0 + k + 4 * it) * ld + cp);
-    }
-}
-
-template <bool KC>
-__device__ __forceinline__ void gt2_r2s(double* s, const d2 (&r)[2], int t) {
-    if (KC) {
-        const int row = t >> 2, g = t & 3;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) *reinterpret_cast<d2*>(s + gt2_kc_pos(row + 64 * it, g)) = r[it];
-    } else {
-        const int k = t >> 6, cp = (t & 63) * 2;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) *reinterpret_cast<d2*>(s + (k + 4 * it) * GT2_SMN + cp) = r[it];
-    }
-}
-
-// both k-slices of one 16-row/col group: f[0] -> slice 0 (k = 2kq), f[1] -> slice 1 (k = 2kq + 1)
-template <bool KC>
-__device__ __forceinline__ d2 gt2_frag(const double* s, int idx, int kq) {
-    if (KC) return *reinterpret_cast<const d2*>(s + gt2_kc_pos(idx, kq));
-    return (d2){s[(2 * kq) * GT2_SMN + idx], s[(2 * kq + 1) * GT2_SMN + idx]};
-}
-
-template <bool AK, bool BK, bool NEGA = false>
-__device__ __forceinline__ void gemm_tile_128_v2(const double* __restrict__ A, long lda,
-                                                 const double* __restrict__ B, long ldb, int K, d4 (&acc)[4][4],
-                                                 double* smem) {
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
-    const int nk = K / GT2_BK;
-    const int arow = wr * 64 + (lane & 15), bcol = wc * 64 + (lane & 15), kq = lane >> 4;
-    d2 ra[2][2], rb[2][2];          // two register sets: global loads run two slabs ahead of the LDS writes
-    d2 fa[2][4], fb[2][4];          // fragment double buffer
-    auto stage = [&](int j) { return smem + (j & 1) * 2 * GT2_OP; };
-    auto load_frags = [&](int j, d2 (&a)[4], d2 (&b)[4]) {
-        const double* as = stage(j);
-        const double* bs = as + GT2_OP;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) a[mi] = gt2_frag<AK>(as, arow + mi * 16, kq);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) b[ni] = gt2_frag<BK>(bs, bcol + ni * 16, kq);
-    };
-    // prologue: slabs 0, 1 in LDS; slabs 2, 3 in flight in the two register sets; fragments of slab 0 in registers
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        if (j < nk) {
-            gt2_g2r<AK>(A, lda, j * GT2_BK, ra[j], t);
-            gt2_g2r<BK>(B, ldb, j * GT2_BK, rb[j], t);
-            gt2_r2s<AK>(stage(j), ra[j], t);
-            gt2_r2s<BK>(stage(j) + GT2_OP, rb[j], t);
-        }
-#pragma unroll
-    for (int j = 2; j < 4; ++j)
-        if (j < nk) {
-            gt2_g2r<AK>(A, lda, j * GT2_BK, ra[j & 1], t);
-            gt2_g2r<BK>(B, ldb, j * GT2_BK, rb[j & 1], t);
-        }
-    __syncthreads();
-    load_frags(0, fa[0], fb[0]);
-    __syncthreads();                // iteration 0 overwrites stage 0: every wave must hold slab 0's fragments first
-    // iteration j (ONE barrier):  request slab j+1's fragments (stage (j+1)&1, written in iteration j-1)
-    //                             | slab j+2: registers -> stage j&1 (its previous content, slab j, was read in iteration j-1)
-    //                             | global loads of slab j+4 | 32 MFMAs on slab j's fragments | barrier
-    for (int j = 0; j < nk; j += 2) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {       // unrolled by two so that every register array index is a compile-time constant
-            const int jj = j + p;
-            if (jj >= nk) break;
-            if (jj + 1 < nk) load_frags(jj + 1, fa[p ^ 1], fb[p ^ 1]);
-            if (jj + 2 < nk) {
-                gt2_r2s<AK>(stage(jj), ra[p], t);
-                gt2_r2s<BK>(stage(jj) + GT2_OP, rb[p], t);
-            }
-            if (jj + 4 < nk) {
-                gt2_g2r<AK>(A, lda, (jj + 4) * GT2_BK, ra[p], t);
-                gt2_g2r<BK>(B, ldb, (jj + 4) * GT2_BK, rb[p], t);
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        const double a = NEGA ? -fa[p][mi][s] : fa[p][mi][s];
-                        acc[mi][ni] = mfma_f64(a, fb[p][ni][s], acc[mi][ni]);
-                    }
-            __syncthreads();
-        }
-    }
-}
-
-// =====================================================================================================================
-// v3 pipeline (experiment, NW = 4): operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
+// v3 pipeline (the shipping one for 4-wave workgroups): operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
 // VGPRs, no ds_write pass.  The DMA destination is wave-uniform base + lane*16 B (linear), so the bank-conflict-free
 // layout is obtained by permuting the per-lane SOURCE address:
 //   k-contiguous operand : [128][16] unpadded; one DMA moves 8 rows x 128 B; lane l = (row l>>3, slot l&7) fetches the
@@ -456,90 +334,6 @@ __device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, l
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) before the barrier: slab kt+1 is in LDS
         __syncthreads();
     }
-}
-
-// =====================================================================================================================
-// v4 pipeline (experiment): LDS-DMA as v3 but K in slabs of 8 on a 4-stage LDS ring with the DMAs running three slabs
-// ahead: counted s_waitcnt vmcnt(8/4/0) + a raw s_barrier per slab (a __syncthreads() would drain the DMA queue), so the
-// loads of slabs j+1, j+2 stay in flight across the barrier of slab j.  Layouts: k-contiguous [128][8] with the XOR
-// swizzle of gt2_kc_pos applied on the DMA source side, one ds_read_b128 per fragment (physical k = 2kq + s);
-// m/n-contiguous [8][136], ds_read_b64.
-#define GT4_NS 4
-#define GT4_OP 1088
-#define GT4_LDS_BYTES (GT4_NS * 2 * GT4_OP * 8)     // 69,632 B
-
-template <bool KC>
-__device__ __forceinline__ void gt4_src_offsets(long ld, int lane, int w, int (&voff)[2]) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-        const int i = 2 * w + ii;
-        if (KC) {
-            const int row = 16 * i + (lane >> 2);
-            const int h = (0x1230 >> (((row >> 2) & 3) * 4)) & 3;
-            voff[ii] = (int)((row * ld + 2 * ((lane & 3) ^ h)) * 8);
-        } else {
-            voff[ii] = (int)((i * ld + 2 * lane) * 8);
-        }
-    }
-}
-
-template <bool KC>
-__device__ __forceinline__ void gt4_issue(const double* P, const int (&voff)[2], double* sdst, int w) {
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-        const int i = 2 * w + ii;
-        double* d = KC ? sdst + i * 128 : sdst + i * GT2_SMN;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, d, 16, voff[ii], 0, 0, 0);
-    }
-}
-
-template <bool AK, bool BK, bool NEGA = false>
-__device__ __forceinline__ void gemm_tile_128_v4(const double* __restrict__ A, long lda,
-                                                 const double* __restrict__ B, long ldb, int K, d4 (&acc)[4][4],
-                                                 double* smem) {
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
-    const int nk = K / 8;
-    const int arow = wr * 64 + (lane & 15), bcol = wc * 64 + (lane & 15), kq = lane >> 4;
-    int va[2], vb[2];
-    gt4_src_offsets<AK>(lda, lane, w, va);
-    gt4_src_offsets<BK>(ldb, lane, w, vb);
-    const long sa = AK ? 8 : 8 * lda, sb = BK ? 8 : 8 * ldb;
-    auto stage = [&](int j) { return smem + (j & (GT4_NS - 1)) * 2 * GT4_OP; };
-    auto issue = [&](int j) {
-        gt4_issue<AK>(A + j * sa, va, stage(j), w);
-        gt4_issue<BK>(B + j * sb, vb, stage(j) + GT4_OP, w);
-    };
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-        if (j < nk) issue(j);
-    for (int j = 0; j < nk; ++j) {
-        // slab j's DMAs (issued three iterations ago) must have landed; those of slabs j+1, j+2 may stay in flight
-        if (j + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
-        else if (j + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // every wave's share of slab j is in LDS, and nobody still reads slab j-1
-        asm volatile("" ::: "memory");
-        if (j + 3 < nk) issue(j + 3);          // into the stage slab j-1 occupied
-        const double* a_s = stage(j);
-        const double* b_s = a_s + GT4_OP;
-        d2 af[4], bf[4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) af[mi] = gt2_frag<AK>(a_s, arow + mi * 16, kq);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bf[ni] = gt2_frag<BK>(b_s, bcol + ni * 16, kq);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = mfma_f64(NEGA ? -af[mi][s] : af[mi][s], bf[ni][s], acc[mi][ni]);
-    }
-    // the workgroup may reuse the LDS ring for its next tile: nobody may still be reading the last slabs
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 }
 
 // =====================================================================================================================

@@ -6,17 +6,13 @@
 
 // ---- gemm.hip : tiled fp64 MFMA GEMM family (all dimensions multiples of 128) -------------------
 // C[ti,tj] -= A[ti,:] * B[tj,:]^T over a (ntr x ntc)-tile region; tiles with (col0t+tj) > (row0t+ti) skipped.
-// max_wgs > 0: at most that many resident workgroups, each walking the tile list with a grid stride
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
-                      int K, int ntr, int ntc, int row0t, int col0t, int max_wgs = 0);
+                      int K, int ntr, int ntc, int row0t, int col0t);
 // one bottom-up level of the batched triangular inverse: X21 = -X22 * (L21 * X11) for every block pair
 void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level,
                         int stages = 3);
 // W (lower tiles) = X^T X for lower-triangular X
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt);
-// rows-below-the-diagonal-block part of a panel: Out[ti, tj] = sum_{k < (tj+1)*128} R[ti, k] * XD[tj, k]  (= R * XD^T with XD
-// lower triangular, w/128 column tiles), ntr row tiles; R, XD, Out share the leading dimension ld
-void launch_panel_trmm(hipStream_t st, const double* R, const double* XD, double* Out, long ld, int ntr, int ntc);
 void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
                        int ntr, int ntc);
 void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
@@ -29,14 +25,8 @@ void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long 
 // to dinv (8*256 doubles), sum(log diag) to logsum[0], first failing 1-based global column to *info.
 void launch_diag128(hipStream_t st, double* A, long ld, long c0, double* dinv, double* logsum, int* info,
                     int exclusive = 0);
-void launch_diag_server(hipStream_t st, double* A, long ld, int nblk, double* dinv, double* logsum, int* info, int* ready,
-                        int* done, int gen);
-void launch_diag_call(hipStream_t st, int* ready, int* done, int blk, int gen, int* info);
-// whole outer panel (ns 128-column steps over nrb 128-row blocks) in one launch; returns -1 if the grid cannot hold it
-int launch_panel_fused(hipStream_t st, double* A, long ld, long c0, int ns, int nrb, double* dinv, double* logsum,
-                       int* info, int* flags, int gen, int max_wgs, long long* dbg = nullptr);
 // rows [r0, r0+mrows) of the 128-wide panel at column c0:  P <- P * L_cc^{-T}   (mrows % 16 == 0)
-void launch_trsm128(hipStream_t st, double* A, long ld, long c0, long r0, long mrows, const double* dinv, int lds = 0);
+void launch_trsm128(hipStream_t st, double* A, long ld, long c0, long r0, long mrows, const double* dinv);
 // X_cc = L_cc^{-1} for all nblk diagonal blocks (upper tiles of the diagonal blocks of X zeroed)
 // stage 1 of one level with a shared tile counter (zeroed by the caller): see k_trtri_stage1_steal
 void launch_trtri_stage1_steal(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level,
@@ -67,42 +57,25 @@ struct FactorWs {
     double* logsum = nullptr;   // nblk doubles: sum(log diag L) per 128-block
     int* info = nullptr;        // device int: 0 or first failing column (1-based)
     long nblk = 0;
-    hipStream_t st_panel = nullptr;          // high-priority stream of the look-ahead panel factorisation
-    static const int MAX_UPD = 4;
-    hipStream_t st_upd[MAX_UPD] = {};        // trailing-update streams: column chunk c lives on st_upd[c % n_upd]
-    int n_upd = 2;
+    hipStream_t st_panel = nullptr;          // high-priority stream of the look-ahead panel factorisation (shared engine stream)
     std::vector<hipEvent_t> ev_panel;        // [p]: outer panel p is factored
     std::vector<hipEvent_t> ev_cols;         // [p]: every update of panel p's columns has been issued (-> its factorisation)
-    hipEvent_t ev_fork = nullptr, ev_join[MAX_UPD] = {};
-    int lookahead = 1;
+    hipEvent_t ev_fork = nullptr;
+    int lookahead = 1;          // 1: panel p+1 factored on st_panel while the big update of step p runs; 0: serial reference schedule
     // outer panel width of the two-level right-looking Cholesky: NBO (512) keeps the big trailing update at 64 flop per
-    // byte of C traffic; small factorisations are bound by the panel chain and the K = nbo "part 1" update on it, so
-    // they take narrower outer panels (MI355GP_NBO overrides; a multiple of 128)
+    // byte of C traffic (measured round 2: 128 / 256 are slower at every N from 2048 to 8192; MI355GP_NBO overrides)
     int nbo_override = 0;
     long nbo_for(long npad) const {
         long w = nbo_override > 0 ? nbo_override : (npad <= FACTOR_NBO_SMALL_N ? FACTOR_NBO_SMALL : NBO);
         w = (w / NB) * NB;
         return w < NB ? NB : w;
     }
-    // Optional scratch for the inverse-based panel solve (factor.hip: factor_panel_inv): two npad x npad buffers with the
-    // same leading dimension as A that are free during the factorisation (the context's X = L^-1 and W buffers).
-    // nullptr -> the trsm128-based panel path.
+    // Scratch for the overlapped inverse: two npad x npad buffers with the same leading dimension as A that are free during
+    // the factorisation (the context's X = L^-1 and T buffers of the trtri_device call that follows); nullptr: no overlap.
     double* scratchX = nullptr;
     double* scratchT = nullptr;
-    int panel_inv = 0;          // option MI355GP_OPT_PANEL: 1 = inverse-based panel when scratch is available (measured slower)
-    hipStream_t st_rest = nullptr;   // split panel: the wide below-the-diagonal-block kernels of a panel (factor_panel_split)
-    hipEvent_t ev_d[4] = {}, ev_t[4] = {}, ev_rest = nullptr;
-    int panel_split = 0;             // env MI355GP_PANEL_SPLIT: measured slower (cross-stream event waits cost more than they hide)
-    hipStream_t st_bulk = nullptr;   // trailing updates of the look-ahead schedule: CU-masked so that `reserve_cus` CUs stay
-    int reserve_cus = 0;             // free of MFMA-saturating workgroups and the latency-bound panel kernels run there
-    int panel_fused = FACTOR_DEFAULT_PANEL_FUSED, panel_gen = 0, panel_max_wgs = 192;
-    int panel_fused_max_nrb = FACTOR_DEFAULT_PANEL_FUSED_MAX_NRB, panel_fused_min_nrb = FACTOR_DEFAULT_PANEL_FUSED_MIN_NRB;   // panels taller than this many 128-row blocks use the launch-per-step path   // k_panel_fused: one launch per outer panel
-    int diag_server = FACTOR_DEFAULT_DIAG_SERVER, diag_server_on = 0, diag_gen = 0;   // resident diagonal-block server (k_diag_server)
-    int* diag_flags = nullptr;       // ready[nblk], done[nblk]
-    hipStream_t st_diag = nullptr;
-    hipEvent_t ev_diag = nullptr;
     // trtri of the finished leading block + the top-level T21 = L21 X11 run on st_tri while potrf's chain-bound second
-    // half leaves the GPU mostly idle (needs scratchX / scratchT = the X / T buffers of the trtri_device call that follows)
+    // half leaves the GPU mostly idle
     int tri_overlap = FACTOR_DEFAULT_TRI_OVERLAP, tri_cu_pct = 75, tri_min_nt = 48, tri_wgs = 0, ovl_h = 0;
     hipStream_t st_tri = nullptr, st_tri_half = nullptr, st_tri_cur = nullptr;   // 75 % / 50 % of every XCD / the one in use
     int tri_half_ok = 1, tri_cur_pct = 75;
@@ -110,17 +83,9 @@ struct FactorWs {
     int* tri_counter = nullptr;
     int tri_h_override = 0;          // MI355GP_TRI_H: leading tiles inverted early (0 = time model)
     // the first k_diag128 of a panel starts when part 1 has just drained the GPU: with the exclusive LDS request it takes a
-    // CU that no part-2 workgroup can join afterwards (27 us instead of 85-250 us next to one)
+    // CU that no part-2 workgroup can join afterwards (27 us instead of 85-250 us next to one); small factorisations only
     int diag_excl_first = FACTOR_DEFAULT_DIAG_EXCL_FIRST, excl_first_ok = 0;
     int solve_overlap = 1;           // MI355GP_SOLVE_OVERLAP: alpha = X^T (X R) on st_tri underneath lauum
-    int panel_rec = FACTOR_DEFAULT_PANEL_REC;   // recursive (1) or right-looking (0) order inside an outer panel
-    int trsm_lds = FACTOR_DEFAULT_TRSM_LDS;                // k_trsm128 with L_cc staged in LDS (MI355GP_TRSM_LDS)
-    long long* panel_dbg = nullptr;  // MI355GP_PANEL_DBG=1: per-workgroup timestamps of the first fused panel of a call
-    int* panel_flags = nullptr;      // [4 + 16] hand-off flags of k_panel_fused (hold the launch generation)
-    int diag_excl = 0, diag_excl_opt = 1;   // k_diag128 claims a CU without update workgroups (only with reserve_cus > 0)
-    hipEvent_t ev_bulk = nullptr;
-    int part2_wgs = 0;          // > 0: trailing updates that overlap a panel factorisation keep only this many workgroups
-    long part2_tiles = 0;       //      resident (one per CU) once the update has fewer tiles than this
     KernelProf prof;
 };
 // the process-wide main / panel / tri streams of a device (created on first use, shared, never destroyed)

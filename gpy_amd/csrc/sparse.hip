@@ -717,10 +717,6 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
         HIP_CHECK(hipEventElapsedTime(&ms, s->ev[0], s->ev[3]));
         stage_ms[3] = ms;
     }
-    if (info_m < 0 || info_b < 0) {
-        mi355gp_set_error("panel factorisation: workgroup hand-off timed out (k_panel_fused)");
-        return -7;
-    }
     if (info_m > 0) return info_m > m ? (int)m : info_m;                 // Kmm not positive definite: caller adds jitter
     if (info_b > 0) return info_b > m ? (int)m : info_b;
     // sums over ALL shards of the per-point quantities

@@ -162,10 +162,8 @@ int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* 
 /* Options.  PROFILE: bracket launches of the factorisation kernels with hipEvents on the launching stream (adds
  * ~2 us per timed launch).  value 0 = off, 1 = all families, otherwise (bitmask of 1 << MI355GP_PF_*) << 1;
  * LOOKAHEAD: 1 (default) factor panel k+1 on a second, high-priority stream while the trailing update of
- * step k still runs; 0 = everything in order on one stream; 2 = column-chunk streams (experiment).
- * PANEL: 1 (default) rows below a panel's diagonal block are solved with one GEMM against the block's explicit inverse;
- * 0 = four trsm128 + in-panel updates over the whole panel height. */
-enum { MI355GP_OPT_PROFILE = 0, MI355GP_OPT_LOOKAHEAD = 1, MI355GP_OPT_PANEL = 2 };
+ * step k still runs; 0 = everything in order on one stream (reference schedule). */
+enum { MI355GP_OPT_PROFILE = 0, MI355GP_OPT_LOOKAHEAD = 1 };
 int mi355gp_set_option(mi355gp_ctx* ctx, int option, int value);
 /* kernel families of mi355gp_get_profile */
 enum { MI355GP_PF_UPDATE = 0 /* k_update_nt: trailing update of potrf */, MI355GP_PF_TRTRI = 1, MI355GP_PF_LAUUM = 2,

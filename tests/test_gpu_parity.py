@@ -214,13 +214,13 @@ def test_results_are_bit_reproducible_and_independent_of_lookahead(ctx):
     assert outs[0] == outs[1] == outs[2]
 
 
-@pytest.mark.parametrize("env", [{"MI355GP_TRSM_LDS": "0"}, {"MI355GP_TRI_OVERLAP": "0"},
-                                 {"MI355GP_TRI_MIN_NT": "16", "MI355GP_TRI_H": "8"}, {"MI355GP_PANEL_FUSED": "1"},
-                                 {"MI355GP_PANEL_FUSED": "1", "MI355GP_PANEL_WGS": "6"}, {"MI355GP_DIAG_SERVER": "1"},
-                                 {"MI355GP_RESERVE_CUS": "8", "MI355GP_DIAG_EXCL": "1"}])
-def test_experimental_panel_schedules_give_the_same_factorisation(env):
-    """The schedule switches of DESIGN.md 6e (read when a context allocates its factorisation workspace) change how the
-    panel chain is launched, not what it computes: same LML / alpha / gradients as the default to rounding."""
+@pytest.mark.parametrize("env", [{"MI355GP_TRI_OVERLAP": "0"}, {"MI355GP_TRI_MIN_NT": "16", "MI355GP_TRI_H": "8"},
+                                 {"MI355GP_TRI_MIN_NT": "16", "MI355GP_TRI_H": "8", "MI355GP_TRI_HALF": "0"},
+                                 {"MI355GP_NBO": "256"}, {"MI355GP_DIAG_EXCL_FIRST": "0", "MI355GP_SOLVE_OVERLAP": "0"}])
+def test_schedule_switches_give_the_same_factorisation(env):
+    """The schedule switches that remain (read when a context allocates its factorisation workspace) change
+    how the work is launched -- the overlapped leading inverse, its side stream, the outer panel width -- not what is
+    computed: same LML / alpha / gradients as the default to rounding."""
     import os
     X, Y = O.synthetic(2900, 5, seed=7)
     var, ls, noise = O.default_theta(5, True)

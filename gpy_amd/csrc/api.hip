@@ -167,7 +167,7 @@ int mi355gp_set_data(mi355gp_ctx* c, const double* X, int64_t N, int D, const do
     if (factor_ws_alloc(&c->ws, np) != 0) return -3;
     HIP_CHECK(hipMalloc(&c->dAlpha, sizeof(double) * N * Dy));
     HIP_CHECK(hipMalloc(&c->dTmp, sizeof(double) * N * Dy));
-    const long nchunks = (N + 255) / 256;
+    const long nchunks = (N + trmv_chunk_rows(N) - 1) / trmv_chunk_rows(N);
     HIP_CHECK(hipMalloc(&c->dTrmvPart, sizeof(double) * nchunks * N * Dy));
     const int groups = (D + 31) / 32;
     c->gradPartDoubles = (long)groups * 2048 * GP_STRIDE;

@@ -156,6 +156,7 @@ void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long 
 int launch_colreduce_multi(hipStream_t st, const double* M, long ld, long rows, long cols, const double* V, long sr,
                            long sc, int nvt, int ones, double* part);
 void launch_sum_splits(hipStream_t st, const double* src, long cnt, int nsplit, int accumulate, double* dst);
+int trmv_chunk_rows(long n);        // rows per partial-sum chunk of launch_trmv_lower_T / launch_tri_matvec (partials: ceil(n / rows) * n * Dy)
 void launch_trmv_lower(hipStream_t st, const double* X, long ld, long n, const double* R, int Dy, double* y);
 void launch_trmv_lower_T(hipStream_t st, const double* X, long ld, long n, const double* y, int Dy, double* out,
                          double* partials);

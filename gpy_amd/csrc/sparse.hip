@@ -297,7 +297,7 @@ static int alloc_m(mi355gp_sparse* s, long M) {
     HIP_CHECK(hipMalloc(&s->T, sizeof(double) * s->chunk * mp));
     double** vecs[] = {&s->psi1Y, &s->vecA, &s->vecB, &s->cvec, &s->wvec, &s->vvec};
     for (auto p : vecs) HIP_CHECK(hipMalloc(p, sizeof(double) * mp * Dy));
-    const long nchunks = (mp + 255) / 256;
+    const long nchunks = (mp + trmv_chunk_rows(mp) - 1) / trmv_chunk_rows(mp);
     HIP_CHECK(hipMalloc(&s->trmvPart, sizeof(double) * nchunks * mp * Dy));
     const long nvmax = (D + 1 > Dy ? D + 1 : Dy);
     HIP_CHECK(hipMalloc(&s->colPart, sizeof(double) * 64 * mp * nvmax));

@@ -356,7 +356,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_update_nt (fp64 MFMA trailing update of the blocked Cholesky)",
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS,
-                         "traffic": profiled_traffic("k_update_nt") if (N, D, args.kind) == (16384, 32, "matern52")
+                         "traffic": profiled_traffic("k_update_nt<") if (N, D, args.kind) == (16384, 32, "matern52")
                          else None,
                          "launches_per_step": upd_n, "avg_launch_ms": upd_ms / max(upd_n, 1),
                          "algorithmic_flops_per_step": upd_flops},
@@ -378,6 +378,21 @@ def main():
             out["host_path"] = {"drop_in_ms_per_step": out["ms_per_step"], "abi_ms_per_step": abi_ms,
                                 "overhead_frac": out["ms_per_step"] / abi_ms - 1.0, "abi_steps": k2}
             step_model()
+        # the Cholesky ALONE (what a jitchol / lapack.dpotrf call costs, util/linalg.py:56-75): device-resident synthetic SPD
+        # matrix of the same N, factorisation only, without the leading inverse that the pipeline overlaps with it
+        old = os.environ.get("MI355GP_TRI_OVERLAP")
+        os.environ["MI355GP_TRI_OVERLAP"] = "0"
+        try:
+            bf = L.bench_factor(N, reps=3, device=comm.local_rank)
+        finally:
+            if old is None:
+                os.environ.pop("MI355GP_TRI_OVERLAP", None)
+            else:
+                os.environ["MI355GP_TRI_OVERLAP"] = old
+        out["cholesky_standalone"] = {"ms": bf["potrf_ms"], "gflops": 1e3 * bf["potrf_tflops"],
+                                      "frac_of_fp64_peak": bf["potrf_tflops"] / PEAK_FP64_TFLOPS,
+                                      "note": "potrf alone (no overlapped inverse); cholesky_gflops above divides N^3/3 by the "
+                                              "pipeline's potrf STAGE, which also contains ~16 ms of overlapped inverse kernels"}
         out["parity_checked"] = parity is not None
         if parity is not None:
             out["parity"] = {"gate": parity}

@@ -118,3 +118,38 @@ int run_peaks(int device, double* out8) {
     (void)hipEventDestroy(e1);
     return 0;
 }
+
+// ---- diagnostics: where do workgroups land? ------------------------------------------------------------------------
+// Every workgroup records HW_REG_HW_ID and HW_REG_XCC_ID and spins for `spin_us` so that a launch of `nwg` workgroups spreads
+// over the whole machine (or over the CUs of a stream's CU mask).  out[2*b] = hw_id, out[2*b+1] = xcc_id.
+__global__ void k_cu_map(unsigned* __restrict__ out, int spin_ticks) {
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);        // HW_REG_HW_ID, 32 bits
+        out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
+    }
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int mi355gp_dbg_cu_map(int device, int nwg, int mask_bit, unsigned* out) {
+    HIP_CHECK(hipSetDevice(device));
+    unsigned* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, sizeof(unsigned) * 2 * nwg));
+    hipStream_t st = nullptr;
+    if (mask_bit >= 0) {                                    // a stream confined to ONE logical CU of the mask
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        mask[mask_bit / 32] |= 1u << (mask_bit % 32);
+        HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    } else {
+        HIP_CHECK(hipStreamCreate(&st));
+    }
+    hipLaunchKernelGGL(k_cu_map, dim3((unsigned)nwg), dim3(64), 0, st, d, 2000 /* 20 us */);
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipMemcpy(out, d, sizeof(unsigned) * 2 * nwg, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    (void)hipStreamDestroy(st);
+    return 0;
+}

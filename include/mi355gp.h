@@ -264,6 +264,10 @@ int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_
 int mi355gp_dbg_peaks(int device, double* out8);
 /* effective shader clock (MHz) and shader cycles of workgroup 0 of the last mi355gp_dbg_gemm launch */
 int mi355gp_dbg_gemm_clock(double* mhz, double* cycles);
+/* diagnostics: where do workgroups land?  out[2b] = HW_REG_HW_ID, out[2b+1] = HW_REG_XCC_ID of workgroup b of a launch of nwg
+ * spinning workgroups, machine-wide (mask_bit < 0) or on a stream whose CU mask has the single bit mask_bit
+ * (tools/cu_map.py: logical CU b is CU (b/8)/4 of shader engine (b/8)%4 of XCD b%8; an XCD WITHOUT a mask bit is unrestricted) */
+int mi355gp_dbg_cu_map(int device, int nwg, int mask_bit, unsigned* out);
 /* diagnostics: is a CU-masked stream really confined?  out3 = ms of a 4096^3 GEMM on [plain, masked, masked] streams */
 int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3);
 

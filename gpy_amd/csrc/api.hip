@@ -550,6 +550,8 @@ int mi355gp_fetch(mi355gp_ctx* c, int which, double* out, int fortran_order) {
         rc = -4;
     } else if (which == MI355GP_FETCH_L) {
         launch_extract(st, c->A, np, n, 0, nullptr, 0, tmp, fortran_order);
+    } else if (which == MI355GP_FETCH_LINV) {
+        launch_extract(st, c->B, np, n, 0, nullptr, 0, tmp, fortran_order);        // X = L^-1 (lower)
     } else if (which == MI355GP_FETCH_KINV) {
         launch_extract(st, c->C, np, n, 1, nullptr, 0, tmp, 0);
     } else if (which == MI355GP_FETCH_DLDK) {

@@ -309,6 +309,10 @@ struct mi355gp_grid {
     int D = 0, Dy = 0;
     hipEvent_t ev[6] = {};
     bool have_result = false;
+    // Pr = Pc = 1 over the loopback transport degenerates to the dedicated single-GPU pipeline ("with Pr = Pc = 1
+    // degenerate to the single-GPU path"): deep-K trtri / lauum tiles instead of three K = nb read-modify-write updates per
+    // step (N=32768: 527 vs 623 ms).  MI355GP_GRID_FORCE_GENERIC=1 keeps the generic one-pass code (tests).
+    mi355gp_ctx* single = nullptr;
 };
 
 static int cnt_le(long k, int p, int P) { return (k >= p) ? (int)((k - p) / P + 1) : 0; }   // tiles t <= k with t % P == p
@@ -415,6 +419,14 @@ int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb,
     g->nb = nb;
     g->my_rank = rank;
     g->loopback = (id128 == nullptr);
+    {
+        const char* envf = getenv("MI355GP_GRID_FORCE_GENERIC");
+        if (g->loopback && world == 1 && !(envf && atoi(envf))) {
+            if (int rc = mi355gp_create(device, &g->single)) return rc;
+            *out = g;
+            return 0;
+        }
+    }
     HIP_CHECK(hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking));
     {
         int least = 0, greatest = 0;
@@ -454,6 +466,11 @@ int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb,
 
 int mi355gp_grid_destroy(mi355gp_grid* g) {
     if (!g) return 0;
+    if (g->single) {
+        mi355gp_destroy(g->single);
+        delete g;
+        return 0;
+    }
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->st);
     for (GridRank& r : g->ranks) free_rank(r);
@@ -476,6 +493,10 @@ int mi355gp_grid_destroy(mi355gp_grid* g) {
 // Every rank passes the full (replicated) X and R: N*D*8 bytes is small next to the N^2/P matrix share.
 int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, const double* R, int Dy) {
     ARGCHK(g && X && R && N > 0 && D > 0 && Dy > 0, "mi355gp_grid_set_data: bad arguments");
+    if (g->single) {
+        g->n = N;
+        return mi355gp_set_data(g->single, X, N, D, R, Dy);
+    }
     HIP_CHECK(hipSetDevice(g->device));
     HIP_CHECK(hipStreamSynchronize(g->st));
     HIP_CHECK(hipStreamSynchronize(g->sc));
@@ -889,6 +910,21 @@ int mi355gp_grid_exact_inference(mi355gp_grid* g, int kind, int ard, const doubl
                                  double* alpha_out, double* dtheta_out, double* diag_dLdK_out, double* stage_ms) {
     ARGCHK(g && g->n > 0, "mi355gp_grid_exact_inference: set_data first");
     ARGCHK(out_scalars && theta && noise, "mi355gp_grid_exact_inference: NULL argument");
+    if (g->single) {
+        double ms[MI355GP_NUM_T];
+        const int rc = mi355gp_exact_inference(g->single, kind, ard, theta, noise, noise_len, jitter, extra_jitter, out_scalars,
+                                               alpha_out, dtheta_out, diag_dLdK_out, stage_ms ? ms : nullptr);
+        if (stage_ms) {       // the grid's stage layout: the whole factorisation + inversion under POTRF
+            for (int i = 0; i < MI355GP_NUM_T; ++i) stage_ms[i] = 0.0;
+            stage_ms[MI355GP_T_KBUILD] = ms[MI355GP_T_KBUILD];
+            stage_ms[MI355GP_T_POTRF] = ms[MI355GP_T_POTRF] + ms[MI355GP_T_TRTRI] + ms[MI355GP_T_LAUUM];
+            stage_ms[MI355GP_T_SOLVE] = ms[MI355GP_T_SOLVE];
+            stage_ms[MI355GP_T_GRAD] = ms[MI355GP_T_GRAD];
+            stage_ms[MI355GP_T_TOTAL] = ms[MI355GP_T_TOTAL];
+        }
+        g->have_result = (rc == 0);
+        return rc;
+    }
     ARGCHK(kind >= 0 && kind <= 3, "unknown covariance kind");
     ARGCHK(noise_len == 1 || noise_len == g->n, "noise must have 1 or N entries");
     ARGCHK(theta[0] > 0.0, "variance must be positive");
@@ -911,6 +947,7 @@ int mi355gp_grid_exact_inference(mi355gp_grid* g, int kind, int ard, const doubl
 int mi355gp_grid_fetch(mi355gp_grid* g, int which, double* out) {
     ARGCHK(g && out && g->n > 0 && g->have_result, "mi355gp_grid_fetch: run an inference call first");
     ARGCHK(which == MI355GP_FETCH_L || which == 100, "mi355gp_grid_fetch: L (0) or L^-1 (100)");
+    if (g->single) return mi355gp_fetch(g->single, which, out, 0);
     HIP_CHECK(hipSetDevice(g->device));
     const long nb = g->nb, n = g->n;
     std::vector<double> tilebuf((size_t)nb * nb);

@@ -24,6 +24,7 @@ def _check(res, ref, noise_scalar=True):
 CASES = [
     # kind, ARD, N, D, Dy, Pr, Pc, nb
     ("rbf", False, 300, 3, 1, 1, 1, 128),
+    ("matern52", True, 500, 4, 2, 1, 1, 256),
     ("rbf", False, 700, 4, 1, 2, 2, 128),
     ("matern52", True, 1000, 5, 2, 2, 4, 128),
     ("matern32", True, 900, 3, 1, 3, 2, 256),
@@ -38,7 +39,13 @@ def test_loopback_grid_matches_oracle(kind, ARD, N, D, Dy, Pr, Pc, nb):
     X, Y = O.synthetic(N, D, seed=N + Pr, Dy=Dy)
     var, ls, noise = O.default_theta(D, ARD)
     ref = O.parameters_changed(kind, X, Y, var, ls, ARD, noise)
-    g = G.GridContext.loopback(Pr, Pc, nb)
+    import os
+    if Pr * Pc == 1:      # 1 x 1 loopback degenerates to the single-GPU pipeline: keep the generic one-pass code covered too
+        os.environ["MI355GP_GRID_FORCE_GENERIC"] = "1" if nb == 128 else "0"
+    try:
+        g = G.GridContext.loopback(Pr, Pc, nb)
+    finally:
+        os.environ.pop("MI355GP_GRID_FORCE_GENERIC", None)
     try:
         g.set_data(X, Y)
         th = L.theta_vec(var, ls, ARD, D)

@@ -77,27 +77,31 @@ struct mi355gp_ctx {
     std::vector<Part> parts;
     std::vector<std::vector<int>> terms;   // part indices per term, in order of first appearance
     double* Mbuf = nullptr;             // npad x npad product of the OTHER factors of a term (allocated on first product kernel)
-    double* dGradOutAll = nullptr;      // [part][groups][GP_STRIDE]
-    size_t gradOutAllParts = 0;
+    // Everything an evaluation returns -- scalars, info, per-part gradient sums, alpha, diag(dL_dK) -- lives in ONE device
+    // block and travels in ONE copy into ONE pinned host block (five small pageable copies cost ~80 us per evaluation:
+    // 2 % at N = 4096).  Layout (doubles): [scal 8 | grads MAXP*groups*GP_STRIDE | alpha N*Dy | diag N]
+    double *dPack = nullptr, *hPack = nullptr;
+    size_t packDoubles = 0, offGrad = 0, offAlpha = 0, offDiag = 0;
+    double* dGradOutAll = nullptr;      // = dPack + offGrad: [part][groups][GP_STRIDE]
 };
 
 static void free_parts(mi355gp_ctx* c) {
     for (auto& p : c->parts)
         if (p.dXt) (void)hipFree(p.dXt);
     c->parts.clear();
-    if (c->dGradOutAll) (void)hipFree(c->dGradOutAll);
-    c->dGradOutAll = nullptr;
-    c->gradOutAllParts = 0;
 }
 
 static void free_data(mi355gp_ctx* c) {
     free_parts(c);
-    double** ptrs[] = {&c->dX, &c->dR, &c->dXt, &c->dInvLs, &c->dNoise, &c->A, &c->B, &c->C, &c->Mbuf, &c->dAlpha,
-                       &c->dTmp, &c->dTrmvPart, &c->dGradPart, &c->dGradOut, &c->dScal, &c->dDiag};
+    double** ptrs[] = {&c->dX, &c->dR, &c->dXt, &c->dInvLs, &c->dNoise, &c->A, &c->B, &c->C, &c->Mbuf,
+                       &c->dTmp, &c->dTrmvPart, &c->dGradPart, &c->dGradOut, &c->dPack};
     for (auto p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
+    if (c->hPack) (void)hipHostFree(c->hPack);
+    c->hPack = nullptr;
+    c->dAlpha = c->dScal = c->dDiag = c->dGradOutAll = nullptr;      // views into dPack
     factor_ws_free(&c->ws);
     c->have_factor = c->have_kernel = false;
 }
@@ -165,7 +169,6 @@ int mi355gp_set_data(mi355gp_ctx* c, const double* X, int64_t N, int D, const do
     HIP_CHECK(hipMalloc(&c->B, sizeof(double) * np * np));
     HIP_CHECK(hipMalloc(&c->C, sizeof(double) * np * np));
     if (factor_ws_alloc(&c->ws, np) != 0) return -3;
-    HIP_CHECK(hipMalloc(&c->dAlpha, sizeof(double) * N * Dy));
     HIP_CHECK(hipMalloc(&c->dTmp, sizeof(double) * N * Dy));
     const long nchunks = (N + trmv_chunk_rows(N) - 1) / trmv_chunk_rows(N);
     HIP_CHECK(hipMalloc(&c->dTrmvPart, sizeof(double) * nchunks * N * Dy));
@@ -173,8 +176,16 @@ int mi355gp_set_data(mi355gp_ctx* c, const double* X, int64_t N, int D, const do
     c->gradPartDoubles = (long)groups * 2048 * GP_STRIDE;
     HIP_CHECK(hipMalloc(&c->dGradPart, sizeof(double) * c->gradPartDoubles));
     HIP_CHECK(hipMalloc(&c->dGradOut, sizeof(double) * groups * GP_STRIDE));
-    HIP_CHECK(hipMalloc(&c->dScal, sizeof(double) * 8));
-    HIP_CHECK(hipMalloc(&c->dDiag, sizeof(double) * N));
+    c->offGrad = 8;
+    c->offAlpha = c->offGrad + (size_t)16 * groups * GP_STRIDE;
+    c->offDiag = c->offAlpha + (size_t)N * Dy;
+    c->packDoubles = c->offDiag + (size_t)N;
+    HIP_CHECK(hipMalloc(&c->dPack, sizeof(double) * c->packDoubles));
+    HIP_CHECK(hipHostMalloc(&c->hPack, sizeof(double) * c->packDoubles, hipHostMallocDefault));
+    c->dScal = c->dPack;
+    c->dGradOutAll = c->dPack + c->offGrad;
+    c->dAlpha = c->dPack + c->offAlpha;
+    c->dDiag = c->dPack + c->offDiag;
     HIP_CHECK(hipMemcpy(c->dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(c->dR, R, sizeof(double) * N * Dy, hipMemcpyHostToDevice));
     return 0;
@@ -242,18 +253,12 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
     HIP_CHECK(hipEventRecord(c->ev[4], st));
     if (side) HIP_CHECK(hipStreamWaitEvent(st, c->ws.ev_tri, 0));
     else launch_tri_matvec(st, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
-    launch_scalars(st, c->dAlpha, c->dR, c->C, np, n, c->Dy, c->ws.logsum, c->ws.nblk, c->dScal, c->dDiag);
+    launch_scalars(st, c->dAlpha, c->dR, c->C, np, n, c->Dy, c->ws.logsum, c->ws.nblk, c->dScal, c->dDiag, c->ws.info);
     if (studentt_nu > 0.0) launch_studentt_scale(st, c->dScal, studentt_nu, n, c->dScal + 4);
     HIP_CHECK(hipEventRecord(c->ev[5], st));
     const int groups = (c->D + 31) / 32;
     const size_t nparts = with_kernel_grads ? c->parts.size() : 0;
     if (nparts > 0) {
-        if (c->gradOutAllParts < nparts) {
-            if (c->dGradOutAll) (void)hipFree(c->dGradOutAll);
-            c->dGradOutAll = nullptr;
-            HIP_CHECK(hipMalloc(&c->dGradOutAll, sizeof(double) * nparts * groups * GP_STRIDE));
-            c->gradOutAllParts = nparts;
-        }
         HIP_CHECK(hipMemsetAsync(c->dGradOutAll, 0, sizeof(double) * nparts * groups * GP_STRIDE, st));
         const int nb = grad_num_blocks(n);
         for (size_t p = 0; p < nparts; ++p) {       // every part reduces the same dL_dK against its own dK/dtheta
@@ -278,20 +283,16 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
         }
     }
     HIP_CHECK(hipEventRecord(c->ev[6], st));
-    // small D2H transfers
-    double scal[8];
-    int info[4];
-    std::vector<double> sums((nparts ? nparts : 1) * (size_t)groups * GP_STRIDE, 0.0);
-    HIP_CHECK(hipMemcpyAsync(scal, c->dScal, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(info, c->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (nparts > 0)
-        HIP_CHECK(hipMemcpyAsync(sums.data(), c->dGradOutAll, sizeof(double) * nparts * groups * GP_STRIDE,
-                                 hipMemcpyDeviceToHost, st));
-    if (alpha_out)
-        HIP_CHECK(hipMemcpyAsync(alpha_out, c->dAlpha, sizeof(double) * n * c->Dy, hipMemcpyDeviceToHost, st));
-    if (diag_out) HIP_CHECK(hipMemcpyAsync(diag_out, c->dDiag, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    // ONE device -> pinned host copy of the prefix of the result block that the caller asked for
+    const size_t ncopy = diag_out ? c->packDoubles : (alpha_out ? c->offDiag : c->offAlpha);
+    HIP_CHECK(hipMemcpyAsync(c->hPack, c->dPack, sizeof(double) * ncopy, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipGetLastError());
+    const double* scal = c->hPack;
+    int info[1] = {(int)c->hPack[6]};                          // written by k_scalars from the factorisation's info word
+    const double* sumsp = c->hPack + c->offGrad;
+    if (alpha_out) memcpy(alpha_out, c->hPack + c->offAlpha, sizeof(double) * n * c->Dy);
+    if (diag_out) memcpy(diag_out, c->hPack + c->offDiag, sizeof(double) * n);
     if (stage_ms) {
         float ms;
         for (int i = 0; i < MI355GP_NUM_T; ++i) stage_ms[i] = 0.0;
@@ -332,7 +333,7 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
         double* o = dtheta_out;
         for (size_t p = 0; p < nparts; ++p) {
             const mi355gp_ctx::Part& pt = c->parts[p];
-            const double* sp = sums.data() + p * (size_t)groups * GP_STRIDE;
+            const double* sp = sumsp + p * (size_t)groups * GP_STRIDE;
             *o++ = sp[0] / pt.kp.variance;
             if (pt.kp.kind >= 4) continue;                                   // static kernels: variance only
             if (!pt.kp.ard) *o++ = -sp[1] / pt.theta[1];

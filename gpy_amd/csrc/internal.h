@@ -171,9 +171,9 @@ void launch_gram_splitk(hipStream_t st, const double* P, long ldp, long rows, lo
 int grad_generic_num_blocks(long n, long m);
 // sums `nblocks` rows of `stride` doubles in a fixed order into out[stride]
 void launch_reduce_partials(hipStream_t st, const double* partials, int nblocks, int stride, double* out);
-// out4[0]=sum alpha*R ; [1]=sum alpha^2 ; [2]=trace W ; [3]=2*sum(logsum) ; diag_out (n) = 0.5*(|alpha_i|^2 - Dy*W_ii)
+// out4[0]=sum alpha*R ; [1]=sum alpha^2 ; [2]=trace W ; [3]=2*sum(logsum) ; [6]=info[0] ; diag_out (n) = 0.5*(|alpha_i|^2 - Dy*W_ii)
 void launch_scalars(hipStream_t st, const double* alpha, const double* R, const double* W, long ldw, long n,
-                    int Dy, const double* logsum, long nblk, double* out4, double* diag_out);
+                    int Dy, const double* logsum, long nblk, double* out4, double* diag_out, const int* info = nullptr);
 // dense n x n host-shaped outputs from padded device matrices
 //   mode 0: lower triangle of A, strict upper zero;  1: symmetric mirror of lower(A);
 //   2: 0.5*(s * alpha alpha^T - Dy * sym(A)), s = aa_scale[0] (device) or 1;  transpose != 0 writes the transpose

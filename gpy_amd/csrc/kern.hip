@@ -759,7 +759,8 @@ void launch_tri_matvec(hipStream_t st, const double* X, long ld, long n, const d
 __global__ __launch_bounds__(1024) void k_scalars(const double* __restrict__ alpha, const double* __restrict__ R,
                                                   const double* __restrict__ W, long ldw, long n, int Dy,
                                                   const double* __restrict__ logsum, long nblk,
-                                                  double* __restrict__ out4, double* __restrict__ diag_out) {
+                                                  double* __restrict__ out4, double* __restrict__ diag_out,
+                                                  const int* __restrict__ info) {
     __shared__ double red[4][1024];
     const int t = threadIdx.x;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -785,12 +786,15 @@ __global__ __launch_bounds__(1024) void k_scalars(const double* __restrict__ alp
         }
         __syncthreads();
     }
-    if (t == 0) { out4[0] = red[0][0]; out4[1] = red[1][0]; out4[2] = red[2][0]; out4[3] = 2.0 * red[3][0]; }
+    if (t == 0) {
+        out4[0] = red[0][0]; out4[1] = red[1][0]; out4[2] = red[2][0]; out4[3] = 2.0 * red[3][0];
+        if (info) out4[6] = (double)info[0];      // the factorisation's LAPACK-style info rides along with the scalars
+    }
 }
 
 void launch_scalars(hipStream_t st, const double* alpha, const double* R, const double* W, long ldw, long n,
-                       int Dy, const double* logsum, long nblk, double* out4, double* diag_out) {
-    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(1024), 0, st, alpha, R, W, ldw, n, Dy, logsum, nblk, out4, diag_out);
+                       int Dy, const double* logsum, long nblk, double* out4, double* diag_out, const int* info) {
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(1024), 0, st, alpha, R, W, ldw, n, Dy, logsum, nblk, out4, diag_out, info);
 }
 
 // ------------------------------------------------------------------------------------------------

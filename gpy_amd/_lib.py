@@ -52,7 +52,7 @@ FETCH_L, FETCH_KINV, FETCH_DLDK, FETCH_K = 0, 1, 2, 3
 OUT_LML, OUT_LOGDET, OUT_DATAFIT, OUT_DNOISE, OUT_TRKINV, NUM_OUT = 0, 1, 2, 3, 4, 8
 STAGE_NAMES = ("kbuild", "potrf", "trtri", "lauum", "solve", "grad", "total")
 NUM_T = 8
-PROFILE_FAMILIES = ("update_nt", "trtri", "lauum", "diag128", "trsm128")
+PROFILE_FAMILIES = ("update_nt", "trtri", "lauum", "diag128", "trsm128", "update_nt64")
 
 _lib = None
 
@@ -331,7 +331,7 @@ class Context(object):
 
     def get_profile(self):
         """{family: (ms, algorithmic flops, launches)} of the last inference call made with option 'profile' on."""
-        ms, fl, n = np.zeros(5), np.zeros(5), np.zeros(5, dtype=np.int32)
+        ms, fl, n = np.zeros(6), np.zeros(6), np.zeros(6, dtype=np.int32)
         check(lib().mi355gp_get_profile(self._h, ms, fl, n), "mi355gp_get_profile")
         return {k: (ms[i], fl[i], int(n[i])) for i, k in enumerate(PROFILE_FAMILIES)}
 

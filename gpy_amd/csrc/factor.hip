@@ -212,7 +212,8 @@ static void factor_panel(hipStream_t s, double* A, long npad, long K0, long W, F
         const long cd = c + NB, ncols = K0 + W - cd;
         if (ncols <= 0) continue;
         const double* P = A + cd * ld + c;
-        ws->prof.begin(s, PF_UPDATE, syrk_flops((double)ncols, (double)NB) + gemm_flops((double)(below - ncols), (double)ncols, (double)NB));
+        ws->prof.begin(s, update_nt_uses_64((int)(below / NB), (int)(ncols / NB), (int)(cd / NB), (int)(cd / NB)) ? PF_UPDATE64 : PF_UPDATE,
+                       syrk_flops((double)ncols, (double)NB) + gemm_flops((double)(below - ncols), (double)ncols, (double)NB));
         launch_update_nt(s, A + cd * ld + cd, ld, P, ld, P, ld, NB, (int)(below / NB), (int)(ncols / NB), (int)(cd / NB), (int)(cd / NB));
         ws->prof.end(s);
     }
@@ -223,7 +224,8 @@ static void update_cols(hipStream_t s, double* A, long npad, long K0, long W, lo
     if (c1 <= c0) return;
     const long ld = npad, rows = npad - c0, cols = c1 - c0;
     const double* P = A + c0 * ld + K0;
-    ws->prof.begin(s, PF_UPDATE, syrk_flops((double)cols, (double)W) + gemm_flops((double)(rows - cols), (double)cols, (double)W));
+    ws->prof.begin(s, update_nt_uses_64((int)(rows / NB), (int)(cols / NB), (int)(c0 / NB), (int)(c0 / NB)) ? PF_UPDATE64 : PF_UPDATE,
+                   syrk_flops((double)cols, (double)W) + gemm_flops((double)(rows - cols), (double)cols, (double)W));
     launch_update_nt(s, A + c0 * ld + c0, ld, P, ld, P, ld, (int)W, (int)(rows / NB), (int)(cols / NB), (int)(c0 / NB),
                      (int)(c0 / NB));
     ws->prof.end(s);

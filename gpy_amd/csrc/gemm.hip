@@ -92,14 +92,21 @@ __global__ __launch_bounds__(256) void k_update_nt64(double* __restrict__ C, lon
     gt64_store<0>(Ct, ldc, acc);
 }
 
+// does a launch of this shape take the 64 x 64 tile kernel?  (profile family of the caller)
+bool update_nt_uses_64(int ntr, int ntc, int row0t, int col0t) {
+    static const int upd64_max = env_int("MI355GP_UPD64_MAX", GEMM_DEFAULT_UPD64_MAX);
+    const int tri = (row0t == col0t && ntr == ntc) ? 1 : 0;
+    const long nblocks = tri ? (long)ntr * (ntr + 1) / 2 : (long)ntr * ntc;
+    return nblocks <= upd64_max;
+}
+
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
                       int K, int ntr, int ntc, int row0t, int col0t) {
     if (ntr <= 0 || ntc <= 0) return;
     const int tri = (row0t == col0t && ntr == ntc) ? 1 : 0;
     const long nblocks = tri ? (long)ntr * (ntr + 1) / 2 : (long)ntr * ntc;
     // Few tiles: the launch is the latency of ONE tile on ONE CU -> four times as many 64 x 64 tiles (bit-identical result)
-    static const int upd64_max = env_int("MI355GP_UPD64_MAX", GEMM_DEFAULT_UPD64_MAX);
-    if (nblocks <= upd64_max) {
+    if (update_nt_uses_64(ntr, ntc, row0t, col0t)) {
         hipLaunchKernelGGL(k_update_nt64, dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, C, ldc, A, lda, B, ldb,
                            K, ntc, row0t, col0t, tri);
         return;

@@ -6,6 +6,7 @@
 
 // ---- gemm.hip : tiled fp64 MFMA GEMM family (all dimensions multiples of 128) -------------------
 // C[ti,tj] -= A[ti,:] * B[tj,:]^T over a (ntr x ntc)-tile region; tiles with (col0t+tj) > (row0t+ti) skipped.
+bool update_nt_uses_64(int ntr, int ntc, int row0t, int col0t);   // which kernel (and profile family) a launch of this shape takes
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
                       int K, int ntr, int ntc, int row0t, int col0t);
 // one bottom-up level of the batched triangular inverse: X21 = -X22 * (L21 * X11) for every block pair
@@ -36,7 +37,7 @@ void launch_dbg_mfma(hipStream_t st, const double* a, const double* b, double* d
 
 // ---- factor.hip : blocked drivers -------------------------------------------------------------------
 // per-kernel-family device timing (hipEvent pairs on the launching stream) + algorithmic flop counts
-enum { PF_UPDATE = 0, PF_TRTRI = 1, PF_LAUUM = 2, PF_DIAG = 3, PF_TRSM = 4, PF_NUM = 5 };
+enum { PF_UPDATE = 0, PF_TRTRI = 1, PF_LAUUM = 2, PF_DIAG = 3, PF_TRSM = 4, PF_UPDATE64 = 5, PF_NUM = 6 };
 struct KernelProf {
     unsigned mask = 0;          // bit f set: family f is timed
     bool on = false;

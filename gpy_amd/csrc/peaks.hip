@@ -119,6 +119,70 @@ int run_peaks(int device, double* out8) {
     return 0;
 }
 
+
+// ---- do fp64 MFMA and fp64 VALU FMA share one pipe? ------------------------------------------------------------------
+// mode 0: every workgroup runs the MFMA stream; 1: every workgroup the FMA stream; 2: even workgroups MFMA, odd FMA (each
+// SIMD then hosts both kinds of wave).  One loop trip = 8 MFMAs (8 x 64 cycles) or 128 FMAs (128 x 4 cycles).
+__global__ __launch_bounds__(256) void k_peak_mix(double* out, int iters, double seed, int mode) {
+    const bool do_mfma = mode == 0 || (mode == 2 && (blockIdx.x & 1) == 0);
+    double s = 0.0;
+    if (do_mfma) {
+        d4 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = (d4){seed, seed + i, 0.0, 1.0};
+        const double a = seed + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+        }
+        asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        double acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = seed + i;
+        const double a = 1.0 + threadIdx.x * 1e-12, b = 1e-9;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[i];
+    }
+    if (s == 12345.678) out[0] = s;
+}
+
+// out4: milliseconds of the same launch shape (8 workgroups per CU) in mode 0 / 1 / 2, and mode 2 with only HALF the
+// workgroups of each kind removed is not needed: separate pipes give t2 ~ max(t0, t1) / 2, a shared pipe (t0 + t1) / 2.
+extern "C" int mi355gp_dbg_pipe_share(int device, double* out4) {
+    HIP_CHECK(hipSetDevice(device));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    double* dummy;
+    HIP_CHECK(hipMalloc(&dummy, 1024));
+    const int iters = 4000, blocks = 256 * 8;
+    for (int mode = 0; mode < 3; ++mode) {
+        float ms;
+        hipLaunchKernelGGL(k_peak_mix, dim3(blocks), dim3(256), 0, 0, dummy, 100, 0.5, mode);
+        HIP_CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_peak_mix, dim3(blocks), dim3(256), 0, 0, dummy, iters, 0.5, mode);
+        HIP_CHECK(hipEventRecord(e1, 0));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        out4[mode] = ms;
+    }
+    out4[3] = (double)blocks * 4 * iters * 8 * 2048.0 / (out4[0] * 1e-3) / 1e12;
+    (void)hipFree(dummy);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+
 // ---- diagnostics: where do workgroups land? ------------------------------------------------------------------------
 // Every workgroup records HW_REG_HW_ID and HW_REG_XCC_ID and spins for `spin_us` so that a launch of `nwg` workgroups spreads
 // over the whole machine (or over the CUs of a stream's CU mask).  out[2*b] = hw_id, out[2*b+1] = xcc_id.

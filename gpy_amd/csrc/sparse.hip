@@ -224,6 +224,7 @@ struct mi355gp_sparse {
     FactorWs ws;
     bool ws_ok = false, have_result = false, winv_ok = false;
     hipEvent_t ev[6] = {};
+    int h_info[2] = {0, 0};       // LAPACK-style info of the two M x M factorisations (targets of async copies: not on the stack)
     double beta_scalar = 0.0;     // homoscedastic precision of the last call (0: per-point)
 };
 
@@ -545,8 +546,8 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
         launch_kbuild_sym(st, s->parts[i].kp, s->parts[i].XtZ, mp, m, mp, s->Lm, s->zero1, 1, 1e-8 + extra_jitter,
                           /*lower_only=*/1, /*add_diag=*/i == 0, /*accumulate=*/i > 0);
     potrf_device(st, s->Lm, mp, &s->ws);
-    int info_m = 0;
-    HIP_CHECK(hipMemcpyAsync(&info_m, s->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    s->h_info[0] = s->h_info[1] = 0;
+    HIP_CHECK(hipMemcpyAsync(&s->h_info[0], s->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemsetAsync(s->Xm, 0, sizeof(double) * mp * mp, st));
     trtri_device(st, s->Lm, s->Xm, s->Tm, mp, &s->ws);
     // ---- pass 1: psi2 = sum_n beta_n k_n k_n^T (heteroscedastic) or Kuf Kfu (then A carries beta), psi1V = Kuf V -------
@@ -585,8 +586,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->Amat, 1.0, (const double*)nullptr, 0.0, 1.0, mp,
                        s->LB);
     potrf_device(st, s->LB, mp, &s->ws);
-    int info_b = 0;
-    HIP_CHECK(hipMemcpyAsync(&info_b, s->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&s->h_info[1], s->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemsetAsync(s->XB, 0, sizeof(double) * mp * mp, st));
     trtri_device(st, s->LB, s->XB, s->Tm, mp, &s->ws);
     // c = LB^-1 Lm^-1 psi1 V (:141-143), w = LB^-T c (:144), v = Lm^-T w = woodbury_vector (:145)
@@ -717,6 +717,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
         HIP_CHECK(hipEventElapsedTime(&ms, s->ev[0], s->ev[3]));
         stage_ms[3] = ms;
     }
+    const int info_m = s->h_info[0], info_b = s->h_info[1];
     if (info_m > 0) return info_m > m ? (int)m : info_m;                 // Kmm not positive definite: caller adds jitter
     if (info_b > 0) return info_b > m ? (int)m : info_b;
     // sums over ALL shards of the per-point quantities

@@ -166,8 +166,9 @@ int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* 
 enum { MI355GP_OPT_PROFILE = 0, MI355GP_OPT_LOOKAHEAD = 1 };
 int mi355gp_set_option(mi355gp_ctx* ctx, int option, int value);
 /* kernel families of mi355gp_get_profile */
-enum { MI355GP_PF_UPDATE = 0 /* k_update_nt: trailing update of potrf */, MI355GP_PF_TRTRI = 1, MI355GP_PF_LAUUM = 2,
-       MI355GP_PF_DIAG = 3 /* k_diag128 */, MI355GP_PF_TRSM = 4 /* k_trsm128 */, MI355GP_PF_NUM = 5 };
+enum { MI355GP_PF_UPDATE = 0 /* k_update_nt<4,true>: trailing update of potrf on 128 x 128 tiles */, MI355GP_PF_TRTRI = 1, MI355GP_PF_LAUUM = 2,
+       MI355GP_PF_DIAG = 3 /* k_diag128 */, MI355GP_PF_TRSM = 4 /* k_trsm128 */,
+       MI355GP_PF_UPDATE64 = 5 /* k_update_nt64: the same update on 64 x 64 tiles (launches of few tiles) */, MI355GP_PF_NUM = 6 };
 /* Per family, for the last inference call made with PROFILE on: summed launch durations (ms), summed ALGORITHMIC
  * flops of those launches, launch count.  Arrays of MI355GP_PF_NUM. */
 int mi355gp_get_profile(mi355gp_ctx* ctx, double* ms, double* flops, int* launches);
@@ -268,6 +269,9 @@ int mi355gp_dbg_gemm_clock(double* mhz, double* cycles);
  * spinning workgroups, machine-wide (mask_bit < 0) or on a stream whose CU mask has the single bit mask_bit
  * (tools/cu_map.py: logical CU b is CU (b/8)/4 of shader engine (b/8)%4 of XCD b%8; an XCD WITHOUT a mask bit is unrestricted) */
 int mi355gp_dbg_cu_map(int device, int nwg, int mask_bit, unsigned* out);
+/* Diagnostic: do fp64 MFMA and fp64 VALU FMA share one issue pipe?  out4 = ms of the same launch shape with all workgroups
+ * on the MFMA stream / all on the FMA stream / alternating, and the MFMA TF/s of the first. */
+int mi355gp_dbg_pipe_share(int device, double* out4);
 /* diagnostics: is a CU-masked stream really confined?  out3 = ms of a 4096^3 GEMM on [plain, masked, masked] streams */
 int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3);
 

@@ -108,6 +108,7 @@ def lib():
                                               _c_dp]
     L.mi355gp_exact_studentt_sum.argtypes = [vp, ci, ctypes.POINTER(Part), cd, cd, cd, _dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_covariance_between_points.argtypes = [vp, ci, ctypes.POINTER(Part), _dp, i64, _dp, i64, _dp]
+    L.mi355gp_predictive_gradients_sum.argtypes = [vp, ci, ctypes.POINTER(Part), _dp, i64, _c_dp, _c_dp]
     L.mi355gp_predict_sum.argtypes = [vp, ci, ctypes.POINTER(Part), _dp, i64, _c_dp, _c_dp, ci]
     L.mi355gp_inference_given_K.argtypes = [vp, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_fetch.argtypes = [vp, ci, _dp, ci]
@@ -138,6 +139,7 @@ def lib():
     L.mi355gp_dbg_mfma.argtypes = [ci, _dp, _dp, _dp]
     L.mi355gp_dbg_gemm.argtypes = [ci, ci, ci, i64, i64, i64, _dp, _dp, _dp, cd, cd, ci, _c_dp]
     L.mi355gp_dbg_peaks.argtypes = [ci, _dp]
+    L.mi355gp_dbg_pipe_share.argtypes = [ci, _dp]
     L.mi355gp_dbg_gemm_clock.argtypes = [_c_dp, _c_dp]
     L.mi355gp_dbg_mask_probe.argtypes = [ci, ci, ci, _dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
@@ -146,7 +148,8 @@ def lib():
                  "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "sparse_create",
                  "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm", "exact_inference_sum",
                  "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum", "dbg_mask_probe",
-                 "vardtc_inference_sum", "sparse_predict", "sparse_fetch_dLdKnm", "sparse_attach_loopback"):
+                 "vardtc_inference_sum", "sparse_predict", "sparse_fetch_dLdKnm", "sparse_attach_loopback",
+                 "predictive_gradients_sum", "dbg_pipe_share"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -163,6 +166,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_exact_inference_sum", "mi355gp_predict_sum", "mi355gp_dbg_gemm_clock",
             "mi355gp_covariance_between_points", "mi355gp_exact_studentt_sum", "mi355gp_vardtc_inference_sum",
             "mi355gp_sparse_predict", "mi355gp_sparse_fetch_dLdKnm", "mi355gp_sparse_attach_loopback",
+            "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe")
 
 
@@ -298,6 +302,18 @@ class Context(object):
                                                     _opt(alpha), _opt(dtheta), None), "mi355gp_exact_studentt_sum")
         return rc, dict(lml=out[OUT_LML], logdet=out[OUT_LOGDET], beta=out[OUT_DATAFIT], scale=out[5], alpha=alpha,
                         dtheta=dtheta)
+
+    def predictive_gradients(self, specs, Xnew, want_var=True):
+        """(dmu (M x D x Dy), dvar (M x D)) of GP.predictive_gradients (core/gp.py:418-474), reduced on the device."""
+        arr, keep, _ = make_parts(specs)
+        Xnew = f64(Xnew)
+        M = Xnew.shape[0]
+        assert Xnew.shape[1] == self.D
+        dmu = np.empty((M, self.D, self.Dy))
+        dvar = np.empty((M, self.D)) if want_var else None
+        check(lib().mi355gp_predictive_gradients_sum(self._h, len(specs), arr, Xnew, M, dmu.ctypes.data_as(_c_dp), _opt(dvar)),
+              "mi355gp_predictive_gradients_sum")
+        return dmu, dvar
 
     def covariance_between_points(self, specs, X1, X2):
         arr, keep, _ = make_parts(specs)

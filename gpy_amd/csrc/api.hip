@@ -843,6 +843,100 @@ int mi355gp_predict_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, c
     return 0;
 }
 
+// G[i][j] = v[i * stride] for i < n, j < m (row-constant weights: dL_dK of the mean part of predictive_gradients)
+__global__ void k_fill_rows(double* __restrict__ G, long ld, long n, long m, const double* __restrict__ v, int stride) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * m) return;
+    const long i = idx / m, j = idx - i * m;
+    G[i * ld + j] = v[i * stride];
+}
+
+// GP.predictive_gradients (core/gp.py:418-474) for a sum of stationary (+ White / Bias) parts, everything N-sized on device:
+//   dmu[m][q][d]  = sum_n alpha[n][d] dK(x*_m, x_n)/dx*_mq                         (kern.gradients_X(alpha_d^T, X*, X), :448-451)
+//   dvar[m][q]    = dKdiag/dx* (= 0, stationary.py:360-361) - 2 sum_n (Ky^-1 K(X, X*))[n][m] dK(x*_m, x_n)/dx*_mq   (:454,462-465)
+// with Ky^-1 K(X, X*) = X^T (X Kx), X = L^-1 resident from the inference call.  The reductions over n run as the column
+// reductions H^T [x~ | 1] of the sparse path's dL/dZ (H = weights * (dK/dr)/r, k_grad + k_colreduce_multi), per part.
+int mi355gp_predictive_gradients_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, const double* Xnew, int64_t M,
+                                     double* dmu_out, double* dvar_out) {
+    ARG_CHECK(c && c->n > 0 && c->have_factor, "mi355gp_predictive_gradients: run an inference call first");
+    ARG_CHECK(Xnew && M > 0 && (dmu_out || dvar_out), "mi355gp_predictive_gradients: bad arguments");
+    ARG_CHECK(c->D <= 32, "mi355gp_predictive_gradients: D <= 32");
+    HIP_CHECK(hipSetDevice(c->device));
+    if (int rc = prepare_parts(c, nparts, parts)) return rc;
+    ARG_CHECK(!has_product(c), "mi355gp_predictive_gradients: product kernels are not supported on the device");
+    hipStream_t st = c->st;
+    const long n = c->n, np = c->npad, D = c->D, Dy = c->Dy, mp = round_up(M, NB), ld2 = round_up(M, 64);
+    c->kp = c->parts[0].kp;
+    c->theta = c->parts[0].theta;
+    c->have_kernel = true;
+    if (int rc = scale_parts(c)) return rc;
+    DevBuf dXn, dXt2, dU, dT, dG, dH, dPart, dCol, dHX;
+    HIP_CHECK(dXn.alloc(M * D));
+    HIP_CHECK(dXt2.alloc(D * ld2));
+    HIP_CHECK(dU.alloc(np * mp));
+    HIP_CHECK(dT.alloc(np * mp));
+    HIP_CHECK(dG.alloc(np * mp));
+    HIP_CHECK(dH.alloc(np * mp));
+    HIP_CHECK(dPart.alloc(2048 * GP_STRIDE * ((D + 31) / 32)));
+    HIP_CHECK(dCol.alloc(64 * mp * (D + 1)));
+    HIP_CHECK(dHX.alloc(mp * (D + 1)));
+    HIP_CHECK(hipMemcpyAsync(dXn, Xnew, sizeof(double) * M * D, hipMemcpyHostToDevice, st));
+    hipError_t herr = hipSuccess;
+    auto scale_new = [&](const mi355gp_ctx::Part& pt) {
+        hipError_t e = hipMemcpyAsync(c->dInvLs, pt.inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) herr = e;
+        launch_scale_inputs(st, dXn, M, c->D, c->dInvLs, 1, dXt2, ld2);
+    };
+    if (dvar_out) {     // U = Ky^-1 K(X, X*)
+        HIP_CHECK(hipMemsetAsync(dU, 0, sizeof(double) * np * mp, st));
+        build_expression(c, dU, nullptr, true, [&](int p, double* dst, const double* mul, int acc, bool) {
+            const mi355gp_ctx::Part& pt = c->parts[(size_t)p];
+            scale_new(pt);
+            launch_kbuild_cross(st, pt.kp, pt.dXt, np, n, dXt2, ld2, M, dst, mp, acc, 0, mul);
+        });
+        launch_trmm_lower(st, c->B, np, dU, mp, dT, mp, (int)(np / NB), (int)(mp / NB));
+        launch_trmm_lower_T(st, c->B, np, dT, mp, dU, mp, (int)(np / NB), (int)(mp / NB));
+    }
+    HIP_CHECK(herr);
+    // one pass per weight matrix (Dy mean parts, one variance part) and stationary part
+    const size_t hx = (size_t)M * (D + 1);
+    std::vector<double> HX(hx);
+    const int npass = (dmu_out ? (int)Dy : 0) + (dvar_out ? 1 : 0);
+    if (dmu_out) std::fill(dmu_out, dmu_out + (size_t)M * D * Dy, 0.0);
+    if (dvar_out) std::fill(dvar_out, dvar_out + (size_t)M * D, 0.0);
+    for (int pass = 0; pass < npass; ++pass) {
+        const bool is_var = dvar_out && pass == npass - 1;
+        const double* W = dU;
+        if (!is_var) {
+            const long cnt = n * M;
+            hipLaunchKernelGGL(k_fill_rows, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (double*)dG, mp, n, (long)M,
+                               c->dAlpha + pass, (int)Dy);
+            W = dG;
+        }
+        for (size_t pi = 0; pi < c->parts.size(); ++pi) {
+            const mi355gp_ctx::Part& pt = c->parts[pi];
+            if (pt.kp.kind >= 4) continue;                              // White / Bias: no dependence on X* (static.py)
+            scale_new(pt);
+            HIP_CHECK(herr);
+            launch_grad_generic(st, pt.kp, pt.dXt, np, n, dXt2, ld2, M, 0, W, mp, dPart, GP_STRIDE, dH, mp);
+            const int ns = launch_colreduce_multi(st, dH, mp, n, M, pt.dXt, 1, np, (int)D, 1, dCol);
+            launch_sum_splits(st, dCol, (long)hx, ns, 0, dHX);
+            HIP_CHECK(hipMemcpyAsync(HX.data(), dHX, sizeof(double) * hx, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            for (int64_t m = 0; m < M; ++m)
+                for (long q = 0; q < D; ++q) {
+                    const double il = pt.inv_ls[(size_t)q];                  // 0 for dimensions outside active_dims
+                    const double g = (Xnew[m * D + q] * il * HX[(size_t)m * (D + 1) + D] - HX[(size_t)m * (D + 1) + q]) * il;
+                    if (is_var) dvar_out[m * D + q] += -2.0 * g;
+                    else dmu_out[((size_t)m * D + q) * Dy + pass] += g;
+                }
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // Posterior covariance between two point sets (Posterior.covariance_between_points, posterior.py:109-130):
 //   K(X1, X2) - (L^-1 K(X, X1))^T (L^-1 K(X, X2)),  out: M1 x M2 row-major
 int mi355gp_covariance_between_points(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, const double* X1,

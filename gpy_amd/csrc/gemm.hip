@@ -324,6 +324,27 @@ __global__ LB(NW) void k_trmm_lower(const double* __restrict__ X, long ldx,
     gt_store<0, NW>(Out + (long)ti * NB * ldo + (long)tj * NB, ldo, acc);
 }
 
+// Out[ti,tj] = sum_{tk>=ti} X[tk,ti]^T * B[tk,tj]: the transposed product X^T B (with k_trmm_lower: Ky^-1 B = X^T (X B) for
+// the variance part of GP.predictive_gradients, core/gp.py:463-465)
+template <int NW>
+__global__ LB(NW) void k_trmm_lower_T(const double* __restrict__ X, long ldx, const double* __restrict__ B, long ldb,
+                                      double* __restrict__ Out, long ldo, int ntc, int nt) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
+    d4 acc[4][GTCfg<NW>::NI];
+    gt_zero<NW>(acc);
+    gemm_tile_128<false, false, NW>(X + (long)ti * NB * ldx + (long)ti * NB, ldx, B + (long)ti * NB * ldb + (long)tj * NB, ldb,
+                                    (nt - ti) * NB, acc, smem);
+    gt_store<0, NW>(Out + (long)ti * NB * ldo + (long)tj * NB, ldo, acc);
+}
+
+void launch_trmm_lower_T(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
+                         int ntr, int ntc) {
+    LDS_OPT_IN((k_trmm_lower_T<4>));
+    hipLaunchKernelGGL((k_trmm_lower_T<4>), dim3((unsigned)(ntr * ntc)), dim3(256), GT_LDS_BYTES, st, X, ldx, B, ldb, Out,
+                       ldo, ntc, ntr);
+}
+
 template <int NW>
 static void launch_trmm_lower_t(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out,
                                 long ldo, int ntr, int ntc) {

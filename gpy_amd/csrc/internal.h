@@ -16,6 +16,9 @@ void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, l
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt);
 void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
                        int ntr, int ntc);
+// Out = X^T B (X lower triangular npad x npad, B npad x mpad)
+void launch_trmm_lower_T(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
+                         int ntr, int ntc);
 void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
                        double beta);
 void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A,

@@ -65,6 +65,26 @@ class _DeviceState(object):
         return self.ctx.covariance_between_points([(kern.kind, kern.ARD, kern._theta(), None)], kern._slice_X(X1),
                                                   kern._slice_X(X2))
 
+    def predictive_gradients(self, kern, Xnew, want_var=True):
+        """(dmu (M x D x Dy), dvar (M x D)) -- reference `core/gp.py:418-474`; raises NotImplementedError for kernel
+        expressions the device entry does not take (products), which the caller then evaluates on the host."""
+        from .kern import Prod
+        if isinstance(kern, CombinationKernel):
+            if isinstance(kern, Prod) or any(isinstance(p, Prod) for p in kern.parts):
+                raise NotImplementedError("product kernels")
+            return self.ctx.predictive_gradients(kern.part_specs(), _lib.f64(Xnew), want_var=want_var)
+        Xs = kern._slice_X(Xnew)
+        dmu, dvar = self.ctx.predictive_gradients([(kern.kind, kern.ARD, kern._theta(), None)], Xs, want_var=want_var)
+        if Xs.shape[1] == np.asarray(Xnew).shape[1]:
+            return dmu, dvar
+        full_mu = np.zeros((Xs.shape[0], np.asarray(Xnew).shape[1], dmu.shape[2]))   # active_dims of a single kernel
+        full_mu[:, kern.active_dims, :] = dmu
+        full_var = None
+        if dvar is not None:
+            full_var = np.zeros((Xs.shape[0], np.asarray(Xnew).shape[1]))
+            full_var[:, kern.active_dims] = dvar
+        return full_mu, full_var
+
     def predict(self, kern, Xnew, full_cov=False):
         if isinstance(kern, CombinationKernel):
             return self.ctx.predict_sum(kern.part_specs(), _lib.f64(Xnew), full_cov=full_cov)

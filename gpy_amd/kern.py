@@ -287,6 +287,10 @@ class Static(Parameterized):
     def gradients_X(self, dL_dK, X, X2=None):
         return np.zeros(np.asarray(X).shape)
 
+    def gradients_X_diag(self, dL_dKdiag, X):
+        """(reference `static.py:40-41`)"""
+        return np.zeros(np.asarray(X).shape)
+
     def to_dict(self):
         return {"class": self._gpy_class, "name": self.name, "input_dim": self.input_dim,
                 "active_dims": self.active_dims.tolist(), "variance": self.variance.values.tolist()}
@@ -336,6 +340,11 @@ class CombinationKernel(Parameterized):
         self.device = parts[0].device
         for p in parts:
             self.link_parameter(p)
+
+    def gradients_X_diag(self, dL_dKdiag, X):
+        """Stationary and static leaves have a constant diagonal (reference `stationary.py:360-361`, `static.py:40-41`), and so
+        has every sum / product of them (`add.py:102-106`, `prod.py:123-128`)."""
+        return np.zeros(np.asarray(X).shape)
 
     def leaves(self):
         """the stationary / static kernels of the expression in link (= parameter, = gradient) order"""

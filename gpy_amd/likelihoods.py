@@ -27,6 +27,21 @@ class Gaussian(Parameterized):
             var = var + float(self.variance.values[0])
         return mu, var
 
+    def predictive_quantiles(self, mu, var, quantiles, Y_metadata=None):
+        """(reference `gaussian.py:118-119`)"""
+        from scipy import stats
+        return [stats.norm.ppf(q / 100.) * np.sqrt(var + float(self.variance.values[0])) + mu for q in quantiles]
+
+    def log_predictive_density(self, y_test, mu_star, var_star, Y_metadata=None):
+        """independent Gaussian predictive densities (reference `gaussian.py:329-334`)"""
+        v = var_star + float(self.variance.values[0])
+        return -0.5 * np.log(2 * np.pi) - 0.5 * np.log(v) - 0.5 * np.square(y_test - mu_star) / v
+
+    def samples(self, gp, Y_metadata=None):
+        """observations drawn around latent values (reference `gaussian.py:316-327`)"""
+        gp = np.asarray(gp)
+        return gp + np.sqrt(float(self.variance.values[0])) * np.random.normal(size=gp.shape)
+
     def to_dict(self):
         return {"class": "GPy.likelihoods.Gaussian", "name": self.name, "variance": self.variance.values.tolist()}
 
@@ -54,6 +69,12 @@ class HeteroscedasticGaussian(Gaussian):
         if full_cov:
             return mu, var + np.eye(var.shape[0]) * s
         return mu, var + s[:, None]
+
+    def predictive_quantiles(self, mu, var, quantiles, Y_metadata=None):
+        """(reference `gaussian.py:375-377`)"""
+        from scipy import stats
+        s = self.variance.values[np.asarray(Y_metadata["output_index"]).flatten()]
+        return [stats.norm.ppf(q / 100.) * np.sqrt(var + s[:, None]) + mu for q in quantiles]
 
     def to_dict(self):
         return {"class": "GPy.likelihoods.HeteroscedasticGaussian", "name": self.name,

@@ -49,6 +49,27 @@ class PosteriorExact(object):
             raise RuntimeError("this posterior is not attached to a device context")
         return self._state.predict(kern, Xnew, full_cov=full_cov)
 
+    def predictive_gradients(self, kern, Xnew):
+        """d mean / d Xnew (M x D x Dy) and d var / d Xnew (M x D) (reference `core/gp.py:418-474`): on the device for sums
+        of stationary / White / Bias parts, composed on the host from `kern.gradients_X` and the fetched `woodbury_inv`
+        for anything else."""
+        if self._state is not None:
+            try:
+                return self._state.predictive_gradients(kern, Xnew)
+            except NotImplementedError:
+                pass
+        X = self._state.X if self._state is not None else None
+        if X is None:
+            raise RuntimeError("this posterior is not attached to a device context")
+        Xnew = np.asarray(Xnew, dtype=np.float64)
+        alpha = np.asarray(self.woodbury_vector)
+        mean_jac = np.empty((Xnew.shape[0], Xnew.shape[1], alpha.shape[1]))
+        for i in range(alpha.shape[1]):
+            mean_jac[:, :, i] = kern.gradients_X(alpha[:, i:i + 1].T * np.ones((Xnew.shape[0], 1)), Xnew, X)
+        var_jac = kern.gradients_X_diag(np.ones(Xnew.shape[0]), Xnew)
+        a2 = -2.0 * np.dot(kern.K(Xnew, X), np.asarray(self.woodbury_inv))
+        return mean_jac, var_jac + kern.gradients_X(a2, Xnew, X)
+
     def covariance_between_points(self, kern, X, X1, X2):
         """K(X1,X2) - (L^-1 K(X,X1))^T (L^-1 K(X,X2)) (reference `posterior.py:109-130`), on the device."""
         if self._state is None:
@@ -70,3 +91,9 @@ class StudentTPosterior(PosteriorExact):
         beta = self._beta if self._beta is not None else float(np.sum(self.woodbury_vector * self.mean))
         N = self.woodbury_vector.shape[0]
         return mu, (self.nu + beta - 2.0) / (self.nu + N - 2.0) * var
+
+    def predictive_gradients(self, kern, Xnew):
+        mean_jac, var_jac = super(StudentTPosterior, self).predictive_gradients(kern, Xnew)
+        beta = self._beta if self._beta is not None else float(np.sum(self.woodbury_vector * self.mean))
+        N = self.woodbury_vector.shape[0]
+        return mean_jac, (self.nu + beta - 2.0) / (self.nu + N - 2.0) * var_jac

@@ -148,6 +148,15 @@ int mi355gp_predict(mi355gp_ctx* ctx, int kind, int ard, const double* theta, co
 int mi355gp_predict_sum(mi355gp_ctx* ctx, int nparts, const mi355gp_part* parts, const double* Xnew, int64_t M,
                         double* mu_out, double* var_out, int full_cov);
 
+/* GP.predictive_gradients (core/gp.py:418-474) for a sum of stationary (+ White / Bias) parts, no product terms, D <= 32:
+ *   dmu_out  (M x D x Dy, row-major)  d mean[m][d] / d Xnew[m][q] = kern.gradients_X(woodbury_vector[:, d]^T, Xnew, X)  (:448-451)
+ *   dvar_out (M x D)                  d var[m]    / d Xnew[m][q] = gradients_X_diag (0 for stationary kernels,
+ *                                     stationary.py:360-361) + kern.gradients_X(-2 K(Xnew, X) Ky^-1, Xnew, X)           (:454,462-465)
+ * Ky^-1 K(X, Xnew) is formed on the device as X^T (X K(X, Xnew)) with X = L^-1 from the last inference call; nothing N x N or
+ * N x M crosses PCIe.  Either output may be NULL. */
+int mi355gp_predictive_gradients_sum(mi355gp_ctx* ctx, int nparts, const mi355gp_part* parts, const double* Xnew, int64_t M,
+                                     double* dmu_out, double* dvar_out);
+
 /* Posterior covariance between two point sets (Posterior.covariance_between_points, posterior.py:109-130) */
 int mi355gp_covariance_between_points(mi355gp_ctx* ctx, int nparts, const mi355gp_part* parts, const double* X1,
                                       int64_t M1, const double* X2, int64_t M2, double* out);

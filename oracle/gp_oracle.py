@@ -283,6 +283,46 @@ def predict(kind, X, Xnew, L, alpha, variance, lengthscale, ARD, noise=None, ful
     return mu, var
 
 
+# ----------------------------------------------------------------------------- prediction-side callers (core/gp.py)
+def gradients_X(kind, dL_dK, X, X2, variance, lengthscale, ARD):
+    """`Stationary._gradients_X_pure` (stationary.py:330-346): derivative w.r.t. the rows of X."""
+    ls = _as_ls(lengthscale, X.shape[1], ARD)
+    r = scaled_dist(X, X2, ls, ARD)
+    inv = 1.0 / np.where(r != 0.0, r, np.inf)
+    tmp = inv * dK_dr(kind, r, float(variance)) * dL_dK
+    if X2 is None:
+        tmp = tmp + tmp.T
+        X2 = X
+    grad = np.empty(X.shape)
+    for q in range(X.shape[1]):
+        grad[:, q] = np.sum(tmp * (X[:, q][:, None] - X2[:, q][None, :]), axis=1)
+    lsq = ls if ARD else np.full(X.shape[1], ls[0])
+    return grad / lsq ** 2
+
+
+def predictive_gradients(kind, X, Xnew, alpha, Wi, variance, lengthscale, ARD):
+    """`GP.predictive_gradients` (core/gp.py:440-474, woodbury_inv.ndim == 2, no normaliser): (mean_jac (N*, Q, D),
+    var_jac (N*, Q)); `gradients_X_diag` of a stationary kernel is zero (stationary.py:360-361)."""
+    M, Q = Xnew.shape
+    mean_jac = np.empty((M, Q, alpha.shape[1]))
+    for i in range(alpha.shape[1]):
+        mean_jac[:, :, i] = gradients_X(kind, alpha[:, i:i + 1].T, Xnew, X, variance, lengthscale, ARD)
+    a2 = -2.0 * np.dot(kern_K(kind, Xnew, X, variance, lengthscale, ARD), Wi)
+    return mean_jac, gradients_X(kind, a2, Xnew, X, variance, lengthscale, ARD)
+
+
+def predictive_quantiles(mu, var, noise, quantiles):
+    """`Gaussian.predictive_quantiles` (likelihoods/gaussian.py:118-119)"""
+    from scipy import stats
+    return [stats.norm.ppf(q / 100.) * np.sqrt(var + noise) + mu for q in quantiles]
+
+
+def log_predictive_density(y_test, mu_star, var_star, noise):
+    """`Gaussian.log_predictive_density` (likelihoods/gaussian.py:329-334)"""
+    v = var_star + noise
+    return -0.5 * np.log(2 * np.pi) - 0.5 * np.log(v) - 0.5 * np.square(y_test - mu_star) / v
+
+
 # ----------------------------------------------------------------------------- synthetic workload
 def synthetic(N, D, seed=0, Dy=1):
     """SURVEY 8(d) synthetic inputs: X~N(0,1), Y = sin(x0)+0.5cos(2 x1)+0.1 eps."""

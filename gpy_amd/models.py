@@ -44,7 +44,80 @@ class Standardize(object):
         return {"class": "GPy.util.normalizer.Standardize", "mean": self.mean.tolist(), "std": self.std.tolist()}
 
 
-class GP(Parameterized):
+class PredictionCallers(object):
+    """The prediction-side callers of the hot path in the reference's `GP` class (`core/gp.py:367-474,601-652,700-790`), shared
+    by the exact and the sparse model driver: everything here is a thin wrapper around `_raw_predict` / the posterior, exactly as
+    in the reference (`SparseGP` inherits them from `GP`; `_predictive_variable` is X for the exact model and Z for the sparse
+    one, `core/gp.py:201-203`, `core/sparse_gp.py:72-74`)."""
+    normalizer = None
+    output_dim = 1
+
+    def predict_noiseless(self, Xnew, full_cov=False):
+        """(reference `core/gp.py:367-393`)"""
+        return self.predict(Xnew, full_cov=full_cov, include_likelihood=False)
+
+    def predict_quantiles(self, X, quantiles=(2.5, 97.5), Y_metadata=None, kern=None, likelihood=None):
+        """(reference `core/gp.py:395-416`)"""
+        m, v = self._raw_predict(X, full_cov=False) if kern is None else self._raw_predict(X, full_cov=False, kern=kern)
+        likelihood = self.likelihood if likelihood is None else likelihood
+        qs = likelihood.predictive_quantiles(m, v, quantiles, Y_metadata=Y_metadata)
+        if self.normalizer is not None:
+            qs = [self.normalizer.inverse_mean(q) for q in qs]
+        return qs
+
+    def log_predictive_density(self, x_test, y_test, Y_metadata=None):
+        """(reference `core/gp.py:700-714`)"""
+        mu_star, var_star = self._raw_predict(x_test)
+        return self.likelihood.log_predictive_density(y_test, mu_star, var_star, Y_metadata=Y_metadata)
+
+    def predictive_gradients(self, Xnew, kern=None):
+        """d mean / d X* (N* x Q x D) and d var / d X* (N* x Q) of the latent prediction (reference `core/gp.py:418-474`),
+        reduced on the device (`mi355gp_predictive_gradients_sum`)."""
+        mean_jac, var_jac = self.posterior.predictive_gradients(self.kern if kern is None else kern, np.asarray(Xnew),
+                                                                pred_var=self._predictive_variable)
+        if self.normalizer is not None:              # (reference `core/gp.py:467-472`)
+            mean_jac = self.normalizer.inverse_mean(mean_jac) - self.normalizer.inverse_mean(0.)
+            var_jac = (self.normalizer.inverse_covariance(var_jac) if self.output_dim > 1
+                       else self.normalizer.inverse_variance(var_jac))
+        return mean_jac, var_jac
+
+    def posterior_samples_f(self, X, size=10, **predict_kwargs):
+        """samples of the latent function at X: N* x D x size (reference `core/gp.py:601-629`)"""
+        predict_kwargs["full_cov"] = True
+        m, v = self._raw_predict(X, **predict_kwargs)
+        if self.normalizer is not None:
+            m, v = self.normalizer.inverse_mean(m), self.normalizer.inverse_variance(v)
+
+        def sim_one_dim(mm, vv):
+            return np.random.multivariate_normal(mm, vv, size).T
+        if self.output_dim == 1:
+            return sim_one_dim(m.flatten(), v)[:, np.newaxis, :]
+        fsim = np.empty((np.asarray(X).shape[0], self.output_dim, size))
+        for d in range(self.output_dim):
+            fsim[:, d, :] = sim_one_dim(m[:, d], v[:, :, d] if v.ndim == 3 else v)
+        return fsim
+
+    def posterior_samples(self, X, size=10, Y_metadata=None, likelihood=None, **predict_kwargs):
+        """samples of observations at X (reference `core/gp.py:631-652`)"""
+        fsim = self.posterior_samples_f(X, size, **predict_kwargs)
+        likelihood = self.likelihood if likelihood is None else likelihood
+        for d in range(fsim.shape[1]):
+            fsim[:, d] = likelihood.samples(fsim[:, d], Y_metadata=Y_metadata)
+        return fsim
+
+    def posterior_covariance_between_points(self, X1, X2, Y_metadata=None, likelihood=None, include_likelihood=True):
+        """(reference `core/gp.py:735-790`)"""
+        cov = self.posterior.covariance_between_points(self.kern, self._predictive_variable, np.asarray(X1), np.asarray(X2))
+        if include_likelihood:
+            mean, _ = self._raw_predict(X1, full_cov=True)
+            likelihood = self.likelihood if likelihood is None else likelihood
+            _, cov = likelihood.predictive_values(mean, cov, full_cov=True, Y_metadata=Y_metadata)
+        if self.normalizer is not None:
+            cov = self.normalizer.inverse_covariance(cov) if self.output_dim > 1 else self.normalizer.inverse_variance(cov)
+        return cov
+
+
+class GP(PredictionCallers, Parameterized):
     def __init__(self, X, Y, kernel, likelihood, mean_function=None, inference_method=None, name="gp",
                  Y_metadata=None, device=0, normalizer=False):
         super(GP, self).__init__(name)
@@ -125,67 +198,9 @@ class GP(Parameterized):
                 var = self.normalizer.inverse_variance(var)
         return mu, var
 
-    def predict_noiseless(self, Xnew, full_cov=False):
-        return self.predict(Xnew, full_cov=full_cov, include_likelihood=False)
-
-    def predict_quantiles(self, X, quantiles=(2.5, 97.5), Y_metadata=None, kern=None, likelihood=None):
-        """(reference `core/gp.py:395-416`)"""
-        m, v = self._raw_predict(X, full_cov=False, kern=kern)
-        likelihood = self.likelihood if likelihood is None else likelihood
-        qs = likelihood.predictive_quantiles(m, v, quantiles, Y_metadata=Y_metadata)
-        if self.normalizer is not None:
-            qs = [self.normalizer.inverse_mean(q) for q in qs]
-        return qs
-
-    def log_predictive_density(self, x_test, y_test, Y_metadata=None):
-        """(reference `core/gp.py:700-714`)"""
-        mu_star, var_star = self._raw_predict(x_test)
-        return self.likelihood.log_predictive_density(y_test, mu_star, var_star, Y_metadata=Y_metadata)
-
-    def predictive_gradients(self, Xnew, kern=None):
-        """d mean / d X* (N* x Q x D) and d var / d X* (N* x Q) of the latent prediction (reference `core/gp.py:418-474`),
-        reduced on the device (`mi355gp_predictive_gradients_sum`)."""
-        mean_jac, var_jac = self.posterior.predictive_gradients(self.kern if kern is None else kern, np.asarray(Xnew))
-        if self.normalizer is not None:              # (reference `core/gp.py:467-472`)
-            mean_jac = self.normalizer.inverse_mean(mean_jac) - self.normalizer.inverse_mean(0.)
-            var_jac = (self.normalizer.inverse_covariance(var_jac) if self.output_dim > 1
-                       else self.normalizer.inverse_variance(var_jac))
-        return mean_jac, var_jac
-
-    def posterior_samples_f(self, X, size=10, **predict_kwargs):
-        """samples of the latent function at X: N* x D x size (reference `core/gp.py:601-629`)"""
-        predict_kwargs["full_cov"] = True
-        m, v = self._raw_predict(X, **predict_kwargs)
-        if self.normalizer is not None:
-            m, v = self.normalizer.inverse_mean(m), self.normalizer.inverse_variance(v)
-
-        def sim_one_dim(mm, vv):
-            return np.random.multivariate_normal(mm, vv, size).T
-        if self.output_dim == 1:
-            return sim_one_dim(m.flatten(), v)[:, np.newaxis, :]
-        fsim = np.empty((np.asarray(X).shape[0], self.output_dim, size))
-        for d in range(self.output_dim):
-            fsim[:, d, :] = sim_one_dim(m[:, d], v[:, :, d] if v.ndim == 3 else v)
-        return fsim
-
-    def posterior_samples(self, X, size=10, Y_metadata=None, likelihood=None, **predict_kwargs):
-        """samples of observations at X (reference `core/gp.py:631-652`)"""
-        fsim = self.posterior_samples_f(X, size, **predict_kwargs)
-        likelihood = self.likelihood if likelihood is None else likelihood
-        for d in range(fsim.shape[1]):
-            fsim[:, d] = likelihood.samples(fsim[:, d], Y_metadata=Y_metadata)
-        return fsim
-
-    def posterior_covariance_between_points(self, X1, X2, Y_metadata=None, likelihood=None, include_likelihood=True):
-        """(reference `core/gp.py:735-790`)"""
-        cov = self.posterior.covariance_between_points(self.kern, self.X, np.asarray(X1), np.asarray(X2))
-        if include_likelihood:
-            mean, _ = self._raw_predict(X1, full_cov=True)
-            likelihood = self.likelihood if likelihood is None else likelihood
-            _, cov = likelihood.predictive_values(mean, cov, full_cov=True, Y_metadata=Y_metadata)
-        if self.normalizer is not None:
-            cov = self.normalizer.inverse_covariance(cov) if self.output_dim > 1 else self.normalizer.inverse_variance(cov)
-        return cov
+    @property
+    def _predictive_variable(self):
+        return self.X
 
     def set_X(self, X):
         """(reference `core/gp.py:251-258`)"""

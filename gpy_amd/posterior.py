@@ -49,7 +49,7 @@ class PosteriorExact(object):
             raise RuntimeError("this posterior is not attached to a device context")
         return self._state.predict(kern, Xnew, full_cov=full_cov)
 
-    def predictive_gradients(self, kern, Xnew):
+    def predictive_gradients(self, kern, Xnew, pred_var=None):
         """d mean / d Xnew (M x D x Dy) and d var / d Xnew (M x D) (reference `core/gp.py:418-474`): on the device for sums
         of stationary / White / Bias parts, composed on the host from `kern.gradients_X` and the fetched `woodbury_inv`
         for anything else."""
@@ -92,8 +92,8 @@ class StudentTPosterior(PosteriorExact):
         N = self.woodbury_vector.shape[0]
         return mu, (self.nu + beta - 2.0) / (self.nu + N - 2.0) * var
 
-    def predictive_gradients(self, kern, Xnew):
-        mean_jac, var_jac = super(StudentTPosterior, self).predictive_gradients(kern, Xnew)
+    def predictive_gradients(self, kern, Xnew, pred_var=None):
+        mean_jac, var_jac = super(StudentTPosterior, self).predictive_gradients(kern, Xnew, pred_var)
         beta = self._beta if self._beta is not None else float(np.sum(self.woodbury_vector * self.mean))
         N = self.woodbury_vector.shape[0]
         return mean_jac, (self.nu + beta - 2.0) / (self.nu + N - 2.0) * var_jac

@@ -15,6 +15,7 @@ import numpy as np
 from . import _lib
 from .kern import RBF, Stationary
 from .likelihoods import Gaussian
+from .models import PredictionCallers
 from .param import Param, Parameterized
 
 LinAlgError = np.linalg.LinAlgError
@@ -124,6 +125,28 @@ class SparsePosterior(object):
             var = np.clip(var, 1e-15, np.inf)                        # posterior.py:248
         return mu, var
 
+    def predictive_gradients(self, kern, Xnew, pred_var=None):
+        """(reference `core/gp.py:418-474` with `_predictive_variable` = Z): M is small, the M x M Woodbury inverse comes to
+        the host and the reductions over the inducing points run through `kern.gradients_X`."""
+        return _host_predictive_gradients(kern, Xnew, pred_var, self.woodbury_vector, self.woodbury_inv)
+
+    def covariance_between_points(self, kern, X, X1, X2):
+        """K(X1, X2) - K(X1, Z) woodbury_inv K(Z, X2) (reference `posterior.py:109-130`)"""
+        return kern.K(X1, X2) - np.dot(kern.K(X1, X), np.dot(np.asarray(self.woodbury_inv), kern.K(X, X2)))
+
+
+def _host_predictive_gradients(kern, Xnew, pred_var, woodbury_vector, woodbury_inv):
+    """`GP.predictive_gradients` (reference `core/gp.py:440-474`, woodbury_inv.ndim == 2) composed from `kern.gradients_X`
+    (device reductions) and the M x M / N x N Woodbury inverse."""
+    Xnew = np.asarray(Xnew, dtype=np.float64)
+    wv = np.asarray(woodbury_vector)
+    mean_jac = np.empty((Xnew.shape[0], Xnew.shape[1], wv.shape[1]))
+    for i in range(wv.shape[1]):
+        mean_jac[:, :, i] = kern.gradients_X(wv[:, i:i + 1].T * np.ones((Xnew.shape[0], 1)), Xnew, pred_var)
+    var_jac = kern.gradients_X_diag(np.ones(Xnew.shape[0]), Xnew)
+    a2 = -2.0 * np.dot(kern.K(Xnew, pred_var), np.asarray(woodbury_inv))
+    return mean_jac, var_jac + kern.gradients_X(a2, Xnew, pred_var)
+
 
 def _specs(kern):
     """[(kind, ARD, theta, active_dims, term)] of a stationary kernel (its own column slicing applied to X on upload) or
@@ -230,7 +253,7 @@ class VarDTC(object):
         return post, lml, grad_dict
 
 
-class SparseGP(Parameterized):
+class SparseGP(PredictionCallers, Parameterized):
     """Model driver: the `SparseGP.parameters_changed` sequence (reference `core/sparse_gp.py:76-119`).
     Flat parameter order follows GPy's links: [Z, kern.variance, kern.lengthscale..., noise variance]
     (`sparse_gp.py:59`: Z is linked at index 0)."""
@@ -242,6 +265,7 @@ class SparseGP(Parameterized):
         self.X, self.Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
         self.Y_normalized = self.Y
         self.num_data, self.input_dim = self.X.shape
+        self.output_dim = self.Y.shape[1]
         self.Z = Param("inducing inputs", np.asarray(Z, dtype=np.float64), positive=False)
         self.num_inducing = self.Z.shape[0]
         self.kern, self.likelihood = kernel, likelihood
@@ -280,7 +304,13 @@ class SparseGP(Parameterized):
     def objective_function_gradients(self):
         return -self.gradient
 
+    @property
+    def _predictive_variable(self):
+        """(reference `core/sparse_gp.py:72-74`)"""
+        return self.Z.values
+
     def _raw_predict(self, Xnew, full_cov=False):
+        """(reference `core/sparse_gp.py:121-160` -> `posterior.py:198-262`)"""
         mu, var = self.posterior._raw_predict(self.kern, np.asarray(Xnew), self.Z.values, full_cov=full_cov)
         if self.mean_function is not None:
             mu = mu + self.mean_function.f(Xnew)

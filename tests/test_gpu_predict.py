@@ -116,3 +116,38 @@ def test_predictive_gradients_entry_point_at_a_larger_size():
     mj, vj = O.predictive_gradients("matern52", X, Xs, ref["alpha"], ref["Wi"], var, ls, True)
     assert np.abs(dmu - mj).max() <= 1e-8 * np.abs(mj).max()
     assert np.abs(dvar - vj).max() <= 1e-7 * np.abs(vj).max()
+
+
+def _sparse_names():
+    import glob
+    import os
+    from conftest import GOLDEN_DIR
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "predsparse_*.npz")))
+
+
+@pytest.mark.parametrize("name", _sparse_names())
+def test_sparse_model_prediction_callers_match_reference_golden(name):
+    """SparseGP inherits the same callers (core/sparse_gp.py: `_predictive_variable` = Z): golden vectors from the reference's
+    VarDTC posterior."""
+    import os
+    from conftest import GOLDEN_DIR
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+    kind, ARD = str(g["kind"]), bool(g["ARD"])
+    D = g["X"].shape[1]
+    ls = g["lengthscale"] if ARD else float(g["lengthscale"][0])
+    k = KCLS[kind](D, variance=float(g["variance"]), lengthscale=ls, ARD=ARD)
+    m = gpy_amd.SparseGPRegression(g["X"], g["Y"], kernel=k, Z=g["Z"], noise_var=float(g["noise"]))
+    assert abs(m.log_likelihood() - float(g["lml"])) <= 1e-9 * abs(float(g["lml"]))
+    q = m.predict_quantiles(g["Xs"])
+    assert np.abs(np.stack(q) - g["quantiles"]).max() <= 1e-7 * np.abs(g["quantiles"]).max()
+    lpd = m.log_predictive_density(g["Xs"], g["ys"])
+    assert np.abs(lpd - g["lpd"]).max() <= 1e-7 * np.abs(g["lpd"]).max()
+    mj, vj = m.predictive_gradients(g["Xs"])
+    assert np.abs(mj - g["mean_jac"]).max() <= 1e-6 * np.abs(g["mean_jac"]).max()
+    assert np.abs(vj - g["var_jac"]).max() <= 1e-6 * np.abs(g["var_jac"]).max()
+    # posterior covariance between points: consistent with the model's own full-covariance prediction
+    cov = m.posterior_covariance_between_points(g["Xs"][:8], g["Xs"][:8], include_likelihood=False)
+    _, full = m.predict_noiseless(g["Xs"][:8], full_cov=True)
+    assert np.abs(cov - full).max() <= 1e-8
+    f = m.posterior_samples_f(g["Xs"][:5], size=3)
+    assert f.shape == (5, m.output_dim, 3)

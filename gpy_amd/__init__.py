@@ -11,9 +11,23 @@ from ._lib import MI355GPError, build, device_count
 from .inference import ExactGaussianInference, ExactStudentTInference
 from .kern import RBF, Add, Prod, Bias, ExpQuad, Exponential, Matern32, Matern52, Stationary, White
 from .likelihoods import Gaussian, HeteroscedasticGaussian
-from .models import GP, GPRegression
+from .models import GP, GPHeteroscedasticRegression, GPRegression
 from .posterior import PosteriorExact, StudentTPosterior
 from .sparse import SparseGP, SparseGPRegression, VarDTC
 
 __all__ = ["RBF", "ExpQuad", "HeteroscedasticGaussian", "StudentTPosterior", "Matern52", "Matern32", "Exponential", "Stationary", "White", "Bias", "Add", "Prod", "Gaussian", "ExactGaussianInference", "ExactStudentTInference",
-           "PosteriorExact", "GP", "GPRegression", "VarDTC", "SparseGP", "SparseGPRegression", "MI355GPError", "build", "device_count"]
+           "PosteriorExact", "GP", "GPRegression", "GPHeteroscedasticRegression", "VarDTC", "SparseGP", "SparseGPRegression", "MI355GPError", "build", "device_count"]
+
+# GPy's import paths, so that `import gpy_amd as GPy` reads like the reference on this path:
+#   GPy.kern.RBF, GPy.likelihoods.Gaussian, GPy.models.GPRegression / SparseGPRegression / GPHeteroscedasticRegression,
+#   GPy.core.GP / SparseGP, GPy.inference.latent_function_inference.ExactGaussianInference / VarDTC
+from . import inference, kern, likelihoods, models, sparse  # noqa: E402
+import types as _types  # noqa: E402
+
+models.SparseGPRegression = SparseGPRegression
+core = _types.SimpleNamespace(GP=GP, SparseGP=SparseGP)
+inference.latent_function_inference = _types.SimpleNamespace(
+    ExactGaussianInference=ExactGaussianInference, ExactStudentTInference=ExactStudentTInference, VarDTC=VarDTC,
+    PosteriorExact=PosteriorExact, StudentTPosterior=StudentTPosterior,
+    exact_gaussian_inference=_types.SimpleNamespace(ExactGaussianInference=ExactGaussianInference),
+    var_dtc=_types.SimpleNamespace(VarDTC=VarDTC))

@@ -185,11 +185,13 @@ class GP(PredictionCallers, Parameterized):
             mu = mu + self.mean_function.f(Xnew)
         return mu, var
 
-    def predict(self, Xnew, full_cov=False, include_likelihood=True):
-        """(reference `core/gp.py:308-365`)"""
-        mu, var = self._raw_predict(Xnew, full_cov=full_cov)
+    def predict(self, Xnew, full_cov=False, Y_metadata=None, kern=None, likelihood=None, include_likelihood=True):
+        """(reference `core/gp.py:308-365`, same argument order)"""
+        mu, var = self._raw_predict(Xnew, full_cov=full_cov, kern=kern)
         if include_likelihood:
-            mu, var = self.likelihood.predictive_values(mu, var, full_cov=full_cov, Y_metadata=self.Y_metadata)
+            likelihood = self.likelihood if likelihood is None else likelihood
+            mu, var = likelihood.predictive_values(mu, var, full_cov=full_cov,
+                                                   Y_metadata=self.Y_metadata if Y_metadata is None else Y_metadata)
         if self.normalizer is not None:              # (reference `core/gp.py:353-363`)
             mu = self.normalizer.inverse_mean(mu)
             if full_cov and mu.shape[1] > 1:
@@ -238,3 +240,21 @@ class GPRegression(GP):
                                            Y_metadata=Y_metadata, mean_function=mean_function, device=device,
                                            normalizer=bool(normalizer) if normalizer in (None, True, False)
                                            else normalizer)
+
+
+class GPHeteroscedasticRegression(GP):
+    """One Gaussian noise variance per data point (reference `GPy/models/gp_heteroscedastic_regression.py:10-40`): the
+    length-N noise vector goes to the device with the inference call and the N noise gradients come back as diag(dL_dK)."""
+
+    def __init__(self, X, Y, kernel=None, Y_metadata=None, device=0):
+        from .likelihoods import HeteroscedasticGaussian
+        Ny = np.asarray(Y).shape[0]
+        if Y_metadata is None:
+            Y_metadata = {"output_index": np.arange(Ny)[:, None]}
+        else:
+            assert np.asarray(Y_metadata["output_index"]).shape[0] == Ny
+        if kernel is None:
+            kernel = RBF(np.asarray(X).shape[1], device=device)
+        super(GPHeteroscedasticRegression, self).__init__(X, Y, kernel, HeteroscedasticGaussian(Y_metadata),
+                                                          name="gp_heteroscedastic_regression", Y_metadata=Y_metadata,
+                                                          device=device)

@@ -151,3 +151,22 @@ def test_sparse_model_prediction_callers_match_reference_golden(name):
     assert np.abs(cov - full).max() <= 1e-8
     f = m.posterior_samples_f(g["Xs"][:5], size=3)
     assert f.shape == (5, m.output_dim, 3)
+
+
+def test_heteroscedastic_regression_model_matches_oracle():
+    """GPHeteroscedasticRegression (models/gp_heteroscedastic_regression.py): per-point noise in, N noise gradients out."""
+    X, Y = O.synthetic(300, 3, seed=6)
+    k = gpy_amd.Matern32(3, variance=1.1, lengthscale=[0.9, 1.4, 2.0], ARD=True)
+    m = gpy_amd.GPHeteroscedasticRegression(X, Y, k)
+    noise = np.random.default_rng(2).uniform(0.03, 0.3, 300)
+    m.likelihood.variance[:] = noise
+    m.parameters_changed()
+    K = O.kern_K("matern32", X, None, 1.1, np.array([0.9, 1.4, 2.0]), True)
+    ref = O.exact_inference(K, Y, noise)
+    assert abs(m.log_likelihood() - ref["lml"]) <= 1e-10 * abs(ref["lml"])
+    assert np.abs(m.likelihood.variance.gradient - np.diag(ref["dL_dK"])).max() <= 1e-8 * np.abs(np.diag(ref["dL_dK"])).max()
+    dv, dl = O.update_gradients_full("matern32", ref["dL_dK"], X, None, 1.1, np.array([0.9, 1.4, 2.0]), True)
+    assert np.abs(m.kern.gradient - np.concatenate([[dv], dl])).max() <= 1e-8 * np.abs(dl).max()
+    mu, var = m.predict(X[:5], Y_metadata={"output_index": np.arange(5)[:, None]})
+    mu0, var0 = m.predict_noiseless(X[:5])
+    assert np.allclose(var - var0, noise[:5, None], rtol=1e-9, atol=1e-12) and np.allclose(mu, mu0)

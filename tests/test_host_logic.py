@@ -183,3 +183,18 @@ def test_combination_kernels_flatten_and_describe_themselves_to_the_c_abi():
     k2 = r1 * m32 + r2 * b
     assert [s[4] for s in k2.part_specs()] == [1, 1, 2, 2]
     assert gpy_amd.lazy.kernel_signature(k2) != gpy_amd.lazy.kernel_signature(r1 * m32 + r2 + b)
+
+
+def test_gpy_style_import_paths():
+    """`import gpy_amd as GPy` reads like the reference on this path (no device needed for the lookups)."""
+    import gpy_amd as GPy
+    assert GPy.kern.RBF is GPy.RBF and GPy.kern.Matern52 is GPy.Matern52
+    assert GPy.models.GPRegression is GPy.GPRegression and GPy.models.SparseGPRegression is GPy.SparseGPRegression
+    assert GPy.models.GPHeteroscedasticRegression.__mro__[1] is GPy.core.GP
+    assert GPy.likelihoods.Gaussian is GPy.Gaussian
+    lfi = GPy.inference.latent_function_inference
+    assert lfi.ExactGaussianInference is GPy.ExactGaussianInference and lfi.VarDTC is GPy.VarDTC
+    assert lfi.exact_gaussian_inference.ExactGaussianInference is GPy.ExactGaussianInference
+    for name in ("predict", "predict_noiseless", "predict_quantiles", "predictive_gradients", "log_predictive_density",
+                 "posterior_samples_f", "posterior_samples", "posterior_covariance_between_points"):
+        assert callable(getattr(GPy.core.GP, name)) and callable(getattr(GPy.core.SparseGP, name))

@@ -9,13 +9,13 @@ HIP kernel in gpy_amd/csrc.  No PyTorch, no NumPy fallback: without an MI355X th
 from . import _lib
 from ._lib import MI355GPError, build, device_count
 from .inference import ExactGaussianInference, ExactStudentTInference
-from .kern import RBF, Add, Prod, Bias, ExpQuad, Exponential, Matern32, Matern52, Stationary, White
+from .kern import OU, RBF, Add, Prod, Bias, ExpQuad, Exponential, Matern32, Matern52, Stationary, White
 from .likelihoods import Gaussian, HeteroscedasticGaussian
 from .models import GP, GPHeteroscedasticRegression, GPRegression
 from .posterior import PosteriorExact, StudentTPosterior
 from .sparse import SparseGP, SparseGPRegression, VarDTC
 
-__all__ = ["RBF", "ExpQuad", "HeteroscedasticGaussian", "StudentTPosterior", "Matern52", "Matern32", "Exponential", "Stationary", "White", "Bias", "Add", "Prod", "Gaussian", "ExactGaussianInference", "ExactStudentTInference",
+__all__ = ["RBF", "OU", "ExpQuad", "HeteroscedasticGaussian", "StudentTPosterior", "Matern52", "Matern32", "Exponential", "Stationary", "White", "Bias", "Add", "Prod", "Gaussian", "ExactGaussianInference", "ExactStudentTInference",
            "PosteriorExact", "GP", "GPRegression", "GPHeteroscedasticRegression", "VarDTC", "SparseGP", "SparseGPRegression", "MI355GPError", "build", "device_count"]
 
 # GPy's import paths, so that `import gpy_amd as GPy` reads like the reference on this path:

@@ -143,6 +143,15 @@ class Stationary(Parameterized):
         self.variance.gradient = np.sum(dL_dKdiag)
         self.lengthscale.gradient = 0.
 
+    def update_gradients_direct(self, dL_dVar, dL_dLen):
+        """install gradients computed elsewhere (reference `stationary.py:215-223`)"""
+        self.variance.gradient = dL_dVar
+        self.lengthscale.gradient = dL_dLen
+
+    def input_sensitivity(self, summarize=True):
+        """variance / lengthscale^2 per input dimension (reference `stationary.py:363-364`)"""
+        return float(self.variance.values[0]) * np.ones(self.input_dim) / np.asarray(self.lengthscale.values) ** 2
+
     def gradients_X(self, dL_dK, X, X2=None):
         """dL/dX from dL_dK (reference `stationary.py:245-252,330-358`), reduced on the device."""
         g = _lib.gradients_X(self.kind, self.ARD, self._theta(), np.asarray(dL_dK), self._slice_X(X),
@@ -255,6 +264,14 @@ class Exponential(Stationary):
 
     def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="Exponential", **kw):
         super(Exponential, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name, **kw)
+
+
+class OU(Exponential):
+    """Ornstein-Uhlenbeck = the exponential kernel under its other name (reference `stationary.py:416-454`)."""
+    _gpy_class = "GPy.kern.OU"
+
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="OU", **kw):
+        super(OU, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name, **kw)
 
 
 class Static(Parameterized):

@@ -52,6 +52,10 @@ class PredictionCallers(object):
     normalizer = None
     output_dim = 1
 
+    def input_sensitivity(self, summarize=True):
+        """(reference `core/gp.py:654-658`)"""
+        return self.kern.input_sensitivity(summarize=summarize)
+
     def predict_noiseless(self, Xnew, full_cov=False):
         """(reference `core/gp.py:367-393`)"""
         return self.predict(Xnew, full_cov=full_cov, include_likelihood=False)

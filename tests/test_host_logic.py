@@ -198,3 +198,14 @@ def test_gpy_style_import_paths():
     for name in ("predict", "predict_noiseless", "predict_quantiles", "predictive_gradients", "log_predictive_density",
                  "posterior_samples_f", "posterior_samples", "posterior_covariance_between_points"):
         assert callable(getattr(GPy.core.GP, name)) and callable(getattr(GPy.core.SparseGP, name))
+
+
+def test_small_stationary_methods_follow_the_reference():
+    import gpy_amd
+    k = gpy_amd.OU(3, variance=2.0, lengthscale=[0.5, 1.0, 2.0], ARD=True)
+    assert k.kind == "exponential" and k.to_dict()["class"] == "GPy.kern.OU"
+    assert np.allclose(k.input_sensitivity(), 2.0 / np.array([0.25, 1.0, 4.0]))       # stationary.py:363-364
+    k.update_gradients_direct(1.5, np.array([0.1, 0.2, 0.3]))                           # stationary.py:215-223
+    assert np.allclose(k.variance.gradient, 1.5) and np.allclose(k.lengthscale.gradient, [0.1, 0.2, 0.3])
+    k.update_gradients_diag(np.ones(7), np.zeros((7, 3)))                               # stationary.py:182-191
+    assert np.allclose(k.variance.gradient, 7.0) and np.allclose(k.lengthscale.gradient, 0.0)

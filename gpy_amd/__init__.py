@@ -21,11 +21,12 @@ __all__ = ["RBF", "OU", "ExpQuad", "HeteroscedasticGaussian", "StudentTPosterior
 # GPy's import paths, so that `import gpy_amd as GPy` reads like the reference on this path:
 #   GPy.kern.RBF, GPy.likelihoods.Gaussian, GPy.models.GPRegression / SparseGPRegression / GPHeteroscedasticRegression,
 #   GPy.core.GP / SparseGP, GPy.inference.latent_function_inference.ExactGaussianInference / VarDTC
-from . import inference, kern, likelihoods, models, sparse  # noqa: E402
+from . import inference, kern, likelihoods, linalg, models, sparse  # noqa: E402
 import types as _types  # noqa: E402
 
 models.SparseGPRegression = SparseGPRegression
 core = _types.SimpleNamespace(GP=GP, SparseGP=SparseGP)
+util = _types.SimpleNamespace(linalg=linalg)
 inference.latent_function_inference = _types.SimpleNamespace(
     ExactGaussianInference=ExactGaussianInference, ExactStudentTInference=ExactStudentTInference, VarDTC=VarDTC,
     PosteriorExact=PosteriorExact, StudentTPosterior=StudentTPosterior,

@@ -115,6 +115,7 @@ def lib():
     L.mi355gp_predict.argtypes = [vp, ci, ci, _dp, _dp, i64, _c_dp, _c_dp, ci]
     L.mi355gp_potrf.argtypes = [ci, _dp, i64, _c_dp]
     L.mi355gp_pdinv.argtypes = [ci, _dp, i64, _c_dp, _c_dp, _c_dp, _c_dp]
+    L.mi355gp_pdinv_full.argtypes = [ci, _dp, i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_set_option.argtypes = [vp, ci, ci]
     L.mi355gp_bench_factor.argtypes = [ci, i64, ci, _c_dp, _c_dp, _c_dp]
     L.mi355gp_bench_factor.restype = ci
@@ -149,7 +150,7 @@ def lib():
                  "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm", "exact_inference_sum",
                  "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum", "dbg_mask_probe",
                  "vardtc_inference_sum", "sparse_predict", "sparse_fetch_dLdKnm", "sparse_attach_loopback",
-                 "predictive_gradients_sum", "dbg_pipe_share"):
+                 "predictive_gradients_sum", "dbg_pipe_share", "pdinv_full"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -166,7 +167,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_exact_inference_sum", "mi355gp_predict_sum", "mi355gp_dbg_gemm_clock",
             "mi355gp_covariance_between_points", "mi355gp_exact_studentt_sum", "mi355gp_vardtc_inference_sum",
             "mi355gp_sparse_predict", "mi355gp_sparse_fetch_dLdKnm", "mi355gp_sparse_attach_loopback",
-            "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share",
+            "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share", "mi355gp_pdinv_full",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe")
 
 
@@ -552,6 +553,18 @@ def pdinv(A, device=0):
     info = check(lib().mi355gp_pdinv(device, A, n, Ai.ctypes.data_as(_c_dp), L.ctypes.data_as(_c_dp),
                                      ctypes.byref(ld), ctypes.byref(ms)), "mi355gp_pdinv")
     return Ai, L, ld.value, info, ms.value
+
+
+def pdinv_full(A, device=0):
+    """(Ainv, L, Li, logdet, info): all four members of GPy's pdinv tuple (GPy/util/linalg.py:193-214)."""
+    require_device(device)
+    A = f64(A)
+    n = A.shape[0]
+    Ai, L, Li = np.empty((n, n)), np.empty((n, n)), np.empty((n, n))
+    ld, ms = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    info = check(lib().mi355gp_pdinv_full(device, A, n, Ai.ctypes.data_as(_c_dp), L.ctypes.data_as(_c_dp),
+                                          Li.ctypes.data_as(_c_dp), ctypes.byref(ld), ctypes.byref(ms)), "mi355gp_pdinv_full")
+    return Ai, L, Li, ld.value, info
 
 
 def bench_factor(N, reps=3, device=0):

@@ -705,7 +705,7 @@ int mi355gp_gradients_X(int device, int kind, int ard, const double* theta, cons
 
 // ---- standalone dense routines ------------------------------------------------------------------------
 static int dense_factor(int device, const double* A_host, int64_t N, bool invert, double* L_out, double* Ainv_out,
-                        double* logdet, double* ms) {
+                        double* logdet, double* ms, double* Li_out = nullptr) {
     HIP_CHECK(hipSetDevice(device));
     const long np = round_up(N, NB);
     double *A = nullptr, *B = nullptr, *C = nullptr, *tmp = nullptr, *dScal = nullptr;
@@ -749,6 +749,10 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
             launch_extract(0, C, np, N, 1, nullptr, 0, tmp, 0);
             HIP_CHECK(hipMemcpy(Ainv_out, tmp, sizeof(double) * N * N, hipMemcpyDeviceToHost));
         }
+        if (invert && Li_out) {                                   // L^-1: the dtrtri result pdinv also returns (linalg.py:207)
+            launch_extract(0, B, np, N, 0, nullptr, 0, tmp, 0);
+            HIP_CHECK(hipMemcpy(Li_out, tmp, sizeof(double) * N * N, hipMemcpyDeviceToHost));
+        }
         if (logdet) {
             std::vector<double> ls(ws.nblk);
             HIP_CHECK(hipMemcpy(ls.data(), ws.logsum, sizeof(double) * ws.nblk, hipMemcpyDeviceToHost));
@@ -774,6 +778,12 @@ int mi355gp_potrf(int device, double* A, int64_t N, double* ms) {
 int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* L_out, double* logdet, double* ms) {
     ARG_CHECK(A && N > 0, "mi355gp_pdinv: bad arguments");
     return dense_factor(device, A, N, true, L_out, Ainv, logdet, ms);
+}
+
+int mi355gp_pdinv_full(int device, const double* A, int64_t N, double* Ainv, double* L_out, double* Li_out, double* logdet,
+                       double* ms) {
+    ARG_CHECK(A && N > 0, "mi355gp_pdinv_full: bad arguments");
+    return dense_factor(device, A, N, true, L_out, Ainv, logdet, ms, Li_out);
 }
 
 int mi355gp_predict_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, const double* Xnew, int64_t M,

@@ -167,6 +167,9 @@ int mi355gp_covariance_between_points(mi355gp_ctx* ctx, int nparts, const mi355g
 int mi355gp_potrf(int device, double* A, int64_t N, double* ms);
 /* Ainv (symmetric, full) from A; replaces pdinv's dpotrf+dpotri+symmetrify (util/linalg.py:193-214). */
 int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* L_out, double* logdet, double* ms);
+/* the same with the third member of GPy's pdinv tuple, Li = L^-1 (dtrtri, linalg.py:207): (Ai, L, Li, logdet) */
+int mi355gp_pdinv_full(int device, const double* A, int64_t N, double* Ainv, double* L_out, double* Li_out, double* logdet,
+                       double* ms);
 
 /* Options.  PROFILE: bracket launches of the factorisation kernels with hipEvents on the launching stream (adds
  * ~2 us per timed launch).  value 0 = off, 1 = all families, otherwise (bitmask of 1 << MI355GP_PF_*) << 1;

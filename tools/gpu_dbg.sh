@@ -1,5 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
 O=gpurun_out/r2t; mkdir -p $O
-( timeout 600 python -m pytest tests/test_gpu_linalg.py -m gpu -q -x 2>&1 | tail -25 ) > $O/pytest_linalg.log 2>&1
-cat $O/pytest_linalg.log
+timeout 600 python tools/time_callers.py 2>$O/tc.err | tee $O/time_callers.json; tail -3 $O/tc.err

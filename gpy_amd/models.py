@@ -52,6 +52,27 @@ class PredictionCallers(object):
     normalizer = None
     output_dim = 1
 
+    def checkgrad(self, verbose=False, step=1e-6, tolerance=1e-3):
+        """The gradient check the reference's tests lean on (`paramz.Model.checkgrad`, used e.g. at
+        `testing/test_model.py:790-898`): central difference of the objective along a random direction of the flat parameter
+        vector against the analytic gradient; True when the ratio is within `tolerance` of one (or both are ~0)."""
+        x = self.param_array.copy()
+        try:
+            g = self.objective_function_gradients().copy()
+            dx = np.where(np.random.uniform(size=x.shape) > 0.5, 1.0, -1.0) * step * np.maximum(np.abs(x), 1e-3)
+            self.param_array = x + dx
+            f1 = self.objective_function()
+            self.param_array = x - dx
+            f2 = self.objective_function()
+        finally:
+            self.param_array = x
+        num, ana = (f1 - f2) / 2.0, float(np.dot(dx, g))
+        if verbose:
+            print("checkgrad: numerical %.10e analytic %.10e ratio %.8f" % (num, ana, num / ana if ana != 0 else np.nan))
+        if abs(ana) < 1e-14 and abs(num) < 1e-14:
+            return True
+        return bool(abs(1.0 - num / ana) < tolerance) if ana != 0 else False
+
     def input_sensitivity(self, summarize=True):
         """(reference `core/gp.py:654-658`)"""
         return self.kern.input_sensitivity(summarize=summarize)

@@ -116,3 +116,19 @@ def test_product_kernel_on_a_grid_equals_the_kronecker_evaluation():
     lml = -0.5 * X.shape[0] * np.log(2 * np.pi) - 0.5 * np.sum(np.log(W)) - 0.5 * float(np.sum(alpha * Y))
     assert abs(m.log_likelihood() - lml) <= 1e-9 * abs(lml)
     assert np.allclose(m.posterior.woodbury_vector, alpha, rtol=1e-7, atol=1e-9)
+
+
+def test_checkgrad_like_the_reference_tests():
+    """`assert m.checkgrad()` on the model families of this path (testing/test_model.py:790-898, test_kernel.py:57-70)."""
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((150, 3))
+    Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((150, 1))
+    np.random.seed(1)
+    for k in (gpy_amd.RBF(3, ARD=True, lengthscale=[0.9, 1.3, 2.0]), gpy_amd.Matern52(3) + gpy_amd.White(3, 0.1),
+              gpy_amd.RBF(2, active_dims=[0, 1]) * gpy_amd.Matern32(1, active_dims=[2]), gpy_amd.Exponential(3, lengthscale=1.5)):
+        m = gpy_amd.GPRegression(X, Y, k, noise_var=0.2)
+        assert m.checkgrad(), k
+    ms = gpy_amd.SparseGPRegression(X, Y, kernel=gpy_amd.RBF(3, lengthscale=1.2), num_inducing=15, noise_var=0.2, seed=0)
+    assert ms.checkgrad()
+    mh = gpy_amd.GPHeteroscedasticRegression(X, Y, gpy_amd.RBF(3))
+    assert mh.checkgrad()

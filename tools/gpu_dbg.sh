@@ -1,5 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
-O=gpurun_out/r2t; mkdir -p $O
-( timeout 600 python -m pytest tests/test_gpu_reference_tests.py -m gpu -q -x 2>&1 | tail -40 ) > $O/pytest_reft.log 2>&1
-cat $O/pytest_reft.log
+O=gpurun_out/r2u; mkdir -p $O
+timeout 600 python examples/gp_regression.py 4096 4 > $O/example.log 2>&1; echo rc=$?; tail -12 $O/example.log

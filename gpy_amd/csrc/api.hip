@@ -708,21 +708,29 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
                         double* logdet, double* ms, double* Li_out = nullptr) {
     HIP_CHECK(hipSetDevice(device));
     const long np = round_up(N, NB);
-    double *A = nullptr, *B = nullptr, *C = nullptr, *tmp = nullptr, *dScal = nullptr;
-    FactorWs ws;
-    HIP_CHECK(hipMalloc(&A, sizeof(double) * np * np));
-    HIP_CHECK(hipMalloc(&tmp, sizeof(double) * N * N));
-    HIP_CHECK(hipMalloc(&dScal, sizeof(double) * 8));
+    DevBuf A, B, C, tmp;                                      // released on every return path
+    struct WsGuard {                                          // ... and so are the workspace and the two events
+        FactorWs ws;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~WsGuard() {
+            factor_ws_free(&ws);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } guard;
+    FactorWs& ws = guard.ws;
+    HIP_CHECK(A.alloc((size_t)np * np));
+    HIP_CHECK(tmp.alloc((size_t)N * N));
     if (invert) {
-        HIP_CHECK(hipMalloc(&B, sizeof(double) * np * np));
-        HIP_CHECK(hipMalloc(&C, sizeof(double) * np * np));
+        HIP_CHECK(B.alloc((size_t)np * np));
+        HIP_CHECK(C.alloc((size_t)np * np));
     }
     if (factor_ws_alloc(&ws, np) != 0) return -3;
-    ws.scratchX = B;                                          // both null without `invert`: trsm128-based panels
-    ws.scratchT = C;
-    hipEvent_t e0, e1;
-    HIP_CHECK(hipEventCreate(&e0));
-    HIP_CHECK(hipEventCreate(&e1));
+    ws.scratchX = invert ? (double*)B : nullptr;              // both null without `invert`: trsm128-based panels
+    ws.scratchT = invert ? (double*)C : nullptr;
+    HIP_CHECK(hipEventCreate(&guard.e0));
+    HIP_CHECK(hipEventCreate(&guard.e1));
+    hipEvent_t e0 = guard.e0, e1 = guard.e1;
     HIP_CHECK(hipMemcpy(tmp, A_host, sizeof(double) * N * N, hipMemcpyHostToDevice));
     launch_pad_from_dense(0, tmp, N, A, np, nullptr, 0, 0.0);
     HIP_CHECK(hipEventRecord(e0, 0));
@@ -761,11 +769,6 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
             *logdet = 2.0 * s;
         }
     }
-    (void)hipFree(A); (void)hipFree(tmp); (void)hipFree(dScal);
-    if (B) (void)hipFree(B);
-    if (C) (void)hipFree(C);
-    factor_ws_free(&ws);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (info > N) info = (int)N;
     return info;
 }

@@ -227,7 +227,7 @@ def golden_check(kind, ARD, N, D, seed, lml, alpha, grad):
     return None
 
 
-def grid_leg(comm, args, timeout=420.0):
+def grid_leg(comm, args, timeout=180.0):
     """BASELINE configs[3] (RBF, N=32768, D=8) on the 2D block-cyclic grid over ALL ranks of this launch
     (grid_shape(world); loopback transport when there is one process), run in CHILD processes with a timeout so that a
     fault of the never-before-timed multi-GPU path cannot take the headline line down.  Returns the sub-record (rank 0)."""

@@ -80,6 +80,12 @@ struct mi355gp_ctx {
     // Everything an evaluation returns -- scalars, info, per-part gradient sums, alpha, diag(dL_dK) -- lives in ONE device
     // block and travels in ONE copy into ONE pinned host block (five small pageable copies cost ~80 us per evaluation:
     // 2 % at N = 4096).  Layout (doubles): [scal 8 | grads MAXP*groups*GP_STRIDE | alpha N*Dy | diag N]
+    // The factorisation region of an evaluation (potrf -> trtri -> alpha solve || lauum: ~110 launches on up to three streams at
+    // N = 4096, every argument a fixed pointer or size of this context) replayed from ONE hipGraph for the sizes whose
+    // factorisation is launch- / latency-bound (no CU-masked overlap stream below the overlapped-inverse threshold, so nothing
+    // a graph node cannot carry): N = 4096 3.37 -> 3.21 ms, N = 2048 1.33 -> 1.26, N = 512 0.31 -> 0.28 (mi355gp_dbg_graph_factor).
+    hipGraphExec_t fgraph = nullptr;
+    int fgraph_calls = 0, fgraph_lookahead = -1, graph_enabled = 1;     // MI355GP_GRAPH=0 turns it off
     double *dPack = nullptr, *hPack = nullptr;
     size_t packDoubles = 0, offGrad = 0, offAlpha = 0, offDiag = 0;
     double* dGradOutAll = nullptr;      // = dPack + offGrad: [part][groups][GP_STRIDE]
@@ -91,7 +97,14 @@ static void free_parts(mi355gp_ctx* c) {
     c->parts.clear();
 }
 
+static void drop_graph(mi355gp_ctx* c) {
+    if (c->fgraph) (void)hipGraphExecDestroy(c->fgraph);
+    c->fgraph = nullptr;
+    c->fgraph_calls = 0;
+}
+
 static void free_data(mi355gp_ctx* c) {
+    drop_graph(c);                                            // every node holds pointers into the buffers freed below
     free_parts(c);
     double** ptrs[] = {&c->dX, &c->dR, &c->dXt, &c->dInvLs, &c->dNoise, &c->A, &c->B, &c->C, &c->Mbuf,
                        &c->dTmp, &c->dTrmvPart, &c->dGradPart, &c->dGradOut, &c->dPack};
@@ -134,6 +147,10 @@ int mi355gp_create(int device, mi355gp_ctx** out) {
     c->device = device;
     if (factor_engine(device, &c->st, nullptr, nullptr) != 0) return -2;    // the device's shared main stream (factor.hip)
     for (auto& e : c->ev) HIP_CHECK(hipEventCreate(&e));
+    {
+        const char* e = getenv("MI355GP_GRAPH");
+        if (e && *e) c->graph_enabled = atoi(e) ? 1 : 0;
+    }
     *out = c;
     return 0;
 }
@@ -234,25 +251,61 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
     hipStream_t st = c->st;
     const long n = c->n, np = c->npad;
     c->ws.prof.reset();
-    HIP_CHECK(hipEventRecord(c->ev[1], st));
     c->ws.scratchX = c->B;                                   // free until trtri / lauum overwrite them
     c->ws.scratchT = c->C;
-    potrf_device(st, c->A, np, &c->ws);
-    HIP_CHECK(hipEventRecord(c->ev[2], st));
-    trtri_device(st, c->A, c->B, c->C, np, &c->ws);
-    HIP_CHECK(hipEventRecord(c->ev[3], st));
-    // alpha = X^T (X R) only needs X: the two bandwidth-bound triangular mat-vecs run on the side stream underneath the
-    // compute-bound W = X^T X instead of after it
-    hipStream_t side = (c->ws.st_tri && c->ws.solve_overlap) ? c->ws.st_tri : nullptr;
-    if (side) {
-        HIP_CHECK(hipStreamWaitEvent(side, c->ev[3], 0));
-        launch_tri_matvec(side, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
-        HIP_CHECK(hipEventRecord(c->ws.ev_tri, side));
+    // The factorisation region: potrf -> trtri -> (alpha solve on the side stream) || lauum.  `timing`: record the stage events.
+    auto region = [&](bool timing) -> int {
+        if (timing) HIP_CHECK(hipEventRecord(c->ev[1], st));
+        potrf_device(st, c->A, np, &c->ws);
+        if (timing) HIP_CHECK(hipEventRecord(c->ev[2], st));
+        trtri_device(st, c->A, c->B, c->C, np, &c->ws);
+        HIP_CHECK(hipEventRecord(c->ev[3], st));
+        // alpha = X^T (X R) only needs X: the two bandwidth-bound triangular mat-vecs run on the side stream underneath the
+        // compute-bound W = X^T X instead of after it
+        hipStream_t side = (c->ws.st_tri && c->ws.solve_overlap) ? c->ws.st_tri : nullptr;
+        if (side) {
+            HIP_CHECK(hipStreamWaitEvent(side, c->ev[3], 0));
+            launch_tri_matvec(side, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
+            HIP_CHECK(hipEventRecord(c->ws.ev_tri, side));
+        }
+        lauum_device(st, c->B, c->C, np, &c->ws);
+        if (timing) HIP_CHECK(hipEventRecord(c->ev[4], st));
+        if (side) HIP_CHECK(hipStreamWaitEvent(st, c->ws.ev_tri, 0));
+        else launch_tri_matvec(st, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
+        return 0;
+    };
+    // hipGraph replay when nothing in the region needs a CU-masked stream (sizes below the overlapped-inverse threshold), no
+    // stage timing was asked for and launch bracketing is off; the first evaluation of a context runs plain (one-time
+    // function attributes), the second captures, every later one replays.
+    const bool structural = c->graph_enabled && !c->ws.prof.on && c->ws.lookahead == 1 &&
+                            (!c->ws.tri_overlap || (int)(np / NB) < c->ws.tri_min_nt);
+    if (c->fgraph && !structural) drop_graph(c);
+    const bool graphable = structural && !stage_ms;          // a call that wants the stage timings runs plain, the graph stays
+    if (!graphable) {
+        if (int rc = region(true)) return rc;
+    } else if (c->fgraph) {
+        HIP_CHECK(hipGraphLaunch(c->fgraph, st));
+    } else if (c->fgraph_calls++ == 0) {
+        if (int rc = region(false)) return rc;
+    } else {
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            const int rc = region(false);
+            ok = (hipStreamEndCapture(st, &g) == hipSuccess) && rc == 0 && g != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&c->fgraph, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+        if (!ok) {                                            // capture not possible here: stay on plain launches
+            (void)hipGetLastError();
+            c->fgraph = nullptr;
+            c->graph_enabled = 0;
+            if (int rc = region(false)) return rc;
+        } else {
+            c->fgraph_lookahead = c->ws.lookahead;
+            HIP_CHECK(hipGraphLaunch(c->fgraph, st));
+        }
     }
-    lauum_device(st, c->B, c->C, np, &c->ws);
-    HIP_CHECK(hipEventRecord(c->ev[4], st));
-    if (side) HIP_CHECK(hipStreamWaitEvent(st, c->ws.ev_tri, 0));
-    else launch_tri_matvec(st, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
     launch_scalars(st, c->dAlpha, c->dR, c->C, np, n, c->Dy, c->ws.logsum, c->ws.nblk, c->dScal, c->dDiag, c->ws.info);
     if (studentt_nu > 0.0) launch_studentt_scale(st, c->dScal, studentt_nu, n, c->dScal + 4);
     HIP_CHECK(hipEventRecord(c->ev[5], st));
@@ -1105,6 +1158,85 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
     factor_ws_free(&ws);
     HIP_CHECK(hipGetLastError());
     return info > 0 ? info : 0;
+}
+
+// Diagnostic: the same build + factorisation sequence as mi355gp_bench_factor, once launched kernel by kernel and once
+// replayed from a hipGraph captured from the same streams (main + look-ahead panel stream; sizes below the overlapped-inverse
+// threshold use no CU-masked stream).  out3: ms per repetition launched / replayed, number of graph nodes.
+int mi355gp_dbg_graph_factor(int device, int64_t N, int reps, double* out3) {
+    ARG_CHECK(N >= NB && reps >= 1 && out3, "mi355gp_dbg_graph_factor: N >= 128, reps >= 1");
+    HIP_CHECK(hipSetDevice(device));
+    const long np = round_up(N, NB);
+    const int D = 4;
+    std::vector<double> X((size_t)N * D);
+    unsigned long long state = 0x9E3779B97F4A7C15ull;
+    for (double& v : X) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        v = ((double)(state >> 11) / 9007199254740992.0 - 0.5) * 4.0;
+    }
+    DevBuf dX, dXt, dIl, dNoise, A, B, C;
+    HIP_CHECK(dX.alloc(N * D));
+    HIP_CHECK(dXt.alloc(D * np));
+    HIP_CHECK(dIl.alloc(D));
+    HIP_CHECK(dNoise.alloc(1));
+    HIP_CHECK(A.alloc(np * np));
+    HIP_CHECK(B.alloc(np * np));
+    HIP_CHECK(C.alloc(np * np));
+    const double il[4] = {0.7, 0.7, 0.7, 0.7}, noise = 0.1;
+    HIP_CHECK(hipMemcpy(dX, X.data(), sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dIl, il, sizeof(il), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dNoise, &noise, sizeof(double), hipMemcpyHostToDevice));
+    hipStream_t st;
+    if (factor_engine(device, &st, nullptr, nullptr) != 0) return -2;
+    FactorWs ws;
+    if (factor_ws_alloc(&ws, np) != 0) return -3;
+    ws.tri_overlap = 0;                                        // no CU-masked side stream inside the captured region
+    ws.scratchX = B;
+    ws.scratchT = C;
+    const KernParams kp{MI355GP_RBF, 0, D, 1.0};
+    launch_scale_inputs(st, dX, N, D, dIl, 0, dXt, np);
+    auto sequence = [&]() {
+        launch_kbuild_sym(st, kp, dXt, np, N, np, A, dNoise, 1, 1e-8, 1, 1);
+        potrf_device(st, A, np, &ws);
+        trtri_device(st, A, B, C, np, &ws);
+        lauum_device(st, B, C, np, &ws);
+    };
+    sequence();                                                // warm-up: one-time function attributes, lazy module load
+    HIP_CHECK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    float ms;
+    HIP_CHECK(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) sequence();
+    HIP_CHECK(hipEventRecord(e1, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    out3[0] = ms / reps;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    sequence();
+    HIP_CHECK(hipStreamEndCapture(st, &graph));
+    size_t nnodes = 0;
+    HIP_CHECK(hipGraphGetNodes(graph, nullptr, &nnodes));
+    out3[2] = (double)nnodes;
+    HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphLaunch(exec, st));                       // warm-up replay
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) HIP_CHECK(hipGraphLaunch(exec, st));
+    HIP_CHECK(hipEventRecord(e1, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    out3[1] = ms / reps;
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    factor_ws_free(&ws);
+    HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // ---- diagnostics ------------------------------------------------------------------------------------------

@@ -284,6 +284,9 @@ int mi355gp_dbg_cu_map(int device, int nwg, int mask_bit, unsigned* out);
 /* Diagnostic: do fp64 MFMA and fp64 VALU FMA share one issue pipe?  out4 = ms of the same launch shape with all workgroups
  * on the MFMA stream / all on the FMA stream / alternating, and the MFMA TF/s of the first. */
 int mi355gp_dbg_pipe_share(int device, double* out4);
+/* Diagnostic: build + potrf + trtri + lauum of a synthetic N x N problem launched kernel by kernel vs replayed from a hipGraph
+ * captured from the same streams.  out3 = ms launched, ms replayed, graph nodes. */
+int mi355gp_dbg_graph_factor(int device, int64_t N, int reps, double* out3);
 /* diagnostics: is a CU-masked stream really confined?  out3 = ms of a 4096^3 GEMM on [plain, masked, masked] streams */
 int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3);
 

@@ -479,3 +479,42 @@ def test_expquad_kernel_cache_and_heteroscedastic_likelihood():
     ref = O.exact_inference(O.kern_K("rbf", X, None, 1.1, 1.0, False), Y, lik.variance.values)
     assert abs(m.log_likelihood() - ref["lml"]) <= TOL_LML * abs(ref["lml"])
     assert np.abs(lik.variance.gradient - ref["diag_dL_dK"]).max() <= TOL_GRAD * np.abs(ref["diag_dL_dK"]).max()
+
+
+def test_graph_replay_is_bit_identical_to_plain_launches_and_survives_set_data():
+    """Below the overlapped-inverse threshold the factorisation region of a context's 2nd evaluation is captured into a hipGraph
+    and replayed from the 3rd on: every replay, with theta / noise changing between calls, must give the
+    bits of a fresh context's first (plain) evaluation; set_data drops the graph (its nodes point into the old buffers)."""
+    rng = np.random.default_rng(12)
+    X, Y = O.synthetic(1800, 4, seed=3)
+    c = L.Context(0)
+    try:
+        c.set_data(X, Y)
+        for it in range(6):
+            var, noise = 0.8 + 0.3 * it, 0.05 + 0.02 * it
+            ls = rng.uniform(0.6, 2.0, 4)
+            th = L.theta_vec(var, ls, True, 4)
+            info, r = c.exact_inference("matern32", True, th, noise)
+            f = L.Context(0)
+            try:
+                f.set_data(X, Y)
+                info2, r2 = f.exact_inference("matern32", True, th, noise)          # first call of a context: plain launches
+            finally:
+                f.close()
+            assert info == info2 == 0
+            assert r["lml"] == r2["lml"] and r["dtheta"].tobytes() == r2["dtheta"].tobytes()
+            assert r["alpha"].tobytes() == r2["alpha"].tobytes() and r["dnoise"] == r2["dnoise"]
+        # a call with stage timings runs plain and leaves the graph in place; the next one replays again
+        info, r3 = c.exact_inference("matern32", True, th, noise, want_stage_ms=True)
+        info, r4 = c.exact_inference("matern32", True, th, noise)
+        assert r3["lml"] == r4["lml"] == r["lml"] and r3["stage_ms"]["potrf"] > 0
+        # new data of another size: the old graph must be gone
+        X2, Y2 = O.synthetic(1300, 4, seed=4)
+        c.set_data(X2, Y2)
+        for _ in range(3):
+            info, r5 = c.exact_inference("matern32", True, th, noise)
+        ref = O.parameters_changed("matern32", X2, Y2, var, ls, True, noise)
+        assert abs(r5["lml"] - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+        assert np.linalg.norm(r5["alpha"] - ref["alpha"]) <= TOL_ALPHA * np.linalg.norm(ref["alpha"])
+    finally:
+        c.close()

@@ -1,11 +1,5 @@
 #!/bin/bash
-python - <<'PY'
-import sys, numpy as np
-sys.path.insert(0, '.')
-from gpy_amd import _lib as L
-lib = L.lib()
-for n in (8192, 16384, 8192, 16384):
-    out = np.zeros(3)
-    rc = lib.mi355gp_dbg_graph_factor(0, n, 5, out)
-    print(n, "rc", rc, "launched %.3f ms  graph %.3f ms  nodes %d" % tuple(out), flush=True)
-PY
+export TMPDIR=/tmp
+O=gpurun_out/r2x; mkdir -p $O
+( timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "graph_replay" 2>&1 | tail -15 ) > $O/pytest_graph.log 2>&1
+cat $O/pytest_graph.log

@@ -59,7 +59,9 @@ enum {
     MI355GP_NUM_OUT = 8
 };
 
-/* stage_ms[] layout (hipEvent timings of the last inference call, milliseconds) */
+/* stage_ms[] layout (hipEvent timings of the last inference call, milliseconds).  Passing stage_ms makes the call run plain
+ * launches: below N = 6144 a context otherwise replays its factorisation region (potrf, trtri, alpha solve, lauum) from a hipGraph
+ * captured at its second evaluation (MI355GP_GRAPH=0 disables it), and graph nodes carry no timing events. */
 enum {
     MI355GP_T_KBUILD = 0, MI355GP_T_POTRF = 1, MI355GP_T_TRTRI = 2, MI355GP_T_LAUUM = 3,
     MI355GP_T_SOLVE = 4, MI355GP_T_GRAD = 5, MI355GP_T_TOTAL = 6, MI355GP_NUM_T = 8

@@ -65,6 +65,7 @@ struct FactorWs {
     std::vector<hipEvent_t> ev_panel;        // [p]: outer panel p is factored
     std::vector<hipEvent_t> ev_cols;         // [p]: every update of panel p's columns has been issued (-> its factorisation)
     hipEvent_t ev_fork = nullptr;
+    int part1_on_panel = 1;     // MI355GP_PART1_ON_PANEL: part 1 of a step on the panel stream (no cross-stream hop before the next chain)
     int lookahead = 1;          // 1: panel p+1 factored on st_panel while the big update of step p runs; 0: serial reference schedule
     // outer panel width of the two-level right-looking Cholesky: NBO (512) keeps the big trailing update at 64 flop per
     // byte of C traffic (measured round 2: 128 / 256 are slower at every N from 2048 to 8192; MI355GP_NBO overrides)

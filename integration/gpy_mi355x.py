@@ -192,3 +192,127 @@ def make_classes(L, gpy=None):
     return types.SimpleNamespace(LazyFetch=LazyFetch, ExactGaussianInference=ExactGaussianInference,
                                  RBF=device_kernel(gpy.RBF, 0), Matern52=device_kernel(gpy.Matern52, 1),
                                  Matern32=device_kernel(gpy.Matern32, 2), Exponential=device_kernel(gpy.Exponential, 3))
+
+
+def bind_sparse(L):
+    """argument types of the sparse (VarDTC) entry points of include/mi355gp.h on an already bound library"""
+    from numpy.ctypeslib import ndpointer
+    dp = ndpointer(np.float64, flags="C_CONTIGUOUS")
+    ci, i64, cd, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+    L.mi355gp_sparse_create.argtypes = [ci, ctypes.POINTER(vp)]
+    L.mi355gp_sparse_destroy.argtypes = [vp]
+    L.mi355gp_sparse_set_data.argtypes = [vp, dp, i64, ci, dp, ci]
+    L.mi355gp_vardtc_inference.argtypes = [vp, ci, ci, dp, dp, i64, cd, cd, dp, _p, _p, _p, _p]
+    L.mi355gp_sparse_fetch.argtypes = [vp, ci, dp]
+    L.mi355gp_sparse_fetch_dLdKnm.argtypes = [vp, i64, i64, dp]
+    return L
+
+
+SP_DLDKMM, SP_WOODBURY_INV, SP_LM, SP_KMM = 0, 1, 2, 3
+
+
+def make_sparse_classes(L, gpy=None):
+    """`inference_method=` object for GPy.core.SparseGP (core/sparse_gp.py:49-56,76-119): a `VarDTC` whose `inference` runs on
+    the device and hands the reference's own `SparseGP._update_gradients` a `grad_dict` with the reference's keys.
+    `gpy`: namespace with LatentFunctionInference and Posterior (default: imported from an installed GPy)."""
+    if gpy is None:
+        from GPy.inference.latent_function_inference import LatentFunctionInference
+        from GPy.inference.latent_function_inference.posterior import Posterior
+        gpy = types.SimpleNamespace(LatentFunctionInference=LatentFunctionInference, Posterior=Posterior)
+    LinAlgError = np.linalg.LinAlgError
+
+    def check(rc, what):
+        if rc < 0:
+            raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, L.mi355gp_last_error().decode()))
+        return rc
+
+    class LazyNM(object):
+        """dL_dKnm (N x M): never resident as a whole on the device (3.3 GB at N=200000, M=2048); a consumer that needs the
+        array (a foreign kernel's update_gradients_full / gradients_X, core/sparse_gp.py:112-118) gets it assembled from row
+        blocks, the device-capable kernels of this module take `fused` instead."""
+        __array_priority__ = 100.0
+        ndim = 2
+
+        def __init__(self, owner, N, M, token, block=8192):
+            self._owner, self._token, self._block, self._host = owner, token, block, None
+            self.shape = (N, M)
+
+        def __array__(self, dtype=None, copy=None):
+            if self._host is None:
+                if self._owner._token != self._token:
+                    raise RuntimeError("device-resident result overwritten by a later inference call")
+                N, M = self.shape
+                out = np.empty((N, M))
+                for r0 in range(0, N, self._block):
+                    nr = min(self._block, N - r0)
+                    blk = np.empty((nr, M))
+                    check(L.mi355gp_sparse_fetch_dLdKnm(self._owner._ctx, r0, nr, blk), "mi355gp_sparse_fetch_dLdKnm")
+                    out[r0:r0 + nr] = blk
+                self._host = out
+            return self._host if dtype is None else self._host.astype(dtype, copy=False)
+
+        @property
+        def T(self):
+            return self.__array__().T
+
+    class VarDTC(gpy.LatentFunctionInference):
+        const_jitter = 1e-8
+
+        def __init__(self, device=0, maxtries=5):
+            self.device, self.maxtries = device, maxtries
+            self._ctx, self._X, self._Y, self._token = None, None, None, 0
+
+        def _ctx_for(self, X, Y):
+            if self._ctx is None:
+                self._ctx = ctypes.c_void_p()
+                check(L.mi355gp_sparse_create(self.device, ctypes.byref(self._ctx)), "mi355gp_sparse_create")
+            if self._X is None or self._X.shape != X.shape or self._Y.shape != Y.shape or \
+                    not (np.array_equal(self._X, X) and np.array_equal(self._Y, Y)):
+                check(L.mi355gp_sparse_set_data(self._ctx, X, X.shape[0], X.shape[1], Y, Y.shape[1]), "mi355gp_sparse_set_data")
+                self._X, self._Y = X.copy(), Y.copy()
+            return self._ctx
+
+        def _fetch(self, which, M):
+            out = np.empty((M, M))
+            check(L.mi355gp_sparse_fetch(self._ctx, which, out), "mi355gp_sparse_fetch")
+            return out
+
+        def inference(self, kern, X, Z, likelihood, Y, Y_metadata=None, mean_function=None, precision=None, Lm=None,
+                      dL_dKmm=None, psi0=None, psi1=None, psi2=None, Z_tilde=None):
+            """(reference `var_dtc.py:66-215`) for a device kernel of this module, certain inputs, a homoscedastic Gaussian
+            likelihood and no mean function -- anything else belongs to the reference's own VarDTC."""
+            kind = getattr(kern, "_mi355gp_kind", None)
+            if kind is None or mean_function is not None or precision is not None or psi1 is not None:
+                raise NotImplementedError("mi355gp VarDTC: device stationary kernel, certain inputs, no mean function")
+            noise = float(np.asarray(likelihood.gaussian_variance(Y_metadata)).ravel()[0])
+            Xd, Zd, Yd = _f64(kern._slice_X(X) if hasattr(kern, "_slice_X") else X), _f64(Z), _f64(Y)
+            ctx = self._ctx_for(Xd, Yd)
+            self._token += 1
+            N, M, Dy = Xd.shape[0], Zd.shape[0], Yd.shape[1]
+            theta = _f64(np.r_[float(np.asarray(kern.variance).ravel()[0]), np.asarray(kern.lengthscale, dtype=float).ravel()])
+            out, dtheta, dZ, wv = np.zeros(8), np.empty(theta.size), np.empty((M, Zd.shape[1])), np.empty((M, Dy))
+
+            def attempt(extra):
+                return check(L.mi355gp_vardtc_inference(ctx, kind, int(kern.ARD), theta, Zd, M, noise, extra, out, _ptr(dtheta),
+                                                        _ptr(dZ), _ptr(wv), None), "mi355gp_vardtc_inference")
+            if attempt(0.0) != 0:                                   # jitchol's ladder on Kmm / B (util/linalg.py:56-75)
+                jitter, tries, ok = theta[0] * 1e-6, 1, False
+                while tries <= self.maxtries and not ok:
+                    ok = attempt(jitter) == 0
+                    jitter *= 10
+                    tries += 1
+                if not ok:
+                    raise LinAlgError("not positive definite, even with jitter.")
+            beta = out[5]
+            post = gpy.Posterior(woodbury_inv=self._fetch(SP_WOODBURY_INV, M), woodbury_vector=wv,
+                                 K=self._fetch(SP_KMM, M), mean=None, cov=None, K_chol=self._fetch(SP_LM, M))
+            grad_dict = {"dL_dKmm": self._fetch(SP_DLDKMM, M),
+                         "dL_dKdiag": -0.5 * Dy * beta * np.ones(N),                 # var_dtc.py:218 (dL_dpsi0)
+                         "dL_dKnm": LazyNM(self, N, M, self._token),
+                         "dL_dthetaL": out[1],
+                         # what SparseGP._update_gradients would assemble from the three matrices above
+                         # (core/sparse_gp.py:108-118), reduced on the device in the same two passes:
+                         "fused": {"kern": kern, "dtheta": dtheta, "dZ": dZ}}
+            return post, out[0] + (0.0 if Z_tilde is None else Z_tilde), grad_dict
+
+    return types.SimpleNamespace(VarDTC=VarDTC, LazyNM=LazyNM)

@@ -301,3 +301,40 @@ def test_two_process_rccl_over_xgmi(mode, tmp_path):
         gref = np.concatenate([[ref["dvar"]], ref["dlen"]])
         assert abs(res[0]["lml"] - ref["lml"]) <= 1e-10 * abs(ref["lml"])
         assert np.abs(np.array(res[0]["dtheta"]) - gref).max() <= 1e-8 * np.abs(gref).max()
+
+
+def test_sparse_integration_stub_against_the_real_library():
+    """integration/gpy_mi355x.py `make_sparse_classes` (the reference-side VarDTC binding of INTEGRATION.md) bound to the real
+    libmi355gp.so, with gpy_amd's classes standing in for GPy's: posterior, LML, the fused gradients and the row-block
+    materialisation of dL_dKnm against the sparse oracle (the CPU suite runs the same file against the reference's own
+    classes with the library mocked by the oracle: tests/test_integration_stub.py)."""
+    import os
+    import sys
+    import types
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "integration"))
+    import gpy_amd
+    import gpy_mi355x
+    from oracle import sparse_oracle as SO
+    from gpy_amd.sparse import SparsePosterior
+    lib = gpy_mi355x.bind_sparse(gpy_mi355x.bind(L.LIB_PATH))
+    ns = types.SimpleNamespace(RBF=gpy_amd.RBF, Matern52=gpy_amd.Matern52, Matern32=gpy_amd.Matern32,
+                               Exponential=gpy_amd.Exponential, PosteriorExact=gpy_amd.PosteriorExact,
+                               LatentFunctionInference=object,
+                               Posterior=lambda woodbury_inv, woodbury_vector, K, mean, cov, K_chol: SparsePosterior(
+                                   woodbury_inv, woodbury_vector, K, K_chol))
+    C = gpy_mi355x.make_classes(lib, ns)
+    SC = gpy_mi355x.make_sparse_classes(lib, ns)
+    X, Y = O.synthetic(9000, 4, seed=21)                   # more than one 8192-row block of dL_dKnm
+    Z = SO.synthetic_Z(X, 70, 3)
+    var, ls, noise = O.default_theta(4, True)
+    ref = SO.vardtc("rbf", X, Z, Y, var, ls, True, noise)
+    k = C.RBF(4, variance=var, lengthscale=ls, ARD=True)
+    post, lml, gd = SC.VarDTC().inference(k, X, Z, gpy_amd.Gaussian(variance=noise), Y)
+    assert abs(lml - ref["lml"]) <= 1e-9 * abs(ref["lml"])
+    assert np.abs(post.woodbury_vector - ref["woodbury_vector"]).max() <= 1e-6 * np.abs(ref["woodbury_vector"]).max()
+    assert np.abs(gd["fused"]["dtheta"] - ref["dtheta"]).max() <= 1e-6 * np.abs(ref["dtheta"]).max()
+    assert np.abs(gd["fused"]["dZ"] - ref["dZ"]).max() <= 1e-6 * np.abs(ref["dZ"]).max()
+    assert abs(gd["dL_dthetaL"] - ref["dnoise"]) <= 1e-6 * abs(ref["dnoise"])
+    G = np.asarray(gd["dL_dKnm"])
+    assert G.shape == (9000, 70) and np.abs(G - ref["dL_dKnm"]).max() <= 1e-6 * np.abs(ref["dL_dKnm"]).max()
+    assert np.abs(np.asarray(gd["dL_dKmm"]) - ref["dL_dKmm"]).max() <= 1e-4 * np.abs(ref["dL_dKmm"]).max()

@@ -99,6 +99,44 @@ class OracleMockLib(object):
         self.calls.append("update_gradients_full")
         return 0
 
+    # ---- sparse (VarDTC) entry points, computed by oracle/sparse_oracle.py ----------------------------------------------
+    def mi355gp_sparse_create(self, device, ref):
+        return self.mi355gp_create(device, ref)
+
+    def mi355gp_sparse_set_data(self, ctx, X, N, D, Y, Dy):
+        assert X.shape == (N, D) and Y.shape == (N, Dy)
+        self.ctxs[ctx.value].update(X=X.copy(), R=Y.copy())
+        self.calls.append("sparse_set_data")
+        return 0
+
+    def mi355gp_vardtc_inference(self, ctx, kind, ard, theta, Z, M, noise_var, extra, out, dtheta, dZ, wv, ms):
+        from oracle import sparse_oracle as SO
+        c = self.ctxs[ctx.value]
+        self.calls.append("vardtc_inference")
+        self.extras.append(extra)
+        if len(self.extras) <= self.fail_first:
+            return 2
+        assert Z.shape == (M, c["X"].shape[1]) and extra == 0.0 or self.fail_first
+        r = SO.vardtc(KINDS[kind], c["X"], Z, c["R"], theta[0], theta[1:], bool(ard), noise_var)
+        out[:] = 0.0
+        out[0], out[1], out[5] = r["lml"], r["dnoise"], 1.0 / max(noise_var, 1e-8)
+        _arr(dtheta, theta.size)[:] = r["dtheta"]
+        _arr(dZ, Z.size)[:] = r["dZ"].ravel()
+        _arr(wv, M * c["R"].shape[1])[:] = r["woodbury_vector"].ravel()
+        c["sparse"] = r
+        return 0
+
+    def mi355gp_sparse_fetch(self, ctx, which, out):
+        r = self.ctxs[ctx.value]["sparse"]
+        out[:] = {0: r["dL_dKmm"], 1: r["woodbury_inv"], 2: r["Lm"], 3: r["Kmm"]}[which]
+        self.calls.append("sparse_fetch%d" % which)
+        return 0
+
+    def mi355gp_sparse_fetch_dLdKnm(self, ctx, row0, nrows, out):
+        out[:] = self.ctxs[ctx.value]["sparse"]["dL_dKnm"][row0:row0 + nrows]
+        self.calls.append("sparse_fetch_dLdKnm")
+        return 0
+
 
 @pytest.fixture(scope="module")
 def env():
@@ -182,3 +220,57 @@ def test_stub_given_K_heteroscedastic_variance_and_Z_tilde(env):
                                                          Z_tilde=1.25)
     assert "inference_given_K" in mock.calls and abs(lml - ref["lml"]) <= 1e-12 * abs(ref["lml"])
     assert abs(gd["dL_dthetaL"] - ref["dL_dnoise"]) <= 1e-10 * abs(ref["dL_dnoise"])
+
+
+@pytest.mark.parametrize("kind,cls,ARD,Dy", [("rbf", "RBF", True, 1), ("matern52", "Matern52", False, 2)])
+def test_sparse_stub_feeds_the_reference_update_gradients(env, kind, cls, ARD, Dy):
+    """integration `make_sparse_classes(...).VarDTC` against the reference's own `VarDTC` + the body of
+    `SparseGP._update_gradients` (core/sparse_gp.py:108-118) run with the REFERENCE's kernel on the stub's grad_dict: same
+    posterior, LML and gradients; the fused device reductions agree with what the reference assembles from the three matrices."""
+    import importlib
+    from oracle.sparse_oracle import synthetic_Z
+    ns, stub, gpy = env
+    gpy.Posterior = importlib.import_module("GPy.inference.latent_function_inference.posterior").Posterior
+    vd = importlib.import_module("GPy.inference.latent_function_inference.var_dtc")
+    mock = OracleMockLib()
+    S = stub.make_sparse_classes(mock, gpy)
+    C = stub.make_classes(mock, gpy)
+    X, Y = O.synthetic(260, 3, seed=5, Dy=Dy)
+    Z = synthetic_Z(X, 19, 5)
+    var, ls, noise = O.default_theta(3, ARD)
+    ls_arg = ls if ARD else float(ls[0])
+
+    def update_gradients(k, gd, Zv):                      # core/sparse_gp.py:108-118, verbatim order
+        k.update_gradients_diag(gd["dL_dKdiag"], X)
+        kg = np.r_[np.asarray(k.variance.gradient, float).ravel(), np.asarray(k.lengthscale.gradient, float).ravel()].copy()
+        k.update_gradients_full(np.asarray(gd["dL_dKnm"]), X, Zv)
+        kg += np.r_[np.asarray(k.variance.gradient, float).ravel(), np.asarray(k.lengthscale.gradient, float).ravel()]
+        k.update_gradients_full(np.asarray(gd["dL_dKmm"]), Zv, None)
+        kg += np.r_[np.asarray(k.variance.gradient, float).ravel(), np.asarray(k.lengthscale.gradient, float).ravel()]
+        dZ = k.gradients_X(np.asarray(gd["dL_dKmm"]), Zv) + k.gradients_X(np.asarray(gd["dL_dKnm"]).T, Zv, X)
+        return kg, dZ
+
+    k_ref = ref_loader.make_kernel(ns, kind, 3, var, ls_arg, ARD)
+    post_r, lml_r, gd_r = vd.VarDTC().inference(k_ref, X, Z, ns.Gaussian(variance=noise), Y)
+    kg_r, dZ_r = update_gradients(k_ref, gd_r, Z)
+
+    k_dev = getattr(C, cls)(3, variance=var, lengthscale=ls_arg, ARD=ARD)            # device kernel class of the stub
+    post, lml, gd = S.VarDTC().inference(k_dev, X, Z, ns.Gaussian(variance=noise), Y)
+    assert abs(lml - float(np.asarray(lml_r).ravel()[0])) <= 1e-10 * abs(float(np.asarray(lml_r).ravel()[0]))
+    assert np.abs(post.woodbury_vector - post_r.woodbury_vector).max() <= 1e-8 * np.abs(post_r.woodbury_vector).max()
+    assert np.abs(post.woodbury_inv - post_r.woodbury_inv).max() <= 1e-6 * np.abs(post_r.woodbury_inv).max()
+    assert abs(gd["dL_dthetaL"] - float(np.asarray(gd_r["dL_dthetaL"]).ravel()[0])) <= 1e-7 * abs(float(np.asarray(gd_r["dL_dthetaL"]).ravel()[0]))
+    assert np.allclose(gd["dL_dKdiag"], gd_r["dL_dKdiag"], rtol=1e-12)
+    # the reference's own gradient assembly, with the REFERENCE kernel, on the stub's grad_dict (dL_dKnm materialised in blocks)
+    k_ref2 = ref_loader.make_kernel(ns, kind, 3, var, ls_arg, ARD)
+    kg, dZ = update_gradients(k_ref2, gd, Z)
+    assert "sparse_fetch_dLdKnm" in mock.calls
+    assert np.abs(kg - kg_r).max() <= 1e-6 * np.abs(kg_r).max() and np.abs(dZ - dZ_r).max() <= 1e-6 * np.abs(dZ_r).max()
+    # ... and the fused reductions that travel with it are the same numbers
+    assert np.abs(gd["fused"]["dtheta"] - kg_r).max() <= 1e-6 * np.abs(kg_r).max()
+    assert np.abs(gd["fused"]["dZ"] - dZ_r).max() <= 1e-6 * np.abs(dZ_r).max()
+    # prediction through the reference's Posterior object (posterior.py:198-262)
+    Xs = np.random.default_rng(1).standard_normal((11, 3))
+    mu, v = post._raw_predict(k_ref2, Xs, Z, full_cov=False)
+    mu_r, v_r = post_r._raw_predict(k_ref, Xs, Z, full_cov=False)
+    assert np.abs(mu - mu_r).max() <= 1e-8 and np.abs(v - v_r).max() <= 1e-8

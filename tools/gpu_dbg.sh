@@ -1,5 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
 O=gpurun_out/r2z; mkdir -p $O
-( timeout 600 python -m pytest tests/test_gpu_sparse.py -m gpu -q -x -k "integration_stub" 2>&1 | tail -25 ) > $O/pytest_sp.log 2>&1
-cat $O/pytest_sp.log
+( python tools/sweep_env.py MI355GP_NBO 512,384,640,1024 --n 16384 --reps 3 --full
+  python tools/sweep_env.py MI355GP_NBO 512,384,1024 --n 8192 --reps 3 --full
+  python tools/sweep_env.py MI355GP_TRI_MIN_NT 48,32 --n 4096,5120 --reps 3 --full ) > $O/sweep12.log 2>&1
+cat $O/sweep12.log | cut -c1-150

@@ -48,13 +48,21 @@ class Comm(object):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # MI355GP_BENCH_BACKEND=gloo: rank plumbing over gloo (a dry run of the multi-rank flow on a box with fewer
+                # GPUs than ranks: ranks then share devices, local_rank is taken modulo the visible device count)
+                backend = os.environ.get("MI355GP_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device_tensor = True
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
             self.dist = dist
             self.torch = torch
+            if backend != "nccl" and os.environ.get("MI355GP_BENCH_BACKEND"):
+                try:
+                    from gpy_amd import _lib as _L
+                    self.local_rank %= max(1, _L.device_count())
+                except Exception:
+                    pass
 
     def _sync_device(self):
         if self.dist is not None and self.device_tensor:

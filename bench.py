@@ -14,7 +14,15 @@ Multi-GPU: the exact path does not shard without a panel exchange every 128 colu
 --gpus N runs N independent replicas (one process per GPU, no data-path collective, weak scaling); ranks only
 meet at the barriers that bracket the timed region and for the MAX-over-ranks of the elapsed time.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).  Besides the headline (configs[2]) the
+line carries one sub-record per other GPU configuration of BASELINE.json, each measured by a CHILD process with a timeout
+(a fault there cannot take the headline down) and each with its own parity block against the committed golden fixture:
+    "c2"             configs[1]  RBF N=4096 D=8 (one GPU; roofline + cpu_baseline)
+    "grid"           configs[3]  RBF N=32768 D=8 on the 2D block-cyclic grid: 2x4 LOGICAL ranks over the loopback transport
+                                 when the launch has one GPU (the real block-cyclic code, all ranks time-sharing the device),
+                                 RCCL over all ranks of the launch otherwise
+    "c5"             configs[4]  VarDTC N=200000 (per GPU) M=2048 D=16 (rows sharded over the ranks of the launch; roofline of
+                                 its dominant MFMA GEMM + cpu_baseline from the sparse oracle)
 """
 import argparse
 import json
@@ -175,17 +183,31 @@ def cpu_baseline(kind, ARD, D, n_small, n_full, full=False):
     return rec
 
 
-def profiled_traffic(kernel_prefix):
+def profiled_traffic(kernel_prefix, with_source=False):
     """HBM-side bytes per launch of the roofline kernel from the committed PMC summary (profiles/*_traffic.json, written
     by tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if no summary is committed."""
     import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")) if "sparse" not in f)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))
+                   if "sparse" not in f and "_c2_" not in f)
     if not files:
-        return None
+        return (None, None) if with_source else None
     try:
         ks = json.load(open(files[-1]))["kernels"]
         for name, v in ks.items():
+            if name.startswith(kernel_prefix):
+                return (v["hbm_bytes_per_launch"], os.path.basename(files[-1])) if with_source else v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return (None, None) if with_source else None
+
+
+def profiled_sparse_traffic(kernel_prefix):
+    """HBM-side bytes per launch of a sparse-path kernel from the committed PMC summary (profiles/*sparse_traffic.json)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*sparse_traffic.json")))
+    try:
+        for name, v in json.load(open(files[-1]))["kernels"].items():
             if name.startswith(kernel_prefix):
                 return v["hbm_bytes_per_launch"]
     except Exception:
@@ -235,13 +257,68 @@ def golden_check(kind, ARD, N, D, seed, lml, alpha, grad):
     return None
 
 
+def run_child(argv, timeout, env=None, single=True):
+    """`python bench.py <argv>` in a child process; returns the parsed JSON line (or {"error": ...}).  single: the child is a
+    one-process run of its own (rank variables of the parent launch are removed)."""
+    import subprocess
+    env = dict(os.environ if env is None else env)
+    if single:
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
+            env.pop(k, None)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, capture_output=True, text=True,
+                           timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %.0f s" % timeout}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": ("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-400:]}
+    try:
+        rec = json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": "unparsable child output: %s" % e}
+    rec["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+    return rec
+
+
+C2_KEEP = ("ms_per_step", "value", "unit", "steps", "warmup", "config", "stage_ms", "iteration_tflops",
+           "iteration_frac_of_fp64_peak", "cholesky_stage_gflops", "cholesky_stage_frac_of_fp64_peak", "cholesky_gflops",
+           "cholesky_frac_of_fp64_peak", "roofline", "families", "parity_checked", "parity", "cpu_baseline", "host_path", "lml",
+           "leg_wall_s", "error")
+
+
+def c2_leg(comm, args):
+    """BASELINE configs[1]: RBF iso, N=4096, D=8 on ONE GPU (rank 0's), through the drop-in classes."""
+    rec = run_child(["--n", "4096", "--d", "8", "--kind", "rbf", "--iso", "--steps", "300", "--warmup", "20", "--no-legs",
+                     "--device", str(comm.local_rank), "--cpu-sample-n", "2048"], timeout=240.0)
+    return {k: rec[k] for k in C2_KEEP if k in rec}
+
+
+def sparse_leg(comm, args, timeout=300.0):
+    """BASELINE configs[4] over ALL ranks of this launch (rows sharded, one all-reduce per pass) -- every rank spawns its own
+    child with its rank variables, like the grid leg."""
+    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 29))
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    argv = ["--sparse", "--steps", "12", "--warmup", "3"]
+    if comm.world == 1:
+        argv += ["--device", str(comm.local_rank)]
+    rec = run_child(argv, timeout, env=env, single=comm.world == 1)
+    if comm.rank != 0:
+        return None
+    rec.pop("metric", None)
+    return rec
+
+
 def grid_leg(comm, args, timeout=180.0):
     """BASELINE configs[3] (RBF, N=32768, D=8) on the 2D block-cyclic grid over ALL ranks of this launch
     (grid_shape(world); loopback transport when there is one process), run in CHILD processes with a timeout so that a
     fault of the never-before-timed multi-GPU path cannot take the headline line down.  Returns the sub-record (rank 0)."""
     import subprocess
     from gpy_amd import grid as G
-    Pr, Pc = G.grid_shape(comm.world)
+    # one GPU: the 2 x 4 grid of configs[3] as LOGICAL ranks over the loopback transport -- the block-cyclic code itself
+    # (tiles, panel broadcasts as device copies, look-ahead streams), not the degenerate 1 x 1 grid
+    Pr, Pc = G.grid_shape(comm.world) if comm.world > 1 else (2, 4)
     out_path = os.path.join(ROOT, "gpurun_out", "grid_leg_%s_%d.json" % (os.environ.get("MASTER_PORT", "0"), os.getpid()))
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     env = dict(os.environ, MI355GP_GRID_LEG_OUT=out_path if comm.rank == 0 else "",
@@ -249,8 +326,13 @@ def grid_leg(comm, args, timeout=180.0):
     env.pop("TORCHELASTIC_RUN_ID", None)
     cmd = [sys.executable, os.path.abspath(__file__), "--grid", "%dx%d" % (Pr, Pc), "--n", str(args.grid_n), "--d", "8",
            "--kind", "rbf", "--iso", "--steps", "3", "--warmup", "1", "--nb", str(args.nb), "--grid-child"]
-    rec = {"workload": "RBF iso exact GP N=%d D=8, one parameters_changed on a %dx%d block-cyclic grid" % (
-        args.grid_n, Pr, Pc)}
+    rec = {"workload": "RBF iso exact GP N=%d D=8, one parameters_changed on a %dx%d block-cyclic grid (%s)" % (
+        args.grid_n, Pr, Pc, "RCCL, one rank per GPU" if comm.world > 1 else "8 logical ranks time-sharing ONE GPU over the "
+        "loopback transport: the per-rank code path of the multi-GPU mode, no xGMI")}
+    if comm.world == 1:
+        cmd += ["--device", str(comm.local_rank)]
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
         ok = r.returncode == 0
@@ -281,6 +363,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     ap.add_argument("--no-grid-leg", action="store_true", help="skip the block-cyclic sub-record (configs[3])")
+    ap.add_argument("--no-legs", action="store_true", help="headline only: no c2 / grid / c5 sub-records")
+    ap.add_argument("--device", type=int, default=-1, help="HIP device of a one-process run (default: LOCAL_RANK)")
     ap.add_argument("--grid-n", type=int, default=32768)
     ap.add_argument("--grid-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--abi-only", action="store_true", help="time the bare C-ABI call instead of the drop-in classes")
@@ -299,6 +383,10 @@ def main():
 
     comm = Comm()
     assert comm.world == max(1, args.gpus) or comm.world == 1, "launch with torch.distributed.run for --gpus > 1"
+    if args.device >= 0 and comm.world == 1:
+        comm.local_rank = args.device
+    if args.no_legs:
+        args.no_grid_leg = True
     import gpy_amd
     from gpy_amd import _lib as L
     from gpy_amd.datasets import default_theta, synthetic
@@ -340,11 +428,15 @@ def main():
         st = last["r"]["stage_ms"]
         # roofline leg: the same step once more with hipEvent pairs around every k_update_nt / k_lauum launch (the timed
         # region above runs without them: ~2 us per bracketed launch)
-        ctx.set_option("profile", ("update_nt", "update_nt64", "lauum"))
+        ctx.set_option("profile", 1)
         step_abi()
         step_abi()
         pf = ctx.get_profile()
         ctx.set_option("profile", 0)
+        # every bracketed kernel family of ONE evaluation: summed launch ms, launches, algorithmic flops (the chain kernels
+        # k_diag128 / k_trsm128 run on the panel stream underneath the updates: their sum is not wall time)
+        families = {k: {"ms": round(v[0], 4), "launches": v[2], "flops": v[1],
+                        "tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else 0.0} for k, v in pf.items() if v[2] > 0}
         upd_ms, upd_flops, upd_n = pf["update_nt"]
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
         out = {
@@ -368,8 +460,12 @@ def main():
                                                     "kernels and the overlapped inverse)",
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS,
+                         # HBM-side bytes per launch from the PMC passes of THIS command (rocprofv3 cannot run inside the
+                         # timed process): the committed summary of the shipped schedule, named in traffic_source
                          "traffic": profiled_traffic("k_update_nt<") if (N, D, args.kind) == (16384, 32, "matern52")
                          else None,
+                         "traffic_source": ("profiles/%s" % profiled_traffic("k_update_nt<", True)[1])
+                         if (N, D, args.kind) == (16384, 32, "matern52") else None,
                          "launches_per_step": upd_n, "avg_launch_ms": upd_ms / max(upd_n, 1),
                          "algorithmic_flops_per_step": upd_flops,
                          "k_update_nt64": {"launches_per_step": pf["update_nt64"][2],
@@ -380,6 +476,7 @@ def main():
                                  "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                                  "frac": (pf["lauum"][1] / (pf["lauum"][0] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS)
                                  if pf["lauum"][0] > 0 else 0.0},
+            "families": families,
             "lml": lml,
         }
         if not args.abi_only:
@@ -420,11 +517,21 @@ def main():
                     out["parity"]["timed_config_vs_reference"] = g
     ctx.close()
     del m
+    if not args.no_legs:
+        comm.barrier()
+        if comm.rank == 0:
+            out["c2"] = c2_leg(comm, args)                    # configs[1], one GPU
+        comm.barrier()
     if not args.no_grid_leg:
         comm.barrier()
-        rec = grid_leg(comm, args)
+        rec = grid_leg(comm, args, timeout=240.0)
         if out is not None:
             out["grid"] = rec
+    if not args.no_legs:
+        comm.barrier()
+        rec = sparse_leg(comm, args)                          # configs[4], rows sharded over all ranks of the launch
+        if out is not None:
+            out["c5"] = rec
     if comm.rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.kind, ARD, D, min(args.cpu_sample_n, N // 2), N, full=args.cpu_full)
@@ -432,18 +539,81 @@ def main():
     comm.close()
 
 
+def sparse_cpu_baseline(D, M, n_full, n_small=4000):
+    """The sparse oracle (NumPy/SciPy restatement of GPy's VarDTC + SparseGP._update_gradients, oracle/sparse_oracle.py;
+    kind "port") on the host cores at TWO bounded sizes; the path is a + b N in the number of rows at fixed M (three N-column
+    dtrtrs, one syrk and one GEMM of M^2 N each, N M elementwise passes; the M^3 algebra is the constant), fitted through
+    both and evaluated at n_full."""
+    from oracle import gp_oracle as O
+    from oracle import sparse_oracle as S
+    var, ls, noise = O.default_theta(D, False)
+
+    def seconds(n):
+        X, Y = O.synthetic(n, D, seed=0)
+        Z = S.synthetic_Z(X, M, 0)
+        t0 = time.perf_counter()
+        S.vardtc("rbf", X, Z, Y, var, ls, False, noise)
+        return time.perf_counter() - t0
+    seconds(600)                                               # warm BLAS threads
+    threads = _cpu_threads()
+    n1, n2 = n_small, 2 * n_small
+    t1, t2 = seconds(n1), seconds(n2)
+    b = max((t2 - t1) / (n2 - n1), 0.0)
+    a = max(t1 - b * n1, 0.0)
+    if b == 0.0:
+        a, b = 0.0, t2 / n2
+    est = a + b * n_full
+    rec = {"unit": "iters/s", "cores": int(threads), "kind": "port", "host_cores": os.cpu_count() or 1, "value": 1.0 / est,
+           "estimated_seconds": est, "fit": {"a": a, "b_per_row": b, "n": [n1, n2], "seconds": [t1, t2]},
+           "sample": "one SparseGP.parameters_changed of the NumPy/SciPy sparse oracle (GPy's VarDTC algorithm) at N=%d (%.2f s) "
+                     "and N=%d (%.2f s), M=%d D=%d, on %d BLAS threads of %d host cores; t = a + b N fitted through both and "
+                     "evaluated at N=%d (%.0f s)" % (n1, t1, n2, t2, M, D, threads, os.cpu_count() or 1, n_full, est)}
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "baseline_c5_sparse_rbf_n200000_m2048_d16.npz"), allow_pickle=False)
+        if (int(g["N"]), int(g["M"]), int(g["D"])) == (n_full, M, D):
+            rec["committed_full_size"] = {"kind": "reference", "seconds": float(g["seconds"]), "host_cores": 8,
+                                          "what": "the REFERENCE'S OWN VarDTC + SparseGP._update_gradients at the full size on "
+                                                  "the 8-core build container (oracle/make_golden_baseline.py, stored in the "
+                                                  "golden fixture)"}
+    except Exception:
+        pass
+    return rec
+
+
+def sparse_golden_check(N, M, D, r):
+    """tests/golden/baseline_c5_*.npz holds the REFERENCE's outputs for exactly configs[4] (seed 0)."""
+    f = os.path.join(ROOT, "tests", "golden", "baseline_c5_sparse_rbf_n200000_m2048_d16.npz")
+    if not os.path.exists(f):
+        return None
+    g = np.load(f, allow_pickle=False)
+    if (int(g["N"]), int(g["M"]), int(g["D"])) != (N, M, D):
+        return None
+    err = {"fixture": os.path.basename(f), "against": str(g["source"]),
+           "lml_rel": abs(r["lml"] - float(g["lml"])) / abs(float(g["lml"])),
+           "dtheta_rel": float(np.abs(r["dtheta"] - g["dtheta"]).max() / np.abs(g["dtheta"]).max()),
+           "dnoise_rel": abs(r["dnoise"] - float(g["dnoise"])) / abs(float(g["dnoise"])),
+           "dZ_rel": float(np.abs(r["dZ"] - g["dZ"]).max() / np.abs(g["dZ"]).max()),
+           "woodbury_vector_rel": float(np.linalg.norm(r["woodbury_vector"] - g["woodbury_vector"]) /
+                                        np.linalg.norm(g["woodbury_vector"]))}
+    if not (err["lml_rel"] <= 1e-9 and err["dtheta_rel"] <= 1e-6 and err["dnoise_rel"] <= 1e-6 and err["dZ_rel"] <= 1e-6):
+        raise SystemExit("bench.py --sparse: the timed configuration disagrees with the reference golden: %r" % (err,))
+    return err
+
+
 def main_sparse(args):
     """BASELINE configs[4]: one SparseGP.parameters_changed (VarDTC + all gradients) per step; rows sharded over ranks
     (weak scaling: N rows PER GPU), Z / theta replicated, psi2 + gradient sums all-reduced over RCCL."""
     comm = Comm()
+    if args.device >= 0 and comm.world == 1:
+        comm.local_rank = args.device
     from gpy_amd import _lib as L
     from gpy_amd import grid as G
-    from gpy_amd.datasets import default_theta, synthetic
+    from gpy_amd.datasets import default_theta, synthetic, synthetic_Z
     n_per = 200000 if args.n == WORKLOAD["N"] else args.n
     D = 16 if args.d == WORKLOAD["D"] else args.d
     M, world = args.m, comm.world
     X, Y = synthetic(n_per * world, D, seed=0)                 # every rank generates the same global set ...
-    Z = X[np.random.default_rng(1).permutation(X.shape[0])[:M]].copy()
+    Z = synthetic_Z(X, M, 0)                                   # (the draw of the golden fixture)
     lo, hi = G.shard_rows(X.shape[0], comm.rank, world)        # ... and uploads only its shard
     var, ls, noise = default_theta(D, False)
     theta = L.theta_vec(var, ls, False, D)
@@ -464,6 +634,9 @@ def main_sparse(args):
         r = last["r"]
         N = X.shape[0]
         flops = 3.0 * N * M * M                               # psi2 (lower half) N M^2 + Kfu dL_dpsi2 2 N M^2
+        pf = c.get_profile()                                  # launch timing of the two MFMA kernels of the last timed step
+        gm_ms, gm_fl, gm_n = pf["gemm_T"]
+        gr_ms, gr_fl, gr_n = pf["gram_psi2"]
         out = {"metric": "sparse-GP (VarDTC) log_lik+grad iters/sec", "value": args.steps / dt, "unit": "iters/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -472,7 +645,25 @@ def main_sparse(args):
                           "N": N, "M": M, "D": D, "parallelism": "rows sharded x%d" % world},
                "rows_per_s": N * args.steps / dt, "gemm_tflops": flops / (dt / args.steps) / 1e12,
                "gemm_frac_of_fp64_peak": flops / (dt / args.steps) / 1e12 / (PEAK_FP64_TFLOPS * world),
-               "stage_ms": {k: round(float(v), 3) for k, v in r["stage_ms"].items()}, "lml": r["lml"]}
+               "stage_ms": {k: round(float(v), 3) for k, v in r["stage_ms"].items()}, "lml": r["lml"],
+               # dominant kernel of the path: T = Kfu dL_dpsi2 (var_dtc.py:231), 2 N M^2 flops on this rank's rows
+               "roofline": {"bound": "mfma", "kernel": "k_gemm_full<true, false, 4> (fp64 MFMA tile GEMM T = Kfu dL_dpsi2 of pass 2, "
+                                                       "128 x 128 tiles, K = M)",
+                            "achieved": gm_fl / (gm_ms * 1e-3) / 1e12 if gm_ms > 0 else 0.0, "peak": PEAK_FP64_TFLOPS,
+                            "unit": "TFLOP/s", "frac": (gm_fl / (gm_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS) if gm_ms > 0 else 0.0,
+                            "traffic": profiled_sparse_traffic("k_gemm_full<true, false"),
+                            "launches_per_step": gm_n, "avg_launch_ms": gm_ms / max(gm_n, 1),
+                            "algorithmic_flops_per_step": gm_fl,
+                            "k_gram_splitk": {"launches_per_step": gr_n, "avg_launch_ms": gr_ms / max(gr_n, 1),
+                                              "algorithmic_flops_per_step": gr_fl,
+                                              "frac": (gr_fl / (gr_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS) if gr_ms > 0 else 0.0}}}
+        if world == 1:
+            gc = sparse_golden_check(N, M, D, r)
+            out["parity_checked"] = gc is not None
+            if gc is not None:
+                out["parity"] = {"timed_config_vs_reference": gc}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = sparse_cpu_baseline(D, M, N)
         print(json.dumps(out), flush=True)
     c.close()
     comm.close()
@@ -481,6 +672,8 @@ def main_sparse(args):
 def main_grid(args):
     """Optional mode (north_star config 4): all GPUs factor ONE N x N problem, 2D block-cyclic over Pr x Pc."""
     comm = Comm()
+    if args.device >= 0 and comm.world == 1:
+        comm.local_rank = args.device
     from gpy_amd import _lib as L
     from gpy_amd import grid as G
     from gpy_amd.datasets import default_theta, synthetic

@@ -117,6 +117,8 @@ def lib():
     L.mi355gp_pdinv.argtypes = [ci, _dp, i64, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_pdinv_full.argtypes = [ci, _dp, i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_set_option.argtypes = [vp, ci, ci]
+    L.mi355gp_get_option.argtypes = [vp, ci, ctypes.POINTER(ci)]
+    L.mi355gp_sparse_get_profile.argtypes = [vp, _dp]
     L.mi355gp_bench_factor.argtypes = [ci, i64, ci, _c_dp, _c_dp, _c_dp]
     L.mi355gp_bench_factor.restype = ci
     L.mi355gp_get_profile.argtypes = [vp, _dp, _dp, ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
@@ -151,7 +153,8 @@ def lib():
                  "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm", "exact_inference_sum",
                  "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum", "dbg_mask_probe",
                  "vardtc_inference_sum", "sparse_predict", "sparse_fetch_dLdKnm", "sparse_attach_loopback",
-                 "predictive_gradients_sum", "dbg_pipe_share", "pdinv_full", "dbg_graph_factor"):
+                 "predictive_gradients_sum", "dbg_pipe_share", "pdinv_full", "dbg_graph_factor", "get_option",
+                 "sparse_get_profile"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -169,7 +172,13 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_covariance_between_points", "mi355gp_exact_studentt_sum", "mi355gp_vardtc_inference_sum",
             "mi355gp_sparse_predict", "mi355gp_sparse_fetch_dLdKnm", "mi355gp_sparse_attach_loopback",
             "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share", "mi355gp_pdinv_full", "mi355gp_dbg_graph_factor",
-            "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe")
+            "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe", "mi355gp_get_option",
+            "mi355gp_sparse_get_profile")
+
+
+# mi355gp_set_option / mi355gp_get_option ids (include/mi355gp.h, MI355GP_OPT_*)
+OPTIONS = {"profile": 0, "lookahead": 1, "tri_overlap": 2, "tri_min_nt": 3, "tri_h": 4, "tri_wgs": 5, "tri_half": 6,
+           "part1_on_panel": 7, "nbo": 8, "solve_overlap": 9, "diag_excl_first": 10, "graph": 11, "persist": 12}
 
 
 def last_error():
@@ -342,10 +351,17 @@ class Context(object):
         return rc, res
 
     def set_option(self, name, value):
-        """'lookahead': 0/1.  'profile': 0 = off, 1 = every kernel family, or a tuple of family names."""
+        """Options of THIS context through the C-ABI (`mi355gp_set_option`; the MI355GP_* environment variables only give the
+        process-wide defaults).  'profile': 0 = off, 1 = every kernel family, or a tuple of family names; 'lookahead': 0/1;
+        the schedule switches of OPTIONS take an int, -1 = back to the process default."""
         if name == "profile" and not isinstance(value, (int, bool)):
             value = sum(1 << PROFILE_FAMILIES.index(f) for f in value) << 1
-        check(lib().mi355gp_set_option(self._h, {"profile": 0, "lookahead": 1}[name], int(value)), "mi355gp_set_option")
+        check(lib().mi355gp_set_option(self._h, OPTIONS[name], int(value)), "mi355gp_set_option")
+
+    def get_option(self, name):
+        v = ctypes.c_int(0)
+        check(lib().mi355gp_get_option(self._h, OPTIONS[name], ctypes.byref(v)), "mi355gp_get_option")
+        return int(v.value)
 
     def get_profile(self):
         """{family: (ms, algorithmic flops, launches)} of the last inference call made with option 'profile' on."""
@@ -404,6 +420,13 @@ class SparseContext(object):
         self.N, self.D = X.shape
         self.Dy = Y.shape[1]
         check(lib().mi355gp_sparse_set_data(self._h, X, self.N, self.D, Y, self.Dy), "mi355gp_sparse_set_data")
+
+    def get_profile(self):
+        """Launch timing of the two MFMA kernels of the LAST vardtc call (hipEvent pairs on the launching stream):
+        {"gemm_T": (ms, algorithmic flops, launches), "gram_psi2": (...)} (`mi355gp_sparse_get_profile`)."""
+        o = np.zeros(6)
+        check(lib().mi355gp_sparse_get_profile(self._h, o), "mi355gp_sparse_get_profile")
+        return {"gemm_T": (o[0], o[1], int(o[2])), "gram_psi2": (o[3], o[4], int(o[5]))}
 
     def vardtc(self, kind, ARD, theta, Z, noise_var, extra_jitter=0.0, want_stage_ms=False):
         """(info, dict(lml, dnoise, dtheta, dZ, woodbury_vector[, stage_ms]))"""

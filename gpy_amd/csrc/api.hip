@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <climits>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -88,8 +89,28 @@ struct mi355gp_ctx {
     int fgraph_calls = 0, fgraph_lookahead = -1, graph_enabled = 1;     // MI355GP_GRAPH=0 turns it off
     double *dPack = nullptr, *hPack = nullptr;
     size_t packDoubles = 0, offGrad = 0, offAlpha = 0, offDiag = 0;
+    // schedule switches set through mi355gp_set_option (INT_MIN: the process default that factor_ws_alloc read)
+    int opt[MI355GP_OPT_NUM];
     double* dGradOutAll = nullptr;      // = dPack + offGrad: [part][groups][GP_STRIDE]
 };
+
+// (re)applies the context's option overrides to its factorisation workspace (after every factor_ws_alloc and set_option)
+static void apply_options(mi355gp_ctx* c) {
+    FactorWs& w = c->ws;
+    auto set = [&](int o, int* field) { if (c->opt[o] != INT_MIN) *field = c->opt[o]; };
+    set(MI355GP_OPT_LOOKAHEAD, &w.lookahead);
+    set(MI355GP_OPT_TRI_OVERLAP, &w.tri_overlap);
+    set(MI355GP_OPT_TRI_MIN_NT, &w.tri_min_nt);
+    set(MI355GP_OPT_TRI_H, &w.tri_h_override);
+    set(MI355GP_OPT_TRI_WGS, &w.tri_wgs);
+    set(MI355GP_OPT_TRI_HALF, &w.tri_half_ok);
+    set(MI355GP_OPT_PART1_ON_PANEL, &w.part1_on_panel);
+    set(MI355GP_OPT_NBO, &w.nbo_override);
+    set(MI355GP_OPT_SOLVE_OVERLAP, &w.solve_overlap);
+    set(MI355GP_OPT_DIAG_EXCL_FIRST, &w.diag_excl_first);
+    set(MI355GP_OPT_PERSIST, &w.persist);
+    if (c->opt[MI355GP_OPT_GRAPH] != INT_MIN) c->graph_enabled = c->opt[MI355GP_OPT_GRAPH] ? 1 : 0;
+}
 
 static void free_parts(mi355gp_ctx* c) {
     for (auto& p : c->parts)
@@ -145,6 +166,7 @@ int mi355gp_create(int device, mi355gp_ctx** out) {
     HIP_CHECK(hipSetDevice(device));
     mi355gp_ctx* c = new mi355gp_ctx();
     c->device = device;
+    for (int& o : c->opt) o = INT_MIN;
     if (factor_engine(device, &c->st, nullptr, nullptr) != 0) return -2;    // the device's shared main stream (factor.hip)
     for (auto& e : c->ev) HIP_CHECK(hipEventCreate(&e));
     {
@@ -170,6 +192,7 @@ int mi355gp_destroy(mi355gp_ctx* c) {
 int mi355gp_set_data(mi355gp_ctx* c, const double* X, int64_t N, int D, const double* R, int Dy) {
     ARG_CHECK(c && X && R && N > 0 && D > 0 && Dy > 0, "mi355gp_set_data: bad arguments");
     HIP_CHECK(hipSetDevice(c->device));
+    EngineShared gate(c->device);
     HIP_CHECK(hipStreamSynchronize(c->st));
     free_data(c);
     c->n = N;
@@ -186,6 +209,13 @@ int mi355gp_set_data(mi355gp_ctx* c, const double* X, int64_t N, int D, const do
     HIP_CHECK(hipMalloc(&c->B, sizeof(double) * np * np));
     HIP_CHECK(hipMalloc(&c->C, sizeof(double) * np * np));
     if (factor_ws_alloc(&c->ws, np) != 0) return -3;
+    {
+        const int lookahead = c->ws.lookahead;
+        const char* e = getenv("MI355GP_GRAPH");
+        c->graph_enabled = (e && *e) ? (atoi(e) ? 1 : 0) : 1;
+        apply_options(c);
+        if (c->opt[MI355GP_OPT_LOOKAHEAD] == INT_MIN) c->ws.lookahead = lookahead;
+    }
     HIP_CHECK(hipMalloc(&c->dTmp, sizeof(double) * N * Dy));
     const long nchunks = (N + trmv_chunk_rows(N) - 1) / trmv_chunk_rows(N);
     HIP_CHECK(hipMalloc(&c->dTrmvPart, sizeof(double) * nchunks * N * Dy));
@@ -211,6 +241,7 @@ int mi355gp_set_data(mi355gp_ctx* c, const double* X, int64_t N, int D, const do
 int mi355gp_set_targets(mi355gp_ctx* c, const double* R, int Dy) {
     ARG_CHECK(c && R && c->n > 0 && Dy == c->Dy, "mi355gp_set_targets: set_data first / Dy mismatch");
     HIP_CHECK(hipSetDevice(c->device));
+    EngineShared gate(c->device);
     HIP_CHECK(hipStreamSynchronize(c->st));
     HIP_CHECK(hipMemcpy(c->dR, R, sizeof(double) * c->n * Dy, hipMemcpyHostToDevice));
     return 0;
@@ -245,8 +276,8 @@ static void finish_dtheta(const KernParams& kp, const double* theta, const doubl
 }
 
 // Shared tail: given Ky (lower) in c->A: factor, invert, alpha, scalars [, kernel gradients].
-static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* theta, double* out_scalars,
-                        double* alpha_out, double* dtheta_out, double* diag_out, double* stage_ms,
+static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_grads, const double* theta,
+                        double* out_scalars, double* alpha_out, double* dtheta_out, double* diag_out, double* stage_ms,
                         double studentt_nu = 0.0) {
     hipStream_t st = c->st;
     const long n = c->n, np = c->npad;
@@ -288,12 +319,17 @@ static int run_pipeline(mi355gp_ctx* c, bool with_kernel_grads, const double* th
     } else if (c->fgraph_calls++ == 0) {
         if (int rc = region(false)) return rc;
     } else {
+        // The capture runs on the device's SHARED streams: while it is open, a launch that another host thread makes on
+        // them would be recorded into this graph instead of executed.  Entry points hold the engine gate shared;
+        // the capture window takes it exclusively (nothing inside the window waits for another thread).
         hipGraph_t g = nullptr;
+        gate->exclusive();
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
             const int rc = region(false);
             ok = (hipStreamEndCapture(st, &g) == hipSuccess) && rc == 0 && g != nullptr;
         }
+        gate->share();
         if (ok) ok = hipGraphInstantiate(&c->fgraph, g, nullptr, nullptr, 0) == hipSuccess;
         if (g) (void)hipGraphDestroy(g);
         if (!ok) {                                            // capture not possible here: stay on plain launches
@@ -509,6 +545,7 @@ int mi355gp_exact_inference_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* 
     ARG_CHECK(c && c->n > 0, "mi355gp_exact_inference: set_data first");
     ARG_CHECK(out_scalars != nullptr, "out_scalars is NULL");
     HIP_CHECK(hipSetDevice(c->device));
+    EngineShared gate(c->device);
     if (int rc = prepare_parts(c, nparts, parts)) return rc;
     if (int rc = upload_noise(c, noise, noise_len)) return rc;
     hipStream_t st = c->st;
@@ -522,7 +559,7 @@ int mi355gp_exact_inference_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* 
         launch_kbuild_sym(st, c->parts[(size_t)p].kp, c->parts[(size_t)p].dXt, c->npad, c->n, c->npad, dst, c->dNoise,
                           noise_len, jitter + extra_jitter, /*lower_only=*/1, /*add_diag=*/first, acc, mul);
     });
-    return run_pipeline(c, true, nullptr, out_scalars, alpha_out, dtheta_out, diag_dLdK_out, stage_ms);
+    return run_pipeline(c, &gate, true, nullptr, out_scalars, alpha_out, dtheta_out, diag_dLdK_out, stage_ms);
 }
 
 // Student-t PROCESS inference (ExactStudentTInference.inference, exact_studentt_inference.py:20-52): the same pdinv +
@@ -534,6 +571,7 @@ int mi355gp_exact_studentt_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* p
     ARG_CHECK(c && c->n > 0, "mi355gp_exact_studentt_sum: set_data first");
     ARG_CHECK(out_scalars != nullptr && nu > 2.0, "mi355gp_exact_studentt_sum: nu must exceed 2");
     HIP_CHECK(hipSetDevice(c->device));
+    EngineShared gate(c->device);
     if (int rc = prepare_parts(c, nparts, parts)) return rc;
     const double zero = 0.0;
     if (int rc = upload_noise(c, &zero, 1)) return rc;
@@ -547,7 +585,7 @@ int mi355gp_exact_studentt_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* p
         launch_kbuild_sym(st, c->parts[(size_t)p].kp, c->parts[(size_t)p].dXt, c->npad, c->n, c->npad, dst, c->dNoise, 1,
                           jitter + extra_jitter, 1, first, acc, mul);
     });
-    return run_pipeline(c, true, nullptr, out_scalars, alpha_out, dtheta_out, nullptr, stage_ms, nu);
+    return run_pipeline(c, &gate, true, nullptr, out_scalars, alpha_out, dtheta_out, nullptr, stage_ms, nu);
 }
 
 int mi355gp_exact_inference(mi355gp_ctx* c, int kind, int ard, const double* theta, const double* noise,
@@ -565,6 +603,7 @@ int mi355gp_inference_given_K(mi355gp_ctx* c, const double* K_host, const double
     ARG_CHECK(c && c->n > 0, "mi355gp_inference_given_K: set_data first");
     ARG_CHECK(K_host && out_scalars, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
+    EngineShared gate(c->device);
     if (int rc = upload_noise(c, noise, noise_len)) return rc;
     hipStream_t st = c->st;
     c->have_kernel = false;
@@ -572,12 +611,13 @@ int mi355gp_inference_given_K(mi355gp_ctx* c, const double* K_host, const double
     HIP_CHECK(hipMemcpyAsync(c->C, K_host, sizeof(double) * c->n * c->n, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipEventRecord(c->ev[0], st));
     launch_pad_from_dense(st, c->C, c->n, c->A, c->npad, c->dNoise, noise_len, jitter + extra_jitter);
-    return run_pipeline(c, false, nullptr, out_scalars, alpha_out, nullptr, diag_dLdK_out, stage_ms);
+    return run_pipeline(c, &gate, false, nullptr, out_scalars, alpha_out, nullptr, diag_dLdK_out, stage_ms);
 }
 
 int mi355gp_fetch(mi355gp_ctx* c, int which, double* out, int fortran_order) {
     ARG_CHECK(c && c->n > 0 && out, "mi355gp_fetch: bad arguments");
     HIP_CHECK(hipSetDevice(c->device));
+    EngineShared gate(c->device);
     const long n = c->n, np = c->npad;
     hipStream_t st = c->st;
     double* tmp = nullptr;
@@ -847,6 +887,7 @@ int mi355gp_predict_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* parts, c
     ARG_CHECK(c && c->n > 0 && c->have_factor, "mi355gp_predict: run an inference call first");
     ARG_CHECK(Xnew && M > 0 && mu_out, "mi355gp_predict: bad arguments");
     HIP_CHECK(hipSetDevice(c->device));
+    EngineShared gate(c->device);
     if (int rc = prepare_parts(c, nparts, parts)) return rc;
     hipStream_t st = c->st;
     const long n = c->n, np = c->npad, D = c->D, mp = round_up(M, NB), ld2 = round_up(M, 64);
@@ -928,6 +969,7 @@ int mi355gp_predictive_gradients_sum(mi355gp_ctx* c, int nparts, const mi355gp_p
     ARG_CHECK(Xnew && M > 0 && (dmu_out || dvar_out), "mi355gp_predictive_gradients: bad arguments");
     ARG_CHECK(c->D <= 32, "mi355gp_predictive_gradients: D <= 32");
     HIP_CHECK(hipSetDevice(c->device));
+    EngineShared gate(c->device);
     if (int rc = prepare_parts(c, nparts, parts)) return rc;
     ARG_CHECK(!has_product(c), "mi355gp_predictive_gradients: product kernels are not supported on the device");
     hipStream_t st = c->st;
@@ -1010,6 +1052,7 @@ int mi355gp_covariance_between_points(mi355gp_ctx* c, int nparts, const mi355gp_
     ARG_CHECK(c && c->n > 0 && c->have_factor, "mi355gp_covariance_between_points: run an inference call first");
     ARG_CHECK(X1 && X2 && M1 > 0 && M2 > 0 && out, "mi355gp_covariance_between_points: bad arguments");
     HIP_CHECK(hipSetDevice(c->device));
+    EngineShared gate(c->device);
     if (int rc = prepare_parts(c, nparts, parts)) return rc;
     hipStream_t st = c->st;
     const long n = c->n, np = c->npad, D = c->D;
@@ -1079,9 +1122,53 @@ int mi355gp_predict(mi355gp_ctx* c, int kind, int ard, const double* theta, cons
 
 int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
     ARG_CHECK(c != nullptr, "mi355gp_set_option: NULL context");
-    if (option == MI355GP_OPT_PROFILE) { c->ws.prof.on = (value != 0); c->ws.prof.mask = (value == 1) ? 0xffu : (unsigned)value >> 1; }
-    else if (option == MI355GP_OPT_LOOKAHEAD) c->ws.lookahead = (value == 0) ? 0 : 1;
-    else { mi355gp_set_error("mi355gp_set_option: unknown option %d", option); return -1; }
+    if (option == MI355GP_OPT_PROFILE) {
+        c->ws.prof.on = (value != 0);
+        c->ws.prof.mask = (value == 1) ? 0xffu : (unsigned)value >> 1;
+        return 0;
+    }
+    if (option < 0 || option >= MI355GP_OPT_NUM) {
+        mi355gp_set_error("mi355gp_set_option: unknown option %d", option);
+        return -1;
+    }
+    if (option == MI355GP_OPT_LOOKAHEAD) value = (value == 0) ? 0 : 1;
+    if (option == MI355GP_OPT_NBO && value > 0 && value % NB != 0) {
+        mi355gp_set_error("mi355gp_set_option: NBO must be a multiple of %d", NB);
+        return -1;
+    }
+    c->opt[option] = (value < 0) ? INT_MIN : value;
+    if (value < 0) {
+        // back to the process default: re-read what factor_ws_alloc reads (only the fields of this option are touched)
+        FactorWs d;
+        auto env = [](const char* n, int dflt) { const char* v = getenv(n); return (v && *v) ? atoi(v) : dflt; };
+        switch (option) {
+            case MI355GP_OPT_LOOKAHEAD: c->ws.lookahead = d.lookahead; break;
+            case MI355GP_OPT_TRI_OVERLAP: c->ws.tri_overlap = env("MI355GP_TRI_OVERLAP", d.tri_overlap) ? 1 : 0; break;
+            case MI355GP_OPT_TRI_MIN_NT: c->ws.tri_min_nt = env("MI355GP_TRI_MIN_NT", d.tri_min_nt); break;
+            case MI355GP_OPT_TRI_H: c->ws.tri_h_override = env("MI355GP_TRI_H", d.tri_h_override); break;
+            case MI355GP_OPT_TRI_WGS: c->ws.tri_wgs = env("MI355GP_TRI_WGS", d.tri_wgs); break;
+            case MI355GP_OPT_TRI_HALF: c->ws.tri_half_ok = env("MI355GP_TRI_HALF", d.tri_half_ok) ? 1 : 0; break;
+            case MI355GP_OPT_PART1_ON_PANEL: c->ws.part1_on_panel = env("MI355GP_PART1_ON_PANEL", d.part1_on_panel) ? 1 : 0; break;
+            case MI355GP_OPT_NBO: c->ws.nbo_override = env("MI355GP_NBO", d.nbo_override); break;
+            case MI355GP_OPT_SOLVE_OVERLAP: c->ws.solve_overlap = env("MI355GP_SOLVE_OVERLAP", d.solve_overlap) ? 1 : 0; break;
+            case MI355GP_OPT_DIAG_EXCL_FIRST: c->ws.diag_excl_first = env("MI355GP_DIAG_EXCL_FIRST", d.diag_excl_first) ? 1 : 0; break;
+            case MI355GP_OPT_PERSIST: c->ws.persist = env("MI355GP_PERSIST", d.persist); break;
+            case MI355GP_OPT_GRAPH: c->graph_enabled = env("MI355GP_GRAPH", 1) ? 1 : 0; break;
+            default: break;
+        }
+    }
+    apply_options(c);
+    drop_graph(c);                        // a captured factorisation region carries the old schedule
+    return 0;
+}
+
+int mi355gp_get_option(mi355gp_ctx* c, int option, int* value) {
+    ARG_CHECK(c && value && option > MI355GP_OPT_PROFILE && option < MI355GP_OPT_NUM, "mi355gp_get_option: bad arguments");
+    const FactorWs& w = c->ws;
+    const int v[MI355GP_OPT_NUM] = {0, w.lookahead, w.tri_overlap, w.tri_min_nt, w.tri_h_override, w.tri_wgs, w.tri_half_ok,
+                                    w.part1_on_panel, w.nbo_override, w.solve_overlap, w.diag_excl_first, c->graph_enabled,
+                                    w.persist};
+    *value = v[option];
     return 0;
 }
 

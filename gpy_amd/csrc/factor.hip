@@ -62,6 +62,8 @@ struct FactorEngine {
 };
 static FactorEngine g_engine[16];
 static std::mutex g_engine_mutex;
+static std::shared_mutex g_engine_gate[16];
+std::shared_mutex& engine_gate(int device) { return g_engine_gate[device & 15]; }
 
 int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t* tri, hipStream_t* tri_half) {
     if (device < 0 || device >= 16) return -1;
@@ -150,6 +152,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     if (envso && *envso) ws->solve_overlap = atoi(envso) ? 1 : 0;
     const char* envth = getenv("MI355GP_TRI_HALF");
     if (envth && *envth) ws->tri_half_ok = atoi(envth) ? 1 : 0;
+    const char* envps = getenv("MI355GP_PERSIST");
+    if (envps && *envps) ws->persist = atoi(envps);
     const char* envx = getenv("MI355GP_DIAG_EXCL_FIRST");
     if (envx && *envx) ws->diag_excl_first = atoi(envx) ? 1 : 0;
     HIP_CHECK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));

@@ -1,5 +1,6 @@
 // internal.h -- host-side launcher declarations shared by the translation units of libmi355gp.so.
 #pragma once
+#include <shared_mutex>
 #include <vector>
 
 #include "common.h"
@@ -91,7 +92,33 @@ struct FactorWs {
     // CU that no part-2 workgroup can join afterwards (27 us instead of 85-250 us next to one); small factorisations only
     int diag_excl_first = FACTOR_DEFAULT_DIAG_EXCL_FIRST, excl_first_ok = 0;
     int solve_overlap = 1;           // MI355GP_SOLVE_OVERLAP: alpha = X^T (X R) on st_tri underneath lauum
+    int persist = 0;                 // MI355GP_PERSIST: single-launch dataflow Cholesky for small factorisations (persist.hip)
     KernelProf prof;
+};
+// Gate of a device's shared engine streams.  Entry points that enqueue on them hold it SHARED for the duration of the call
+// (any number of host threads at once -- the loopback transports rendezvous inside such calls); a hipGraph capture window
+// on the shared streams holds it EXCLUSIVELY, so that no other thread's launch is recorded into the graph instead of run.
+std::shared_mutex& engine_gate(int device);
+struct EngineShared {
+    std::shared_mutex* m;
+    bool shared = true;
+    explicit EngineShared(int device) : m(&engine_gate(device)) { m->lock_shared(); }
+    EngineShared(const EngineShared&) = delete;
+    EngineShared& operator=(const EngineShared&) = delete;
+    ~EngineShared() {
+        if (shared) m->unlock_shared();
+        else m->unlock();
+    }
+    void exclusive() {
+        m->unlock_shared();
+        m->lock();
+        shared = false;
+    }
+    void share() {
+        m->unlock();
+        m->lock_shared();
+        shared = true;
+    }
 };
 // the process-wide main / panel / tri streams of a device (created on first use, shared, never destroyed)
 int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t* tri, hipStream_t* tri_half = nullptr);

@@ -226,6 +226,7 @@ struct mi355gp_sparse {
     hipEvent_t ev[6] = {};
     int h_info[2] = {0, 0};       // LAPACK-style info of the two M x M factorisations (targets of async copies: not on the stack)
     double beta_scalar = 0.0;     // homoscedastic precision of the last call (0: per-point)
+    KernelProf mfma_prof;         // launch timing of the two MFMA kernels of a call: family 0 = T = Kfu dL_dpsi2, 1 = split-K Gram
 };
 
 static int sparse_allreduce(mi355gp_sparse* s, double* buf, size_t count) {
@@ -402,6 +403,24 @@ int mi355gp_sparse_create(int device, mi355gp_sparse** out) {
     return 0;
 }
 
+int mi355gp_sparse_get_profile(mi355gp_sparse* s, double* out6) {
+    ARGCHK(s && out6, "mi355gp_sparse_get_profile: NULL argument");
+    HIP_CHECK(hipSetDevice(s->device));
+    HIP_CHECK(hipStreamSynchronize(s->st));
+    double ms[PF_NUM], fl[PF_NUM];
+    int nl[PF_NUM];
+    if (s->mfma_prof.collect(ms, fl, nl) != 0) {
+        mi355gp_set_error("mi355gp_sparse_get_profile: event timing failed");
+        return -5;
+    }
+    for (int f = 0; f < 2; ++f) {
+        out6[3 * f] = ms[f];
+        out6[3 * f + 1] = fl[f];
+        out6[3 * f + 2] = (double)nl[f];
+    }
+    return 0;
+}
+
 int mi355gp_sparse_destroy(mi355gp_sparse* s) {
     if (!s) return 0;
     (void)hipSetDevice(s->device);
@@ -413,6 +432,7 @@ int mi355gp_sparse_destroy(mi355gp_sparse* s) {
     if (s->comm) rccl_comm_destroy(s->comm);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
+    s->mfma_prof.destroy();
     if (s->st) (void)hipStreamSynchronize(s->st);
     delete s;
     return 0;
@@ -422,6 +442,7 @@ int mi355gp_sparse_set_data(mi355gp_sparse* s, const double* X, int64_t N, int D
     ARGCHK(s && X && Y && N > 0 && D > 0 && Dy > 0, "mi355gp_sparse_set_data: bad arguments");
     ARGCHK(D <= 32, "mi355gp_sparse_set_data: D <= 32 in this version (one LDS group of input dimensions)");
     HIP_CHECK(hipSetDevice(s->device));
+    EngineShared gate(s->device);
     HIP_CHECK(hipStreamSynchronize(s->st));
     free_m(s);
     double** ptrs[] = {&s->dX, &s->dY, &s->dV, &s->dBeta, &s->dRowS, &s->dRowT};
@@ -469,6 +490,7 @@ int mi355gp_sparse_set_data(mi355gp_sparse* s, const double* X, int64_t N, int D
 int mi355gp_sparse_attach_comm(mi355gp_sparse* s, int rank, int world, const void* id128) {
     ARGCHK(s && id128 && world >= 1 && rank >= 0 && rank < world, "mi355gp_sparse_attach_comm: bad arguments");
     HIP_CHECK(hipSetDevice(s->device));
+    EngineShared gate(s->device);
     if (s->comm) rccl_comm_destroy(s->comm);
     s->comm = nullptr;
     s->loop = nullptr;
@@ -512,6 +534,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     ARGCHK(!het || s->Dy == 1, "per-point noise needs a single output column (the reference's dL_dR, var_dtc.py:240-256)");
     ARGCHK(!het || dnoise_rows_out, "per-point noise: dnoise_rows_out (N) is required");
     HIP_CHECK(hipSetDevice(s->device));
+    EngineShared gate(s->device);
     const int D = s->D, Dy = s->Dy;
     if (M != s->m)
         if (int rc = alloc_m(s, M)) return rc;
@@ -532,6 +555,9 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     }
     const double beta = het ? 0.0 : hbeta[0];
     s->beta_scalar = beta;
+    s->mfma_prof.on = true;
+    s->mfma_prof.mask = 0x3u;
+    s->mfma_prof.reset();
     s->have_result = s->winv_ok = false;
     HIP_CHECK(hipMemcpyAsync(s->dBeta, hbeta.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(s->dZ, Z, sizeof(double) * m * D, hipMemcpyHostToDevice, st));
@@ -569,7 +595,9 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
             launch_rowscale_sqrt(st, s->Kfu, mp, rc, mp, s->dBeta + r0, s->T);
             G = s->T;
         }
+        s->mfma_prof.begin(st, 1, (double)rc * (double)m * (double)m);            // algorithmic: the lower half of psi2
         launch_gram_splitk(st, G, mp, round_up(rc, 16L * s->splitk), mp, s->splitk, nch > 0, s->psi2part);   // rows >= rc are zero
+        s->mfma_prof.end(st);
         const int ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, s->dV + r0 * Dy, Dy, 1, Dy, 0, s->colPart);
         launch_sum_splits(st, s->colPart, mp * Dy, ns, 1, s->psi1Y);               // psi1V += Kuf V_chunk
     }
@@ -626,7 +654,9 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
             if (rc < chunk) HIP_CHECK(hipMemsetAsync(s->Kfu + rc * mp, 0, sizeof(double) * (chunk - rc) * mp, st));
             build_cross_chunk(s, rc, s->Kfu);
         }
+        s->mfma_prof.begin(st, 0, 2.0 * (double)rc * (double)m * (double)m);
         launch_gemm(st, 0, 1, rcp, mp, mp, s->Kfu, mp, s->Q2, mp, s->T, mp, 1.0, 0.0);
+        s->mfma_prof.end(st);
         // per-row reductions for dL_dm = V - Kfu v (:148) and the per-point noise gradient (t_n = sum_j T_nj Kfu_nj)
         if (want_rows) launch_rowdots(st, s->Kfu, s->T, mp, rc, m, s->vvec, Dy, s->dRowS + r0 * Dy, het ? s->dRowT + r0 : nullptr);
         // dL_dKnm is formed inside the gradient pass (no separate read-modify-write of the chunk).  D <= 16: the same pass
@@ -839,6 +869,7 @@ static int ensure_winv(mi355gp_sparse* s) {
 int mi355gp_sparse_fetch(mi355gp_sparse* s, int which, double* out) {
     ARGCHK(s && out && s->have_result, "mi355gp_sparse_fetch: run mi355gp_vardtc_inference first");
     HIP_CHECK(hipSetDevice(s->device));
+    EngineShared gate(s->device);
     hipStream_t st = s->st;
     const long m = s->m, mp = s->mp;
     const double* src = nullptr;
@@ -871,6 +902,7 @@ int mi355gp_sparse_fetch_dLdKnm(mi355gp_sparse* s, int64_t row0, int64_t nrows, 
     ARGCHK(s && out && s->have_result, "mi355gp_sparse_fetch_dLdKnm: run mi355gp_vardtc_inference first");
     ARGCHK(row0 >= 0 && nrows > 0 && row0 + nrows <= s->n && nrows <= s->chunk, "mi355gp_sparse_fetch_dLdKnm: bad row range");
     HIP_CHECK(hipSetDevice(s->device));
+    EngineShared gate(s->device);
     hipStream_t st = s->st;
     const long m = s->m, mp = s->mp, rc = nrows, rcp = round_up(rc, NB);
     if (int e = scale_for_parts(s, s->dX + row0 * s->D, rc, s->chunk, false)) return e;
@@ -894,6 +926,7 @@ int mi355gp_sparse_predict(mi355gp_sparse* s, int nparts, const mi355gp_part* pa
     ARGCHK(s && s->have_result, "mi355gp_sparse_predict: run mi355gp_vardtc_inference first");
     ARGCHK(Xnew && Mn > 0 && mu_out, "mi355gp_sparse_predict: bad arguments");
     HIP_CHECK(hipSetDevice(s->device));
+    EngineShared gate(s->device);
     if (int rc = prepare_sparse_parts(s, nparts, parts)) return rc;
     hipStream_t st = s->st;
     const long m = s->m, mp = s->mp, D = s->D, Dy = s->Dy, mnp = round_up(Mn, NB), ldn = round_up(Mn, 64);

@@ -17,3 +17,9 @@ def synthetic(N, D, seed=0, Dy=1):
 def default_theta(D, ARD):
     ls = np.linspace(0.5, 2.0, D) * np.sqrt(D / 8.0) if ARD else np.array([0.7 * np.sqrt(D)])
     return 1.3, ls, 0.1
+
+
+def synthetic_Z(X, M, seed=0):
+    """Inducing inputs Z = X[perm[:M]] (reference `models/sparse_gp_regression.py:41-43`), the draw the golden fixtures use."""
+    rng = np.random.default_rng(seed + 77)
+    return np.ascontiguousarray(X[rng.permutation(X.shape[0])[:M]].copy())

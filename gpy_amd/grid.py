@@ -107,12 +107,30 @@ def exchange_id_torch(id_bytes, rank):
     return bytes(t.cpu().tolist())
 
 
-def exchange_id_file(id_bytes, rank, path, timeout=120.0, world=None):
-    """Rank 0 writes the id to `path` (atomically, mode 0600); the others poll for it.  A file is only accepted if it was
-    written no earlier than 30 s before this process started (a left-over of an earlier, crashed job is ignored); with `world` given,
-    every reader drops an acknowledgement next to it and rank 0 removes the files once all have read."""
+def job_nonce():
+    """Identity of THIS launch of the job, common to all its ranks: MI355GP_JOB_NONCE if set, else what torchrun exports
+    (TORCHELASTIC_RUN_ID + restart count), else MASTER_ADDR:MASTER_PORT; '' when the launcher gives nothing."""
+    n = os.environ.get("MI355GP_JOB_NONCE")
+    if n:
+        return n
+    rid = os.environ.get("TORCHELASTIC_RUN_ID")
+    if rid:
+        return "%s#%s" % (rid, os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    if os.environ.get("MASTER_PORT"):
+        return "%s:%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ["MASTER_PORT"])
+    return ""
+
+
+def exchange_id_file(id_bytes, rank, path, timeout=120.0, world=None, nonce=None):
+    """Rank 0 writes the id to `path` (atomically, mode 0600); the others poll for it.  The file carries the launch's
+    `job_nonce()` in front of the id and a reader accepts only a file with ITS OWN nonce: a rank that starts minutes after
+    rank 0 still accepts it, a left-over of a crashed earlier launch (other restart count / run id) never is.
+    Without any nonce from the launcher the modification time decides (not older than this process's start minus 30 s).
+    With `world` given, every reader drops an acknowledgement next to it and rank 0 removes the files once all have read."""
     import time
     t_start = _PROCESS_START
+    nonce = (job_nonce() if nonce is None else nonce).encode()
+    header = b"MI355GPID" + bytes([len(nonce) >> 8, len(nonce) & 255]) + nonce
     if rank == 0:
         for old in (path,):
             try:
@@ -122,7 +140,7 @@ def exchange_id_file(id_bytes, rank, path, timeout=120.0, world=None):
         tmp = path + ".tmp%d" % os.getpid()
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
         with os.fdopen(fd, "wb") as f:
-            f.write(id_bytes)
+            f.write(header + id_bytes)
         os.replace(tmp, path)
         if world:
             t0 = time.time()
@@ -139,12 +157,14 @@ def exchange_id_file(id_bytes, rank, path, timeout=120.0, world=None):
     while time.time() - t0 < timeout:
         try:
             st = os.stat(path)
-            if st.st_size == ID_BYTES and st.st_mtime >= t_start - 30.0:
+            if st.st_size == len(header) + ID_BYTES:
                 with open(path, "rb") as f:
                     data = f.read()
-                if world:
-                    open(path + ".ack%d" % rank, "wb").close()
-                return data
+                fresh = st.st_mtime >= t_start - 30.0 if not nonce else True
+                if data[:len(header)] == header and len(data) == len(header) + ID_BYTES and fresh:
+                    if world:
+                        open(path + ".ack%d" % rank, "wb").close()
+                    return data[len(header):]
         except OSError:
             pass
         time.sleep(0.05)

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from .kern import CombinationKernel, Stationary
-from .lazy import DeviceResult, kernel_signature
+from .lazy import ArrayIdentity, DeviceResult, kernel_signature
 from .likelihoods import Gaussian
 from .posterior import PosteriorExact, StudentTPosterior
 
@@ -25,35 +25,37 @@ class _DeviceState(object):
 
     def __init__(self, device):
         self.ctx = _lib.Context(device)
-        self.X = None
-        self.R = None
-        self._tokX = self._tokR = None
+        self._idX = self._idR = None
         self.call_token = 0
         self.kern = None
 
     def __getstate__(self):              # the HBM buffers and the ctypes handle never travel
-        return {"X": None, "R": None, "_tokX": None, "_tokR": None, "call_token": self.call_token, "kern": None,
-                "ctx": None}
-
-    @staticmethod
-    def _token(a):
-        """O(1) identity token of a host array: the object, its buffer address / shape / strides and 64 strided samples.
-        GPy hands the SAME immutable `ObsAr` X (and the same Y) to every iteration of an optimisation
-        (reference `core/gp.py:44-60`), so the per-iteration check must not cost O(N D) like `np.array_equal` does."""
-        flat = a.reshape(-1)
-        step = max(1, flat.size // 64)
-        return (id(a), a.__array_interface__["data"][0], a.shape, a.strides, flat[::step][:64].tobytes())
+        return {"_idX": None, "_idR": None, "call_token": self.call_token, "kern": None, "ctx": None}
 
     def ensure_data(self, X, R):
-        tx, tr = self._token(X), self._token(R)
-        same_x = self.X is not None and (tx == self._tokX or (self.X.shape == X.shape and np.array_equal(self.X, X)))
-        if not same_x or self.R.shape != R.shape:
+        """Upload X / R unless the device already holds exactly these data.  An array the caller froze (the model drivers
+        keep private read-only copies of X and Y, like GPy's `ObsAr`, reference `core/gp.py:44-60`) is recognised by
+        identity in O(1); anything writable is compared element by element with a private copy (O(N D), negligible next
+        to the N^3 step) -- an in-place edit of a caller-owned buffer is never missed."""
+        same_x = self._idX is not None and self._idX.matches(X)
+        if not same_x or self._idR is None or self._idR.value().shape != R.shape:
             self.ctx.set_data(X, R)
-            self.X, self.R = X.copy(), R.copy()
-        elif not (tr == self._tokR or np.array_equal(self.R, R)):
+            self._idX, self._idR = ArrayIdentity(X), ArrayIdentity(R)
+        elif not self._idR.matches(R):
             self.ctx.set_targets(R)
-            self.R = R.copy()
-        self._tokX, self._tokR = tx, tr
+            self._idR = ArrayIdentity(R)
+
+    @property
+    def X(self):
+        return None if self._idX is None else self._idX.value()
+
+    @property
+    def R(self):
+        return None if self._idR is None else self._idR.value()
+
+    def invalidate(self):
+        """Forget what was uploaded: the next inference call uploads X and R again."""
+        self._idX = self._idR = None
 
     def fetch(self, which, fortran_order=False):
         return self.ctx.fetch(which, fortran_order=fortran_order)

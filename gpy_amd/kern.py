@@ -11,38 +11,34 @@ All array math runs in hand-written HIP kernels (csrc/kern.hip); there is no Num
 import numpy as np
 
 from . import _lib
-from .lazy import DeviceResult
+from .lazy import ArrayIdentity, DeviceResult
 from .param import Param, Parameterized
 
 
 class _KCache(object):
     """`@Cache_this(limit=3)` of the reference's `Stationary.K` (`stationary.py:96-105`, paramz `Cacher`): the last
-    `limit` results keyed by the identity of (X, X2) and the exact parameter bits, so the K that the inference step
-    evaluated is not recomputed (upload + build + download) when the gradient / prediction step asks for it again.
-    paramz invalidates through `ObsAr` observers; here an entry carries an O(1) fingerprint of its inputs (buffer
-    address, shape, strides and 64 strided samples) that is re-checked on every hit."""
+    `limit` results keyed by (X, X2) and the exact parameter bits, so the K that the inference step evaluated is not
+    recomputed (upload + build + download) when the gradient / prediction step asks for it again.
+    paramz caches only for `Observable` inputs and invalidates through their observers.  Here an input is recognised either
+    by identity -- only if it is FROZEN (read-only through its whole base chain, which is how the model drivers hold X) --
+    or by a full element-wise comparison with a private copy (O(N D), nothing next to the N^2 D build); never by a sampled
+    fingerprint or by the address of a writable buffer.  The cached matrix is shared between callers and therefore
+    read-only: `K = k.K(X).copy()` before editing it in place (the reference hands out its cache entry writable, and an
+    in-place edit silently corrupts later hits)."""
 
     def __init__(self, limit=3):
         self.limit = limit
-        self.entries = []            # [(key, value)], most recent last
-
-    @staticmethod
-    def _fp(a):
-        if a is None:
-            return None
-        flat = a.reshape(-1)
-        step = max(1, flat.size // 64)
-        return (id(a), a.__array_interface__["data"][0], a.shape, a.strides, flat[::step][:64].tobytes())
+        self.entries = []            # [(idX, idX2, theta bytes, value)], most recent last
 
     def get(self, X, X2, theta, compute):
-        key = (self._fp(X), self._fp(X2), theta.tobytes())
-        for i, (k, v) in enumerate(self.entries):
-            if k == key:
+        tb = theta.tobytes()
+        for i, (ix, ix2, t, v) in enumerate(self.entries):
+            if t == tb and ix.matches(X) and ix2.matches(X2):
                 self.entries.append(self.entries.pop(i))
                 return v
         v = compute()
         v.setflags(write=False)      # shared between callers, like paramz's cached arrays
-        self.entries.append((key, v))
+        self.entries.append((ArrayIdentity(X), ArrayIdentity(X2), tb, v))
         if len(self.entries) > self.limit:
             self.entries.pop(0)
         return v

@@ -11,6 +11,59 @@ import numpy as np
 from . import _lib
 
 
+def frozen(a):
+    """True when nobody can write through `a` or any array it is a view of: every ndarray in its base chain is
+    read-only and the chain ends in memory NumPy itself owns.  Only such arrays can be recognised by IDENTITY from one
+    call to the next; GPy gets the same guarantee from `ObsAr` observers (reference `core/gp.py:44-60`)."""
+    while isinstance(a, np.ndarray):
+        if a.flags.writeable:
+            return False
+        a = a.base
+    return a is None
+
+
+def freeze(a):
+    """A private, read-only float64 C-contiguous copy of `a` (what the model drivers keep as X / Y)."""
+    b = np.array(a, dtype=np.float64, order="C", copy=True)
+    b.setflags(write=False)
+    return b
+
+
+class ArrayIdentity(object):
+    """Remembers one host array so that a later call can tell whether it was handed THE SAME DATA.
+    A frozen array (see `frozen`) is remembered by object identity: O(1) per call, and it cannot have been edited in place.
+    Anything else is remembered as a private copy and compared element by element (O(size), like paramz would re-run the
+    computation for a plain ndarray): a sampled fingerprint can miss an in-place edit, identity of a writable buffer can
+    alias a different array after the allocator reuses the address."""
+
+    __slots__ = ("obj", "copy")
+
+    def __init__(self, a):
+        if a is None:
+            self.obj = self.copy = None
+        elif frozen(a):
+            self.obj, self.copy = a, None
+        else:
+            self.obj, self.copy = None, np.array(a, copy=True)
+
+    def matches(self, b):
+        if b is None:
+            return self.obj is None and self.copy is None
+        if self.obj is not None:
+            if b is self.obj and frozen(b):
+                return True
+            ref = self.obj
+        elif self.copy is not None:
+            ref = self.copy
+        else:
+            return False
+        b = np.asarray(b)
+        return ref.shape == b.shape and ref.dtype == b.dtype and np.array_equal(ref, b)
+
+    def value(self):
+        return self.obj if self.obj is not None else self.copy
+
+
 class DeviceResult(object):
     __array_priority__ = 100.0
 

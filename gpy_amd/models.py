@@ -11,6 +11,7 @@ import numpy as np
 
 from .inference import ExactGaussianInference
 from .kern import RBF
+from .lazy import freeze
 from .likelihoods import Gaussian
 from .param import Parameterized
 
@@ -146,14 +147,17 @@ class GP(PredictionCallers, Parameterized):
     def __init__(self, X, Y, kernel, likelihood, mean_function=None, inference_method=None, name="gp",
                  Y_metadata=None, device=0, normalizer=False):
         super(GP, self).__init__(name)
-        X, Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+        # private read-only copies, as GPy wraps X / Y in `ObsAr` (reference `core/gp.py:44-60`): a frozen array is what
+        # lets the per-iteration "same data?" check of the inference method be O(1) without ever missing an edit.  New
+        # data go through set_XY / set_X / set_Y; `m.X[i] = ...` raises instead of silently leaving the device stale.
+        X, Y = freeze(X), freeze(Y)
         assert X.ndim == 2 and Y.ndim == 2
         self.X, self.Y = X, Y
         # (reference `core/gp.py:49-60`): normalizer=True -> Standardize
         self.normalizer = Standardize() if normalizer is True else (None if normalizer is False else normalizer)
         if self.normalizer is not None:
             self.normalizer.scale_by(Y)
-            self.Y_normalized = self.normalizer.normalize(Y)
+            self.Y_normalized = freeze(self.normalizer.normalize(Y))
         else:
             self.Y_normalized = Y
         self.num_data, self.input_dim = X.shape
@@ -191,13 +195,13 @@ class GP(PredictionCallers, Parameterized):
     def set_XY(self, X=None, Y=None):
         """(reference `core/gp.py:188-246`)"""
         if X is not None:
-            self.X = np.asarray(X, dtype=np.float64)
+            self.X = freeze(X)                      # a copy: later in-place edits of the caller's buffer do not alias it
             self.num_data = self.X.shape[0]
         if Y is not None:
-            self.Y = np.asarray(Y, dtype=np.float64)
+            self.Y = freeze(Y)
             if self.normalizer is not None:
                 self.normalizer.scale_by(self.Y)
-                self.Y_normalized = self.normalizer.normalize(self.Y)
+                self.Y_normalized = freeze(self.normalizer.normalize(self.Y))
             else:
                 self.Y_normalized = self.Y
         self.parameters_changed()

@@ -14,6 +14,7 @@ import numpy as np
 
 from . import _lib
 from .kern import RBF, Stationary
+from .lazy import ArrayIdentity, freeze
 from .likelihoods import Gaussian
 from .models import PredictionCallers
 from .param import Param, Parameterized
@@ -190,10 +191,10 @@ class VarDTC(object):
     def _ensure(self, X, Y):
         if self._ctx is None:
             self._ctx = _lib.SparseContext(self.device)
-        if self._X is None or self._X.shape != X.shape or self._Y.shape != Y.shape or \
-                not (np.array_equal(self._X, X) and np.array_equal(self._Y, Y)):
+        # frozen arrays (the model driver's X / Y) are recognised by identity, anything else by a full comparison
+        if self._X is None or not (self._X.matches(X) and self._Y.matches(Y)):
             self._ctx.set_data(X, Y)
-            self._X, self._Y = X.copy(), Y.copy()
+            self._X, self._Y = ArrayIdentity(X), ArrayIdentity(Y)
 
     def inference(self, kern, X, Z, likelihood, Y, Y_metadata=None, mean_function=None, precision=None, Lm=None,
                   dL_dKmm=None, psi0=None, psi1=None, psi2=None, Z_tilde=None):
@@ -262,7 +263,7 @@ class SparseGP(PredictionCallers, Parameterized):
                  Y_metadata=None):
         super(SparseGP, self).__init__(name)
         self.mean_function, self.Y_metadata = mean_function, Y_metadata
-        self.X, self.Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+        self.X, self.Y = freeze(X), freeze(Y)        # private read-only copies (cf. `ObsAr`, reference `core/gp.py:44-60`)
         self.Y_normalized = self.Y
         self.num_data, self.input_dim = self.X.shape
         self.output_dim = self.Y.shape[1]
@@ -309,17 +310,21 @@ class SparseGP(PredictionCallers, Parameterized):
         """(reference `core/sparse_gp.py:72-74`)"""
         return self.Z.values
 
-    def _raw_predict(self, Xnew, full_cov=False):
-        """(reference `core/sparse_gp.py:121-160` -> `posterior.py:198-262`)"""
-        mu, var = self.posterior._raw_predict(self.kern, np.asarray(Xnew), self.Z.values, full_cov=full_cov)
+    def _raw_predict(self, Xnew, full_cov=False, kern=None):
+        """(reference `core/sparse_gp.py:121-160` -> `posterior.py:198-262`; same signature as `GP._raw_predict`)"""
+        mu, var = self.posterior._raw_predict(self.kern if kern is None else kern, np.asarray(Xnew), self.Z.values,
+                                              full_cov=full_cov)
         if self.mean_function is not None:
             mu = mu + self.mean_function.f(Xnew)
         return mu, var
 
-    def predict(self, Xnew, full_cov=False, include_likelihood=True, Y_metadata=None):
-        mu, var = self._raw_predict(Xnew, full_cov)
+    def predict(self, Xnew, full_cov=False, Y_metadata=None, kern=None, likelihood=None, include_likelihood=True):
+        """(reference `core/gp.py:308-365`, inherited by `SparseGP`: same argument order)"""
+        mu, var = self._raw_predict(Xnew, full_cov, kern=kern)
         if include_likelihood:
-            mu, var = self.likelihood.predictive_values(mu, var, full_cov=full_cov, Y_metadata=Y_metadata)
+            likelihood = self.likelihood if likelihood is None else likelihood
+            mu, var = likelihood.predictive_values(mu, var, full_cov=full_cov,
+                                                   Y_metadata=self.Y_metadata if Y_metadata is None else Y_metadata)
         return mu, var
 
     def optimize(self, max_iters=100, messages=False, gtol=1e-6):

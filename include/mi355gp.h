@@ -173,12 +173,25 @@ int mi355gp_pdinv(int device, const double* A, int64_t N, double* Ainv, double* 
 int mi355gp_pdinv_full(int device, const double* A, int64_t N, double* Ainv, double* L_out, double* Li_out, double* logdet,
                        double* ms);
 
-/* Options.  PROFILE: bracket launches of the factorisation kernels with hipEvents on the launching stream (adds
- * ~2 us per timed launch).  value 0 = off, 1 = all families, otherwise (bitmask of 1 << MI355GP_PF_*) << 1;
- * LOOKAHEAD: 1 (default) factor panel k+1 on a second, high-priority stream while the trailing update of
- * step k still runs; 0 = everything in order on one stream (reference schedule). */
-enum { MI355GP_OPT_PROFILE = 0, MI355GP_OPT_LOOKAHEAD = 1 };
+/* Options of ONE context, set through the ABI (the MI355GP_* environment variables of DESIGN.md 6e only provide the
+ * process-wide DEFAULTS that a context starts from; an option set here survives mi355gp_set_data).
+ * PROFILE: bracket launches of the factorisation kernels with hipEvents on the launching stream (adds ~2 us per timed
+ *   launch).  value 0 = off, 1 = all families, otherwise (bitmask of 1 << MI355GP_PF_*) << 1;
+ * LOOKAHEAD: 1 (default) factor panel k+1 on a second, high-priority stream while the trailing update of step k still
+ *   runs; 0 = everything in order on one stream (reference schedule);
+ * the schedule switches (value -1 = back to the process default): TRI_OVERLAP 0/1 inverse of the leading block underneath
+ *   potrf; TRI_MIN_NT smallest number of 128-tiles for that overlap (and for PART1_ON_PANEL); TRI_H leading tiles inverted
+ *   early (0 = time model); TRI_WGS workgroups of the early T21 instance (0 = CU share); TRI_HALF 0/1 allow the
+ *   two-shader-engine side stream; PART1_ON_PANEL 0/1; NBO outer panel width (multiple of 128, 0 = default 512);
+ *   SOLVE_OVERLAP 0/1 alpha underneath lauum; DIAG_EXCL_FIRST 0/1; GRAPH 0/1 hipGraph replay of the factorisation region
+ *   below the overlap threshold; PERSIST 0/1 the single-launch dataflow Cholesky for small N. */
+enum { MI355GP_OPT_PROFILE = 0, MI355GP_OPT_LOOKAHEAD = 1, MI355GP_OPT_TRI_OVERLAP = 2, MI355GP_OPT_TRI_MIN_NT = 3,
+       MI355GP_OPT_TRI_H = 4, MI355GP_OPT_TRI_WGS = 5, MI355GP_OPT_TRI_HALF = 6, MI355GP_OPT_PART1_ON_PANEL = 7,
+       MI355GP_OPT_NBO = 8, MI355GP_OPT_SOLVE_OVERLAP = 9, MI355GP_OPT_DIAG_EXCL_FIRST = 10, MI355GP_OPT_GRAPH = 11,
+       MI355GP_OPT_PERSIST = 12, MI355GP_OPT_NUM = 13 };
 int mi355gp_set_option(mi355gp_ctx* ctx, int option, int value);
+/* the value in effect for a schedule switch (options above MI355GP_OPT_PROFILE) */
+int mi355gp_get_option(mi355gp_ctx* ctx, int option, int* value);
 /* kernel families of mi355gp_get_profile */
 enum { MI355GP_PF_UPDATE = 0 /* k_update_nt<4,true>: trailing update of potrf on 128 x 128 tiles */, MI355GP_PF_TRTRI = 1, MI355GP_PF_LAUUM = 2,
        MI355GP_PF_DIAG = 3 /* k_diag128 */, MI355GP_PF_TRSM = 4 /* k_trsm128 */,
@@ -265,6 +278,10 @@ int mi355gp_sparse_attach_comm(mi355gp_sparse* s, int rank, int world, const voi
 int mi355gp_sparse_attach_loopback(mi355gp_sparse* s, int rank, int world, int group_key);
 /* M x M results of the last call: 0 dL_dKmm, 1 woodbury_inv (var_dtc.py:206-210), 2 Lm, 3 Kmm (+1e-8 I), 4 psi2 */
 int mi355gp_sparse_fetch(mi355gp_sparse* s, int which, double* out);
+/* Launch timing of the two MFMA kernels of the last mi355gp_vardtc_inference_sum call (hipEvent pairs on the launching
+ * stream, recorded on every call): out6 = [T = Kfu dL_dpsi2 GEMM: summed ms, algorithmic flops (2 rows M^2), launches,
+ * split-K Gram psi2: summed ms, algorithmic flops (rows M^2, lower half), launches]. */
+int mi355gp_sparse_get_profile(mi355gp_sparse* s, double* out6);
 
 /* ---- diagnostics (used by tests/ and tools/) --------------------------------------------------------- */
 /* raw lane dump of one v_mfma_f64_16x16x4_f64: a[64], b[64] -> d[64*4] */

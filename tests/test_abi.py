@@ -60,7 +60,7 @@ def test_product_never_imports_the_oracle():
     # bench.py: the oracle is the CHECKER (parity gate before the timed region) and the CPU-baseline leg, nothing else
     import ast
     tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
-    allowed = {"cpu_baseline", "_oracle_seconds", "parity_gate"}
+    allowed = {"cpu_baseline", "_oracle_seconds", "parity_gate", "sparse_cpu_baseline"}
 
     def oracle_imports(node):
         return [n for n in ast.walk(node) if (isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle")) or
@@ -74,3 +74,14 @@ def test_product_never_imports_the_oracle():
 def test_kdiag_is_host_side_and_exact():
     out = _lib.kern_Kdiag("matern52", np.array([1.7, 0.3]), 5)
     assert np.array_equal(out, np.full(5, 1.7))
+
+
+def test_option_ids_of_the_python_binding_match_the_header():
+    """`Context.set_option` configures ONE context through the C-ABI: the name -> id table of the binding
+    is the header's MI355GP_OPT_* enum."""
+    text = open(os.path.join(ROOT, "include", "mi355gp.h")).read()
+    m = re.search(r"enum \{ (MI355GP_OPT_PROFILE.*?) \};", text, flags=re.S)
+    ids = {k.strip()[len("MI355GP_OPT_"):].lower(): int(v) for k, v in
+           (item.split("=") for item in m.group(1).replace("\n", " ").split(","))}
+    num = ids.pop("num")
+    assert ids == _lib.OPTIONS and num == len(ids)

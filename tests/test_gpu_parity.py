@@ -518,3 +518,77 @@ def test_graph_replay_is_bit_identical_to_plain_launches_and_survives_set_data()
         assert np.linalg.norm(r5["alpha"] - ref["alpha"]) <= TOL_ALPHA * np.linalg.norm(ref["alpha"])
     finally:
         c.close()
+
+
+def test_schedule_switches_through_the_c_abi_per_context():
+    """a context's schedule is configured through `mi355gp_set_option` (not the environment), the value
+    survives `set_data`, -1 returns to the process default, and two contexts of one process hold different settings."""
+    X, Y = O.synthetic(2900, 5, seed=7)
+    var, ls, noise = O.default_theta(5, True)
+    th = L.theta_vec(var, ls, True, 5)
+    a, b = L.Context(0), L.Context(0)
+    try:
+        a.set_data(X, Y)
+        b.set_data(X, Y)
+        _, ref = a.exact_inference("rbf", True, th, noise)
+        dflt = {k: b.get_option(k) for k in ("nbo", "tri_min_nt", "tri_h", "tri_overlap", "graph", "solve_overlap", "persist")}
+        assert dflt["nbo"] == 0 and dflt["tri_overlap"] == 1 and dflt["graph"] == 1
+        for opts in ({"nbo": 256}, {"tri_min_nt": 16, "tri_h": 8}, {"tri_min_nt": 16, "tri_h": 8, "tri_half": 0},
+                     {"tri_overlap": 0, "graph": 0}, {"diag_excl_first": 0, "solve_overlap": 0}):
+            for k, v in opts.items():
+                b.set_option(k, v)
+                assert b.get_option(k) == v
+            b.set_data(X, Y)                                         # a new workspace: the options must still hold
+            for k, v in opts.items():
+                assert b.get_option(k) == v
+            assert a.get_option("nbo") == 0 and a.get_option("tri_h") == dflt["tri_h"]      # the other context is untouched
+            for _ in range(3):                                       # plain, capture, replay where the graph applies
+                info, r = b.exact_inference("rbf", True, th, noise)
+                assert info == 0
+                assert abs(r["lml"] - ref["lml"]) <= 1e-12 * abs(ref["lml"])
+                assert np.abs(r["alpha"] - ref["alpha"]).max() <= 1e-11 * np.abs(ref["alpha"]).max()
+                assert np.abs(r["dtheta"] - ref["dtheta"]).max() <= 1e-10 * np.abs(ref["dtheta"]).max()
+            for k in opts:
+                b.set_option(k, -1)
+                assert b.get_option(k) == dflt.get(k, b.get_option(k))
+        with pytest.raises(L.MI355GPError):
+            b.set_option("nbo", 200)                                 # not a multiple of 128
+    finally:
+        a.close()
+        b.close()
+
+
+def test_in_place_edits_of_caller_buffers_reach_the_device():
+    """`X_buf[i] = x_new; m.set_XY(X_buf, Y_buf)` and an in-place edit of an array handed straight to
+    `inference()` must never leave stale data on the device (the sampled identity token of round 2 missed them)."""
+    import gpy_amd
+    X, Y = O.synthetic(1500, 3, seed=21)
+    var, ls, noise = O.default_theta(3, False)
+    Xb, Yb = X.copy(), Y.copy()
+    m = gpy_amd.GPRegression(Xb, Yb, gpy_amd.RBF(3, variance=var, lengthscale=float(ls[0])), noise_var=noise)
+    assert not m.X.flags.writeable and m.X is not Xb                 # the model holds frozen private copies
+    with pytest.raises(ValueError):
+        m.X[0, 0] = 1.0
+    Xb[777, 1] += 0.25                                               # an element no 64-sample fingerprint of 4500 looks at
+    Yb[1234, 0] -= 0.5
+    m.set_XY(Xb, Yb)
+    ref = O.parameters_changed("rbf", Xb, Yb, var, ls, False, noise)
+    assert abs(m.log_likelihood() - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+    # the inference method called directly with WRITABLE arrays (what GPy's own GP class would do with plain ndarrays)
+    inf = gpy_amd.ExactGaussianInference()
+    k, lik = gpy_amd.RBF(3, variance=var, lengthscale=float(ls[0])), gpy_amd.Gaussian(variance=noise)
+    _, l1, _ = inf.inference(k, Xb, lik, Yb)
+    assert abs(l1 - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+    Xb[3, 2] -= 0.125
+    _, l2, _ = inf.inference(k, Xb, lik, Yb)                         # same object, same address, one element changed
+    ref2 = O.parameters_changed("rbf", Xb, Yb, var, ls, False, noise)
+    assert abs(l2 - ref2["lml"]) <= TOL_LML * abs(ref2["lml"]) and l2 != l1
+    Yb[5, 0] += 1.0
+    _, l3, _ = inf.inference(k, Xb, lik, Yb)
+    ref3 = O.parameters_changed("rbf", Xb, Yb, var, ls, False, noise)
+    assert abs(l3 - ref3["lml"]) <= TOL_LML * abs(ref3["lml"])
+    # kernel-matrix cache: an edited buffer must not hit
+    K1 = k.K(Xb)
+    Xb[100, 0] += 0.5
+    K2 = k.K(Xb)
+    assert K2 is not K1 and np.abs(K2 - O.kern_K("rbf", Xb, None, var, ls, False)).max() <= TOL_K * var

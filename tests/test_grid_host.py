@@ -114,3 +114,30 @@ def test_shard_rows_partitions_like_divide_data(N, world):
         assert (lo, hi) == (offset, offset + size)
         covered.extend(range(lo, hi))
     assert covered == list(range(N))
+
+
+def test_id_file_is_validated_by_job_nonce_not_by_age(tmp_path, monkeypatch):
+    """a reader accepts an id file only with its own launch nonce -- however old the file is -- and never the
+    left-over of another launch."""
+    import threading
+    import time
+    from gpy_amd import grid as G
+    path = str(tmp_path / "id.bin")
+    ida, idb = bytes(range(128)), bytes(reversed(range(128)))
+    G.exchange_id_file(ida, 0, path, nonce="job-A#0")              # rank 0 of a launch that then crashed
+    old = time.time() - 3600.0
+    os.utime(path, (old, old))                                     # ... an hour ago
+    assert G.exchange_id_file(b"", 1, path, timeout=1.0, nonce="job-A#0") == ida       # same launch: age does not matter
+    with pytest.raises(Exception):
+        G.exchange_id_file(b"", 1, path, timeout=0.3, nonce="job-A#1")                 # the relaunch must not read it
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault("id", G.exchange_id_file(b"", 1, path, timeout=10.0, nonce="job-A#1")))
+    t.start()
+    time.sleep(0.2)
+    G.exchange_id_file(idb, 0, path, nonce="job-A#1")              # rank 0 of the relaunch replaces the stale file
+    t.join()
+    assert got["id"] == idb
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "abc")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "2")
+    monkeypatch.delenv("MI355GP_JOB_NONCE", raising=False)
+    assert G.job_nonce() == "abc#2"

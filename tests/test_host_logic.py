@@ -209,3 +209,98 @@ def test_small_stationary_methods_follow_the_reference():
     assert np.allclose(k.variance.gradient, 1.5) and np.allclose(k.lengthscale.gradient, [0.1, 0.2, 0.3])
     k.update_gradients_diag(np.ones(7), np.zeros((7, 3)))                               # stationary.py:182-191
     assert np.allclose(k.variance.gradient, 7.0) and np.allclose(k.lengthscale.gradient, 0.0)
+
+
+def test_array_identity_never_misses_an_in_place_edit():
+    """ADVICE r2 (high / medium): a host array is recognised either by identity -- only when it is frozen through its whole
+    base chain -- or by a full comparison; never by a sampled fingerprint or by the address of a writable buffer."""
+    from gpy_amd.lazy import ArrayIdentity, freeze, frozen
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((1000, 7))
+    ida = ArrayIdentity(a)
+    assert ida.matches(a) and ida.matches(a.copy())
+    a[501, 3] += 1e-9                            # one element that 64 strided samples of 7000 would not see
+    assert not ida.matches(a)
+    f = freeze(a)
+    assert frozen(f) and not frozen(a) and not f.flags.writeable and f is not a
+    with pytest.raises(ValueError):
+        f[0, 0] = 1.0
+    idf = ArrayIdentity(f)
+    assert idf.obj is f and idf.copy is None and idf.matches(f)
+    assert idf.matches(f.copy()) and not idf.matches(f + 1.0)        # other objects: compared, not assumed different
+    v = a[:500]                                  # a read-only VIEW of a writable buffer is not frozen: the base can be edited
+    v.setflags(write=False)
+    assert not frozen(v)
+    idv = ArrayIdentity(v)
+    a[10, 0] = 42.0
+    assert not idv.matches(v)
+    assert ArrayIdentity(None).matches(None) and not ArrayIdentity(None).matches(a) and not ida.matches(None)
+
+
+def test_kernel_K_cache_confirms_hits_with_the_data():
+    """`Stationary.K`'s Cache_this(limit=3) stand-in: same-shaped arrays at a reused address, or an edited buffer, must
+    not hit (the loop `Xp = base.copy(); Xp[i, j] += eps; k.K(Xp)` false-hit 19 times out of 19 in round 2)."""
+    from gpy_amd.kern import _KCache
+    c = _KCache(limit=3)
+    calls = []
+
+    def compute_for(X):
+        def compute():
+            calls.append(1)
+            return np.array([[float((X * np.arange(X.size).reshape(X.shape)).sum())]])
+        return compute
+    base = np.random.default_rng(1).standard_normal((300, 4))
+    theta = np.array([1.0, 2.0])
+    seen = set()
+    for i in range(19):
+        Xp = base.copy()
+        Xp[(7 * i + 3) % 300, i % 4] += 1e-3
+        seen.add(float(c.get(Xp, None, theta, compute_for(Xp))[0, 0]))
+        del Xp
+    assert len(calls) == 19 and len(seen) == 19
+    Xb = base.copy()
+    k1 = c.get(Xb, None, theta, compute_for(Xb))
+    n = len(calls)
+    assert c.get(Xb, None, theta, compute_for(Xb)) is k1 and len(calls) == n        # a true hit, confirmed by comparison
+    assert not k1.flags.writeable
+    Xb[123, 2] -= 0.5                                                                # in-place edit of the same object
+    assert c.get(Xb, None, theta, compute_for(Xb))[0, 0] != k1[0, 0] and len(calls) == n + 1
+    assert c.get(Xb, None, theta * 2, compute_for(Xb)) is not None and len(calls) == n + 2   # parameters are part of the key
+
+
+def test_device_state_uploads_again_after_an_unsampled_in_place_edit():
+    """`_DeviceState.ensure_data` with a recording stand-in for the device context (no GPU work)."""
+    from gpy_amd.inference import _DeviceState
+    from gpy_amd.lazy import freeze
+
+    class Rec(object):
+        def __init__(self):
+            self.log = []
+
+        def set_data(self, X, R):
+            self.log.append(("data", float(X.sum()), float(R.sum())))
+
+        def set_targets(self, R):
+            self.log.append(("targets", float(R.sum())))
+    st = _DeviceState.__new__(_DeviceState)
+    st.ctx, st._idX, st._idR, st.call_token, st.kern = Rec(), None, None, 0, None
+    rng = np.random.default_rng(2)
+    X, Y = rng.standard_normal((4000, 3)), rng.standard_normal((4000, 1))
+    st.ensure_data(X, Y)
+    st.ensure_data(X, Y)
+    assert [e[0] for e in st.ctx.log] == ["data"]
+    X[1777, 1] += 1e-3                            # the update pattern `X_buf[i] = x_new; m.set_XY(X_buf, Y_buf)`
+    st.ensure_data(X, Y)
+    assert [e[0] for e in st.ctx.log] == ["data", "data"]
+    Y[3001, 0] -= 1.0
+    st.ensure_data(X, Y)
+    assert [e[0] for e in st.ctx.log] == ["data", "data", "targets"]
+    Xf, Yf = freeze(X), freeze(Y)                 # what the model drivers hold: O(1) identity hits from now on
+    st.ensure_data(Xf, Yf)
+    n = len(st.ctx.log)                           # equal contents: recognised by comparison, nothing uploaded
+    st.ensure_data(Xf, Yf)
+    st.ensure_data(Xf, Yf)
+    assert len(st.ctx.log) == n
+    st.invalidate()
+    st.ensure_data(Xf, Yf)
+    assert st.ctx.log[-1][0] == "data"

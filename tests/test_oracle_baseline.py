@@ -40,6 +40,27 @@ def test_lean_large_n_oracle_matches_the_pinned_oracle(kind):
     assert np.abs(a["diag_dL_dK"] - b["diag_dL_dK"]).max() <= 1e-11 * np.abs(b["diag_dL_dK"]).max()
 
 
+def test_lean_large_n_oracle_with_the_production_blocking_matches_the_pinned_oracle():
+    """the N=32768 fixture came from lean_exact with block=2048 and the 2 x 2 split, pinned before only at N=900 /
+    block=256.  Here: the production block size (several 2048-row build blocks per matrix block, a ragged last one) and an
+    uneven 2 x 2 split at N > 4096, against the reference-pinned oracle, RBF D=8 like configs[3]."""
+    from oracle.make_golden_baseline import lean_exact
+    N = 4608
+    X, Y = O.synthetic(N, 8, seed=0)
+    var, ls, noise = O.default_theta(8, False)
+    b = O.parameters_changed("rbf", X, Y, var, ls, False, noise)
+    for n1 in (None, 2560):                       # the default N // 2 split and an uneven one (blocks of 2560 / 2048 rows)
+        a = lean_exact("rbf", X, Y, var, ls, noise, block=2048, n1=n1)
+        assert abs(a["lml"] - b["lml"]) <= 1e-12 * abs(b["lml"])
+        assert np.abs(a["alpha"] - b["alpha"]).max() <= 1e-10 * np.abs(b["alpha"]).max()
+        assert abs(a["dvar"][0] - b["dvar"]) <= 1e-9 * abs(b["dvar"])
+        assert abs(a["dlen"][0] - b["dlen"][0]) <= 1e-9 * abs(b["dlen"][0])
+        assert abs(a["dnoise"][0] - b["dL_dnoise"]) <= 1e-9 * abs(b["dL_dnoise"])
+        assert np.abs(a["Wi_rows"] - b["Wi"][a["rows"]]).max() <= 1e-10 * np.abs(b["Wi"]).max()
+        assert np.abs(a["L_rows"] - b["L"][a["rows"]]).max() <= 1e-12
+        assert np.abs(a["diag_dL_dK"] - b["diag_dL_dK"]).max() <= 1e-10 * np.abs(b["diag_dL_dK"]).max()
+
+
 def test_baseline_fixtures_are_self_consistent():
     """Cheap identities on the stored full-size outputs (no N^3 work): dnoise = sum diag(dL_dK);
     diag(dL_dK)_i = 0.5 (alpha_i^2 - Wi_ii) on the sampled rows."""

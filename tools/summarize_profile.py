@@ -6,7 +6,7 @@
                                    FETCH_SIZE and WRITE_SIZE are in KiB-like units of 1024 B? -- rocprofv3 reports them in
                                    kilobytes; FETCH_SIZE counts 128-B requests as 64 B on gfx950 for wide coalesced reads,
                                    so fetch bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is left uncorrected (uncalibrated).
-   <tag>_sparse_kernel_stats.csv   the same for bench.py --sparse
+   <tag>_sparse_kernel_stats.csv   the same for bench.py --sparse (configs[4]); <tag>_c2_* for configs[1] (N=4096)
 usage: python tools/summarize_profile.py gpurun_out/prof_r1 r1
 """
 import collections
@@ -42,11 +42,12 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out, exist_ok=True)
-    for sub, name in (("stats", "%s_kernel_stats.csv" % tag), ("sparse_stats", "%s_sparse_kernel_stats.csv" % tag)):
+    for sub, name in (("stats", "%s_kernel_stats.csv" % tag), ("sparse_stats", "%s_sparse_kernel_stats.csv" % tag),
+                      ("c2_stats", "%s_c2_kernel_stats.csv" % tag)):
         f = find(os.path.join(src, sub), "kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(out, name))
-    for prefix, label in (("pmc", ""), ("sparse_pmc", "sparse_")):
+    for prefix, label in (("pmc", ""), ("sparse_pmc", "sparse_"), ("c2_pmc", "c2_")):
         merged = collections.defaultdict(dict)
         for p in ("a", "b", "c"):
             for k, cs in agg_counters(find(os.path.join(src, "%s_%s" % (prefix, p)), "counter_collection.csv")).items():

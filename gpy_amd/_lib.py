@@ -52,7 +52,7 @@ FETCH_L, FETCH_KINV, FETCH_DLDK, FETCH_K = 0, 1, 2, 3
 OUT_LML, OUT_LOGDET, OUT_DATAFIT, OUT_DNOISE, OUT_TRKINV, NUM_OUT = 0, 1, 2, 3, 4, 8
 STAGE_NAMES = ("kbuild", "potrf", "trtri", "lauum", "solve", "grad", "total")
 NUM_T = 8
-PROFILE_FAMILIES = ("update_nt", "trtri", "lauum", "diag128", "trsm128", "update_nt64")
+PROFILE_FAMILIES = ("update_nt", "trtri", "lauum", "diag128", "trsm128", "update_nt64", "potrf_persist")
 
 _lib = None
 
@@ -146,6 +146,7 @@ def lib():
     L.mi355gp_dbg_graph_factor.argtypes = [ci, i64, ci, _dp]
     L.mi355gp_dbg_gemm_clock.argtypes = [_c_dp, _c_dp]
     L.mi355gp_dbg_mask_probe.argtypes = [ci, ci, ci, _dp]
+    L.mi355gp_dbg_persist.argtypes = [ci, i64, ci, ci, _dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
@@ -154,7 +155,7 @@ def lib():
                  "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum", "dbg_mask_probe",
                  "vardtc_inference_sum", "sparse_predict", "sparse_fetch_dLdKnm", "sparse_attach_loopback",
                  "predictive_gradients_sum", "dbg_pipe_share", "pdinv_full", "dbg_graph_factor", "get_option",
-                 "sparse_get_profile"):
+                 "sparse_get_profile", "dbg_persist"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -173,7 +174,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_sparse_predict", "mi355gp_sparse_fetch_dLdKnm", "mi355gp_sparse_attach_loopback",
             "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share", "mi355gp_pdinv_full", "mi355gp_dbg_graph_factor",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe", "mi355gp_get_option",
-            "mi355gp_sparse_get_profile")
+            "mi355gp_sparse_get_profile", "mi355gp_dbg_persist")
 
 
 # mi355gp_set_option / mi355gp_get_option ids (include/mi355gp.h, MI355GP_OPT_*)
@@ -365,7 +366,7 @@ class Context(object):
 
     def get_profile(self):
         """{family: (ms, algorithmic flops, launches)} of the last inference call made with option 'profile' on."""
-        ms, fl, n = np.zeros(6), np.zeros(6), np.zeros(6, dtype=np.int32)
+        ms, fl, n = np.zeros(8), np.zeros(8), np.zeros(8, dtype=np.int32)
         check(lib().mi355gp_get_profile(self._h, ms, fl, n), "mi355gp_get_profile")
         return {k: (ms[i], fl[i], int(n[i])) for i, k in enumerate(PROFILE_FAMILIES)}
 
@@ -600,6 +601,19 @@ def bench_factor(N, reps=3, device=0):
     fl = float(N) ** 3 / 3.0
     return {"potrf_ms": p.value, "trtri_ms": t.value, "lauum_ms": l.value,
             "potrf_tflops": fl / p.value / 1e9, "trtri_tflops": fl / t.value / 1e9, "lauum_tflops": fl / l.value / 1e9}
+
+
+def dbg_persist(N, reps=3, kcap=0, device=0):
+    """The persistent dataflow Cholesky (persist.hip) next to the launch-per-step schedule on the same resident SPD matrix:
+    dict(ms_steps, ms_persist, mismatches (doubles of the lower triangle of L that differ BITWISE), info, steps = per chain
+    step the six wall-clock stamps in microseconds relative to the first)."""
+    require_device(device)
+    nt = (int(N) + 127) // 128
+    out = np.zeros(8 + 8 * nt)
+    check(lib().mi355gp_dbg_persist(device, int(N), int(reps), int(kcap), out), "mi355gp_dbg_persist")
+    st = out[8:].reshape(nt, 8)[:, :6]
+    return dict(ms_steps=out[0], ms_persist=out[1], mismatches=int(out[2]), info=int(out[3]), abort=int(out[4]), nt=nt,
+                steps=(st - st[0, 0]) / 100.0)
 
 
 def dbg_mask_probe(pct=75, order=0, device=0):

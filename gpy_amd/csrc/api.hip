@@ -394,6 +394,14 @@ static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_gra
         HIP_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[6]));
         stage_ms[MI355GP_T_TOTAL] = ms;
     }
+    if (info[0] >= (1 << 30)) {                                // a wait inside the persistent factorisation timed out
+        c->have_factor = false;
+        c->ws.persist = 0;                                     // fall back to the launch-per-step schedule from now on
+        drop_graph(c);
+        mi355gp_set_error("the persistent factorisation aborted on a wait timeout (another process holding CUs?); this "
+                          "context continues with the launch-per-step schedule -- repeat the call");
+        return -6;
+    }
     if (info[0] > 0) {
         c->have_factor = false;
         if (info[0] > n) info[0] = (int)n;
@@ -1245,6 +1253,102 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
     factor_ws_free(&ws);
     HIP_CHECK(hipGetLastError());
     return info > 0 ? info : 0;
+}
+
+__global__ void k_count_lower_mismatch(const double* __restrict__ a, const double* __restrict__ b, long n, long ld,
+                                       unsigned long long* __restrict__ count) {
+    unsigned long long c = 0;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += (long)gridDim.x * blockDim.x) {
+        const long i = idx / n, j = idx - i * n;
+        if (j <= i && __double_as_longlong(a[i * ld + j]) != __double_as_longlong(b[i * ld + j])) ++c;
+    }
+    if (c) atomicAdd(count, c);
+}
+
+int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out) {
+    ARG_CHECK(N >= 2 * NB && reps >= 1 && out, "mi355gp_dbg_persist: N >= 256, reps >= 1");
+    HIP_CHECK(hipSetDevice(device));
+    const long np = round_up(N, NB);
+    const int nt = (int)(np / NB), D = 4;
+    std::vector<double> X((size_t)N * D);
+    unsigned long long state = 0x9E3779B97F4A7C15ull;
+    for (double& v : X) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        v = ((double)(state >> 11) / 9007199254740992.0 - 0.5) * 4.0;
+    }
+    DevBuf dX, dXt, dIl, dNoise, A, B, dStamp, dCount;
+    HIP_CHECK(dX.alloc(N * D));
+    HIP_CHECK(dXt.alloc(D * np));
+    HIP_CHECK(dIl.alloc(D));
+    HIP_CHECK(dNoise.alloc(1));
+    HIP_CHECK(A.alloc(np * np));
+    HIP_CHECK(B.alloc(np * np));
+    HIP_CHECK(dStamp.alloc(8 * nt));
+    HIP_CHECK(dCount.alloc(1));
+    const double il[4] = {0.7, 0.7, 0.7, 0.7}, noise = 0.1;
+    HIP_CHECK(hipMemcpy(dX, X.data(), sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dIl, il, sizeof(il), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dNoise, &noise, sizeof(double), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(dStamp, 0, sizeof(double) * 8 * nt));
+    HIP_CHECK(hipMemset(dCount, 0, sizeof(double)));
+    hipStream_t st;
+    if (factor_engine(device, &st, nullptr, nullptr) != 0) return -2;
+    EngineShared gate(device);
+    FactorWs ws;
+    if (factor_ws_alloc(&ws, np) != 0) return -3;
+    ws.tri_overlap = 0;
+    if (kcap > 0) ws.persist_kcap = kcap;
+    ws.persist_max_nt = 64;
+    hipEvent_t e[2];
+    for (auto& ev : e) HIP_CHECK(hipEventCreate(&ev));
+    const KernParams kp{MI355GP_RBF, 0, D, 1.0};
+    launch_scale_inputs(st, dX, N, D, dIl, 0, dXt, np);
+    for (int i = 0; i < 8 + 8 * nt; ++i) out[i] = 0.0;
+    int info[4] = {0, 0, 0, 0};
+    for (int mode = 0; mode < 2; ++mode) {                      // 0: launch per step into B, 1: persistent into A
+        double* M = mode == 0 ? (double*)B : (double*)A;
+        ws.persist = mode;
+        if (mode == 1 && !potrf_persist_eligible(np, &ws)) {
+            mi355gp_set_error("mi355gp_dbg_persist: N = %ld is not eligible for the persistent factorisation", (long)N);
+            for (auto& ev : e) (void)hipEventDestroy(ev);
+            factor_ws_free(&ws);
+            return -1;
+        }
+        double acc = 0.0;
+        for (int r = -1; r < reps; ++r) {                       // r = -1: warm-up
+            launch_kbuild_sym(st, kp, dXt, np, N, np, M, dNoise, 1, 1e-8, 1, 1);
+            HIP_CHECK(hipEventRecord(e[0], st));
+            if (mode == 1) launch_potrf_persist(st, M, np, &ws, reinterpret_cast<long long*>((double*)dStamp));
+            else potrf_device(st, M, np, &ws);
+            HIP_CHECK(hipEventRecord(e[1], st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (r < 0) continue;
+            float ms;
+            HIP_CHECK(hipEventElapsedTime(&ms, e[0], e[1]));
+            acc += ms;
+        }
+        out[mode] = acc / reps;
+        if (mode == 1) {
+            int sync[2] = {0, 0};
+            HIP_CHECK(hipMemcpy(info, ws.info, sizeof(int) * 4, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(sync, ws.persist_sync, sizeof(sync), hipMemcpyDeviceToHost));
+            out[3] = info[0];
+            out[4] = sync[1];
+        }
+    }
+    hipLaunchKernelGGL(k_count_lower_mismatch, dim3(1024), dim3(256), 0, st, (const double*)A, (const double*)B, (long)N, np,
+                       reinterpret_cast<unsigned long long*>((double*)dCount));
+    unsigned long long cnt = 0;
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipMemcpy(&cnt, dCount, sizeof(cnt), hipMemcpyDeviceToHost));
+    out[2] = (double)cnt;
+    std::vector<long long> stamps((size_t)8 * nt);
+    HIP_CHECK(hipMemcpy(stamps.data(), dStamp, sizeof(long long) * 8 * nt, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8 * nt; ++i) out[8 + i] = (double)stamps[(size_t)i];
+    for (auto& ev : e) (void)hipEventDestroy(ev);
+    factor_ws_free(&ws);
+    HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // Diagnostic: the same build + factorisation sequence as mi355gp_bench_factor, once launched kernel by kernel and once

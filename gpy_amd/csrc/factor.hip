@@ -154,6 +154,18 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     if (envth && *envth) ws->tri_half_ok = atoi(envth) ? 1 : 0;
     const char* envps = getenv("MI355GP_PERSIST");
     if (envps && *envps) ws->persist = atoi(envps);
+    const char* envpm = getenv("MI355GP_PERSIST_MAX_NT");
+    if (envpm && *envpm) ws->persist_max_nt = atoi(envpm);
+    const char* envpk = getenv("MI355GP_PERSIST_KCAP");
+    if (envpk && *envpk) ws->persist_kcap = atoi(envpk) > 0 ? atoi(envpk) : 1;
+    {
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        ws->persist_cus = prop.multiProcessorCount;
+        const char* envpc = getenv("MI355GP_PERSIST_WGS");
+        if (envpc && *envpc && atoi(envpc) >= 2 && atoi(envpc) <= ws->persist_cus) ws->persist_cus = atoi(envpc);
+        HIP_CHECK(hipMalloc(&ws->persist_sync, sizeof(int) * potrf_persist_sync_ints()));
+    }
     const char* envx = getenv("MI355GP_DIAG_EXCL_FIRST");
     if (envx && *envx) ws->diag_excl_first = atoi(envx) ? 1 : 0;
     HIP_CHECK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
@@ -188,6 +200,8 @@ void factor_ws_free(FactorWs* ws) {
     ws->ev_tri_lead = nullptr;
     if (ws->tri_counter) (void)hipFree(ws->tri_counter);
     ws->tri_counter = nullptr;
+    if (ws->persist_sync) (void)hipFree(ws->persist_sync);
+    ws->persist_sync = nullptr;
     ws->prof.destroy();
 }
 
@@ -255,6 +269,11 @@ static void potrf_serial(hipStream_t st, double* A, long npad, FactorWs* ws) {
 // while part 2 of step p still runs, so the latency-bound diag/trsm chain hides behind MFMA-bound work.  All
 // trailing updates stay in order on `st`: their launch durations are not inflated by overlapping each other.
 void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
+    ws->ovl_h = 0;
+    if (potrf_persist_eligible(npad, ws)) {                     // small factorisation: one persistent dataflow launch
+        launch_potrf_persist(st, A, npad, ws);
+        return;
+    }
     if (ws->lookahead != 1) {
         potrf_serial(st, A, npad, ws);
         return;

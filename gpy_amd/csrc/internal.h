@@ -41,7 +41,7 @@ void launch_dbg_mfma(hipStream_t st, const double* a, const double* b, double* d
 
 // ---- factor.hip : blocked drivers -------------------------------------------------------------------
 // per-kernel-family device timing (hipEvent pairs on the launching stream) + algorithmic flop counts
-enum { PF_UPDATE = 0, PF_TRTRI = 1, PF_LAUUM = 2, PF_DIAG = 3, PF_TRSM = 4, PF_UPDATE64 = 5, PF_NUM = 6 };
+enum { PF_UPDATE = 0, PF_TRTRI = 1, PF_LAUUM = 2, PF_DIAG = 3, PF_TRSM = 4, PF_UPDATE64 = 5, PF_PERSIST = 6, PF_NUM = 7 };
 struct KernelProf {
     unsigned mask = 0;          // bit f set: family f is timed
     bool on = false;
@@ -92,7 +92,9 @@ struct FactorWs {
     // CU that no part-2 workgroup can join afterwards (27 us instead of 85-250 us next to one); small factorisations only
     int diag_excl_first = FACTOR_DEFAULT_DIAG_EXCL_FIRST, excl_first_ok = 0;
     int solve_overlap = 1;           // MI355GP_SOLVE_OVERLAP: alpha = X^T (X R) on st_tri underneath lauum
-    int persist = 0;                 // MI355GP_PERSIST: single-launch dataflow Cholesky for small factorisations (persist.hip)
+    // MI355GP_PERSIST: the single-launch dataflow Cholesky of persist.hip for factorisations of at most persist_max_nt tiles
+    int persist = FACTOR_DEFAULT_PERSIST, persist_max_nt = 47, persist_kcap = 2, persist_cus = 0;
+    int* persist_sync = nullptr;     // progress words of the persistent launch (zeroed before every launch)
     KernelProf prof;
 };
 // Gate of a device's shared engine streams.  Entry points that enqueue on them hold it SHARED for the duration of the call
@@ -130,6 +132,12 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws);
 void trtri_device(hipStream_t st, const double* L, double* X, double* T, long npad, FactorWs* ws);
 // W = X^T X (lower tiles)
 void lauum_device(hipStream_t st, const double* X, double* W, long npad, FactorWs* ws);
+
+// ---- persist.hip : the whole factorisation of a small matrix as one persistent dataflow launch ------------------------
+bool potrf_persist_eligible(long npad, const FactorWs* ws);
+int potrf_persist_sync_ints();
+// dbg (optional, 8 * nt wall-clock stamps): per chain step [factor start, factor end, sub tile seen, solve end, diag tile seen, update end]
+void launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg = nullptr);
 
 // ---- kern.hip : covariance assembly, reductions, solves, fetch helpers ----------------------------
 struct KernParams {

@@ -1,0 +1,337 @@
+// persist.hip -- the blocked Cholesky (LAPACK dpotrf, reached by GPy through GPy/util/linalg.py:56-75) of a SMALL matrix
+// as ONE persistent launch: a tile dataflow with the sequential chain confined to one workgroup.
+//
+// Why: below N ~ 6000 the launch-per-step schedule of factor.hip is bound by its chain of dependent launches
+// (k_diag128 -> k_trsm128 -> k_update_nt per 128 columns, ~68 us per step of which ~40 us are kernel boundaries and the
+// wide kernels' latencies).  Here
+//   * workgroup 0 (the CHAIN, alone on its CU) walks the diagonal: factor block (j,j) in LDS, then -- without leaving the
+//     CU -- solve block row j+1 against it (L(j+1,j) = A(j+1,j) L_jj^-T) and apply that column to block (j+1,j+1),
+//     which is the next block to factor.  Per step: potf2 of 128 columns + one 128^3 trsm + one 128^3 syrk, no kernel
+//     boundary and no inter-workgroup hand-off in between;
+//   * every other workgroup (WORKERS, one per CU) owns a fixed set of 128 x 128 tiles and applies to each the columns of L
+//     that are final, K = 128 per column, several columns per pass when they are available (same LDS-DMA MFMA tile
+//     pipeline as k_update_nt), solves the finished tile against L_kk and publishes it.  Tiles (j+1,j) and (j+1,j+1) are
+//     handed to the chain one column short; the hand-off has the whole potf2 of block j (~25 us) as slack.
+// Ownership is static and every workgroup is resident (one per CU, grid <= number of CUs), so there is no work queue and
+// no possibility of deadlock: the dependence graph is the acyclic tile DAG of the right-looking Cholesky.
+//
+// Inter-workgroup visibility (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
+// per-XCD L2s are not coherent and a CU's L1 is never refreshed by other CUs' stores.  Every value that another workgroup
+// reads is stored write-through (agent-scope relaxed atomic store = global_store ... sc1, which also drops the line from
+// the writer's L2), the writing waves drain (s_waitcnt vmcnt(0)), the workgroup synchronises and ONE lane then publishes a
+// progress word with an sc1 store.  A reader polls the word with ONE lane (relaxed sc1 loads + s_sleep), then either reads
+// the payload with sc1 loads (the chain) or issues one agent-scope acquire (buffer_inv sc1: this CU's L1) before plain /
+// LDS-DMA loads (the workers).  A tile is read by other workgroups only after its LAST write, and cache lines (128 B) never
+// straddle tiles, so no L2 can hold a stale copy.
+//
+// Arithmetic: the chain runs diag128_factor / trsm_strip_core of chain_dev.h, the workers gemm_tile_128_v3 with C preloaded
+// and negated A fragments, and the chain's own 128^3 update issues its MFMAs in the k-order of that tile pipeline
+// (slab of 16, MFMA m of a slab covers k = 4 (lane >> 4) + m): the factor is bit-identical to factor.hip's.
+#include "chain_dev.h"
+#include "gemm_tile.h"
+#include "internal.h"
+
+#define PS_MAXNT 64                        // tiles per dimension the sync block is laid out for
+#define PS_MAXT 48                         // tiles one worker can own
+#define PS_LDS_BYTES (64 * TSZ * 8)        // 147,456 B: the chain's Y image (64 tiles); one workgroup per CU
+#define PS_ABORT_INFO (1 << 30)            // written to info[0] when a wait timed out (results are garbage)
+#define PS_TIMEOUT_TICKS 50000000LL        // 0.5 s of the 100 MHz wall clock: no wait of a sane run comes near it
+
+// sync block (ints, zeroed before every launch)
+#define PS_DCNT 0                          // diagonal blocks factored (L_jj and dinv(j) final for j < dcnt)
+#define PS_ABORT 1
+#define PS_CNT 16                          // [nt] cnt[i]: L(i, 0 .. cnt[i]-1) final
+#define PS_SUB (16 + PS_MAXNT)             // [nt] tile (i, i-1) holds columns 0 .. i-2, published for the chain
+#define PS_DIA (16 + 2 * PS_MAXNT)         // [nt] tile (i, i)   holds columns 0 .. i-2, published for the chain
+#define PS_SYNC_INTS (16 + 3 * PS_MAXNT)
+
+__device__ __forceinline__ int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_flag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// thread 0 only: wait until *p >= target.  Returns false on abort / timeout (the abort word is set).
+__device__ __forceinline__ bool wait_ge(const int* p, int target, int* sync) {
+    if (ld_flag(p) >= target) return true;
+    const long long t0 = wall_clock64();
+    for (int it = 1;; ++it) {
+        __builtin_amdgcn_s_sleep(1);
+        if (ld_flag(p) >= target) return true;
+        if ((it & 31) == 0) {
+            if (ld_flag(sync + PS_ABORT) != 0) return false;
+            if (wall_clock64() - t0 > PS_TIMEOUT_TICKS) {
+                st_flag(sync + PS_ABORT, 1);
+                return false;
+            }
+        }
+    }
+}
+
+// tile (i, k), i >= k, of linear index t = i (i + 1) / 2 + k
+__device__ __forceinline__ void tile_of(int t, int& i, int& k) {
+    i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > t) --i;
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    k = t - i * (i + 1) / 2;
+}
+
+// C tile = acc, write-through (the tile's LAST write before another workgroup reads it)
+__device__ __forceinline__ void store_tile_coherent(double* __restrict__ C, long ldc, const d4 (&acc)[4][4]) {
+    double* base = gt_cbase<4>(C, ldc);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg<true>(base + (long)(mi * 16 + 4 * r) * ldc + ni * 16, acc[mi][ni][r]);
+}
+
+// ---- the chain workgroup ----------------------------------------------------------------------------------------------
+// LDS map (doubles): phase "factor": Tt = sm[0 .. 36 TSZ), Dinv8 = sm[36 TSZ .. 44 TSZ); phase "update": Yim = sm[0 .. 64 TSZ)
+// Yim tile (a, jb) = rows 16a .. 16a+15, columns 16jb .. 16jb+15 of Y = L(j+1, j), element (row, col 4q + m) stored at
+// row * TS + q + 4m (the k-index transposed 4 x 4): the fragment read of MFMA m, lane (fi, fk), is row fi, position fk + 4m --
+// the bank-conflict-free pattern of chain_dev.h.
+__device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double* __restrict__ dinv_all,
+                                double* __restrict__ logsum, int* __restrict__ info, int* __restrict__ sync,
+                                long long* __restrict__ dbg, double* sm) {
+    __shared__ int s_ok;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, fi = lane & 15, fk = lane >> 4;
+    double* Tt = sm;
+    double* Dinv8 = sm + NTILE * TSZ;
+    diag128_load<false>(A, ld, Tt);                            // block (0,0): written by the previous kernel
+    __syncthreads();
+    for (int j = 0; j < nt; ++j) {
+        const long c0 = (long)j * NB;
+        double* dv = dinv_all + (long)j * 8 * 256;
+        if (dbg && t == 0) dbg[8 * j + 0] = wall_clock64();
+        diag128_factor<true, TSZ>(Tt, Dinv8, c0, dv, info);    // ends with a barrier
+        if (dbg && t == 0) dbg[8 * j + 1] = wall_clock64();
+        diag128_store<true>(A + c0 * ld + c0, ld, Tt, logsum + j);
+        drain_stores();
+        __syncthreads();
+        if (t == 0) st_flag(sync + PS_DCNT, j + 1);            // L_jj and dinv(j) are final
+        if (j + 1 == nt) break;
+        // ---- block row j+1: wait for tile (j+1, j) (columns 0 .. j-1 applied by its owner)
+        if (t == 0) s_ok = wait_ge(sync + PS_SUB + j + 1, 1, sync) ? 1 : 0;
+        __syncthreads();
+        if (!s_ok) return;
+        if (dbg && t == 0) dbg[8 * j + 2] = wall_clock64();
+        const long r1 = c0 + NB;                               // first row / column of block j+1
+        d4 Y[2][8];
+        {
+            d4 Pin[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double* P = A + (r1 + 16 * (w + 4 * h) + fi) * ld + c0;
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Pin[h][jb][r] = ldg<true>(P + jb * 16 + fk + 4 * r);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                trsm_strip_core(Pin[h], Y[h], [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
+                                [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
+        }
+        // L(j+1, j) is final: write-through to global, then publish row j+1's progress
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double* P = A + (r1 + 16 * (w + 4 * h) + fi) * ld + c0;
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg<true>(P + jb * 16 + fk + 4 * r, Y[h][jb][r]);
+        }
+        __syncthreads();                                       // every wave is done reading Tt / Dinv8
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) {
+                double* T = sm + ((w + 4 * h) * 8 + jb) * TSZ + fi * TS + 4 * fk;      // column fk + 4r -> position r + 4 fk
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[r] = Y[h][jb][r];
+            }
+        drain_stores();
+        __syncthreads();
+        if (t == 0) st_flag(sync + PS_CNT + j + 1, j + 1);     // L(j+1, 0 .. j) final
+        if (dbg && t == 0) dbg[8 * j + 3] = wall_clock64();
+        // ---- block (j+1, j+1) -= Y Y^T on its 36 lower 16 x 16 tiles (columns 0 .. j-1 were applied by its owner)
+        if (t == 0) s_ok = wait_ge(sync + PS_DIA + j + 1, 1, sync) ? 1 : 0;
+        __syncthreads();
+        if (!s_ok) return;
+        if (dbg && t == 0) dbg[8 * j + 4] = wall_clock64();
+        d4 acc[9];
+        const double* Cb = A + r1 * ld + r1;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int u = w + 4 * q, I = tile_I(u), J = tile_J(u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q][r] = ldg<true>(Cb + (long)(16 * I + fk + 4 * r) * ld + 16 * J + fi);
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int u = w + 4 * q, I = tile_I(u), J = tile_J(u);
+            const double* Ya = sm + (I * 8) * TSZ + fi * TS + fk;
+            const double* Yb = sm + (J * 8) * TSZ + fi * TS + fk;
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[q] = mfma_f64(-Ya[jb * TSZ + 4 * m], Yb[jb * TSZ + 4 * m], acc[q]);
+        }
+        __syncthreads();                                       // Yim is dead: its space becomes Tt again
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int u = w + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tt[u * TSZ + (fk + 4 * r) * TS + fi] = acc[q][r];
+        }
+        __syncthreads();
+        if (dbg && t == 0) dbg[8 * j + 5] = wall_clock64();
+    }
+}
+
+// ---- a worker workgroup -----------------------------------------------------------------------------------------------
+__device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
+                                 int* __restrict__ sync, int kcap, double* sm) {
+    __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
+    __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished
+    __shared__ int s_wait[PS_MAXT];                            // 1: all columns applied, waiting for L_kk (general tiles)
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
+    const int ntl = nt * (nt + 1) / 2;
+    int nmine = 0;
+    for (int tt = me; tt < ntl; tt += nw) ++nmine;
+    if (nmine == 0) return;
+    for (int s = t; s < PS_MAXT; s += blockDim.x) {
+        s_prog[s] = (s == 0 && me == 0) ? -1 : 0;              // tile 0 = block (0,0): the chain's
+        s_wait[s] = 0;
+    }
+    int left = nmine - ((me == 0) ? 1 : 0);
+    long long idle0 = 0;
+    __syncthreads();
+    while (left > 0) {
+        // ---- snapshot of the progress words (one wave, sc1 loads), then one agent acquire for this CU's L1
+        if (t < nt) s_cnt[t] = ld_flag(sync + PS_CNT + t);
+        if (t == 64) s_cnt[nt] = ld_flag(sync + PS_DCNT);
+        if (t == 65) s_cnt[nt + 1] = ld_flag(sync + PS_ABORT);
+        if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        if (s_cnt[nt + 1] != 0) return;
+        // ---- pick the first owned tile (ascending row: the chain needs low rows first) that has something to do
+        int pick = -1, pi = 0, pk = 0, pj0 = 0, pj1 = 0, ptrsm = 0;
+        for (int s = 0; s < nmine; ++s) {
+            const int p = s_prog[s];
+            if (p < 0) continue;
+            int i, k;
+            tile_of(me + s * nw, i, k);
+            const int limit = (i == k) ? i - 1 : k;            // diagonal tiles stop one column short (the chain's)
+            if (s_wait[s]) {
+                if (s_cnt[nt] >= k + 1) { pick = s; pi = i; pk = k; pj0 = pj1 = limit; ptrsm = 1; break; }
+                continue;
+            }
+            int jmax = s_cnt[i] < s_cnt[k] ? s_cnt[i] : s_cnt[k];
+            if (jmax > limit) jmax = limit;
+            if (jmax > p || p == limit) {
+                pick = s; pi = i; pk = k; pj0 = p;
+                pj1 = (jmax > p + kcap) ? p + kcap : (jmax > p ? jmax : p);
+                ptrsm = (pj1 == limit && i >= k + 2 && s_cnt[nt] >= k + 1) ? 1 : 0;
+                break;
+            }
+        }
+        if (pick < 0) {                                        // nothing ready: back off, give up after the timeout
+            if (t == 0) {
+                if (idle0 == 0) idle0 = wall_clock64();
+                else if (wall_clock64() - idle0 > PS_TIMEOUT_TICKS) st_flag(sync + PS_ABORT, 1);
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+            continue;
+        }
+        idle0 = 0;
+        const int limit = (pi == pk) ? pi - 1 : pk;
+        const bool general = pi >= pk + 2;
+        double* Ct = A + (long)pi * NB * ld + (long)pk * NB;
+        if (pj1 > pj0) {                                       // ---- columns [pj0, pj1): C -= L(i, cols) L(k, cols)^T
+            d4 acc[4][4];
+            gt_load_buf<4>(Ct, ld, acc);
+            gemm_tile_128<true, true, 4, true>(A + (long)pi * NB * ld + (long)pj0 * NB, ld,
+                                               A + (long)pk * NB * ld + (long)pj0 * NB, ld, (pj1 - pj0) * NB, acc, sm);
+            if (pj1 == limit && !general) store_tile_coherent(Ct, ld, acc);      // the last write before the chain reads it
+            else gt_store<0, 4>(Ct, ld, acc);
+        }
+        if (pj1 == limit && !general) {                        // ---- hand the tile to the chain
+            drain_stores();
+            __syncthreads();
+            if (t == 0) {
+                st_flag(sync + ((pi == pk) ? PS_DIA : PS_SUB) + pi, 1);
+                s_prog[pick] = -1;
+            }
+            --left;
+        } else if (pj1 == limit && !ptrsm) {                   // ---- general tile complete, L_kk not there yet
+            drain_stores();
+            __syncthreads();
+            if (t == 0) { s_prog[pick] = pj1; s_wait[pick] = 1; }
+        } else if (ptrsm) {                                    // ---- L(i,k) = C L_kk^-T, final
+            drain_stores();
+            __syncthreads();                                   // the tile's own stores are done, the GEMM's LDS stages are free
+            trsm_stage_L(A, ld, (long)pk * NB, dinv_all + (long)pk * 8 * 256, sm);
+            __syncthreads();
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h)
+                trsm_strip<true>(A, ld, (long)pk * NB, (long)pi * NB + 16 * (w + 4 * h), sm, lane);
+            drain_stores();
+            __syncthreads();
+            if (t == 0) {
+                st_flag(sync + PS_CNT + pi, pk + 1);
+                s_prog[pick] = -1;
+            }
+            --left;
+        } else {
+            __syncthreads();
+            if (t == 0) s_prog[pick] = pj1;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_potrf_persist(double* __restrict__ A, long ld, int nt,
+                                                          double* __restrict__ dinv_all, double* __restrict__ logsum,
+                                                          int* __restrict__ info, int* __restrict__ sync, int kcap,
+                                                          long long* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (blockIdx.x == 0) {
+        chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, dbg, sm);
+        if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicExch(info, PS_ABORT_INFO);
+    } else {
+        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, sm);
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+bool potrf_persist_eligible(long npad, const FactorWs* ws) {
+    const long nt = npad / NB;
+    if (!ws->persist || !ws->persist_sync || ws->lookahead != 1) return false;
+    if (nt < 2 || nt > PS_MAXNT || nt > ws->persist_max_nt) return false;
+    const long ntl = nt * (nt + 1) / 2;
+    return ws->persist_cus >= 2 && (ntl + ws->persist_cus - 2) / (ws->persist_cus - 1) <= PS_MAXT;
+}
+
+int potrf_persist_sync_ints() { return PS_SYNC_INTS; }
+
+void launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg) {
+    static bool opted = false;
+    if (!opted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_persist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PS_LDS_BYTES);
+        opted = true;
+    }
+    const int nt = (int)(npad / NB);
+    const long ntl = (long)nt * (nt + 1) / 2;
+    long grid = ws->persist_cus;                               // one workgroup per CU: all resident
+    if (grid > ntl + 1) grid = ntl + 1;
+    (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
+    (void)hipMemsetAsync(ws->persist_sync, 0, sizeof(int) * PS_SYNC_INTS, st);
+    ws->prof.begin(st, PF_PERSIST, (double)npad * npad * npad / 3.0);
+    hipLaunchKernelGGL(k_potrf_persist, dim3((unsigned)grid), dim3(256), PS_LDS_BYTES, st, A, npad, nt, ws->dinv, ws->logsum,
+                       ws->info, ws->persist_sync, ws->persist_kcap, dbg);
+    ws->prof.end(st);
+}

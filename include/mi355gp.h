@@ -195,7 +195,9 @@ int mi355gp_get_option(mi355gp_ctx* ctx, int option, int* value);
 /* kernel families of mi355gp_get_profile */
 enum { MI355GP_PF_UPDATE = 0 /* k_update_nt<4,true>: trailing update of potrf on 128 x 128 tiles */, MI355GP_PF_TRTRI = 1, MI355GP_PF_LAUUM = 2,
        MI355GP_PF_DIAG = 3 /* k_diag128 */, MI355GP_PF_TRSM = 4 /* k_trsm128 */,
-       MI355GP_PF_UPDATE64 = 5 /* k_update_nt64: the same update on 64 x 64 tiles (launches of few tiles) */, MI355GP_PF_NUM = 6 };
+       MI355GP_PF_UPDATE64 = 5 /* k_update_nt64: the same update on 64 x 64 tiles (launches of few tiles) */,
+       MI355GP_PF_PERSIST = 6 /* k_potrf_persist: the whole factorisation of a small matrix as one persistent launch */,
+       MI355GP_PF_NUM = 7 };
 /* Per family, for the last inference call made with PROFILE on: summed launch durations (ms), summed ALGORITHMIC
  * flops of those launches, launch count.  Arrays of MI355GP_PF_NUM. */
 int mi355gp_get_profile(mi355gp_ctx* ctx, double* ms, double* flops, int* launches);
@@ -306,6 +308,12 @@ int mi355gp_dbg_pipe_share(int device, double* out4);
 /* Diagnostic: build + potrf + trtri + lauum of a synthetic N x N problem launched kernel by kernel vs replayed from a hipGraph
  * captured from the same streams.  out3 = ms launched, ms replayed, graph nodes. */
 int mi355gp_dbg_graph_factor(int device, int64_t N, int reps, double* out3);
+/* Diagnostic: the persistent dataflow Cholesky (persist.hip) against the launch-per-step schedule on the same resident SPD
+ * matrix.  out[0] ms per factorisation launch-per-step, [1] persistent, [2] doubles of the lower triangle of L that differ
+ * bitwise between the two, [3] info, [4] abort word; out[8 + 8 j + q]: wall-clock stamps (100 MHz ticks) of chain step j
+ * (q = 0 factor start, 1 factor end, 2 sub-diagonal tile seen, 3 solve end, 4 diagonal tile seen, 5 update end).
+ * kcap: columns a worker applies per pass (0 = default).  out: 8 + 8 ceil(N / 128) doubles. */
+int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out);
 /* diagnostics: is a CU-masked stream really confined?  out3 = ms of a 4096^3 GEMM on [plain, masked, masked] streams */
 int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3);
 

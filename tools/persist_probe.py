@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""GPU: the persistent dataflow Cholesky (persist.hip) against the launch-per-step schedule -- time, bitwise equality of L and
+the chain's per-step timeline.   python tools/persist_probe.py 1024,4096 [kcap]"""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from gpy_amd import _lib as L  # noqa: E402
+
+
+def main():
+    sizes = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "512,1024,2048,4096").split(",")]
+    kcaps = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0").split(",")]
+    for n in sizes:
+        for kc in kcaps:
+            r = L.dbg_persist(n, reps=5, kcap=kc)
+            st = r["steps"]
+            nt = r["nt"]
+            fac = st[:, 1] - st[:, 0]
+            wait_sub = st[:-1, 2] - st[:-1, 1]               # includes the store of L_jj
+            solve = st[:-1, 3] - st[:-1, 2]
+            wait_dia = st[:-1, 4] - st[:-1, 3]
+            upd = st[:-1, 5] - st[:-1, 4]
+            step = np.diff(st[:, 0])
+            print("N=%d kcap=%d: steps %.3f ms, persistent %.3f ms, mismatches %d, info %d, abort %d" % (
+                n, kc, r["ms_steps"], r["ms_persist"], r["mismatches"], r["info"], r["abort"]))
+            if nt > 1:
+                print("   per chain step (us): factor %.1f | store+wait sub %.1f (max %.1f) | solve %.1f | wait diag %.1f (max %.1f) | "
+                      "update %.1f | step %.1f (max %.1f)" % (fac.mean(), wait_sub.mean(), wait_sub.max(), solve.mean(),
+                                                            wait_dia.mean(), wait_dia.max(), upd.mean(), step.mean(), step.max()))
+                if len(sys.argv) > 3:
+                    for j in range(nt - 1):
+                        print("   j=%2d %s" % (j, " ".join("%7.1f" % v for v in (st[j] - st[j, 0]))))
+
+
+if __name__ == "__main__":
+    main()

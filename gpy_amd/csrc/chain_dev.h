@@ -285,6 +285,70 @@ __device__ __forceinline__ void trsm_strip_core(const d4 (&Pin)[8], d4 (&Y)[8], 
     }
 }
 
+// Two strips at once: the same operations per strip, in the same order (same bits), with the two dependence chains
+// interleaved -- the L / Dinv fragments are read once for both and each MFMA has an independent neighbour to hide behind.
+template <class LT, class DT>
+__device__ __forceinline__ void trsm_strip_core2(const d4 (&P0)[8], const d4 (&P1)[8], d4 (&Y0)[8], d4 (&Y1)[8], LT Lt, DT Dt,
+                                                 int lane) {
+    const int fi = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        d4 a0 = P0[jb], a1 = {0.0, 0.0, 0.0, 0.0}, b0 = P1[jb], b1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < jb; ++k) {
+            const double* Ls = Lt(jb, k) + fi * TS + fk;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double a = -Ls[4 * s];
+                if (k & 1) {
+                    a1 = mfma_f64(a, Y0[k][s], a1);
+                    b1 = mfma_f64(a, Y1[k][s], b1);
+                } else {
+                    a0 = mfma_f64(a, Y0[k][s], a0);
+                    b0 = mfma_f64(a, Y1[k][s], b0);
+                }
+            }
+        }
+        const d4 acca = a0 + a1, accb = b0 + b1;
+        d4 ya = {0.0, 0.0, 0.0, 0.0}, yb = {0.0, 0.0, 0.0, 0.0};
+        const double* Ds = Dt(jb) + fi * TS + fk;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double dd = Ds[4 * s];
+            ya = mfma_f64(dd, acca[s], ya);
+            yb = mfma_f64(dd, accb[s], yb);
+        }
+        Y0[jb] = ya;
+        Y1[jb] = yb;
+    }
+}
+
+// strips at rows prow0 and prow0 + 64 of the panel at column c0 together (trsm_stage_L's packing of L_cc)
+template <bool COH>
+__device__ __forceinline__ void trsm_strip2(double* __restrict__ A, long ld, long c0, long prow0, const double* sm, int lane) {
+    const int fi = lane & 15, fk = lane >> 4;
+    double* Pa = A + (prow0 + fi) * ld + c0;
+    double* Pb = A + (prow0 + 64 + fi) * ld + c0;
+    d4 P0[8], P1[8];
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            P0[jb][r] = Pa[jb * 16 + fk + 4 * r];
+            P1[jb][r] = Pb[jb * 16 + fk + 4 * r];
+        }
+    d4 Y0[8], Y1[8];
+    trsm_strip_core2(P0, P1, Y0, Y1, [sm](int jb, int k) { return sm + tix_sl(jb, k) * TSZ; },
+                     [sm](int jb) { return sm + (28 + jb) * TSZ; }, lane);
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            stg<COH>(Pa + jb * 16 + fk + 4 * r, Y0[jb][r]);
+            stg<COH>(Pb + jb * 16 + fk + 4 * r, Y1[jb][r]);
+        }
+}
+
 // strip rows [prow0, prow0+16) of the panel at column c0, L_cc image = trsm_stage_L's packing
 template <bool COH>
 __device__ __forceinline__ void trsm_strip(double* __restrict__ A, long ld, long c0, long prow0, const double* sm,

@@ -66,13 +66,42 @@ __device__ __forceinline__ bool wait_ge(const int* p, int target, int* sync) {
     }
 }
 
-// tile (i, k), i >= k, of linear index t = i (i + 1) / 2 + k
-__device__ __forceinline__ void tile_of(int t, int& i, int& k) {
-    i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while (i * (i + 1) / 2 > t) --i;
-    while ((i + 1) * (i + 2) / 2 <= t) ++i;
-    k = t - i * (i + 1) / 2;
-}
+// Static tile ownership.  NEAR tiles (i - k <= 2: the diagonal, the sub-diagonal and the one below it) feed the chain within
+// one step of becoming computable, so they get dedicated owners that own nothing else (H workers, about one tile each): an
+// owner busy with a deep update of a far tile would stall the chain by that update's length.  FAR tiles go round-robin
+// over the remaining workers.  Both enumerations ascend by row, the order in which the chain needs the tiles.
+//   near: e = 0 is (0,0) (the chain's own); e >= 1: i = e / 3 + 1, k = i - 2 + e % 3          (3 nt - 3 tiles)
+//   far : f = r (r + 1) / 2 + k, i = r + 3                                                     ((nt-3)(nt-2)/2 tiles)
+struct Ownership {
+    int H, nnear, nfar, nw;
+    __device__ Ownership(int nt, int nworkers) : nw(nworkers) {
+        nnear = 3 * nt - 3;
+        nfar = nt >= 3 ? (nt - 3) * (nt - 2) / 2 : 0;
+        H = nw / 2 > 0 ? nw / 2 : 1;
+        if (H > nnear) H = nnear;
+        if (nfar == 0) H = nw < nnear ? nw : nnear;
+    }
+    __device__ int count(int me) const {
+        if (me < H) return (nnear - me + H - 1) / H;
+        const int m = me - H, W = nw - H;
+        return m < nfar ? (nfar - m + W - 1) / W : 0;
+    }
+    __device__ void tile(int me, int s, int& i, int& k) const {
+        if (me < H) {
+            const int e = me + s * H;
+            if (e == 0) { i = 0; k = 0; return; }
+            i = e / 3 + 1;
+            k = i - 2 + e % 3;
+        } else {
+            const int f = (me - H) + s * (nw - H);
+            int r = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
+            while (r * (r + 1) / 2 > f) --r;
+            while ((r + 1) * (r + 2) / 2 <= f) ++r;
+            i = r + 3;
+            k = f - r * (r + 1) / 2;
+        }
+    }
+};
 
 // C tile = acc, write-through (the tile's LAST write before another workgroup reads it)
 __device__ __forceinline__ void store_tile_coherent(double* __restrict__ C, long ldc, const d4 (&acc)[4][4]) {
@@ -90,6 +119,68 @@ __device__ __forceinline__ void store_tile_coherent(double* __restrict__ C, long
 // Yim tile (a, jb) = rows 16a .. 16a+15, columns 16jb .. 16jb+15 of Y = L(j+1, j), element (row, col 4q + m) stored at
 // row * TS + q + 4m (the k-index transposed 4 x 4): the fragment read of MFMA m, lane (fi, fk), is row fi, position fk + 4m --
 // the bank-conflict-free pattern of chain_dev.h.
+// barrier for LDS traffic only: outstanding GLOBAL stores / loads keep flying (a __syncthreads() would drain them)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void chain_load_sub(const double* __restrict__ A, long ld, long r1, long c0, int w, int fi, int fk,
+                                               d4 (&P0)[8], d4 (&P1)[8]) {
+    const double* Pa = A + (r1 + 16 * w + fi) * ld + c0;
+    const double* Pb = A + (r1 + 16 * (w + 4) + fi) * ld + c0;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            P0[jb][r] = ldg<true>(Pa + jb * 16 + fk + 4 * r);
+            P1[jb][r] = ldg<true>(Pb + jb * 16 + fk + 4 * r);
+        }
+}
+
+// the nine 16 x 16 tiles u = W + 4q of wave W: tile numbers are compile-time constants (immediate LDS / global offsets)
+template <int W>
+__device__ __forceinline__ void chain_load_diag_w(const double* __restrict__ Cb, long ld, int fi, int fk, d4 (&acc)[9]) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int u = W + 4 * q, I = tile_I(u), J = tile_J(u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] = ldg<true>(Cb + (long)(16 * I + fk + 4 * r) * ld + 16 * J + fi);
+    }
+}
+__device__ __forceinline__ void chain_load_diag(const double* __restrict__ Cb, long ld, int w, int fi, int fk, d4 (&acc)[9]) {
+    switch (w) {
+        case 0: chain_load_diag_w<0>(Cb, ld, fi, fk, acc); break;
+        case 1: chain_load_diag_w<1>(Cb, ld, fi, fk, acc); break;
+        case 2: chain_load_diag_w<2>(Cb, ld, fi, fk, acc); break;
+        default: chain_load_diag_w<3>(Cb, ld, fi, fk, acc); break;
+    }
+}
+
+// acc (tile u = W + 4q) -= Y[I] Y[J]^T from the Yim image, then the tiles go to their places in Tt.
+// MFMA order per tile = the tile GEMM's: slab jb, then m; the nine tiles of a wave advance together so that every MFMA has
+// eight independent neighbours and the fragment reads of the next (jb, m) run ahead.
+template <int W>
+__device__ __forceinline__ void chain_update_w(const double* sm, int fi, int fk, d4 (&acc)[9]) {
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const double* Ys = sm + jb * TSZ + fi * TS + fk + 4 * m;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int u = W + 4 * q, I = tile_I(u), J = tile_J(u);
+                acc[q] = mfma_f64(-Ys[I * 8 * TSZ], Ys[J * 8 * TSZ], acc[q]);
+            }
+        }
+}
+template <int W>
+__device__ __forceinline__ void chain_put_w(double* Tt, int fi, int fk, const d4 (&acc)[9]) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int u = W + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tt[u * TSZ + (fk + 4 * r) * TS + fi] = acc[q][r];
+    }
+}
+
 __device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double* __restrict__ dinv_all,
                                 double* __restrict__ logsum, int* __restrict__ info, int* __restrict__ sync,
                                 long long* __restrict__ dbg, double* sm) {
@@ -100,91 +191,79 @@ __device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double*
     diag128_load<false>(A, ld, Tt);                            // block (0,0): written by the previous kernel
     __syncthreads();
     for (int j = 0; j < nt; ++j) {
-        const long c0 = (long)j * NB;
+        const long c0 = (long)j * NB, r1 = c0 + NB;            // r1: first row / column of block j+1
         double* dv = dinv_all + (long)j * 8 * 256;
+        const bool last = (j + 1 == nt);
+        d4 P0[8], P1[8], acc[9];
         if (dbg && t == 0) dbg[8 * j + 0] = wall_clock64();
         diag128_factor<true, TSZ>(Tt, Dinv8, c0, dv, info);    // ends with a barrier
         if (dbg && t == 0) dbg[8 * j + 1] = wall_clock64();
-        diag128_store<true>(A + c0 * ld + c0, ld, Tt, logsum + j);
-        drain_stores();
-        __syncthreads();
-        if (t == 0) st_flag(sync + PS_DCNT, j + 1);            // L_jj and dinv(j) are final
-        if (j + 1 == nt) break;
-        // ---- block row j+1: wait for tile (j+1, j) (columns 0 .. j-1 applied by its owner)
-        if (t == 0) s_ok = wait_ge(sync + PS_SUB + j + 1, 1, sync) ? 1 : 0;
-        __syncthreads();
+        if (last) {
+            diag128_store<true>(A + c0 * ld + c0, ld, Tt, logsum + j);
+            drain_stores();
+            __syncthreads();
+            if (t == 0) st_flag(sync + PS_DCNT, j + 1);
+            break;
+        }
+        // The two tiles of block row j+1 that the chain completes (published by their owners one column short): their sc1
+        // loads go out FIRST, the write-through stores of L_jj behind them -- one drain covers both, and dcnt is published
+        // before the solve (the owners of row j+2 need L_jj for their own solves: it is the head of their critical path).
+        if (t == 0) s_ok = (wait_ge(sync + PS_SUB + j + 1, 1, sync) && wait_ge(sync + PS_DIA + j + 1, 1, sync)) ? 1 : 0;
+        lds_barrier();
         if (!s_ok) return;
         if (dbg && t == 0) dbg[8 * j + 2] = wall_clock64();
-        const long r1 = c0 + NB;                               // first row / column of block j+1
-        d4 Y[2][8];
+        chain_load_sub(A, ld, r1, c0, w, fi, fk, P0, P1);
+        chain_load_diag(A + r1 * ld + r1, ld, w, fi, fk, acc);
+        diag128_store<true>(A + c0 * ld + c0, ld, Tt, logsum + j);
+        drain_stores();
+        lds_barrier();
+        if (t == 0) st_flag(sync + PS_DCNT, j + 1);            // L_jj and dinv(j) are final
+        if (dbg && t == 0) dbg[8 * j + 4] = wall_clock64();
+        // ---- L(j+1, j) = A(j+1, j) L_jj^-T: strips w and w + 4 of this wave, interleaved
+        d4 Y0[8], Y1[8];
+        trsm_strip_core2(P0, P1, Y0, Y1, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
+                         [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
         {
-            d4 Pin[2][8];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const double* P = A + (r1 + 16 * (w + 4 * h) + fi) * ld + c0;
-#pragma unroll
-                for (int jb = 0; jb < 8; ++jb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Pin[h][jb][r] = ldg<true>(P + jb * 16 + fk + 4 * r);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                trsm_strip_core(Pin[h], Y[h], [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
-                                [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
-        }
-        // L(j+1, j) is final: write-through to global, then publish row j+1's progress
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double* P = A + (r1 + 16 * (w + 4 * h) + fi) * ld + c0;
+            double* Pa = A + (r1 + 16 * w + fi) * ld + c0;
+            double* Pb = A + (r1 + 16 * (w + 4) + fi) * ld + c0;
 #pragma unroll
             for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) stg<true>(P + jb * 16 + fk + 4 * r, Y[h][jb][r]);
+                for (int r = 0; r < 4; ++r) {
+                    stg<true>(Pa + jb * 16 + fk + 4 * r, Y0[jb][r]);
+                    stg<true>(Pb + jb * 16 + fk + 4 * r, Y1[jb][r]);
+                }
         }
-        __syncthreads();                                       // every wave is done reading Tt / Dinv8
+        lds_barrier();                                         // every wave is done reading Tt / Dinv8
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int jb = 0; jb < 8; ++jb) {
+            double* Ta = sm + (w * 8 + jb) * TSZ + fi * TS + 4 * fk;          // column fk + 4r -> position r + 4 fk
+            double* Tb = sm + ((w + 4) * 8 + jb) * TSZ + fi * TS + 4 * fk;
 #pragma unroll
-            for (int jb = 0; jb < 8; ++jb) {
-                double* T = sm + ((w + 4 * h) * 8 + jb) * TSZ + fi * TS + 4 * fk;      // column fk + 4r -> position r + 4 fk
-#pragma unroll
-                for (int r = 0; r < 4; ++r) T[r] = Y[h][jb][r];
+            for (int r = 0; r < 4; ++r) {
+                Ta[r] = Y0[jb][r];
+                Tb[r] = Y1[jb][r];
             }
-        drain_stores();
+        }
+        drain_stores();                                        // L_jj, dinv(j) and L(j+1, j) have left this CU
         __syncthreads();
         if (t == 0) st_flag(sync + PS_CNT + j + 1, j + 1);     // L(j+1, 0 .. j) final
         if (dbg && t == 0) dbg[8 * j + 3] = wall_clock64();
         // ---- block (j+1, j+1) -= Y Y^T on its 36 lower 16 x 16 tiles (columns 0 .. j-1 were applied by its owner)
-        if (t == 0) s_ok = wait_ge(sync + PS_DIA + j + 1, 1, sync) ? 1 : 0;
-        __syncthreads();
-        if (!s_ok) return;
-        if (dbg && t == 0) dbg[8 * j + 4] = wall_clock64();
-        d4 acc[9];
-        const double* Cb = A + r1 * ld + r1;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int u = w + 4 * q, I = tile_I(u), J = tile_J(u);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[q][r] = ldg<true>(Cb + (long)(16 * I + fk + 4 * r) * ld + 16 * J + fi);
+        switch (w) {
+            case 0: chain_update_w<0>(sm, fi, fk, acc); break;
+            case 1: chain_update_w<1>(sm, fi, fk, acc); break;
+            case 2: chain_update_w<2>(sm, fi, fk, acc); break;
+            default: chain_update_w<3>(sm, fi, fk, acc); break;
         }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int u = w + 4 * q, I = tile_I(u), J = tile_J(u);
-            const double* Ya = sm + (I * 8) * TSZ + fi * TS + fk;
-            const double* Yb = sm + (J * 8) * TSZ + fi * TS + fk;
-#pragma unroll
-            for (int jb = 0; jb < 8; ++jb)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[q] = mfma_f64(-Ya[jb * TSZ + 4 * m], Yb[jb * TSZ + 4 * m], acc[q]);
+        lds_barrier();                                         // Yim is dead: its space becomes Tt again
+        switch (w) {
+            case 0: chain_put_w<0>(Tt, fi, fk, acc); break;
+            case 1: chain_put_w<1>(Tt, fi, fk, acc); break;
+            case 2: chain_put_w<2>(Tt, fi, fk, acc); break;
+            default: chain_put_w<3>(Tt, fi, fk, acc); break;
         }
-        __syncthreads();                                       // Yim is dead: its space becomes Tt again
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int u = w + 4 * q;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Tt[u * TSZ + (fk + 4 * r) * TS + fi] = acc[q][r];
-        }
-        __syncthreads();
+        lds_barrier();
         if (dbg && t == 0) dbg[8 * j + 5] = wall_clock64();
     }
 }
@@ -197,9 +276,8 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
     __shared__ int s_wait[PS_MAXT];                            // 1: all columns applied, waiting for L_kk (general tiles)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
-    const int ntl = nt * (nt + 1) / 2;
-    int nmine = 0;
-    for (int tt = me; tt < ntl; tt += nw) ++nmine;
+    const Ownership own(nt, nw);
+    const int nmine = own.count(me);
     if (nmine == 0) return;
     for (int s = t; s < PS_MAXT; s += blockDim.x) {
         s_prog[s] = (s == 0 && me == 0) ? -1 : 0;              // tile 0 = block (0,0): the chain's
@@ -222,7 +300,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
             const int p = s_prog[s];
             if (p < 0) continue;
             int i, k;
-            tile_of(me + s * nw, i, k);
+            own.tile(me, s, i, k);
             const int limit = (i == k) ? i - 1 : k;            // diagonal tiles stop one column short (the chain's)
             if (s_wait[s]) {
                 if (s_cnt[nt] >= k + 1) { pick = s; pi = i; pk = k; pj0 = pj1 = limit; ptrsm = 1; break; }
@@ -275,9 +353,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
             __syncthreads();                                   // the tile's own stores are done, the GEMM's LDS stages are free
             trsm_stage_L(A, ld, (long)pk * NB, dinv_all + (long)pk * 8 * 256, sm);
             __syncthreads();
-#pragma unroll 1
-            for (int h = 0; h < 2; ++h)
-                trsm_strip<true>(A, ld, (long)pk * NB, (long)pi * NB + 16 * (w + 4 * h), sm, lane);
+            trsm_strip2<true>(A, ld, (long)pk * NB, (long)pi * NB + 16 * w, sm, lane);
             drain_stores();
             __syncthreads();
             if (t == 0) {
@@ -311,8 +387,8 @@ bool potrf_persist_eligible(long npad, const FactorWs* ws) {
     const long nt = npad / NB;
     if (!ws->persist || !ws->persist_sync || ws->lookahead != 1) return false;
     if (nt < 2 || nt > PS_MAXNT || nt > ws->persist_max_nt) return false;
-    const long ntl = nt * (nt + 1) / 2;
-    return ws->persist_cus >= 2 && (ntl + ws->persist_cus - 2) / (ws->persist_cus - 1) <= PS_MAXT;
+    // tiles per worker: near 3 nt / (cus / 2) <= 2, far (nt-3)(nt-2)/2 / (cus / 2)
+    return ws->persist_cus >= 16 && (nt - 3) * (nt - 2) / 2 / (ws->persist_cus / 2 - 1) + 2 <= PS_MAXT;
 }
 
 int potrf_persist_sync_ints() { return PS_SYNC_INTS; }

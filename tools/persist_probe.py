@@ -15,20 +15,20 @@ def main():
     for n in sizes:
         for kc in kcaps:
             r = L.dbg_persist(n, reps=5, kcap=kc)
-            st = r["steps"]
+            st = r["steps"][:, [0, 1, 2, 3, 4, 5]]
             nt = r["nt"]
             fac = st[:, 1] - st[:, 0]
-            wait_sub = st[:-1, 2] - st[:-1, 1]               # includes the store of L_jj
-            solve = st[:-1, 3] - st[:-1, 2]
-            wait_dia = st[:-1, 4] - st[:-1, 3]
-            upd = st[:-1, 5] - st[:-1, 4]
+            wait = st[:-1, 2] - st[:-1, 1]                   # the two tiles of row j+1 published by their owners
+            load = st[:-1, 4] - st[:-1, 2]                   # their sc1 loads + the write-through of L_jj, drained
+            solve = st[:-1, 3] - st[:-1, 4]                  # L(j+1,j) = A(j+1,j) L_jj^-T, its stores, the Y image
+            upd = st[:-1, 5] - st[:-1, 3]
             step = np.diff(st[:, 0])
             print("N=%d kcap=%d: steps %.3f ms, persistent %.3f ms, mismatches %d, info %d, abort %d" % (
                 n, kc, r["ms_steps"], r["ms_persist"], r["mismatches"], r["info"], r["abort"]))
             if nt > 1:
-                print("   per chain step (us): factor %.1f | store+wait sub %.1f (max %.1f) | solve %.1f | wait diag %.1f (max %.1f) | "
-                      "update %.1f | step %.1f (max %.1f)" % (fac.mean(), wait_sub.mean(), wait_sub.max(), solve.mean(),
-                                                            wait_dia.mean(), wait_dia.max(), upd.mean(), step.mean(), step.max()))
+                print("   per chain step (us): factor %.1f | wait %.1f (max %.1f) | load+store %.1f | solve %.1f | update %.1f | "
+                      "step %.1f (max %.1f)" % (fac.mean(), wait.mean(), wait.max(), load.mean(), solve.mean(), upd.mean(),
+                                                step.mean(), step.max()))
                 if len(sys.argv) > 3:
                     for j in range(nt - 1):
                         print("   j=%2d %s" % (j, " ".join("%7.1f" % v for v in (st[j] - st[j, 0]))))

@@ -114,6 +114,51 @@ __device__ __forceinline__ void store_tile_coherent(double* __restrict__ C, long
             for (int r = 0; r < 4; ++r) stg<true>(base + (long)(mi * 16 + 4 * r) * ldc + ni * 16, acc[mi][ni][r]);
 }
 
+// ---- write-through of a finished 128 x 128 tile, coalesced ------------------------------------------------------------------
+// A tile that another workgroup will read leaves its producer through an LDS image (64 tiles [16][18], the whole dynamic
+// LDS of the workgroup) so that the global stores are 16 B per lane and 1 KB contiguous rows per wave instruction: the
+// natural register layouts (MFMA accumulators, chained solve strips) scatter 8-byte stores over 16 cache lines per
+// instruction, which costs a write-through producer ~7 us per tile instead of ~2.
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+
+// GEMM accumulators of gemm_tile_128 (4 waves: wave (wr, wc) owns rows 64 wr .., columns 64 wc ..) -> image
+__device__ __forceinline__ void stage_put_acc(double* sm, const d4 (&acc)[4][4]) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            double* T = sm + ((wr * 4 + mi) * 8 + wc * 4 + ni) * TSZ + (lane >> 4) * TS + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[4 * r * TS] = acc[mi][ni][r];
+        }
+}
+// solve strips a and a + 4 (chained layout: lane (fi, fk) holds column 16 jb + fk + 4 r of row fi) -> image
+__device__ __forceinline__ void stage_put_strips(double* sm, int a, const d4 (&Y0)[8], const d4 (&Y1)[8], int lane) {
+    const int fi = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        double* Ta = sm + (a * 8 + jb) * TSZ + fi * TS + fk;
+        double* Tb = sm + ((a + 4) * 8 + jb) * TSZ + fi * TS + fk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Ta[4 * r] = Y0[jb][r];
+            Tb[4 * r] = Y1[jb][r];
+        }
+    }
+}
+// image -> global, write-through, by the first NTHR threads of the workgroup
+template <int NTHR>
+__device__ __forceinline__ void stage_store_coherent(const double* sm, double* __restrict__ Ct, long ld, int t) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 8192 / NTHR; ++it) {
+        const int idx = it * NTHR + t, row = idx >> 6, cp = idx & 63;          // columns 2 cp, 2 cp + 1 of row `row`
+        const d2 v = *reinterpret_cast<const d2*>(sm + ((row >> 4) * 8 + (cp >> 3)) * TSZ + (row & 15) * TS + 2 * (cp & 7));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, (int)((row * ld + 2 * cp) * 8), 0, 16);
+    }
+}
+
 // ---- the chain workgroup ----------------------------------------------------------------------------------------------
 // LDS map (doubles): phase "factor": Tt = sm[0 .. 36 TSZ), Dinv8 = sm[36 TSZ .. 44 TSZ); phase "update": Yim = sm[0 .. 64 TSZ)
 // Yim tile (a, jb) = rows 16a .. 16a+15, columns 16jb .. 16jb+15 of Y = L(j+1, j), element (row, col 4q + m) stored at
@@ -122,10 +167,22 @@ __device__ __forceinline__ void store_tile_coherent(double* __restrict__ C, long
 // barrier for LDS traffic only: outstanding GLOBAL stores / loads keep flying (a __syncthreads() would drain them)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ void chain_load_sub(const double* __restrict__ A, long ld, long r1, long c0, int w, int fi, int fk,
-                                               d4 (&P0)[8], d4 (&P1)[8]) {
-    const double* Pa = A + (r1 + 16 * w + fi) * ld + c0;
-    const double* Pb = A + (r1 + 16 * (w + 4) + fi) * ld + c0;
+// The chain workgroup has EIGHT waves with two roles:
+//   factor waves 0..3 : diag128_factor exactly as k_diag128 runs it; then, underneath the solve, they write L_jj through,
+//                       publish dcnt and fetch the 36 accumulator tiles of block (j+1, j+1); then the update: wave 0 / 1 own
+//                       the lower triangle of tile rows 0..3 / 4..7 (ten 16 x 16 tiles), waves 2 / 3 the rectangle rows 4..7
+//                       x columns 0..1 / 2..3 (eight tiles) -- every LDS fragment feeds two or more MFMAs;
+//   solver waves 4..7 : idle while block j is factored, so they fetch tile (j+1, j) THEN (strips g and g+4 for wave 4+g),
+//                       keep the factor's sixteen barriers company with bare s_barriers, run the solve the moment L_jj is
+//                       there, write the Y image and -- underneath the update -- store L(j+1, j) through and publish row j+1.
+#define PS_CHAIN_WAVES 8
+
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void chain_load_strips(const double* __restrict__ A, long ld, long r1, long c0, int g, int fi, int fk,
+                                                  d4 (&P0)[8], d4 (&P1)[8]) {
+    const double* Pa = A + (r1 + 16 * g + fi) * ld + c0;
+    const double* Pb = A + (r1 + 16 * (g + 4) + fi) * ld + c0;
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
@@ -135,151 +192,204 @@ __device__ __forceinline__ void chain_load_sub(const double* __restrict__ A, lon
         }
 }
 
-// the nine 16 x 16 tiles u = W + 4q of wave W: tile numbers are compile-time constants (immediate LDS / global offsets)
+// update tiles of factor wave W: (I, J) of its q-th tile
+__device__ __forceinline__ constexpr int ut_count(int W) { return W < 2 ? 10 : 8; }
+__device__ __forceinline__ constexpr int ut_I(int W, int q) {
+    if (W < 2) return 4 * W + tile_I(q);                       // lower triangle of a 4 x 4 block of tiles
+    return 4 + (q >> 1);                                       // rows 4..7
+}
+__device__ __forceinline__ constexpr int ut_J(int W, int q) {
+    if (W < 2) return 4 * W + tile_J(q);
+    return 2 * (W - 2) + (q & 1);                              // columns 0..1 (W = 2) or 2..3 (W = 3)
+}
+
 template <int W>
-__device__ __forceinline__ void chain_load_diag_w(const double* __restrict__ Cb, long ld, int fi, int fk, d4 (&acc)[9]) {
+__device__ __forceinline__ void chain_load_acc_w(const double* __restrict__ Cb, long ld, int fi, int fk, d4 (&acc)[10]) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        const int u = W + 4 * q, I = tile_I(u), J = tile_J(u);
+    for (int q = 0; q < ut_count(W); ++q) {
+        const int I = ut_I(W, q), J = ut_J(W, q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[q][r] = ldg<true>(Cb + (long)(16 * I + fk + 4 * r) * ld + 16 * J + fi);
     }
 }
-__device__ __forceinline__ void chain_load_diag(const double* __restrict__ Cb, long ld, int w, int fi, int fk, d4 (&acc)[9]) {
-    switch (w) {
-        case 0: chain_load_diag_w<0>(Cb, ld, fi, fk, acc); break;
-        case 1: chain_load_diag_w<1>(Cb, ld, fi, fk, acc); break;
-        case 2: chain_load_diag_w<2>(Cb, ld, fi, fk, acc); break;
-        default: chain_load_diag_w<3>(Cb, ld, fi, fk, acc); break;
-    }
-}
 
-// acc (tile u = W + 4q) -= Y[I] Y[J]^T from the Yim image, then the tiles go to their places in Tt.
-// MFMA order per tile = the tile GEMM's: slab jb, then m; the nine tiles of a wave advance together so that every MFMA has
-// eight independent neighbours and the fragment reads of the next (jb, m) run ahead.
+// acc (tile q of wave W) -= Y[I] Y[J]^T from the Yim image.  MFMA order per tile = the tile GEMM's (slab jb, then m); the
+// tiles of a wave advance together, so every MFMA has independent neighbours and the next fragment reads run ahead.
 template <int W>
-__device__ __forceinline__ void chain_update_w(const double* sm, int fi, int fk, d4 (&acc)[9]) {
+__device__ __forceinline__ void chain_update_w(const double* sm, int fi, int fk, d4 (&acc)[10]) {
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const double* Ys = sm + jb * TSZ + fi * TS + fk + 4 * m;
+            double y[8];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const int u = W + 4 * q, I = tile_I(u), J = tile_J(u);
-                acc[q] = mfma_f64(-Ys[I * 8 * TSZ], Ys[J * 8 * TSZ], acc[q]);
+            for (int a = 0; a < 8; ++a) {
+                bool used = false;
+#pragma unroll
+                for (int q = 0; q < ut_count(W); ++q) used = used || ut_I(W, q) == a || ut_J(W, q) == a;
+                y[a] = used ? Ys[a * 8 * TSZ] : 0.0;
             }
+#pragma unroll
+            for (int q = 0; q < ut_count(W); ++q) acc[q] = mfma_f64(-y[ut_I(W, q)], y[ut_J(W, q)], acc[q]);
         }
 }
 template <int W>
-__device__ __forceinline__ void chain_put_w(double* Tt, int fi, int fk, const d4 (&acc)[9]) {
+__device__ __forceinline__ void chain_put_w(double* Tt, int fi, int fk, const d4 (&acc)[10]) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        const int u = W + 4 * q;
+    for (int q = 0; q < ut_count(W); ++q) {
+        const int u = tix(ut_I(W, q), ut_J(W, q));
 #pragma unroll
         for (int r = 0; r < 4; ++r) Tt[u * TSZ + (fk + 4 * r) * TS + fi] = acc[q][r];
     }
+}
+#define CHAIN_DISPATCH(FN, ...)                      \
+    switch (w) {                                     \
+        case 0: FN<0>(__VA_ARGS__); break;           \
+        case 1: FN<1>(__VA_ARGS__); break;           \
+        case 2: FN<2>(__VA_ARGS__); break;           \
+        default: FN<3>(__VA_ARGS__); break;          \
+    }
+
+// one wave blocks until word p is set; false on abort / timeout (wave-uniform answer)
+__device__ __forceinline__ bool wave_wait(int* p, int* sync, int lane) {
+    int ok = 1;
+    if (lane == 0) ok = wait_ge(p, 1, sync) ? 1 : 0;
+    return __builtin_amdgcn_readfirstlane(ok) != 0;
 }
 
 __device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double* __restrict__ dinv_all,
                                 double* __restrict__ logsum, int* __restrict__ info, int* __restrict__ sync,
                                 long long* __restrict__ dbg, double* sm) {
-    __shared__ int s_ok;
+    __shared__ int s_fail, s_arr, s_arr0;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, fi = lane & 15, fk = lane >> 4;
     double* Tt = sm;
     double* Dinv8 = sm + NTILE * TSZ;
-    diag128_load<false>(A, ld, Tt);                            // block (0,0): written by the previous kernel
-    __syncthreads();
-    for (int j = 0; j < nt; ++j) {
-        const long c0 = (long)j * NB, r1 = c0 + NB;            // r1: first row / column of block j+1
-        double* dv = dinv_all + (long)j * 8 * 256;
-        const bool last = (j + 1 == nt);
-        d4 P0[8], P1[8], acc[9];
-        if (dbg && t == 0) dbg[8 * j + 0] = wall_clock64();
-        diag128_factor<true, TSZ>(Tt, Dinv8, c0, dv, info);    // ends with a barrier
-        if (dbg && t == 0) dbg[8 * j + 1] = wall_clock64();
-        if (last) {
+    if (t == 0) { s_fail = 0; s_arr = 0; s_arr0 = 0; }
+    if (w < 4) {
+        // ================================================= factor waves ==================================================
+        diag128_load<false>(A, ld, Tt);                        // block (0,0): written by the previous kernel
+        __syncthreads();
+        for (int j = 0; j < nt; ++j) {
+            const long c0 = (long)j * NB, r1 = c0 + NB;        // r1: first row / column of block j+1
+            const bool last = (j + 1 == nt);
+            if (dbg && t == 0) dbg[8 * j + 0] = wall_clock64();
+            diag128_factor<true, TSZ>(Tt, Dinv8, c0, dinv_all + (long)j * 8 * 256, info);      // 16 barriers, ends with one
+            if (dbg && t == 0) dbg[8 * j + 1] = wall_clock64();
+            // L_jj write-through, dcnt (the owners of row j+2 start from it), then this wave's accumulators: all of it
+            // underneath the solve of the other four waves
             diag128_store<true>(A + c0 * ld + c0, ld, Tt, logsum + j);
             drain_stores();
-            __syncthreads();
-            if (t == 0) st_flag(sync + PS_DCNT, j + 1);
-            break;
+            if (lane == 0 && atomicAdd(&s_arr0, 1) == 4 * (j + 1) - 1) {
+                st_flag(sync + PS_DCNT, j + 1);
+                if (dbg) dbg[8 * j + 4] = wall_clock64();
+            }
+            if (last) break;
+            d4 acc[10];
+            if (!wave_wait(sync + PS_DIA + j + 1, sync, lane)) {
+                if (lane == 0) s_fail = 1;
+            } else {
+                CHAIN_DISPATCH(chain_load_acc_w, A + r1 * ld + r1, ld, fi, fk, acc);
+            }
+            lds_barrier();                                     // (X) every wave is done reading Tt / Dinv8
+            if (s_fail) return;
+            lds_barrier();                                     // (Y) the Y image is written
+            if (dbg && t == 0) dbg[8 * j + 3] = wall_clock64();
+            // ---- block (j+1, j+1) -= Y Y^T on its 36 lower 16 x 16 tiles (columns 0 .. j-1 were applied by its owner)
+            CHAIN_DISPATCH(chain_update_w, sm, fi, fk, acc);
+            if (dbg && t == 0) dbg[8 * j + 7] = wall_clock64();
+            lds_barrier();                                     // (Z) Yim is dead: its space becomes Tt again
+            CHAIN_DISPATCH(chain_put_w, Tt, fi, fk, acc);
+            lds_barrier();                                     // (W)
+            if (dbg && t == 0) dbg[8 * j + 5] = wall_clock64();
         }
-        // The two tiles of block row j+1 that the chain completes (published by their owners one column short): their sc1
-        // loads go out FIRST, the write-through stores of L_jj behind them -- one drain covers both, and dcnt is published
-        // before the solve (the owners of row j+2 need L_jj for their own solves: it is the head of their critical path).
-        if (t == 0) s_ok = (wait_ge(sync + PS_SUB + j + 1, 1, sync) && wait_ge(sync + PS_DIA + j + 1, 1, sync)) ? 1 : 0;
-        lds_barrier();
-        if (!s_ok) return;
-        if (dbg && t == 0) dbg[8 * j + 2] = wall_clock64();
-        chain_load_sub(A, ld, r1, c0, w, fi, fk, P0, P1);
-        chain_load_diag(A + r1 * ld + r1, ld, w, fi, fk, acc);
-        diag128_store<true>(A + c0 * ld + c0, ld, Tt, logsum + j);
-        drain_stores();
-        lds_barrier();
-        if (t == 0) st_flag(sync + PS_DCNT, j + 1);            // L_jj and dinv(j) are final
-        if (dbg && t == 0) dbg[8 * j + 4] = wall_clock64();
-        // ---- L(j+1, j) = A(j+1, j) L_jj^-T: strips w and w + 4 of this wave, interleaved
-        d4 Y0[8], Y1[8];
-        trsm_strip_core2(P0, P1, Y0, Y1, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
-                         [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
-        {
-            double* Pa = A + (r1 + 16 * w + fi) * ld + c0;
-            double* Pb = A + (r1 + 16 * (w + 4) + fi) * ld + c0;
+    } else {
+        // ================================================= solver waves ==================================================
+        const int g = w - 4;
+        __syncthreads();                                       // pairs with the barrier after diag128_load
+        for (int j = 0; j < nt; ++j) {
+            const long c0 = (long)j * NB, r1 = c0 + NB;
+            const bool last = (j + 1 == nt);
+            d4 P0[8], P1[8], Y0[8], Y1[8];
+            // Block j is being factored by the other four waves (sixteen barriers).  Poll the hand-over word of tile (j+1, j)
+            // -- the value is looked at one barrier AFTER its load was issued, so the poll never delays a barrier --, fetch the
+            // two strips as soon as it is set, then keep the remaining barriers company.
+            bool loaded = false;
+            int fs = 0;
+            for (int b = 0; b < 16; ++b) {
+                if (!loaded && !last) {
+                    if (fs >= 1) {
+                        chain_load_strips(A, ld, r1, c0, g, fi, fk, P0, P1);
+                        loaded = true;
+                    } else {
+                        fs = ld_flag(sync + PS_SUB + j + 1);
+                    }
+                }
+                raw_barrier();
+            }
+            if (last) break;
+            if (!loaded) {                                     // rare: the owner was late
+                if (!wave_wait(sync + PS_SUB + j + 1, sync, lane)) {
+                    if (lane == 0) s_fail = 1;
+                } else {
+                    chain_load_strips(A, ld, r1, c0, g, fi, fk, P0, P1);
+                    loaded = true;
+                }
+            }
+            if (dbg && t == 256) dbg[8 * j + 2] = wall_clock64();
+            // ---- L(j+1, j) = A(j+1, j) L_jj^-T, strips g and g + 4
+            if (loaded)
+                trsm_strip_core2(P0, P1, Y0, Y1, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
+                                 [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
+            if (dbg && t == 256) dbg[8 * j + 6] = wall_clock64();
+            lds_barrier();                                     // (X)
+            if (s_fail) return;
 #pragma unroll
-            for (int jb = 0; jb < 8; ++jb)
+            for (int jb = 0; jb < 8; ++jb) {
+                double* Ta = sm + (g * 8 + jb) * TSZ + fi * TS + 4 * fk;       // column fk + 4r -> position r + 4 fk
+                double* Tb = sm + ((g + 4) * 8 + jb) * TSZ + fi * TS + 4 * fk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    stg<true>(Pa + jb * 16 + fk + 4 * r, Y0[jb][r]);
-                    stg<true>(Pb + jb * 16 + fk + 4 * r, Y1[jb][r]);
+                    Ta[r] = Y0[jb][r];
+                    Tb[r] = Y1[jb][r];
                 }
-        }
-        lds_barrier();                                         // every wave is done reading Tt / Dinv8
-#pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
-            double* Ta = sm + (w * 8 + jb) * TSZ + fi * TS + 4 * fk;          // column fk + 4r -> position r + 4 fk
-            double* Tb = sm + ((w + 4) * 8 + jb) * TSZ + fi * TS + 4 * fk;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Ta[r] = Y0[jb][r];
-                Tb[r] = Y1[jb][r];
             }
+            lds_barrier();                                     // (Y)
+            // ---- L(j+1, j) to global from the image: 16 B per lane, 1 KB rows per wave instruction, write-through;
+            //      then row j+1's progress word -- all underneath the update
+            {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(A + r1 * ld + c0, 0, 0x7fffffff, 0x00020000);
+                const int ts = t - 256;
+#pragma unroll
+                for (int it = 0; it < 32; ++it) {
+                    const int idx = it * 256 + ts, row = idx >> 6, cp = idx & 63;      // columns 2 cp, 2 cp + 1
+                    const int jb = cp >> 3, kk = 2 * (cp & 7), q = kk >> 2, m = kk & 3;
+                    const double* T = sm + ((row >> 4) * 8 + jb) * TSZ + (row & 15) * TS + q + 4 * m;
+                    const d2 v = {T[0], T[4]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, (int)((row * ld + 2 * cp) * 8), 0, 16);
+                }
+            }
+            drain_stores();
+            if (lane == 0 && atomicAdd(&s_arr, 1) == 4 * (j + 1) - 1) st_flag(sync + PS_CNT + j + 1, j + 1);
+            lds_barrier();                                     // (Z)
+            lds_barrier();                                     // (W)
         }
-        drain_stores();                                        // L_jj, dinv(j) and L(j+1, j) have left this CU
-        __syncthreads();
-        if (t == 0) st_flag(sync + PS_CNT + j + 1, j + 1);     // L(j+1, 0 .. j) final
-        if (dbg && t == 0) dbg[8 * j + 3] = wall_clock64();
-        // ---- block (j+1, j+1) -= Y Y^T on its 36 lower 16 x 16 tiles (columns 0 .. j-1 were applied by its owner)
-        switch (w) {
-            case 0: chain_update_w<0>(sm, fi, fk, acc); break;
-            case 1: chain_update_w<1>(sm, fi, fk, acc); break;
-            case 2: chain_update_w<2>(sm, fi, fk, acc); break;
-            default: chain_update_w<3>(sm, fi, fk, acc); break;
-        }
-        lds_barrier();                                         // Yim is dead: its space becomes Tt again
-        switch (w) {
-            case 0: chain_put_w<0>(Tt, fi, fk, acc); break;
-            case 1: chain_put_w<1>(Tt, fi, fk, acc); break;
-            case 2: chain_put_w<2>(Tt, fi, fk, acc); break;
-            default: chain_put_w<3>(Tt, fi, fk, acc); break;
-        }
-        lds_barrier();
-        if (dbg && t == 0) dbg[8 * j + 5] = wall_clock64();
     }
 }
 
 // ---- a worker workgroup -----------------------------------------------------------------------------------------------
 __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
-                                 int* __restrict__ sync, int kcap, double* sm) {
+                                 int* __restrict__ sync, int kcap, long long* __restrict__ dbg, double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
     __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished
     __shared__ int s_wait[PS_MAXT];                            // 1: all columns applied, waiting for L_kk (general tiles)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (w >= 4) return;              // the launch has eight waves per workgroup for the chain's sake; a worker uses four
     const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
     const Ownership own(nt, nw);
     const int nmine = own.count(me);
     if (nmine == 0) return;
-    for (int s = t; s < PS_MAXT; s += blockDim.x) {
+    for (int s = t; s < PS_MAXT; s += 256) {
         s_prog[s] = (s == 0 && me == 0) ? -1 : 0;              // tile 0 = block (0,0): the chain's
         s_wait[s] = 0;
     }
@@ -319,7 +429,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
             if (t == 0) {
                 if (idle0 == 0) idle0 = wall_clock64();
                 else if (wall_clock64() - idle0 > PS_TIMEOUT_TICKS) st_flag(sync + PS_ABORT, 1);
-                __builtin_amdgcn_s_sleep(8);
+                if (me >= own.H) __builtin_amdgcn_s_sleep(8);    // owners of near tiles are on the chain's critical path
             }
             __syncthreads();
             continue;
@@ -328,19 +438,30 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
         const int limit = (pi == pk) ? pi - 1 : pk;
         const bool general = pi >= pk + 2;
         double* Ct = A + (long)pi * NB * ld + (long)pk * NB;
+        // diagnostics: the LAST task of a near tile: [picked, compute done, published]
+        long long* dn = (dbg && pi - pk <= 2 && (pj1 == limit)) ? dbg + 8 * nt + 4 * (3 * pi + (pi - pk)) : nullptr;
+        if (dn && t == 0) dn[0] = wall_clock64();
         if (pj1 > pj0) {                                       // ---- columns [pj0, pj1): C -= L(i, cols) L(k, cols)^T
             d4 acc[4][4];
             gt_load_buf<4>(Ct, ld, acc);
             gemm_tile_128<true, true, 4, true>(A + (long)pi * NB * ld + (long)pj0 * NB, ld,
                                                A + (long)pk * NB * ld + (long)pj0 * NB, ld, (pj1 - pj0) * NB, acc, sm);
-            if (pj1 == limit && !general) store_tile_coherent(Ct, ld, acc);      // the last write before the chain reads it
-            else gt_store<0, 4>(Ct, ld, acc);
+            if (pj1 == limit && !general) {                    // the last write before the chain reads it: through the image
+                __syncthreads();                               // the GEMM's LDS stages are free
+                stage_put_acc(sm, acc);
+                __syncthreads();
+                stage_store_coherent<256>(sm, Ct, ld, t);
+            } else {
+                gt_store<0, 4>(Ct, ld, acc);
+            }
         }
+        if (dn && t == 0) dn[1] = wall_clock64();
         if (pj1 == limit && !general) {                        // ---- hand the tile to the chain
             drain_stores();
             __syncthreads();
             if (t == 0) {
                 st_flag(sync + ((pi == pk) ? PS_DIA : PS_SUB) + pi, 1);
+                if (dn) dn[2] = wall_clock64();
                 s_prog[pick] = -1;
             }
             --left;
@@ -353,11 +474,19 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
             __syncthreads();                                   // the tile's own stores are done, the GEMM's LDS stages are free
             trsm_stage_L(A, ld, (long)pk * NB, dinv_all + (long)pk * 8 * 256, sm);
             __syncthreads();
-            trsm_strip2<true>(A, ld, (long)pk * NB, (long)pi * NB + 16 * w, sm, lane);
+            {
+                d4 Y0[8], Y1[8];
+                trsm_strip2_regs(A, ld, (long)pk * NB, (long)pi * NB + 16 * w, sm, lane, Y0, Y1);
+                __syncthreads();                               // the L_kk image is dead
+                stage_put_strips(sm, w, Y0, Y1, lane);
+            }
+            __syncthreads();
+            stage_store_coherent<256>(sm, Ct, ld, t);
             drain_stores();
             __syncthreads();
             if (t == 0) {
                 st_flag(sync + PS_CNT + pi, pk + 1);
+                if (dn) dn[2] = wall_clock64();
                 s_prog[pick] = -1;
             }
             --left;
@@ -369,7 +498,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
     }
 }
 
-__global__ __launch_bounds__(256, 1) void k_potrf_persist(double* __restrict__ A, long ld, int nt,
+__global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A, long ld, int nt,
                                                           double* __restrict__ dinv_all, double* __restrict__ logsum,
                                                           int* __restrict__ info, int* __restrict__ sync, int kcap,
                                                           long long* __restrict__ dbg) {
@@ -378,7 +507,7 @@ __global__ __launch_bounds__(256, 1) void k_potrf_persist(double* __restrict__ A
         chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, dbg, sm);
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicExch(info, PS_ABORT_INFO);
     } else {
-        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, sm);
+        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, dbg, sm);
     }
 }
 
@@ -407,7 +536,7 @@ void launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, lo
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
     (void)hipMemsetAsync(ws->persist_sync, 0, sizeof(int) * PS_SYNC_INTS, st);
     ws->prof.begin(st, PF_PERSIST, (double)npad * npad * npad / 3.0);
-    hipLaunchKernelGGL(k_potrf_persist, dim3((unsigned)grid), dim3(256), PS_LDS_BYTES, st, A, npad, nt, ws->dinv, ws->logsum,
+    hipLaunchKernelGGL(k_potrf_persist, dim3((unsigned)grid), dim3(64 * PS_CHAIN_WAVES), PS_LDS_BYTES, st, A, npad, nt, ws->dinv, ws->logsum,
                        ws->info, ws->persist_sync, ws->persist_kcap, dbg);
     ws->prof.end(st);
 }

@@ -312,7 +312,8 @@ int mi355gp_dbg_graph_factor(int device, int64_t N, int reps, double* out3);
  * matrix.  out[0] ms per factorisation launch-per-step, [1] persistent, [2] doubles of the lower triangle of L that differ
  * bitwise between the two, [3] info, [4] abort word; out[8 + 8 j + q]: wall-clock stamps (100 MHz ticks) of chain step j
  * (q = 0 factor start, 1 factor end, 2 sub-diagonal tile seen, 3 solve end, 4 diagonal tile seen, 5 update end).
- * kcap: columns a worker applies per pass (0 = default).  out: 8 + 8 ceil(N / 128) doubles. */
+ * then for tile row i and d = i - k in 0..2 (the near tiles): out[8 + 8 nt + 4 (3 i + d) + q], q = 0 last task picked, 1 computed,
+ * 2 published.  kcap: columns a worker applies per pass (0 = default).  out: 8 + 20 ceil(N / 128) doubles. */
 int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out);
 /* diagnostics: is a CU-masked stream really confined?  out3 = ms of a 4096^3 GEMM on [plain, masked, masked] streams */
 int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3);

@@ -349,7 +349,7 @@ __device__ __forceinline__ void trsm_strip2(double* __restrict__ A, long ld, lon
         }
 }
 
-// the same, results left in registers (the caller stores them)
+// the same, one strip after the other (half the live registers), results left in registers (the caller stores them)
 __device__ __forceinline__ void trsm_strip2_regs(const double* __restrict__ A, long ld, long c0, long prow0, const double* sm,
                                                  int lane, d4 (&Y0)[8], d4 (&Y1)[8]) {
     const int fi = lane & 15, fk = lane >> 4;
@@ -363,8 +363,10 @@ __device__ __forceinline__ void trsm_strip2_regs(const double* __restrict__ A, l
             P0[jb][r] = Pa[jb * 16 + fk + 4 * r];
             P1[jb][r] = Pb[jb * 16 + fk + 4 * r];
         }
-    trsm_strip_core2(P0, P1, Y0, Y1, [sm](int jb, int k) { return sm + tix_sl(jb, k) * TSZ; },
-                     [sm](int jb) { return sm + (28 + jb) * TSZ; }, lane);
+    trsm_strip_core(P0, Y0, [sm](int jb, int k) { return sm + tix_sl(jb, k) * TSZ; }, [sm](int jb) { return sm + (28 + jb) * TSZ; },
+                    lane);
+    trsm_strip_core(P1, Y1, [sm](int jb, int k) { return sm + tix_sl(jb, k) * TSZ; }, [sm](int jb) { return sm + (28 + jb) * TSZ; },
+                    lane);
 }
 
 // strip rows [prow0, prow0+16) of the panel at column c0, L_cc image = trsm_stage_L's packing

@@ -151,7 +151,7 @@ __device__ __forceinline__ void stage_put_strips(double* sm, int a, const d4 (&Y
 template <int NTHR>
 __device__ __forceinline__ void stage_store_coherent(const double* sm, double* __restrict__ Ct, long ld, int t) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
+#pragma unroll 4
     for (int it = 0; it < 8192 / NTHR; ++it) {
         const int idx = it * NTHR + t, row = idx >> 6, cp = idx & 63;          // columns 2 cp, 2 cp + 1 of row `row`
         const d2 v = *reinterpret_cast<const d2*>(sm + ((row >> 4) * 8 + (cp >> 3)) * TSZ + (row & 15) * TS + 2 * (cp & 7));
@@ -167,75 +167,131 @@ __device__ __forceinline__ void stage_store_coherent(const double* sm, double* _
 // barrier for LDS traffic only: outstanding GLOBAL stores / loads keep flying (a __syncthreads() would drain them)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The chain workgroup has EIGHT waves with two roles:
-//   factor waves 0..3 : diag128_factor exactly as k_diag128 runs it; then, underneath the solve, they write L_jj through,
-//                       publish dcnt and fetch the 36 accumulator tiles of block (j+1, j+1); then the update: wave 0 / 1 own
-//                       the lower triangle of tile rows 0..3 / 4..7 (ten 16 x 16 tiles), waves 2 / 3 the rectangle rows 4..7
-//                       x columns 0..1 / 2..3 (eight tiles) -- every LDS fragment feeds two or more MFMAs;
-//   solver waves 4..7 : idle while block j is factored, so they fetch tile (j+1, j) THEN (strips g and g+4 for wave 4+g),
-//                       keep the factor's sixteen barriers company with bare s_barriers, run the solve the moment L_jj is
-//                       there, write the Y image and -- underneath the update -- store L(j+1, j) through and publish row j+1.
+// The chain workgroup has EIGHT waves, two per SIMD:
+//   factor  : waves 0..3 run diag128_factor exactly as k_diag128 does.  Waves 4..7 are idle then, so they fetch THEIR strip
+//             of tile (j+1, j) and the accumulators of their update tiles during it (sc1 loads in flight underneath the
+//             factorisation) and keep its sixteen barriers company with bare s_barriers;
+//   solve   : wave w owns strip w.  Waves 4..7 start the moment L_jj is there; waves 0..3 first write L_jj through, publish
+//             dcnt and fetch their own strip -- that latency hides behind the MFMAs of the wave they share their SIMD with;
+//   update  : wave W owns a 2 x 2 super-block of 16 x 16 tiles of the lower triangle of block (j+1, j+1) (W < 6: an
+//             off-diagonal one, four tiles; W = 6, 7: two diagonal ones, six tiles): every LDS fragment feeds two MFMAs;
+//   L(j+1,j): stored from the Y image, 16 B per lane and 1 KB rows per wave instruction, underneath the update.
 #define PS_CHAIN_WAVES 8
 
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-__device__ __forceinline__ void chain_load_strips(const double* __restrict__ A, long ld, long r1, long c0, int g, int fi, int fk,
-                                                  d4 (&P0)[8], d4 (&P1)[8]) {
-    const double* Pa = A + (r1 + 16 * g + fi) * ld + c0;
-    const double* Pb = A + (r1 + 16 * (g + 4) + fi) * ld + c0;
+// Global accesses of the chain go through buffer instructions: ONE per-lane 32-bit offset per access pattern, everything
+// else (tile / row / column of the access, the leading dimension) in scalar registers or the immediate.  With 64-bit
+// per-lane pointers the compiler hoists ~150 loop-invariant row * ld products out of the step loop and spills them.
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_at(const double* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ double bld_sc1(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 16));
+}
+__device__ __forceinline__ void bst_sc1(__amdgpu_buffer_rsrc_t rs, int voff, int soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), rs, voff, soff, 16);
+}
+
+// strip a (rows 16a .. 16a+15 of tile (j+1, j)) in the chained layout: lane (fi, fk) gets columns 16 jb + fk + 4 r of row fi
+__device__ __forceinline__ void chain_load_strip(const double* __restrict__ A, long ld, long r1, long c0, int a, int fi, int fk,
+                                                 d4 (&P)[8]) {
+    const __amdgpu_buffer_rsrc_t rs = rsrc_at(A + (r1 + 16 * a) * ld + c0);
+    const int voff = (fi * (int)ld + fk) * 8;
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            P0[jb][r] = ldg<true>(Pa + jb * 16 + fk + 4 * r);
-            P1[jb][r] = ldg<true>(Pb + jb * 16 + fk + 4 * r);
-        }
+        for (int r = 0; r < 4; ++r) P[jb][r] = bld_sc1(rs, voff, (jb * 16 + 4 * r) * 8);
 }
 
-// update tiles of factor wave W: (I, J) of its q-th tile
-__device__ __forceinline__ constexpr int ut_count(int W) { return W < 2 ? 10 : 8; }
+// L_jj from the LDS image to global, write-through (diag128_store with scalar addressing), sum(log diag) -> logsum[0]
+__device__ __forceinline__ void chain_store_diag(double* __restrict__ Ab, long ld, const double* Tt, double* __restrict__ logsum,
+                                                 int t, int lane, int w) {
+    const __amdgpu_buffer_rsrc_t rs = rsrc_at(Ab);
+    const int er = t >> 4, ec = t & 15, voff = (er * (int)ld + ec) * 8;
+#pragma unroll
+    for (int u = 0; u < NTILE; ++u)
+        bst_sc1(rs, voff, (tile_I(u) * 16 * (int)ld + tile_J(u) * 16) * 8, Tt[u * TSZ + er * TS + ec]);
+    if (w == 0) {
+        const int i0 = lane, i1 = lane + 64;
+        double sl = log(Tt[tix(i0 >> 4, i0 >> 4) * TSZ + (i0 & 15) * TS + (i0 & 15)]) +
+                    log(Tt[tix(i1 >> 4, i1 >> 4) * TSZ + (i1 & 15) * TS + (i1 & 15)]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sl += __shfl_down(sl, off);
+        if (lane == 0) logsum[0] = sl;
+    }
+}
+
+// update tiles of wave W: (I, J) of its q-th tile
+__device__ __forceinline__ constexpr int ut_count(int W) { return W < 6 ? 4 : 6; }
 __device__ __forceinline__ constexpr int ut_I(int W, int q) {
-    if (W < 2) return 4 * W + tile_I(q);                       // lower triangle of a 4 x 4 block of tiles
-    return 4 + (q >> 1);                                       // rows 4..7
+    if (W < 6) {
+        const int R = W == 0 ? 1 : (W <= 2 ? 2 : 3);
+        return 2 * R + (q >> 1);
+    }
+    const int R = 2 * (W - 6) + q / 3, t = q % 3;
+    return 2 * R + (t > 0 ? 1 : 0);
 }
 __device__ __forceinline__ constexpr int ut_J(int W, int q) {
-    if (W < 2) return 4 * W + tile_J(q);
-    return 2 * (W - 2) + (q & 1);                              // columns 0..1 (W = 2) or 2..3 (W = 3)
+    if (W < 6) {
+        const int C = W == 0 ? 0 : (W == 1 ? 0 : (W == 2 ? 1 : W - 3));
+        return 2 * C + (q & 1);
+    }
+    const int R = 2 * (W - 6) + q / 3, t = q % 3;
+    return 2 * R + (t == 2 ? 1 : 0);
 }
 
 template <int W>
-__device__ __forceinline__ void chain_load_acc_w(const double* __restrict__ Cb, long ld, int fi, int fk, d4 (&acc)[10]) {
+__device__ __forceinline__ void chain_load_acc_w(const double* __restrict__ Cb, long ld, int fi, int fk, d4 (&acc)[6]) {
+    const __amdgpu_buffer_rsrc_t rs = rsrc_at(Cb);
+    const int voff = (fk * (int)ld + fi) * 8;
 #pragma unroll
     for (int q = 0; q < ut_count(W); ++q) {
         const int I = ut_I(W, q), J = ut_J(W, q);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[q][r] = ldg<true>(Cb + (long)(16 * I + fk + 4 * r) * ld + 16 * J + fi);
+        for (int r = 0; r < 4; ++r) acc[q][r] = bld_sc1(rs, voff, ((16 * I + 4 * r) * (int)ld + 16 * J) * 8);
     }
 }
 
 // acc (tile q of wave W) -= Y[I] Y[J]^T from the Yim image.  MFMA order per tile = the tile GEMM's (slab jb, then m); the
 // tiles of a wave advance together, so every MFMA has independent neighbours and the next fragment reads run ahead.
 template <int W>
-__device__ __forceinline__ void chain_update_w(const double* sm, int fi, int fk, d4 (&acc)[10]) {
+__device__ __forceinline__ constexpr bool ut_uses(int a) {
+    for (int q = 0; q < ut_count(W); ++q)
+        if (ut_I(W, q) == a || ut_J(W, q) == a) return true;
+    return false;
+}
+template <int W, int S0, int S1>
+__device__ __forceinline__ void chain_update_range(const double* sm, int fi, int fk, d4 (&acc)[6]) {
+    // one LDS base per tile row of the image (18,432 B apart); slab and MFMA index go into the 16-bit immediate.
+    // The fragments of step s + 1 are read before the MFMAs of step s are issued (register double buffer).
+    const double* Yrow[8];
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
+    for (int a = 0; a < 8; ++a) Yrow[a] = sm + a * 8 * TSZ + fi * TS + fk;
+    double y[2][8];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const double* Ys = sm + jb * TSZ + fi * TS + fk + 4 * m;
-            double y[8];
+    for (int a = 0; a < 8; ++a) y[S0 & 1][a] = ut_uses<W>(a) ? Yrow[a][(S0 >> 2) * TSZ + 4 * (S0 & 3)] : 0.0;
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                bool used = false;
+    for (int s = S0; s < S1; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < S1) {
+            const int jb = (s + 1) >> 2, m = (s + 1) & 3;
 #pragma unroll
-                for (int q = 0; q < ut_count(W); ++q) used = used || ut_I(W, q) == a || ut_J(W, q) == a;
-                y[a] = used ? Ys[a * 8 * TSZ] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < ut_count(W); ++q) acc[q] = mfma_f64(-y[ut_I(W, q)], y[ut_J(W, q)], acc[q]);
+            for (int a = 0; a < 8; ++a) y[nxt][a] = ut_uses<W>(a) ? Yrow[a][jb * TSZ + 4 * m] : 0.0;
         }
+#pragma unroll
+        for (int q = 0; q < ut_count(W); ++q) acc[q] = mfma_f64(-y[cur][ut_I(W, q)], y[cur][ut_J(W, q)], acc[q]);
+    }
+}
+template <int W> __device__ __forceinline__ void chain_update_head(const double* sm, int fi, int fk, d4 (&acc)[6]) {
+    chain_update_range<W, 0, 8>(sm, fi, fk, acc);
+}
+template <int W> __device__ __forceinline__ void chain_update_tail(const double* sm, int fi, int fk, d4 (&acc)[6]) {
+    chain_update_range<W, 8, 32>(sm, fi, fk, acc);
 }
 template <int W>
-__device__ __forceinline__ void chain_put_w(double* Tt, int fi, int fk, const d4 (&acc)[10]) {
+__device__ __forceinline__ void chain_put_w(double* Tt, int fi, int fk, const d4 (&acc)[6]) {
 #pragma unroll
     for (int q = 0; q < ut_count(W); ++q) {
         const int u = tix(ut_I(W, q), ut_J(W, q));
@@ -248,132 +304,140 @@ __device__ __forceinline__ void chain_put_w(double* Tt, int fi, int fk, const d4
         case 0: FN<0>(__VA_ARGS__); break;           \
         case 1: FN<1>(__VA_ARGS__); break;           \
         case 2: FN<2>(__VA_ARGS__); break;           \
-        default: FN<3>(__VA_ARGS__); break;          \
+        case 3: FN<3>(__VA_ARGS__); break;           \
+        case 4: FN<4>(__VA_ARGS__); break;           \
+        case 5: FN<5>(__VA_ARGS__); break;           \
+        case 6: FN<6>(__VA_ARGS__); break;           \
+        default: FN<7>(__VA_ARGS__); break;          \
     }
 
-// one wave blocks until word p is set; false on abort / timeout (wave-uniform answer)
-__device__ __forceinline__ bool wave_wait(int* p, int* sync, int lane) {
+// one wave blocks until both hand-over words of row i are set; false on abort / timeout (wave-uniform answer)
+__device__ __forceinline__ bool wave_wait_row(int* sync, int i, int lane) {
     int ok = 1;
-    if (lane == 0) ok = wait_ge(p, 1, sync) ? 1 : 0;
+    if (lane == 0) ok = (wait_ge(sync + PS_SUB + i, 1, sync) && wait_ge(sync + PS_DIA + i, 1, sync)) ? 1 : 0;
     return __builtin_amdgcn_readfirstlane(ok) != 0;
 }
 
 __device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double* __restrict__ dinv_all,
                                 double* __restrict__ logsum, int* __restrict__ info, int* __restrict__ sync,
                                 long long* __restrict__ dbg, double* sm) {
-    __shared__ int s_fail, s_arr, s_arr0;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, fi = lane & 15, fk = lane >> 4;
+    __shared__ int s_fail, s_arr, s_arr0, s_pre;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), fi = lane & 15, fk = lane >> 4;
     double* Tt = sm;
     double* Dinv8 = sm + NTILE * TSZ;
-    if (t == 0) { s_fail = 0; s_arr = 0; s_arr0 = 0; }
-    if (w < 4) {
-        // ================================================= factor waves ==================================================
-        diag128_load<false>(A, ld, Tt);                        // block (0,0): written by the previous kernel
-        __syncthreads();
-        for (int j = 0; j < nt; ++j) {
-            const long c0 = (long)j * NB, r1 = c0 + NB;        // r1: first row / column of block j+1
-            const bool last = (j + 1 == nt);
-            if (dbg && t == 0) dbg[8 * j + 0] = wall_clock64();
+    if (t == 0) { s_fail = 0; s_arr = 0; s_arr0 = 0; s_pre = -1; }
+    if (w < 4) diag128_load<false>(A, ld, Tt);                 // block (0,0): written by the previous kernel
+    __syncthreads();
+    for (int j = 0; j < nt; ++j) {
+        const long c0 = (long)j * NB, r1 = c0 + NB;            // r1: first row / column of block j+1
+        const bool last = (j + 1 == nt);
+        const double* Cb = A + r1 * ld + r1;
+        d4 P[8], Y[8], acc[6];
+        bool loaded = false;
+        if (dbg && t == 0) dbg[8 * j + 0] = wall_clock64();
+        if (w < 4) {
             diag128_factor<true, TSZ>(Tt, Dinv8, c0, dinv_all + (long)j * 8 * 256, info);      // 16 barriers, ends with one
-            if (dbg && t == 0) dbg[8 * j + 1] = wall_clock64();
-            // L_jj write-through, dcnt (the owners of row j+2 start from it), then this wave's accumulators: all of it
-            // underneath the solve of the other four waves
-            diag128_store<true>(A + c0 * ld + c0, ld, Tt, logsum + j);
+        } else {
+            // wave 4 polls the two hand-over words of row j+1 (the values are looked at one barrier after their loads were
+            // issued: the poll never delays a barrier) and tells the others through LDS; each wave then fetches its strip
+            int fs = 0, fd = 0;
+            for (int b = 0; b < 16; ++b) {
+                if (!loaded && !last) {
+                    if (w == 4) {
+                        if (fs >= 1 && fd >= 1) {
+                            if (lane == 0) s_pre = j;
+                        } else {
+                            fs = ld_flag(sync + PS_SUB + j + 1);
+                            fd = ld_flag(sync + PS_DIA + j + 1);
+                        }
+                    }
+                    if (b > 0 && *(volatile int*)&s_pre == j) {
+                        chain_load_strip(A, ld, r1, c0, w, fi, fk, P);
+                        CHAIN_DISPATCH(chain_load_acc_w, Cb, ld, fi, fk, acc);
+                        loaded = true;
+                    }
+                }
+                raw_barrier();
+            }
+        }
+        if (dbg && t == 0) dbg[8 * j + 1] = wall_clock64();
+        if (last) {
+            if (w < 4) {
+                chain_store_diag(A + c0 * ld + c0, ld, Tt, logsum + j, t, lane, w);
+                drain_stores();
+                if (lane == 0 && atomicAdd(&s_arr0, 1) == 4 * (j + 1) - 1) st_flag(sync + PS_DCNT, j + 1);
+            }
+            break;
+        }
+        // Waves 0..3: L_jj write-through and dcnt -- the owners of row j+2 start from it, it heads THEIR critical path.  When
+        // the hand-over words were seen during the factorisation the wave's own loads go out first (one drain covers both);
+        // when the owners are late, dcnt goes out before anything waits for them.
+        const bool known = (*(volatile int*)&s_pre == j);
+        if (w < 4) {
+            if (known) {
+                chain_load_strip(A, ld, r1, c0, w, fi, fk, P);
+                CHAIN_DISPATCH(chain_load_acc_w, Cb, ld, fi, fk, acc);
+                loaded = true;
+            }
+            chain_store_diag(A + c0 * ld + c0, ld, Tt, logsum + j, t, lane, w);
             drain_stores();
             if (lane == 0 && atomicAdd(&s_arr0, 1) == 4 * (j + 1) - 1) {
                 st_flag(sync + PS_DCNT, j + 1);
                 if (dbg) dbg[8 * j + 4] = wall_clock64();
             }
-            if (last) break;
-            d4 acc[10];
-            if (!wave_wait(sync + PS_DIA + j + 1, sync, lane)) {
+        }
+        if (!loaded) {                                         // the owners were late
+            if (!known && !wave_wait_row(sync, j + 1, lane)) {
                 if (lane == 0) s_fail = 1;
             } else {
-                CHAIN_DISPATCH(chain_load_acc_w, A + r1 * ld + r1, ld, fi, fk, acc);
+                chain_load_strip(A, ld, r1, c0, w, fi, fk, P);
+                CHAIN_DISPATCH(chain_load_acc_w, Cb, ld, fi, fk, acc);
+                loaded = true;
             }
-            lds_barrier();                                     // (X) every wave is done reading Tt / Dinv8
-            if (s_fail) return;
-            lds_barrier();                                     // (Y) the Y image is written
-            if (dbg && t == 0) dbg[8 * j + 3] = wall_clock64();
-            // ---- block (j+1, j+1) -= Y Y^T on its 36 lower 16 x 16 tiles (columns 0 .. j-1 were applied by its owner)
-            CHAIN_DISPATCH(chain_update_w, sm, fi, fk, acc);
-            if (dbg && t == 0) dbg[8 * j + 7] = wall_clock64();
-            lds_barrier();                                     // (Z) Yim is dead: its space becomes Tt again
-            CHAIN_DISPATCH(chain_put_w, Tt, fi, fk, acc);
-            lds_barrier();                                     // (W)
-            if (dbg && t == 0) dbg[8 * j + 5] = wall_clock64();
         }
-    } else {
-        // ================================================= solver waves ==================================================
-        const int g = w - 4;
-        __syncthreads();                                       // pairs with the barrier after diag128_load
-        for (int j = 0; j < nt; ++j) {
-            const long c0 = (long)j * NB, r1 = c0 + NB;
-            const bool last = (j + 1 == nt);
-            d4 P0[8], P1[8], Y0[8], Y1[8];
-            // Block j is being factored by the other four waves (sixteen barriers).  Poll the hand-over word of tile (j+1, j)
-            // -- the value is looked at one barrier AFTER its load was issued, so the poll never delays a barrier --, fetch the
-            // two strips as soon as it is set, then keep the remaining barriers company.
-            bool loaded = false;
-            int fs = 0;
-            for (int b = 0; b < 16; ++b) {
-                if (!loaded && !last) {
-                    if (fs >= 1) {
-                        chain_load_strips(A, ld, r1, c0, g, fi, fk, P0, P1);
-                        loaded = true;
-                    } else {
-                        fs = ld_flag(sync + PS_SUB + j + 1);
-                    }
-                }
-                raw_barrier();
-            }
-            if (last) break;
-            if (!loaded) {                                     // rare: the owner was late
-                if (!wave_wait(sync + PS_SUB + j + 1, sync, lane)) {
-                    if (lane == 0) s_fail = 1;
-                } else {
-                    chain_load_strips(A, ld, r1, c0, g, fi, fk, P0, P1);
-                    loaded = true;
-                }
-            }
-            if (dbg && t == 256) dbg[8 * j + 2] = wall_clock64();
-            // ---- L(j+1, j) = A(j+1, j) L_jj^-T, strips g and g + 4
-            if (loaded)
-                trsm_strip_core2(P0, P1, Y0, Y1, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
-                                 [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
-            if (dbg && t == 256) dbg[8 * j + 6] = wall_clock64();
-            lds_barrier();                                     // (X)
-            if (s_fail) return;
+        if (dbg && t == 256) dbg[8 * j + 2] = wall_clock64();
+        // ---- L(j+1, j) = A(j+1, j) L_jj^-T, strip w
+        if (loaded)
+            trsm_strip_core(P, Y, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
+                            [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
+        if (dbg && t == 256) dbg[8 * j + 6] = wall_clock64();
+        lds_barrier();                                         // (X) every wave is done reading Tt / Dinv8
+        if (s_fail) return;
 #pragma unroll
-            for (int jb = 0; jb < 8; ++jb) {
-                double* Ta = sm + (g * 8 + jb) * TSZ + fi * TS + 4 * fk;       // column fk + 4r -> position r + 4 fk
-                double* Tb = sm + ((g + 4) * 8 + jb) * TSZ + fi * TS + 4 * fk;
+        for (int jb = 0; jb < 8; ++jb) {
+            double* Ta = sm + (w * 8 + jb) * TSZ + fi * TS + 4 * fk;           // column fk + 4r -> position r + 4 fk
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    Ta[r] = Y0[jb][r];
-                    Tb[r] = Y1[jb][r];
-                }
-            }
-            lds_barrier();                                     // (Y)
-            // ---- L(j+1, j) to global from the image: 16 B per lane, 1 KB rows per wave instruction, write-through;
-            //      then row j+1's progress word -- all underneath the update
-            {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(A + r1 * ld + c0, 0, 0x7fffffff, 0x00020000);
-                const int ts = t - 256;
+            for (int r = 0; r < 4; ++r) Ta[r] = Y[jb][r];
+        }
+        lds_barrier();                                         // (Y) the Y image is complete
+        if (dbg && t == 0) dbg[8 * j + 3] = wall_clock64();
+        // ---- L(j+1, j) to global from the image, write-through, by waves 4..7, in flight underneath the update; a quarter
+        //      into the update they have landed: drain (free) and publish row j+1 -- its owners' GEMMs wait for it
+        if (w >= 4) {
+            // wave 4 + g stores rows g, g + 4, ..., g + 124: lane -> columns 2 lane, 2 lane + 1 (1 KB per wave instruction)
+            const __amdgpu_buffer_rsrc_t rs = rsrc_at(A + r1 * ld + c0);
+            const int jb = lane >> 3, kk = 2 * (lane & 7), q = kk >> 2, m = kk & 3;
+            const double* Tl = sm + jb * TSZ + q + 4 * m;                      // per-lane part of the image address
 #pragma unroll
-                for (int it = 0; it < 32; ++it) {
-                    const int idx = it * 256 + ts, row = idx >> 6, cp = idx & 63;      // columns 2 cp, 2 cp + 1
-                    const int jb = cp >> 3, kk = 2 * (cp & 7), q = kk >> 2, m = kk & 3;
-                    const double* T = sm + ((row >> 4) * 8 + jb) * TSZ + (row & 15) * TS + q + 4 * m;
-                    const d2 v = {T[0], T[4]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, (int)((row * ld + 2 * cp) * 8), 0, 16);
-                }
+            for (int it = 0; it < 32; ++it) {
+                const int row = it * 4 + (w - 4);
+                const double* T = Tl + ((row >> 4) * 8) * TSZ + (row & 15) * TS;
+                const d2 v = {T[0], T[4]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, lane * 16, row * (int)ld * 8, 16);
             }
+        }
+        // ---- block (j+1, j+1) -= Y Y^T on its 36 lower 16 x 16 tiles (columns 0 .. j-1 were applied by its owner)
+        CHAIN_DISPATCH(chain_update_head, sm, fi, fk, acc);
+        if (w >= 4) {
             drain_stores();
             if (lane == 0 && atomicAdd(&s_arr, 1) == 4 * (j + 1) - 1) st_flag(sync + PS_CNT + j + 1, j + 1);
-            lds_barrier();                                     // (Z)
-            lds_barrier();                                     // (W)
         }
+        CHAIN_DISPATCH(chain_update_tail, sm, fi, fk, acc);
+        if (dbg && t == 0) dbg[8 * j + 7] = wall_clock64();
+        lds_barrier();                                         // (Z) Yim is dead: its space becomes Tt again
+        CHAIN_DISPATCH(chain_put_w, Tt, fi, fk, acc);
+        lds_barrier();                                         // (W)
+        if (dbg && t == 0) dbg[8 * j + 5] = wall_clock64();
     }
 }
 

@@ -165,6 +165,7 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
         const char* envpc = getenv("MI355GP_PERSIST_WGS");
         if (envpc && *envpc && atoi(envpc) >= 2 && atoi(envpc) <= ws->persist_cus) ws->persist_cus = atoi(envpc);
         HIP_CHECK(hipMalloc(&ws->persist_sync, sizeof(int) * potrf_persist_sync_ints()));
+        HIP_CHECK(hipMalloc(&ws->persist_hs, sizeof(double) * (size_t)(ws->nblk < 64 ? ws->nblk : 64) * NB * NB));
     }
     const char* envx = getenv("MI355GP_DIAG_EXCL_FIRST");
     if (envx && *envx) ws->diag_excl_first = atoi(envx) ? 1 : 0;
@@ -202,6 +203,8 @@ void factor_ws_free(FactorWs* ws) {
     ws->tri_counter = nullptr;
     if (ws->persist_sync) (void)hipFree(ws->persist_sync);
     ws->persist_sync = nullptr;
+    if (ws->persist_hs) (void)hipFree(ws->persist_hs);
+    ws->persist_hs = nullptr;
     ws->prof.destroy();
 }
 

@@ -95,6 +95,7 @@ struct FactorWs {
     // MI355GP_PERSIST: the single-launch dataflow Cholesky of persist.hip for factorisations of at most persist_max_nt tiles
     int persist = FACTOR_DEFAULT_PERSIST, persist_max_nt = 47, persist_kcap = 2, persist_cus = 0;
     int* persist_sync = nullptr;     // progress words of the persistent launch (zeroed before every launch)
+    double* persist_hs = nullptr;    // [min(nblk, 64)][128 x 128]: sub-diagonal tile of every row, handed to the chain in ITS load order
     KernelProf prof;
 };
 // Gate of a device's shared engine streams.  Entry points that enqueue on them hold it SHARED for the duration of the call

@@ -159,6 +159,23 @@ __device__ __forceinline__ void stage_store_coherent(const double* sm, double* _
     }
 }
 
+// image -> the hand-off buffer of a sub-diagonal tile, in the CHAIN'S LOAD ORDER: strip a (16 rows), chunk c (0..15), lane
+// l = 16 fk + fi holds the pair (row 16a + fi, columns 16 (c >> 1) + fk + 4 r, r = 2 (c & 1), 2 (c & 1) + 1) at doubles
+// ((a * 16 + c) * 64 + l) * 2: the chain's solver waves fetch a strip with sixteen 1-KB-contiguous 16-byte loads instead of
+// thirty-two 8-byte loads that touch sixteen cache lines each (measured: ~16 us per tile that way).
+template <int NTHR>
+__device__ __forceinline__ void stage_store_chain_order(const double* sm, double* __restrict__ hs, int t) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hs, 0, 0x7fffffff, 0x00020000);
+#pragma unroll 4
+    for (int it = 0; it < 8192 / NTHR; ++it) {
+        const int idx = it * NTHR + t, l = idx & 63, c = (idx >> 6) & 15, a = idx >> 10;
+        const int fi = l & 15, fk = l >> 4, jb = c >> 1, r = 2 * (c & 1);
+        const double* T = sm + (a * 8 + jb) * TSZ + fi * TS + fk + 4 * r;
+        const d2 v = {T[0], T[4]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, idx * 16, 0, 16);
+    }
+}
+
 // ---- the chain workgroup ----------------------------------------------------------------------------------------------
 // LDS map (doubles): phase "factor": Tt = sm[0 .. 36 TSZ), Dinv8 = sm[36 TSZ .. 44 TSZ); phase "update": Yim = sm[0 .. 64 TSZ)
 // Yim tile (a, jb) = rows 16a .. 16a+15, columns 16jb .. 16jb+15 of Y = L(j+1, j), element (row, col 4q + m) stored at
@@ -167,15 +184,15 @@ __device__ __forceinline__ void stage_store_coherent(const double* sm, double* _
 // barrier for LDS traffic only: outstanding GLOBAL stores / loads keep flying (a __syncthreads() would drain them)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The chain workgroup has EIGHT waves, two per SIMD:
-//   factor  : waves 0..3 run diag128_factor exactly as k_diag128 does.  Waves 4..7 are idle then, so they fetch THEIR strip
-//             of tile (j+1, j) and the accumulators of their update tiles during it (sc1 loads in flight underneath the
-//             factorisation) and keep its sixteen barriers company with bare s_barriers;
-//   solve   : wave w owns strip w.  Waves 4..7 start the moment L_jj is there; waves 0..3 first write L_jj through, publish
-//             dcnt and fetch their own strip -- that latency hides behind the MFMAs of the wave they share their SIMD with;
-//   update  : wave W owns a 2 x 2 super-block of 16 x 16 tiles of the lower triangle of block (j+1, j+1) (W < 6: an
-//             off-diagonal one, four tiles; W = 6, 7: two diagonal ones, six tiles): every LDS fragment feeds two MFMAs;
-//   L(j+1,j): stored from the Y image, 16 B per lane and 1 KB rows per wave instruction, underneath the update.
+// The chain workgroup has EIGHT waves with two roles:
+//   factor waves 0..3 : diag128_factor exactly as k_diag128 runs it; then, underneath the solve, they write L_jj through,
+//                       publish dcnt and fetch the 36 accumulator tiles of block (j+1, j+1); then the update: wave 0 / 1 own
+//                       the lower triangle of tile rows 0..3 / 4..7 (ten 16 x 16 tiles), waves 2 / 3 the rectangle rows 4..7
+//                       x columns 0..1 / 2..3 (eight tiles) -- every LDS fragment feeds two or more MFMAs;
+//   solver waves 4..7 : idle while block j is factored, so they fetch tile (j+1, j) THEN (strips g and g+4 for wave 4+g,
+//                       sc1 loads in flight underneath the factorisation), keep the factor's sixteen barriers company with
+//                       bare s_barriers, run the solve the moment L_jj is there, write the Y image and -- underneath the
+//                       update -- store L(j+1, j) through and publish row j+1.
 #define PS_CHAIN_WAVES 8
 
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -194,15 +211,16 @@ __device__ __forceinline__ void bst_sc1(__amdgpu_buffer_rsrc_t rs, int voff, int
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), rs, voff, soff, 16);
 }
 
-// strip a (rows 16a .. 16a+15 of tile (j+1, j)) in the chained layout: lane (fi, fk) gets columns 16 jb + fk + 4 r of row fi
-__device__ __forceinline__ void chain_load_strip(const double* __restrict__ A, long ld, long r1, long c0, int a, int fi, int fk,
-                                                 d4 (&P)[8]) {
-    const __amdgpu_buffer_rsrc_t rs = rsrc_at(A + (r1 + 16 * a) * ld + c0);
-    const int voff = (fi * (int)ld + fk) * 8;
+// strip a of the handed-over tile (j+1, j) from the hand-off buffer (chain order, see stage_store_chain_order): sixteen
+// 16-byte loads per lane, each 1 KB contiguous per wave
+__device__ __forceinline__ void chain_load_strip(const double* __restrict__ hs, int a, int lane, d4 (&P)[8]) {
+    const __amdgpu_buffer_rsrc_t rs = rsrc_at(hs + a * 2048);
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) P[jb][r] = bld_sc1(rs, voff, (jb * 16 + 4 * r) * 8);
+    for (int c = 0; c < 16; ++c) {
+        const d2 v = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, c * 1024, 16));
+        P[c >> 1][2 * (c & 1)] = v[0];
+        P[c >> 1][2 * (c & 1) + 1] = v[1];
+    }
 }
 
 // L_jj from the LDS image to global, write-through (diag128_store with scalar addressing), sum(log diag) -> logsum[0]
@@ -223,27 +241,25 @@ __device__ __forceinline__ void chain_store_diag(double* __restrict__ Ab, long l
     }
 }
 
-// update tiles of wave W: (I, J) of its q-th tile
-__device__ __forceinline__ constexpr int ut_count(int W) { return W < 6 ? 4 : 6; }
+// update tiles of factor wave W: (I, J) of its q-th tile
+__device__ __forceinline__ constexpr int ut_count(int W) { return W < 2 ? 10 : 8; }
 __device__ __forceinline__ constexpr int ut_I(int W, int q) {
-    if (W < 6) {
-        const int R = W == 0 ? 1 : (W <= 2 ? 2 : 3);
-        return 2 * R + (q >> 1);
-    }
-    const int R = 2 * (W - 6) + q / 3, t = q % 3;
-    return 2 * R + (t > 0 ? 1 : 0);
+    if (W < 2) return 4 * W + tile_I(q);                       // lower triangle of a 4 x 4 block of tiles
+    return 4 + (q >> 1);                                       // rows 4..7
 }
 __device__ __forceinline__ constexpr int ut_J(int W, int q) {
-    if (W < 6) {
-        const int C = W == 0 ? 0 : (W == 1 ? 0 : (W == 2 ? 1 : W - 3));
-        return 2 * C + (q & 1);
-    }
-    const int R = 2 * (W - 6) + q / 3, t = q % 3;
-    return 2 * R + (t == 2 ? 1 : 0);
+    if (W < 2) return 4 * W + tile_J(q);
+    return 2 * (W - 2) + (q & 1);                              // columns 0..1 (W = 2) or 2..3 (W = 3)
+}
+template <int W>
+__device__ __forceinline__ constexpr bool ut_uses(int a) {
+    for (int q = 0; q < ut_count(W); ++q)
+        if (ut_I(W, q) == a || ut_J(W, q) == a) return true;
+    return false;
 }
 
 template <int W>
-__device__ __forceinline__ void chain_load_acc_w(const double* __restrict__ Cb, long ld, int fi, int fk, d4 (&acc)[6]) {
+__device__ __forceinline__ void chain_load_acc_w(const double* __restrict__ Cb, long ld, int fi, int fk, d4 (&acc)[10]) {
     const __amdgpu_buffer_rsrc_t rs = rsrc_at(Cb);
     const int voff = (fk * (int)ld + fi) * 8;
 #pragma unroll
@@ -255,27 +271,21 @@ __device__ __forceinline__ void chain_load_acc_w(const double* __restrict__ Cb, 
 }
 
 // acc (tile q of wave W) -= Y[I] Y[J]^T from the Yim image.  MFMA order per tile = the tile GEMM's (slab jb, then m); the
-// tiles of a wave advance together, so every MFMA has independent neighbours and the next fragment reads run ahead.
+// tiles of a wave advance together, so every MFMA has independent neighbours.  One LDS base per tile row of the image
+// (18,432 B apart), slab and MFMA index in the 16-bit immediate; the fragments of step s + 1 are read before the MFMAs of
+// step s are issued (register double buffer).
 template <int W>
-__device__ __forceinline__ constexpr bool ut_uses(int a) {
-    for (int q = 0; q < ut_count(W); ++q)
-        if (ut_I(W, q) == a || ut_J(W, q) == a) return true;
-    return false;
-}
-template <int W, int S0, int S1>
-__device__ __forceinline__ void chain_update_range(const double* sm, int fi, int fk, d4 (&acc)[6]) {
-    // one LDS base per tile row of the image (18,432 B apart); slab and MFMA index go into the 16-bit immediate.
-    // The fragments of step s + 1 are read before the MFMAs of step s are issued (register double buffer).
+__device__ __forceinline__ void chain_update_w(const double* sm, int fi, int fk, d4 (&acc)[10]) {
     const double* Yrow[8];
 #pragma unroll
     for (int a = 0; a < 8; ++a) Yrow[a] = sm + a * 8 * TSZ + fi * TS + fk;
     double y[2][8];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) y[S0 & 1][a] = ut_uses<W>(a) ? Yrow[a][(S0 >> 2) * TSZ + 4 * (S0 & 3)] : 0.0;
+    for (int a = 0; a < 8; ++a) y[0][a] = ut_uses<W>(a) ? Yrow[a][0] : 0.0;
 #pragma unroll
-    for (int s = S0; s < S1; ++s) {
+    for (int s = 0; s < 32; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
-        if (s + 1 < S1) {
+        if (s + 1 < 32) {
             const int jb = (s + 1) >> 2, m = (s + 1) & 3;
 #pragma unroll
             for (int a = 0; a < 8; ++a) y[nxt][a] = ut_uses<W>(a) ? Yrow[a][jb * TSZ + 4 * m] : 0.0;
@@ -284,14 +294,8 @@ __device__ __forceinline__ void chain_update_range(const double* sm, int fi, int
         for (int q = 0; q < ut_count(W); ++q) acc[q] = mfma_f64(-y[cur][ut_I(W, q)], y[cur][ut_J(W, q)], acc[q]);
     }
 }
-template <int W> __device__ __forceinline__ void chain_update_head(const double* sm, int fi, int fk, d4 (&acc)[6]) {
-    chain_update_range<W, 0, 8>(sm, fi, fk, acc);
-}
-template <int W> __device__ __forceinline__ void chain_update_tail(const double* sm, int fi, int fk, d4 (&acc)[6]) {
-    chain_update_range<W, 8, 32>(sm, fi, fk, acc);
-}
 template <int W>
-__device__ __forceinline__ void chain_put_w(double* Tt, int fi, int fk, const d4 (&acc)[6]) {
+__device__ __forceinline__ void chain_put_w(double* Tt, int fi, int fk, const d4 (&acc)[10]) {
 #pragma unroll
     for (int q = 0; q < ut_count(W); ++q) {
         const int u = tix(ut_I(W, q), ut_J(W, q));
@@ -304,146 +308,140 @@ __device__ __forceinline__ void chain_put_w(double* Tt, int fi, int fk, const d4
         case 0: FN<0>(__VA_ARGS__); break;           \
         case 1: FN<1>(__VA_ARGS__); break;           \
         case 2: FN<2>(__VA_ARGS__); break;           \
-        case 3: FN<3>(__VA_ARGS__); break;           \
-        case 4: FN<4>(__VA_ARGS__); break;           \
-        case 5: FN<5>(__VA_ARGS__); break;           \
-        case 6: FN<6>(__VA_ARGS__); break;           \
-        default: FN<7>(__VA_ARGS__); break;          \
+        default: FN<3>(__VA_ARGS__); break;          \
     }
 
-// one wave blocks until both hand-over words of row i are set; false on abort / timeout (wave-uniform answer)
-__device__ __forceinline__ bool wave_wait_row(int* sync, int i, int lane) {
+// one wave blocks until word p is set; false on abort / timeout (wave-uniform answer)
+__device__ __forceinline__ bool wave_wait(int* p, int* sync, int lane) {
     int ok = 1;
-    if (lane == 0) ok = (wait_ge(sync + PS_SUB + i, 1, sync) && wait_ge(sync + PS_DIA + i, 1, sync)) ? 1 : 0;
+    if (lane == 0) ok = wait_ge(p, 1, sync) ? 1 : 0;
     return __builtin_amdgcn_readfirstlane(ok) != 0;
 }
 
 __device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double* __restrict__ dinv_all,
                                 double* __restrict__ logsum, int* __restrict__ info, int* __restrict__ sync,
-                                long long* __restrict__ dbg, double* sm) {
-    __shared__ int s_fail, s_arr, s_arr0, s_pre;
+                                const double* __restrict__ hs, long long* __restrict__ dbg, double* sm) {
+    __shared__ int s_fail, s_arr, s_arr0;
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), fi = lane & 15, fk = lane >> 4;
     double* Tt = sm;
     double* Dinv8 = sm + NTILE * TSZ;
-    if (t == 0) { s_fail = 0; s_arr = 0; s_arr0 = 0; s_pre = -1; }
-    if (w < 4) diag128_load<false>(A, ld, Tt);                 // block (0,0): written by the previous kernel
-    __syncthreads();
-    for (int j = 0; j < nt; ++j) {
-        const long c0 = (long)j * NB, r1 = c0 + NB;            // r1: first row / column of block j+1
-        const bool last = (j + 1 == nt);
-        const double* Cb = A + r1 * ld + r1;
-        d4 P[8], Y[8], acc[6];
-        bool loaded = false;
-        if (dbg && t == 0) dbg[8 * j + 0] = wall_clock64();
-        if (w < 4) {
+    if (t == 0) { s_fail = 0; s_arr = 0; s_arr0 = 0; }
+    if (w < 4) {
+        // ================================================= factor waves ==================================================
+        diag128_load<false>(A, ld, Tt);                        // block (0,0): written by the previous kernel
+        __syncthreads();
+        for (int j = 0; j < nt; ++j) {
+            const long c0 = (long)j * NB, r1 = c0 + NB;        // r1: first row / column of block j+1
+            const bool last = (j + 1 == nt);
+            if (dbg && t == 0) dbg[8 * j + 0] = wall_clock64();
             diag128_factor<true, TSZ>(Tt, Dinv8, c0, dinv_all + (long)j * 8 * 256, info);      // 16 barriers, ends with one
-        } else {
-            // wave 4 polls the two hand-over words of row j+1 (the values are looked at one barrier after their loads were
-            // issued: the poll never delays a barrier) and tells the others through LDS; each wave then fetches its strip
-            int fs = 0, fd = 0;
-            for (int b = 0; b < 16; ++b) {
-                if (!loaded && !last) {
-                    if (w == 4) {
-                        if (fs >= 1 && fd >= 1) {
-                            if (lane == 0) s_pre = j;
-                        } else {
-                            fs = ld_flag(sync + PS_SUB + j + 1);
-                            fd = ld_flag(sync + PS_DIA + j + 1);
-                        }
-                    }
-                    if (b > 0 && *(volatile int*)&s_pre == j) {
-                        chain_load_strip(A, ld, r1, c0, w, fi, fk, P);
-                        CHAIN_DISPATCH(chain_load_acc_w, Cb, ld, fi, fk, acc);
-                        loaded = true;
-                    }
-                }
-                raw_barrier();
-            }
-        }
-        if (dbg && t == 0) dbg[8 * j + 1] = wall_clock64();
-        if (last) {
-            if (w < 4) {
-                chain_store_diag(A + c0 * ld + c0, ld, Tt, logsum + j, t, lane, w);
-                drain_stores();
-                if (lane == 0 && atomicAdd(&s_arr0, 1) == 4 * (j + 1) - 1) st_flag(sync + PS_DCNT, j + 1);
-            }
-            break;
-        }
-        // Waves 0..3: L_jj write-through and dcnt -- the owners of row j+2 start from it, it heads THEIR critical path.  When
-        // the hand-over words were seen during the factorisation the wave's own loads go out first (one drain covers both);
-        // when the owners are late, dcnt goes out before anything waits for them.
-        const bool known = (*(volatile int*)&s_pre == j);
-        if (w < 4) {
-            if (known) {
-                chain_load_strip(A, ld, r1, c0, w, fi, fk, P);
-                CHAIN_DISPATCH(chain_load_acc_w, Cb, ld, fi, fk, acc);
-                loaded = true;
-            }
+            if (dbg && t == 0) dbg[8 * j + 1] = wall_clock64();
+            // L_jj write-through, dcnt (the owners of row j+2 start from it), then this wave's accumulators: all of it
+            // underneath the solve of the other four waves
             chain_store_diag(A + c0 * ld + c0, ld, Tt, logsum + j, t, lane, w);
             drain_stores();
             if (lane == 0 && atomicAdd(&s_arr0, 1) == 4 * (j + 1) - 1) {
                 st_flag(sync + PS_DCNT, j + 1);
                 if (dbg) dbg[8 * j + 4] = wall_clock64();
             }
-        }
-        if (!loaded) {                                         // the owners were late
-            if (!known && !wave_wait_row(sync, j + 1, lane)) {
+            if (last) break;
+            d4 acc[10];
+            if (!wave_wait(sync + PS_DIA + j + 1, sync, lane)) {
                 if (lane == 0) s_fail = 1;
             } else {
-                chain_load_strip(A, ld, r1, c0, w, fi, fk, P);
-                CHAIN_DISPATCH(chain_load_acc_w, Cb, ld, fi, fk, acc);
+                CHAIN_DISPATCH(chain_load_acc_w, A + r1 * ld + r1, ld, fi, fk, acc);
+            }
+            lds_barrier();                                     // (X) every wave is done reading Tt / Dinv8
+            if (s_fail) return;
+            lds_barrier();                                     // (Y) the Y image is written
+            if (dbg && t == 0) dbg[8 * j + 3] = wall_clock64();
+            // ---- block (j+1, j+1) -= Y Y^T on its 36 lower 16 x 16 tiles (columns 0 .. j-1 were applied by its owner)
+            CHAIN_DISPATCH(chain_update_w, sm, fi, fk, acc);
+            if (dbg && t == 0) dbg[8 * j + 7] = wall_clock64();
+            lds_barrier();                                     // (Z) Yim is dead: its space becomes Tt again
+            CHAIN_DISPATCH(chain_put_w, Tt, fi, fk, acc);
+            lds_barrier();                                     // (W)
+            if (dbg && t == 0) dbg[8 * j + 5] = wall_clock64();
+        }
+    } else {
+        // ================================================= solver waves ==================================================
+        const int g = w - 4;
+        __syncthreads();                                       // pairs with the barrier after diag128_load
+        for (int j = 0; j < nt; ++j) {
+            const long c0 = (long)j * NB, r1 = c0 + NB;
+            const bool last = (j + 1 == nt);
+            d4 P0[8], P1[8], Y0[8], Y1[8];
+            bool loaded = false;
+            const double* hsj = hs + (long)(j + 1) * (NB * NB);                // hand-off buffer of row j+1
+            if (last) {
+                for (int b = 0; b < 16; ++b) raw_barrier();
+                break;
+            }
+            // Block j is being factored by waves 0..3: keep its sixteen barriers company.  Meanwhile poll the hand-over word
+            // of tile (j+1, j) (looked at one barrier after its load was issued: the poll never delays a barrier).
+            int fs = 0;
+            for (int b = 0; b < 16; ++b) {
+                if (fs < 1) fs = ld_flag(sync + PS_SUB + j + 1);
+                raw_barrier();
+            }
+            if (fs < 1 && !wave_wait(sync + PS_SUB + j + 1, sync, lane)) {     // the owner was late
+                if (lane == 0) s_fail = 1;
+            } else {
+                // two strips from the hand-off buffer: thirty-two 1-KB-contiguous 16-byte loads per wave
+                chain_load_strip(hsj, g, lane, P0);
+                chain_load_strip(hsj, g + 4, lane, P1);
                 loaded = true;
             }
-        }
-        if (dbg && t == 256) dbg[8 * j + 2] = wall_clock64();
-        // ---- L(j+1, j) = A(j+1, j) L_jj^-T, strip w
-        if (loaded)
-            trsm_strip_core(P, Y, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
-                            [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
-        if (dbg && t == 256) dbg[8 * j + 6] = wall_clock64();
-        lds_barrier();                                         // (X) every wave is done reading Tt / Dinv8
-        if (s_fail) return;
-#pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
-            double* Ta = sm + (w * 8 + jb) * TSZ + fi * TS + 4 * fk;           // column fk + 4r -> position r + 4 fk
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ta[r] = Y[jb][r];
-        }
-        lds_barrier();                                         // (Y) the Y image is complete
-        if (dbg && t == 0) dbg[8 * j + 3] = wall_clock64();
-        // ---- L(j+1, j) to global from the image, write-through, by waves 4..7, in flight underneath the update; a quarter
-        //      into the update they have landed: drain (free) and publish row j+1 -- its owners' GEMMs wait for it
-        if (w >= 4) {
-            // wave 4 + g stores rows g, g + 4, ..., g + 124: lane -> columns 2 lane, 2 lane + 1 (1 KB per wave instruction)
-            const __amdgpu_buffer_rsrc_t rs = rsrc_at(A + r1 * ld + c0);
-            const int jb = lane >> 3, kk = 2 * (lane & 7), q = kk >> 2, m = kk & 3;
-            const double* Tl = sm + jb * TSZ + q + 4 * m;                      // per-lane part of the image address
-#pragma unroll
-            for (int it = 0; it < 32; ++it) {
-                const int row = it * 4 + (w - 4);
-                const double* T = Tl + ((row >> 4) * 8) * TSZ + (row & 15) * TS;
-                const d2 v = {T[0], T[4]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, lane * 16, row * (int)ld * 8, 16);
+            if (dbg && t == 256) dbg[8 * j + 2] = wall_clock64();
+            // ---- L(j+1, j) = A(j+1, j) L_jj^-T, strips g and g + 4, one after the other
+            if (loaded) {
+                trsm_strip_core(P0, Y0, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
+                                [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
+                __builtin_amdgcn_sched_barrier(0);             // do not interleave the two strips: 128 live registers more
+                trsm_strip_core(P1, Y1, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
+                                [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
             }
-        }
-        // ---- block (j+1, j+1) -= Y Y^T on its 36 lower 16 x 16 tiles (columns 0 .. j-1 were applied by its owner)
-        CHAIN_DISPATCH(chain_update_head, sm, fi, fk, acc);
-        if (w >= 4) {
+            if (dbg && t == 256) dbg[8 * j + 6] = wall_clock64();
+            lds_barrier();                                     // (X)
+            if (s_fail) return;
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) {
+                double* Ta = sm + (g * 8 + jb) * TSZ + fi * TS + 4 * fk;       // column fk + 4r -> position r + 4 fk
+                double* Tb = sm + ((g + 4) * 8 + jb) * TSZ + fi * TS + 4 * fk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Ta[r] = Y0[jb][r];
+                    Tb[r] = Y1[jb][r];
+                }
+            }
+            lds_barrier();                                     // (Y)
+            // ---- L(j+1, j) to global from the image: 16 B per lane, 1 KB rows per wave instruction, write-through;
+            //      then row j+1's progress word -- all underneath the update
+            {
+                // wave 4 + g stores rows g, g + 4, ..., g + 124: lane -> columns 2 lane, 2 lane + 1
+                const __amdgpu_buffer_rsrc_t rs = rsrc_at(A + r1 * ld + c0);
+                const int jb = lane >> 3, kk = 2 * (lane & 7), q = kk >> 2, m = kk & 3;
+                const double* Tl = sm + jb * TSZ + q + 4 * m;                  // per-lane part of the image address
+#pragma unroll
+                for (int it = 0; it < 32; ++it) {
+                    const int row = it * 4 + g;
+                    const double* T = Tl + ((row >> 4) * 8) * TSZ + (row & 15) * TS;
+                    const d2 v = {T[0], T[4]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, lane * 16, row * (int)ld * 8, 16);
+                }
+            }
             drain_stores();
             if (lane == 0 && atomicAdd(&s_arr, 1) == 4 * (j + 1) - 1) st_flag(sync + PS_CNT + j + 1, j + 1);
+            lds_barrier();                                     // (Z)
+            lds_barrier();                                     // (W)
         }
-        CHAIN_DISPATCH(chain_update_tail, sm, fi, fk, acc);
-        if (dbg && t == 0) dbg[8 * j + 7] = wall_clock64();
-        lds_barrier();                                         // (Z) Yim is dead: its space becomes Tt again
-        CHAIN_DISPATCH(chain_put_w, Tt, fi, fk, acc);
-        lds_barrier();                                         // (W)
-        if (dbg && t == 0) dbg[8 * j + 5] = wall_clock64();
     }
 }
 
 // ---- a worker workgroup -----------------------------------------------------------------------------------------------
 __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
-                                 int* __restrict__ sync, int kcap, long long* __restrict__ dbg, double* sm) {
+                                 int* __restrict__ sync, int kcap, double* __restrict__ hs, long long* __restrict__ dbg,
+                                 double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
     __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished
     __shared__ int s_wait[PS_MAXT];                            // 1: all columns applied, waiting for L_kk (general tiles)
@@ -505,22 +503,29 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
         // diagnostics: the LAST task of a near tile: [picked, compute done, published]
         long long* dn = (dbg && pi - pk <= 2 && (pj1 == limit)) ? dbg + 8 * nt + 4 * (3 * pi + (pi - pk)) : nullptr;
         if (dn && t == 0) dn[0] = wall_clock64();
-        if (pj1 > pj0) {                                       // ---- columns [pj0, pj1): C -= L(i, cols) L(k, cols)^T
+        const bool handover = (pj1 == limit && !general);      // the tile's last write before the chain takes it
+        const bool subdiag = (pi == pk + 1);
+        if (pj1 > pj0 || (handover && subdiag)) {              // ---- columns [pj0, pj1): C -= L(i, cols) L(k, cols)^T
             d4 acc[4][4];
             gt_load_buf<4>(Ct, ld, acc);
-            gemm_tile_128<true, true, 4, true>(A + (long)pi * NB * ld + (long)pj0 * NB, ld,
-                                               A + (long)pk * NB * ld + (long)pj0 * NB, ld, (pj1 - pj0) * NB, acc, sm);
-            if (pj1 == limit && !general) {                    // the last write before the chain reads it: through the image
+            if (pj1 > pj0)
+                gemm_tile_128<true, true, 4, true>(A + (long)pi * NB * ld + (long)pj0 * NB, ld,
+                                                   A + (long)pk * NB * ld + (long)pj0 * NB, ld, (pj1 - pj0) * NB, acc, sm);
+            if (handover || subdiag) {                         // through the LDS image: coalesced write-through
+                // A sub-diagonal tile is written through on EVERY pass: its last version goes to the hand-off buffer and
+                // its place in A is later overwritten by the chain (the final L(j+1, j)) -- a dirty line of an earlier pass
+                // left in this XCD's L2 would shadow that, or be written back over it.
                 __syncthreads();                               // the GEMM's LDS stages are free
                 stage_put_acc(sm, acc);
                 __syncthreads();
-                stage_store_coherent<256>(sm, Ct, ld, t);
+                if (handover && subdiag) stage_store_chain_order<256>(sm, hs + (long)pi * (NB * NB), t);   // the chain's load order
+                else stage_store_coherent<256>(sm, Ct, ld, t);                                             // in place
             } else {
                 gt_store<0, 4>(Ct, ld, acc);
             }
         }
         if (dn && t == 0) dn[1] = wall_clock64();
-        if (pj1 == limit && !general) {                        // ---- hand the tile to the chain
+        if (handover) {                                        // ---- hand the tile to the chain
             drain_stores();
             __syncthreads();
             if (t == 0) {
@@ -565,20 +570,20 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
 __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A, long ld, int nt,
                                                           double* __restrict__ dinv_all, double* __restrict__ logsum,
                                                           int* __restrict__ info, int* __restrict__ sync, int kcap,
-                                                          long long* __restrict__ dbg) {
+                                                          double* __restrict__ hs, long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if (blockIdx.x == 0) {
-        chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, dbg, sm);
+        chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, hs, dbg, sm);
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicExch(info, PS_ABORT_INFO);
     } else {
-        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, dbg, sm);
+        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, sm);
     }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
 bool potrf_persist_eligible(long npad, const FactorWs* ws) {
     const long nt = npad / NB;
-    if (!ws->persist || !ws->persist_sync || ws->lookahead != 1) return false;
+    if (!ws->persist || !ws->persist_sync || !ws->persist_hs || ws->lookahead != 1) return false;
     if (nt < 2 || nt > PS_MAXNT || nt > ws->persist_max_nt) return false;
     // tiles per worker: near 3 nt / (cus / 2) <= 2, far (nt-3)(nt-2)/2 / (cus / 2)
     return ws->persist_cus >= 16 && (nt - 3) * (nt - 2) / 2 / (ws->persist_cus / 2 - 1) + 2 <= PS_MAXT;
@@ -601,6 +606,6 @@ void launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, lo
     (void)hipMemsetAsync(ws->persist_sync, 0, sizeof(int) * PS_SYNC_INTS, st);
     ws->prof.begin(st, PF_PERSIST, (double)npad * npad * npad / 3.0);
     hipLaunchKernelGGL(k_potrf_persist, dim3((unsigned)grid), dim3(64 * PS_CHAIN_WAVES), PS_LDS_BYTES, st, A, npad, nt, ws->dinv, ws->logsum,
-                       ws->info, ws->persist_sync, ws->persist_kcap, dbg);
+                       ws->info, ws->persist_sync, ws->persist_kcap, ws->persist_hs, dbg);
     ws->prof.end(st);
 }

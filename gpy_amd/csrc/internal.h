@@ -93,7 +93,7 @@ struct FactorWs {
     int diag_excl_first = FACTOR_DEFAULT_DIAG_EXCL_FIRST, excl_first_ok = 0;
     int solve_overlap = 1;           // MI355GP_SOLVE_OVERLAP: alpha = X^T (X R) on st_tri underneath lauum
     // MI355GP_PERSIST: the single-launch dataflow Cholesky of persist.hip for factorisations of at most persist_max_nt tiles
-    int persist = FACTOR_DEFAULT_PERSIST, persist_max_nt = 47, persist_kcap = 2, persist_cus = 0;
+    int persist = FACTOR_DEFAULT_PERSIST, persist_max_nt = FACTOR_PERSIST_MAX_NT, persist_kcap = 2, persist_cus = 0;
     int* persist_sync = nullptr;     // progress words of the persistent launch (zeroed before every launch)
     double* persist_hs = nullptr;    // [min(nblk, 64)][128 x 128]: sub-diagonal tile of every row, handed to the chain in ITS load order
     KernelProf prof;

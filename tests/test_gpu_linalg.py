@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import gpy_amd
+from gpy_amd import _lib as L
 from oracle import gp_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -46,3 +47,45 @@ def test_jitchol_ladder_and_errors_follow_the_reference():
     # a positive-definite matrix passes through untouched
     A2 = _spd(200, seed=3)
     assert np.abs(gpy_amd.linalg.jitchol(A2) - O.jitchol(A2)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("N", [256, 384, 1000, 2048, 3333, 4096])
+def test_persistent_dataflow_cholesky_is_bit_identical_to_the_launch_per_step_schedule(N):
+    """persist.hip: one persistent launch (chain workgroup + static tile owners, write-through hand-offs between workgroups on
+    different XCDs) against factor.hip's launch-per-step schedule on the same resident SPD matrix: every double of the lower
+    triangle of L must have the same BITS, no wait may have timed out, and the chain's timeline must be monotone."""
+    r = L.dbg_persist(N, reps=2)
+    assert r["mismatches"] == 0 and r["info"] == 0 and r["abort"] == 0
+    st = r["steps"]
+    assert np.all(np.diff(st[:, 0]) > 0) and np.all(st[:, 1] > st[:, 0])       # factor(j) starts after factor(j-1), ends after it starts
+    assert r["ms_persist"] < 2.0 * r["ms_steps"] + 0.05
+
+
+def test_persistent_cholesky_option_reports_non_pd_and_can_be_switched_off_per_context():
+    """The product path takes the persistent launch below N = 4608 (`FACTOR_PERSIST_MAX_NT`); option "persist" = 0 returns a
+    context to the launch-per-step schedule; both give the same bits, the same LAPACK-style info on a non-PD matrix."""
+    X, Y = O.synthetic(1500, 3, seed=5)
+    var, ls, noise = O.default_theta(3, False)
+    th = L.theta_vec(var, ls, False, 3)
+    c = L.Context(0)
+    try:
+        c.set_data(X, Y)
+        assert c.get_option("persist") == 1
+        outs = []
+        for p in (1, 0, 1):
+            c.set_option("persist", p)
+            info, r = c.exact_inference("rbf", False, th, noise)
+            assert info == 0
+            outs.append((r["lml"], r["dtheta"].tobytes(), r["alpha"].tobytes()))
+        assert outs[0] == outs[1] == outs[2]
+        # duplicated inputs, no noise, negative jitter: the Gram matrix is not positive definite -> same info either way
+        Xd = np.vstack([X[:700], X[:700], X[:100]])
+        c.set_data(Xd, Y)
+        infos = []
+        for p in (1, 0):
+            c.set_option("persist", p)
+            info, _ = c.exact_inference("rbf", False, th, 0.0, jitter=-1e-3)
+            infos.append(info)
+        assert infos[0] == infos[1] and infos[0] > 0
+    finally:
+        c.close()

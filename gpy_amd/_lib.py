@@ -458,7 +458,8 @@ class SparseContext(object):
 
     def vardtc_sum(self, specs, Z, noise, extra_jitter=0.0, want_dL_dm=False, want_stage_ms=False):
         """Sum-of-parts kernel (specs as for `Context.exact_inference_sum`), scalar or per-point noise variances.
-        (info, dict(lml, dnoise (scalar or N-vector), dtheta (concatenated), dZ, woodbury_vector[, dL_dm, stage_ms]))"""
+        (info, dict(lml, dnoise (scalar; per-point noise: the N-vector dL_dR, N x Dy for several output columns), dtheta
+        (concatenated), dZ, woodbury_vector[, dL_dm, stage_ms]))"""
         arr, keep, ntheta = make_parts(specs)
         Z = f64(Z)
         self.M = Z.shape[0]
@@ -469,14 +470,14 @@ class SparseContext(object):
         dtheta = np.zeros(ntheta)
         dZ = np.zeros((self.M, self.D))
         wv = np.zeros((self.M, self.Dy))
-        rows = np.zeros(self.N) if het else None
+        rows = np.zeros((self.N, self.Dy)) if het else None       # dL_dR per point and output column (var_dtc.py:240-256)
         dm = np.zeros((self.N, self.Dy)) if want_dL_dm else None
         ms = np.zeros(4) if want_stage_ms else None
         rc = check(lib().mi355gp_vardtc_inference_sum(self._h, len(specs), arr, Z, self.M, noise, noise.size,
                                                       float(extra_jitter), out, _opt(dtheta), _opt(dZ), _opt(wv), _opt(rows),
                                                       _opt(dm), _opt(ms)), "mi355gp_vardtc_inference_sum")
-        res = dict(lml=out[0], dnoise=rows if het else out[1], trA=out[2], data_fit=out[3], dtheta=dtheta, dZ=dZ,
-                   woodbury_vector=wv, dL_dm=dm)
+        res = dict(lml=out[0], dnoise=(rows[:, 0] if self.Dy == 1 else rows) if het else out[1], trA=out[2],
+                   data_fit=out[3], dtheta=dtheta, dZ=dZ, woodbury_vector=wv, dL_dm=dm)
         if ms is not None:
             res["stage_ms"] = dict(pass1=ms[0], mxm=ms[1], pass2=ms[2], total=ms[3])
         return rc, res

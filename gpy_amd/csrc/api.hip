@@ -761,7 +761,7 @@ int mi355gp_update_gradients_full(int device, int kind, int ard, const double* t
 // Runs as the column reduction H^T [X2~ | 1] of the transposed problem (the same kernels as the sparse path's dL/dZ).
 int mi355gp_gradients_X(int device, int kind, int ard, const double* theta, const double* dL_dK, const double* X,
                         int64_t N, const double* X2, int64_t M, int D, double* out) {
-    ARG_CHECK(dL_dK && X && out && N > 0 && D > 0 && D <= 32, "mi355gp_gradients_X: bad arguments (D <= 32)");
+    ARG_CHECK(dL_dK && X && out && N > 0 && D > 0, "mi355gp_gradients_X: bad arguments");
     HIP_CHECK(hipSetDevice(device));
     std::vector<double> inv_ls;
     if (int rc = check_theta(kind, ard, theta, D, &inv_ls)) return rc;
@@ -975,7 +975,6 @@ int mi355gp_predictive_gradients_sum(mi355gp_ctx* c, int nparts, const mi355gp_p
                                      double* dmu_out, double* dvar_out) {
     ARG_CHECK(c && c->n > 0 && c->have_factor, "mi355gp_predictive_gradients: run an inference call first");
     ARG_CHECK(Xnew && M > 0 && (dmu_out || dvar_out), "mi355gp_predictive_gradients: bad arguments");
-    ARG_CHECK(c->D <= 32, "mi355gp_predictive_gradients: D <= 32");
     HIP_CHECK(hipSetDevice(c->device));
     EngineShared gate(c->device);
     if (int rc = prepare_parts(c, nparts, parts)) return rc;

@@ -582,7 +582,7 @@ void launch_grad_generic(hipStream_t st, KernParams kp, const double* Xt1, long 
 template <int NV>
 __global__ __launch_bounds__(256) void k_colreduce_multi(const double* __restrict__ M, long ld, long rows, long cols,
                                                          const double* __restrict__ V, long sr, long sc, int nvt,
-                                                         int nv, double* __restrict__ part) {
+                                                         int nv, double* __restrict__ part, int nv_total, int c_off) {
     __shared__ double sv[NV][256];
     __shared__ double red[4][64];
     const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -609,32 +609,43 @@ __global__ __launch_bounds__(256) void k_colreduce_multi(const double* __restric
             }
         }
     }
-    double* out = part + ((long)blockIdx.y * cols) * nv;
+    double* out = part + ((long)blockIdx.y * cols) * nv_total + c_off;   // this launch fills columns [c_off, c_off + nv) of nv_total
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
         if (c >= nv) break;
         __syncthreads();
         red[g][tx] = acc[c];
         __syncthreads();
-        if (g == 0 && j < cols) out[j * nv + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        if (g == 0 && j < cols) out[j * nv_total + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
     }
 }
 
-// part must hold nsplit * cols * nv doubles; returns nsplit
+// part must hold nsplit * cols * nv doubles (nv = nvt + ones); returns nsplit.  More than 32 V columns (input dimension
+// D > 32 in gradients_X / the sparse path's dL/dZ, stationary.py:330-358 has no such limit) run as several launches of at
+// most 32 columns each that fill their own column range of the same [split][cols][nv] partials; the all-ones column rides
+// with the last one.
 int launch_colreduce_multi(hipStream_t st, const double* M, long ld, long rows, long cols, const double* V, long sr,
                            long sc, int nvt, int ones, double* part) {
-    const int nv = nvt + (ones ? 1 : 0);
+    const int nv_total = nvt + (ones ? 1 : 0);
     // 64 columns per block: the row split supplies the parallelism (>= 2048 blocks for a 32k x 2k panel)
     int nsplit = (int)((rows + 511) / 512);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 64) nsplit = 64;
     const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)nsplit);
-    if (nv <= 9)
-        hipLaunchKernelGGL((k_colreduce_multi<9>), grid, dim3(256), 0, st, M, ld, rows, cols, V, sr, sc, nvt, nv, part);
-    else if (nv <= 17)
-        hipLaunchKernelGGL((k_colreduce_multi<17>), grid, dim3(256), 0, st, M, ld, rows, cols, V, sr, sc, nvt, nv, part);
-    else
-        hipLaunchKernelGGL((k_colreduce_multi<33>), grid, dim3(256), 0, st, M, ld, rows, cols, V, sr, sc, nvt, nv, part);
+    int c0 = 0;
+    do {
+        const int nvc = nvt - c0 < 32 ? nvt - c0 : 32;                 // V columns of this launch
+        const bool lastc = c0 + nvc >= nvt;
+        const int nv = nvc + ((lastc && ones) ? 1 : 0);                // <= 33
+        const double* Vc = V + (long)c0 * sc;
+        if (nv <= 9)
+            hipLaunchKernelGGL((k_colreduce_multi<9>), grid, dim3(256), 0, st, M, ld, rows, cols, Vc, sr, sc, nvc, nv, part, nv_total, c0);
+        else if (nv <= 17)
+            hipLaunchKernelGGL((k_colreduce_multi<17>), grid, dim3(256), 0, st, M, ld, rows, cols, Vc, sr, sc, nvc, nv, part, nv_total, c0);
+        else
+            hipLaunchKernelGGL((k_colreduce_multi<33>), grid, dim3(256), 0, st, M, ld, rows, cols, Vc, sr, sc, nvc, nv, part, nv_total, c0);
+        c0 += nvc;
+    } while (c0 < nvt);
     return nsplit;
 }
 

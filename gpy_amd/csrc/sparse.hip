@@ -192,6 +192,8 @@ struct SPart {
     std::vector<double> theta, inv_ls;
     std::vector<int> dims;
     double *XtZ = nullptr, *XtC = nullptr, *HX = nullptr, *HZ = nullptr, *gradNM = nullptr, *gradMM = nullptr;
+    int term = 0;                 // parts with the same non-zero id are the factors of one product (GPy/kern/src/prod.py)
+    int tix = 0;                  // index into mi355gp_sparse::terms
     bool stationary() const { return kp.kind <= 3; }
 };
 
@@ -209,7 +211,8 @@ struct mi355gp_sparse {
     LoopGroup* loop = nullptr;    // or the loopback rendezvous
     int world = 1, rank = 0;
     long n_global = 0;
-    double *dX = nullptr, *dY = nullptr, *dV = nullptr, *dBeta = nullptr, *dRowS = nullptr, *dRowT = nullptr, *Kfu = nullptr,
+    double *dX = nullptr, *dY = nullptr, *dV = nullptr, *dBeta = nullptr, *dRowS = nullptr, *dRowT = nullptr, *dRowR = nullptr,
+           *Kfu = nullptr,
            *T = nullptr;
     // M-dependent
     long m = 0, mp = 0;
@@ -221,6 +224,7 @@ struct mi355gp_sparse {
            *trmvPart = nullptr, *colPart = nullptr, *gradPart = nullptr, *gradChunk = nullptr, *scal = nullptr,
            *redbuf = nullptr;
     std::vector<SPart> parts;
+    std::vector<std::vector<int>> terms;   // part indices per summand, in order of first appearance (one part, or the factors of a Prod)
     FactorWs ws;
     bool ws_ok = false, have_result = false, winv_ok = false;
     hipEvent_t ev[6] = {};
@@ -335,7 +339,7 @@ static int prepare_sparse_parts(mi355gp_sparse* s, int nparts, const mi355gp_par
         const mi355gp_part& in = parts[i];
         SPart& p = s->parts[(size_t)i];
         ARGCHK(in.kind >= 0 && in.kind <= 5 && in.theta, "unknown covariance kind / NULL theta in a kernel part");
-        ARGCHK(in.term == 0, "the sparse path evaluates SUMS of kernels (GPy.kern.Add); product terms are not supported");
+        p.term = in.term;
         ARGCHK(in.theta[0] > 0.0, "variance must be positive");
         p.dims.clear();
         if (in.active_dims && in.n_active > 0) {
@@ -358,7 +362,70 @@ static int prepare_sparse_parts(mi355gp_sparse* s, int nparts, const mi355gp_par
             p.inv_ls[(size_t)p.dims[a]] = 1.0 / l;
         }
     }
+    // summands: term id 0 = a part of its own; parts sharing a non-zero id are multiplied (prod.py:58-72)
+    s->terms.clear();
+    std::vector<int> ids;
+    for (int i = 0; i < nparts; ++i) {
+        const int id = s->parts[(size_t)i].term;
+        size_t t = ids.size();
+        if (id != 0)
+            for (t = 0; t < ids.size() && ids[t] != id; ++t) {}
+        if (t == ids.size()) {
+            ids.push_back(id != 0 ? id : -1 - i);
+            s->terms.emplace_back();
+        }
+        s->terms[t].push_back(i);
+        s->parts[(size_t)i].tix = (int)t;
+    }
+    for (const auto& t : s->terms)
+        if (t.size() > 1)
+            for (int f : t) ARGCHK(s->parts[(size_t)f].kp.kind != 4, "a White factor inside a product is not supported by the sparse path");
     return 0;
+}
+
+// Kdiag of the expression (psi0_n): sum over summands of the product of the factors' variances (add.py:74-79, prod.py:67-71)
+static double sparse_kdiag(const mi355gp_sparse* s) {
+    double k = 0.0;
+    for (const auto& t : s->terms) {
+        double v = 1.0;
+        for (int f : t) v *= s->parts[(size_t)f].kp.variance;
+        k += v;
+    }
+    return k;
+}
+// product of the OTHER factors' variances of part p's summand (= dKdiag/dvariance_p; 1 for a plain summand)
+static double sparse_other_variances(const mi355gp_sparse* s, size_t p) {
+    double v = 1.0;
+    for (int f : s->terms[(size_t)s->parts[p].tix])
+        if ((size_t)f != p) v *= s->parts[(size_t)f].kp.variance;
+    return v;
+}
+// out (+)= sum over summands of the element-wise product of their factors: emit(part, dst, mul, accumulate) launches one
+// factor, dst (+)= K_part * mul.  The leading factors of a product are multiplied up in `scratch` (same shape as out).
+// skip_white: cross-covariances (White contributes nothing, static.py:77-81).  Returns false if nothing was emitted.
+template <class Emit>
+static bool sparse_expression(const mi355gp_sparse* s, double* out, double* scratch, bool skip_white, Emit emit) {
+    bool first = true;
+    for (const auto& t : s->terms) {
+        if (skip_white && t.size() == 1 && s->parts[(size_t)t[0]].kp.kind == 4) continue;
+        for (size_t f = 0; f + 1 < t.size(); ++f) emit(t[f], scratch, f > 0 ? scratch : nullptr, 0, false);
+        emit(t.back(), out, t.size() > 1 ? scratch : nullptr, first ? 0 : 1, first);
+        first = false;
+    }
+    return !first;
+}
+// dst = the product of the OTHER factors of part p's summand, evaluated by emit(part, dst, mul, accumulate); false: p stands alone
+template <class Emit>
+static bool sparse_other_factors(const mi355gp_sparse* s, size_t p, double* dst, Emit emit) {
+    const auto& t = s->terms[(size_t)s->parts[p].tix];
+    if (t.size() < 2) return false;
+    bool first = true;
+    for (int f : t) {
+        if ((size_t)f == p) continue;
+        emit(f, dst, first ? nullptr : dst, 0, first);
+        first = false;
+    }
+    return true;
 }
 
 // scaled, dimension-major copies of `rows` points (row-major src) for every part
@@ -370,15 +437,42 @@ static int scale_for_parts(mi355gp_sparse* s, const double* src, long rows, long
     return 0;
 }
 
-// Kfu chunk = sum over parts of K_p(X_chunk, Z)  (add.py:58-72; White contributes nothing off the diagonal, static.py:77-81)
-static void build_cross_chunk(mi355gp_sparse* s, long rc, double* out) {
-    bool first = true;
-    for (SPart& p : s->parts) {
-        if (p.kp.kind == 4) continue;
-        launch_kbuild_cross(s->st, p.kp, p.XtC, s->chunk, rc, p.XtZ, s->mp, s->m, out, s->mp, first ? 0 : 1);
-        first = false;
+// Kfu chunk = sum over summands of (the product of) K_p(X_chunk, Z)  (add.py:58-72, prod.py:58-65; White contributes nothing
+// off the diagonal, static.py:77-81).  Products are multiplied up in `scratch` (chunk x mp, e.g. the T buffer).
+static void build_cross_chunk(mi355gp_sparse* s, long rc, double* out, double* scratch) {
+    const bool any = sparse_expression(s, out, scratch, true, [&](int p, double* dst, const double* mul, int acc, bool) {
+        const SPart& pt = s->parts[(size_t)p];
+        launch_kbuild_cross(s->st, pt.kp, pt.XtC, s->chunk, rc, pt.XtZ, s->mp, s->m, dst, s->mp, acc, 0, mul);
+    });
+    if (!any) (void)hipMemsetAsync(out, 0, sizeof(double) * rc * s->mp, s->st);       // only White parts: K(X, Z) = 0
+}
+// K(Z) (lower tiles; diag != NULL: + diag on the diagonal) of the expression into out (mp x mp), scratch mp x mp
+static void build_kmm(mi355gp_sparse* s, double* out, double* scratch, double jitter, int lower_only) {
+    sparse_expression(s, out, scratch, false, [&](int p, double* dst, const double* mul, int acc, bool first) {
+        const SPart& pt = s->parts[(size_t)p];
+        launch_kbuild_sym(s->st, pt.kp, pt.XtZ, s->mp, s->m, s->mp, dst, s->zero1, 1, jitter, lower_only,
+                          /*add_diag=*/(first && dst == out) ? 1 : 0, acc, mul);
+    });
+}
+// W[i][j] = beta_i (sum_d R[i][d] v[j][d] + 2 T[i][j]) * W[i][j] for i < rows, j < m; 0 in the padding: dL_dKnm times the other
+// factors' covariance (prod.py:86-99), the weights one factor of a product sees
+__global__ void k_form_dLdKnm_times(const double* __restrict__ T, double* __restrict__ W, long ld, long rows, long rows_pad,
+                                    long m, const double* __restrict__ Y, const double* __restrict__ v, int Dy,
+                                    const double* __restrict__ beta) {
+    const long j = (long)blockIdx.y * blockDim.x + threadIdx.x, i = blockIdx.x;
+    if (j >= ld || i >= rows_pad) return;
+    double g = 0.0;
+    if (i < rows && j < m) {
+        double yv = 0.0;
+        for (int d = 0; d < Dy; ++d) yv = fma(Y[i * Dy + d], v[j * Dy + d], yv);
+        g = beta[i] * fma(2.0, T[i * ld + j], yv) * W[i * ld + j];
     }
-    if (first) (void)hipMemsetAsync(out, 0, sizeof(double) * rc * s->mp, s->st);     // only White parts: K(X, Z) = 0
+    W[i * ld + j] = g;
+}
+// A[i][j] *= B[i][j]  (mp x mp)
+__global__ void k_mm_mul(double* __restrict__ A, const double* __restrict__ B, long mp) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j < mp) A[i * mp + j] *= B[i * mp + j];
 }
 
 extern "C" {
@@ -426,7 +520,7 @@ int mi355gp_sparse_destroy(mi355gp_sparse* s) {
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->st);
     free_m(s);
-    double** ptrs[] = {&s->dX, &s->dY, &s->dV, &s->dBeta, &s->dRowS, &s->dRowT};
+    double** ptrs[] = {&s->dX, &s->dY, &s->dV, &s->dBeta, &s->dRowS, &s->dRowT, &s->dRowR};
     for (auto p : ptrs)
         if (*p) (void)hipFree(*p);
     if (s->comm) rccl_comm_destroy(s->comm);
@@ -440,12 +534,11 @@ int mi355gp_sparse_destroy(mi355gp_sparse* s) {
 
 int mi355gp_sparse_set_data(mi355gp_sparse* s, const double* X, int64_t N, int D, const double* Y, int Dy) {
     ARGCHK(s && X && Y && N > 0 && D > 0 && Dy > 0, "mi355gp_sparse_set_data: bad arguments");
-    ARGCHK(D <= 32, "mi355gp_sparse_set_data: D <= 32 in this version (one LDS group of input dimensions)");
     HIP_CHECK(hipSetDevice(s->device));
     EngineShared gate(s->device);
     HIP_CHECK(hipStreamSynchronize(s->st));
     free_m(s);
-    double** ptrs[] = {&s->dX, &s->dY, &s->dV, &s->dBeta, &s->dRowS, &s->dRowT};
+    double** ptrs[] = {&s->dX, &s->dY, &s->dV, &s->dBeta, &s->dRowS, &s->dRowT, &s->dRowR};
     for (auto p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -459,6 +552,7 @@ int mi355gp_sparse_set_data(mi355gp_sparse* s, const double* X, int64_t N, int D
     HIP_CHECK(hipMalloc(&s->dBeta, sizeof(double) * N));
     HIP_CHECK(hipMalloc(&s->dRowS, sizeof(double) * N * Dy));
     HIP_CHECK(hipMalloc(&s->dRowT, sizeof(double) * N));
+    HIP_CHECK(hipMalloc(&s->dRowR, sizeof(double) * N));
     HIP_CHECK(hipMemcpy(s->dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(s->dY, Y, sizeof(double) * N * Dy, hipMemcpyHostToDevice));
     double t = 0.0;
@@ -531,8 +625,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     ARGCHK(parts && Z && M > 0 && out_scalars && noise, "mi355gp_vardtc_inference: bad arguments");
     ARGCHK(noise_len == 1 || noise_len == s->n, "noise must have 1 or N entries");
     const bool het = noise_len > 1;
-    ARGCHK(!het || s->Dy == 1, "per-point noise needs a single output column (the reference's dL_dR, var_dtc.py:240-256)");
-    ARGCHK(!het || dnoise_rows_out, "per-point noise: dnoise_rows_out (N) is required");
+    ARGCHK(!het || dnoise_rows_out, "per-point noise: dnoise_rows_out (N x Dy) is required");
     HIP_CHECK(hipSetDevice(s->device));
     EngineShared gate(s->device);
     const int D = s->D, Dy = s->Dy;
@@ -568,9 +661,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     }
     if (int rc = scale_for_parts(s, s->dZ, m, mp, true)) return rc;
     // Kmm + 1e-8 I (var_dtc.py:93-94) = sum of the parts' K(Z) (White on the diagonal), Lm = chol (jitchol, :95), Xm = Lm^-1
-    for (size_t i = 0; i < s->parts.size(); ++i)
-        launch_kbuild_sym(st, s->parts[i].kp, s->parts[i].XtZ, mp, m, mp, s->Lm, s->zero1, 1, 1e-8 + extra_jitter,
-                          /*lower_only=*/1, /*add_diag=*/i == 0, /*accumulate=*/i > 0);
+    build_kmm(s, s->Lm, s->T1, 1e-8 + extra_jitter, /*lower_only=*/1);
     potrf_device(st, s->Lm, mp, &s->ws);
     s->h_info[0] = s->h_info[1] = 0;
     HIP_CHECK(hipMemcpyAsync(&s->h_info[0], s->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -588,7 +679,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
         } else if (rc < chunk) {
             HIP_CHECK(hipMemsetAsync(s->Kfu + rc * mp, 0, sizeof(double) * (chunk - rc) * mp, st));
         }
-        build_cross_chunk(s, rc, s->Kfu);
+        build_cross_chunk(s, rc, s->Kfu, s->T);
         const double* G = s->Kfu;
         if (het) {                                            // rows scaled by sqrt(beta_n) (var_dtc.py:126-129) into T
             HIP_CHECK(hipMemsetAsync(s->T + rc * mp, 0, sizeof(double) * (round_up(rc, 16L * s->splitk) - rc) * mp, st));
@@ -634,6 +725,14 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
                        s->E);
     launch_gemm(st, 1, 1, mp, mp, mp, s->Xm, mp, s->E, mp, s->T1, mp, 1.0, 0.0);
     launch_gemm(st, 0, 1, mp, mp, mp, s->T1, mp, s->Xm, mp, s->Q2, mp, 1.0, 0.0);
+    const bool het_multi = het && Dy > 1;
+    if (het_multi) {
+        // several output columns with per-point noise: dL_dR (var_dtc.py:240-256) needs r_n = |LB^-1 Lm^-1 k_n|^2 on its own
+        // (for Dy = 1 it folds into t_n and s_n); r_n = k_n^T Gr k_n with Gr = Lm^-T B^-1 Lm^-1, built in the Winv buffer
+        hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->Bi, mp, 1, s->E);
+        launch_gemm(st, 1, 1, mp, mp, mp, s->Xm, mp, s->E, mp, s->T1, mp, 1.0, 0.0);
+        launch_gemm(st, 0, 1, mp, mp, mp, s->T1, mp, s->Xm, mp, s->Winv, mp, 1.0, 0.0);
+    }
     hipLaunchKernelGGL(k_sparse_scalars_rows, dim3((unsigned)m), dim3(256), 0, st, s->Amat, s->P, s->LB, s->cvec, Dy, mp, m,
                        s->colPart);
     hipLaunchKernelGGL(k_sparse_scalars, dim3(1), dim3(256), 0, st, s->colPart, m, s->scal);
@@ -652,7 +751,11 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
         if (!one_chunk) {                                    // a single chunk is still resident from pass 1
             if (int e = scale_for_parts(s, s->dX + r0 * D, rc, chunk, false)) return e;
             if (rc < chunk) HIP_CHECK(hipMemsetAsync(s->Kfu + rc * mp, 0, sizeof(double) * (chunk - rc) * mp, st));
-            build_cross_chunk(s, rc, s->Kfu);
+            build_cross_chunk(s, rc, s->Kfu, s->T);
+        }
+        if (het_multi) {                                     // r_n = sum_j (Kfu Gr)_nj Kfu_nj, before T is needed for anything else
+            launch_gemm(st, 0, 1, rcp, mp, mp, s->Kfu, mp, s->Winv, mp, s->T, mp, 1.0, 0.0);
+            launch_rowdots(st, s->Kfu, s->T, mp, rc, m, s->vvec, Dy, s->dRowS + r0 * Dy, s->dRowR + r0);
         }
         s->mfma_prof.begin(st, 0, 2.0 * (double)rc * (double)m * (double)m);
         launch_gemm(st, 0, 1, rcp, mp, mp, s->Kfu, mp, s->Q2, mp, s->T, mp, 1.0, 0.0);
@@ -669,13 +772,28 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
             SPart& p = s->parts[pi];
             if (p.kp.kind == 4) continue;                    // White: K(X, Z) = 0, no contribution (static.py:89-93)
             int nbk = 0, ns = 0;
-            if (p.stationary() && s->fuse_cols)
-                ns = launch_grad_cols(st, p.kp, p.XtC, chunk, rc, p.XtZ, mp, m, mp, s->T, mp, rk, s->gradPart, s->colPart, &nbk);
-            if (ns == 0) {
+            // a factor of a product sees dL_dKnm TIMES the other factors' covariance (prod.py:86-99): that weight matrix is
+            // materialised in the Kfu buffer (free by now) -- other factors multiplied up, then dL_dKnm formed on top
+            const bool prod = sparse_other_factors(s, pi, s->Kfu, [&](int f, double* dst, const double* mul, int, bool) {
+                const SPart& pf = s->parts[(size_t)f];
+                launch_kbuild_cross(st, pf.kp, pf.XtC, chunk, rc, pf.XtZ, mp, m, dst, mp, 0, 0, mul);
+            });
+            if (prod) {
+                hipLaunchKernelGGL(k_form_dLdKnm_times, dim3((unsigned)rcp, (unsigned)((mp + 255) / 256)), dim3(256), 0, st, s->T,
+                                   s->Kfu, mp, rc, rcp, m, s->dY + r0 * Dy, s->vvec, Dy, s->dBeta + r0);
                 nbk = grad_generic_num_blocks(rc, m);
-                double* Hbuf = p.stationary() ? s->Kfu : nullptr;
-                launch_grad_generic(st, p.kp, p.XtC, chunk, rc, p.XtZ, mp, m, 0, s->T, mp, s->gradPart, GP_STRIDE, Hbuf, mp, rk);
+                launch_grad_generic(st, p.kp, p.XtC, chunk, rc, p.XtZ, mp, m, 0, s->Kfu, mp, s->gradPart, GP_STRIDE,
+                                    p.stationary() ? s->Kfu : nullptr, mp);         // H over the weights, in place
                 if (p.stationary()) ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, p.XtC, 1, chunk, D, 1, s->colPart);
+            } else {
+                if (p.stationary() && s->fuse_cols)
+                    ns = launch_grad_cols(st, p.kp, p.XtC, chunk, rc, p.XtZ, mp, m, mp, s->T, mp, rk, s->gradPart, s->colPart, &nbk);
+                if (ns == 0) {
+                    nbk = grad_generic_num_blocks(rc, m);
+                    double* Hbuf = p.stationary() ? s->Kfu : nullptr;
+                    launch_grad_generic(st, p.kp, p.XtC, chunk, rc, p.XtZ, mp, m, 0, s->T, mp, s->gradPart, GP_STRIDE, Hbuf, mp, rk);
+                    if (p.stationary()) ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, p.XtC, 1, chunk, D, 1, s->colPart);
+                }
             }
             for (int g = 0; g < (p.kp.ard ? groups : 1); ++g)
                 launch_reduce_partials(st, s->gradPart + (long)g * nbk * GP_STRIDE, nbk, GP_STRIDE,
@@ -699,10 +817,17 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
             rb += gsz + hsz;
         }
     }
-    // the M x M part: update_gradients_full(dL_dKmm, Z) and gradients_X(dL_dKmm, Z) (sparse_gp.py:114-117), per part
-    for (SPart& p : s->parts) {
+    // the M x M part: update_gradients_full(dL_dKmm, Z) and gradients_X(dL_dKmm, Z) (sparse_gp.py:114-117), per part; a factor
+    // of a product sees dL_dKmm times the other factors' K(Z) (prod.py:86-99), materialised in T1
+    for (size_t pi = 0; pi < s->parts.size(); ++pi) {
+        SPart& p = s->parts[pi];
         const int nbk = grad_generic_num_blocks(m, m);
-        launch_grad_generic(st, p.kp, p.XtZ, mp, m, p.XtZ, mp, m, 1, s->dLdKmm, mp, s->gradPart, GP_STRIDE,
+        const bool prod = sparse_other_factors(s, pi, s->T1, [&](int f, double* dst, const double* mul, int, bool) {
+            const SPart& pf = s->parts[(size_t)f];
+            launch_kbuild_cross(st, pf.kp, pf.XtZ, mp, m, pf.XtZ, mp, m, dst, mp, 0, /*diag_same=*/1, mul);
+        });
+        if (prod) hipLaunchKernelGGL(k_mm_mul, grid2d(mp, mp), dim3(256), 0, st, s->T1, s->dLdKmm, mp);
+        launch_grad_generic(st, p.kp, p.XtZ, mp, m, p.XtZ, mp, m, 1, prod ? s->T1 : s->dLdKmm, mp, s->gradPart, GP_STRIDE,
                             p.stationary() ? s->T1 : nullptr, mp);
         for (int g = 0; g < (p.kp.ard ? groups : 1); ++g)
             launch_reduce_partials(st, s->gradPart + (long)g * nbk * GP_STRIDE, nbk, GP_STRIDE, p.gradMM + (long)g * GP_STRIDE);
@@ -715,7 +840,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     // ---- small results to the host -------------------------------------------------------------------------------------
     const size_t np_ = s->parts.size();
     std::vector<double> gnm(np_ * gsz), gmm(np_ * gsz), HX(np_ * hsz), HZ(np_ * hsz), Zs(np_ * (size_t)D * mp);
-    std::vector<double> rowS, rowT;
+    std::vector<double> rowS, rowT, rowR;
     double scal[8];
     for (size_t i = 0; i < np_; ++i) {
         SPart& p = s->parts[i];
@@ -734,6 +859,10 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
         if (het) {
             rowT.resize((size_t)n);
             HIP_CHECK(hipMemcpyAsync(rowT.data(), s->dRowT, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+            if (het_multi) {
+                rowR.resize((size_t)n);
+                HIP_CHECK(hipMemcpyAsync(rowR.data(), s->dRowR, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+            }
         }
     }
     HIP_CHECK(hipStreamSynchronize(st));
@@ -760,8 +889,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     }
     const double trA = scal[0], sumAP = scal[1], logLB = scal[2], data_fit = scal[3];
     const double ng = (double)s->n_global, nd = ng * Dy;
-    double kdiag = 0.0;                                          // psi0_n = Kdiag = sum of the parts' variances
-    for (const SPart& p : s->parts) kdiag += p.kp.variance;
+    const double kdiag = sparse_kdiag(s);                        // psi0_n = Kdiag of the expression
     // _compute_log_marginal_likelihood (var_dtc.py:264-276)
     double lik_1, lik_2;
     if (het) {
@@ -784,14 +912,22 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
         dL_dR += beta * (0.5 * sumAP - data_fit);
         out_scalars[1] = dL_dR;
     } else {
-        // per point (var_dtc.py:240-256 with s_n = k_n^T v and q_n - r_n = 2 t_n + s_n^2, Dy = 1):
-        //   dL_dR_n = -0.5 b + 0.5 (b R_n)^2 + 0.5 b^2 psi0 - b^2 t_n - s_n R_n b^2
-        std::vector<double> Rh((size_t)n);
-        HIP_CHECK(hipMemcpy(Rh.data(), s->dY, sizeof(double) * n, hipMemcpyDeviceToHost));
+        // per point and output column (var_dtc.py:240-256 AS WRITTEN there), with s_nd = k_n^T v_d, t_n = sum_j T_nj Kfu_nj,
+        // q_n = |Lm^-1 k_n|^2, r_n = |LB^-1 Lm^-1 k_n|^2 and the identity Dy q_n = 2 t_n + Dy r_n + sum_d s_nd^2:
+        //   dL_dR_nd = -b/2 + (b R_nd)^2/2 + Dy b^2 psi0/2 - b^2 t_n - (Dy - 1) b^2 r_n/2 - b^2 sum_d' s_nd'^2/2
+        //              - b^2 s_nd R_nd + b^2 s_nd^2/2                       (Dy = 1: the r_n and s^2 terms cancel)
+        std::vector<double> Rh((size_t)n * Dy);
+        HIP_CHECK(hipMemcpy(Rh.data(), s->dY, sizeof(double) * n * Dy, hipMemcpyDeviceToHost));
         for (long i = 0; i < n; ++i) {
-            const double b = hbeta[(size_t)i], R = Rh[(size_t)i];
-            dnoise_rows_out[i] = -0.5 * b + 0.5 * b * b * R * R + 0.5 * b * b * kdiag - b * b * rowT[(size_t)i] -
-                                 rowS[(size_t)i] * R * b * b;
+            const double b = hbeta[(size_t)i], b2 = b * b;
+            double ss = 0.0;
+            for (int d = 0; d < Dy; ++d) ss += rowS[(size_t)i * Dy + d] * rowS[(size_t)i * Dy + d];
+            const double common = -0.5 * b + 0.5 * Dy * b2 * kdiag - b2 * rowT[(size_t)i] - 0.5 * b2 * ss -
+                                  (het_multi ? 0.5 * (Dy - 1) * b2 * rowR[(size_t)i] : 0.0);
+            for (int d = 0; d < Dy; ++d) {
+                const double R = Rh[(size_t)i * Dy + d], sv = rowS[(size_t)i * Dy + d];
+                dnoise_rows_out[i * Dy + d] = common + 0.5 * b2 * R * R - b2 * sv * R + 0.5 * b2 * sv * sv;
+            }
         }
     }
     if (dLdm_out) {                                              // dL_dm = V - Kfu v (var_dtc.py:148)
@@ -807,7 +943,8 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
             const double* a = gnm.data() + i * gsz;
             const double* b = gmm.data() + i * gsz;
             // update_gradients_diag(dL_dKdiag = -0.5 Dy beta_n) (sparse_gp.py:110, stationary.py:175-184, static.py:95-96)
-            *o++ = -0.5 * Dy * glob[0] + (a[0] + b[0]) / p.kp.variance;
+            // (a factor of a product: dKdiag / dvariance = the product of the other factors' variances, prod.py:67-71)
+            *o++ = -0.5 * Dy * glob[0] * sparse_other_variances(s, i) + (a[0] + b[0]) / p.kp.variance;
             if (!p.stationary()) continue;
             if (!p.kp.ard) *o++ = -(a[1] + b[1]) / p.theta[1];
             else
@@ -881,8 +1018,7 @@ int mi355gp_sparse_fetch(mi355gp_sparse* s, int which, double* out) {
         launch_extract(st, s->Lm, mp, mp, 0, nullptr, 0, s->E, 0);
         src = s->E;
     } else if (which == 3) {
-        for (size_t i = 0; i < s->parts.size(); ++i)
-            launch_kbuild_sym(st, s->parts[i].kp, s->parts[i].XtZ, mp, m, mp, s->E, s->zero1, 1, 1e-8, 0, i == 0, i > 0);
+        build_kmm(s, s->E, s->T1, 1e-8, /*lower_only=*/0);
         src = s->E;
     } else if (which == 4) src = s->psi2;
     else {
@@ -907,7 +1043,7 @@ int mi355gp_sparse_fetch_dLdKnm(mi355gp_sparse* s, int64_t row0, int64_t nrows, 
     const long m = s->m, mp = s->mp, rc = nrows, rcp = round_up(rc, NB);
     if (int e = scale_for_parts(s, s->dX + row0 * s->D, rc, s->chunk, false)) return e;
     HIP_CHECK(hipMemsetAsync(s->Kfu, 0, sizeof(double) * rcp * mp, st));
-    build_cross_chunk(s, rc, s->Kfu);
+    build_cross_chunk(s, rc, s->Kfu, s->T);
     launch_gemm(st, 0, 1, rcp, mp, mp, s->Kfu, mp, s->Q2, mp, s->T, mp, 1.0, 0.0);
     hipLaunchKernelGGL(k_form_dLdKnm, dim3((unsigned)rcp, (unsigned)((mp + 255) / 256)), dim3(256), 0, st, s->T, mp, rc, rcp, m,
                        s->dY + row0 * s->Dy, s->vvec, s->Dy, s->dBeta + row0);
@@ -952,19 +1088,35 @@ int mi355gp_sparse_predict(mi355gp_sparse* s, int nparts, const mi355gp_part* pa
     (void)hipMemcpyAsync(dXn, Xnew, sizeof(double) * Mn * D, hipMemcpyHostToDevice, st);
     (void)hipMemsetAsync(Kx, 0, sizeof(double) * mp * mnp, st);
     if (full_cov && var_out) (void)hipMemsetAsync(dVar, 0, sizeof(double) * mnp * mnp, st);
-    double kdiag = 0.0;
-    bool first = true, firstxx = true;
-    for (SPart& p : s->parts) {
-        kdiag += p.kp.variance;
+    const double kdiag = sparse_kdiag(s);
+    // K(Z, X*) and (full_cov) K(X*, X*) of the expression: every factor is evaluated with ITS scaling of the new inputs;
+    // products are multiplied up in Tmp / a second M* x M* scratch
+    auto scale_new = [&](const SPart& p) {
         (void)hipMemcpyAsync(s->invls, p.inv_ls.data(), sizeof(double) * D, hipMemcpyHostToDevice, st);
         launch_scale_inputs(st, dXn, Mn, (int)D, s->invls, 1, dXt, ldn);
-        if (p.kp.kind != 4) {                                                        // K(Z, X*): White contributes nothing
-            launch_kbuild_cross(st, p.kp, p.XtZ, mp, m, dXt, ldn, Mn, Kx, mnp, first ? 0 : 1);
-            first = false;
+    };
+    sparse_expression(s, Kx, Tmp, true, [&](int pi, double* dst, const double* mul, int acc, bool) {
+        const SPart& p = s->parts[(size_t)pi];
+        scale_new(p);
+        launch_kbuild_cross(st, p.kp, p.XtZ, mp, m, dXt, ldn, Mn, dst, mnp, acc, 0, mul);
+    });
+    if (full_cov && var_out) {
+        double* scr = nullptr;
+        bool prod = false;
+        for (const auto& t : s->terms) prod = prod || t.size() > 1;
+        if (prod && hipMalloc(&scr, sizeof(double) * mnp * mnp) != hipSuccess) {
+            cleanup();
+            mi355gp_set_error("mi355gp_sparse_predict: out of memory for the product scratch");
+            return -3;
         }
-        if (full_cov && var_out) {
-            launch_kbuild_cross(st, p.kp, dXt, ldn, Mn, dXt, ldn, Mn, dVar, mnp, firstxx ? 0 : 1, /*diag_same=*/1);
-            firstxx = false;
+        sparse_expression(s, dVar, scr, false, [&](int pi, double* dst, const double* mul, int acc, bool) {
+            const SPart& p = s->parts[(size_t)pi];
+            scale_new(p);
+            launch_kbuild_cross(st, p.kp, dXt, ldn, Mn, dXt, ldn, Mn, dst, mnp, acc, /*diag_same=*/1, mul);
+        });
+        if (scr) {
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(scr);
         }
     }
     launch_col_reduce(st, Kx, mnp, m, Mn, s->vvec, (int)Dy, 0.0, 0, dMu);                              // mu = Kx^T v

@@ -198,11 +198,16 @@ class VarDTC(object):
 
     def inference(self, kern, X, Z, likelihood, Y, Y_metadata=None, mean_function=None, precision=None, Lm=None,
                   dL_dKmm=None, psi0=None, psi1=None, psi2=None, Z_tilde=None):
-        from .kern import Add, Prod
-        ok = isinstance(kern, Stationary) or (isinstance(kern, Add) and not any(isinstance(p, Prod) for p in kern.parts))
+        from .kern import Add, Prod, White
+        # stationary kernels, products (Prod, reference `prod.py:58-99`) of stationary / Bias factors, and sums (Add) of those
+        # and of White / Bias parts
+        def _prod_ok(k):
+            return isinstance(k, Prod) and not any(isinstance(f, (White, Add, Prod)) for f in k.parts)
+        ok = isinstance(kern, Stationary) or _prod_ok(kern) or (
+            isinstance(kern, Add) and all(_prod_ok(p) if isinstance(p, Prod) else not isinstance(p, Add) for p in kern.parts))
         if not ok:
-            raise NotImplementedError("the MI355X sparse path covers gpy_amd's stationary kernels and sums (Add) of "
-                                      "stationary / White / Bias parts")
+            raise NotImplementedError("the MI355X sparse path covers gpy_amd's stationary kernels, products of stationary / "
+                                      "Bias factors and sums (Add) of those and of White / Bias parts")
         if any(a is not None for a in (Lm, dL_dKmm, psi0, psi1, psi2)):
             raise NotImplementedError("precomputed statistics are not accepted by the MI355X sparse path")
         Y = np.asarray(Y, dtype=np.float64)
@@ -213,8 +218,6 @@ class VarDTC(object):
         het = noise.size > 1
         if het and mean_function is not None:                          # var_dtc.py:85-86
             raise ValueError("Mean function not implemented with uncertain inputs or heteroscedasticity")
-        if het and Y.shape[1] != 1:
-            raise NotImplementedError("per-point noise: one output column (the reference's dL_dR, var_dtc.py:240-256)")
         m = 0 if mean_function is None else mean_function.f(X)
         single = isinstance(kern, Stationary)
         Xs = kern._slice_X(X) if single else _lib.f64(X)
@@ -244,7 +247,7 @@ class VarDTC(object):
                                K_chol=_LazyMM(self._ctx, C.FETCH_LM, M, self._token, self),
                                device={"ctx": self._ctx, "token": self._token, "owner": self, "sig": _kernel_sig(kern)})
         beta = 1.0 / np.fmax(noise, self.const_jitter)
-        dL_dR = r["dnoise"][:, None] if het else r["dnoise"]
+        dL_dR = (r["dnoise"][:, None] if r["dnoise"].ndim == 1 else r["dnoise"]) if het else r["dnoise"]   # N x Dy (var_dtc.py:240-256)
         grad_dict = {"dL_dKmm": _LazyMM(self._ctx, C.FETCH_DLDKMM, M, self._token, self),
                      "dL_dKdiag": -0.5 * Y.shape[1] * (beta * np.ones(N)),            # var_dtc.py:218
                      "dL_dKnm": _LazyNM(self._ctx, N, M, self._token, self),

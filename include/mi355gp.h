@@ -97,7 +97,7 @@ int mi355gp_update_gradients_full(int device, int kind, int ard, const double* t
                                   double* dtheta_out);
 
 /* dL/dX (N x D) from dL_dK (N x M): Stationary.gradients_X (kern/src/stationary.py:245-252,330-358, native loop
- * kern/src/stationary_utils.c:1-14).  X2 == NULL: the symmetric form (tmp + tmp^T against X itself).  D <= 32. */
+ * kern/src/stationary_utils.c:1-14).  X2 == NULL: the symmetric form (tmp + tmp^T against X itself).  Any D (the reductions run in groups of 32 dimensions). */
 int mi355gp_gradients_X(int device, int kind, int ard, const double* theta, const double* dL_dK, const double* X,
                         int64_t N, const double* X2, int64_t M, int D, double* out);
 
@@ -150,7 +150,7 @@ int mi355gp_predict(mi355gp_ctx* ctx, int kind, int ard, const double* theta, co
 int mi355gp_predict_sum(mi355gp_ctx* ctx, int nparts, const mi355gp_part* parts, const double* Xnew, int64_t M,
                         double* mu_out, double* var_out, int full_cov);
 
-/* GP.predictive_gradients (core/gp.py:418-474) for a sum of stationary (+ White / Bias) parts, no product terms, D <= 32:
+/* GP.predictive_gradients (core/gp.py:418-474) for a sum of stationary (+ White / Bias) parts, no product terms, any D:
  *   dmu_out  (M x D x Dy, row-major)  d mean[m][d] / d Xnew[m][q] = kern.gradients_X(woodbury_vector[:, d]^T, Xnew, X)  (:448-451)
  *   dvar_out (M x D)                  d var[m]    / d Xnew[m][q] = gradients_X_diag (0 for stationary kernels,
  *                                     stationary.py:360-361) + kern.gradients_X(-2 K(Xnew, X) Ky^-1, Xnew, X)           (:454,462-465)
@@ -233,7 +233,7 @@ int mi355gp_grid_fetch(mi355gp_grid* g, int which, double* out);
  * One SparseGP.parameters_changed (core/sparse_gp.py:76-119) for certain inputs and a homoscedastic Gaussian likelihood:
  * VarDTC.inference (inference/latent_function_inference/var_dtc.py:66-215, helpers :217-276) + the kernel and
  * inducing-input gradient assembly of SparseGP._update_gradients (sparse_gp.py:108-118), streamed over row chunks of X
- * like the reference's own VarDTC_minibatch (var_dtc_parallel.py:72-133).  X: N x D (D <= 32), Y: N x Dy, Z: M x D.
+ * like the reference's own VarDTC_minibatch (var_dtc_parallel.py:72-133).  X: N x D, Y: N x Dy, Z: M x D.
  *   out_scalars: [0] log marginal likelihood, [1] dL/d(noise variance), [2] trace(A), [3] data_fit,
  *                [4] sum(log diag LB), [5] beta
  *   dtheta_out: 1 + (ard ? D : 1) (variance, lengthscales; diag + Knm + Kmm terms summed as sparse_gp.py:110-115)
@@ -249,12 +249,13 @@ int mi355gp_vardtc_inference(mi355gp_sparse* s, int kind, int ard, const double*
                              double* dZ_out, double* wv_out, double* stage_ms);
 /* The same evaluation for a SUM of kernel parts (GPy.kern.Add of stationary / White / Bias kernels with active_dims,
  * kern/src/add.py:58-88, static.py:63-98,151-173; product terms are not accepted here), scalar OR per-point noise
- * variances (heteroscedastic precision: var_dtc.py:78-86,126-129,224-226,240-256,267-269; Dy == 1) and targets
+ * variances (heteroscedastic precision: var_dtc.py:78-86,126-129,224-226,240-256,267-269; any Dy) and targets
  * R = Y - mean_function.f(X) uploaded by mi355gp_sparse_set_data (var_dtc.py:73-76,88-89).
  *   noise: noise_len == 1 or N (the rows of this context) noise VARIANCES
  *   out_scalars: as above; [1] (dL/d noise variance) only for noise_len == 1
  *   dtheta_out: concatenation over the parts, each [variance, lengthscale(s)] ([variance] for White / Bias)
- *   dnoise_rows_out (N, required for noise_len == N): dL_dR per point = what likelihood.exact_inference_gradients receives
+ *   dnoise_rows_out (N x Dy, required for noise_len == N): dL_dR per point and output column = what
+ *                                likelihood.exact_inference_gradients receives (var_dtc.py:240-256 as written there)
  *   dLdm_out (optional, N x Dy): dL_dm = beta R - K(X, Z) woodbury_vector (var_dtc.py:148; SparseGP hands it to
  *                                mean_function.update_gradients, sparse_gp.py:84-85) */
 int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_part* parts, const double* Z, int64_t M,

@@ -111,15 +111,16 @@ def vardtc(kind, X, Z, Y, variance, lengthscale, ARD, noise_var):
 
 def vardtc_general(parts, X, Z, R, noise):
     """The same evaluation for a SUM of parts (`GPy.kern.Add` of stationary / White / Bias kernels, add.py:58-84;
-    parts = [(kind, ARD, variance, lengthscale, active_dims)] as in gp_oracle.sum_kern_K), per-point noise variances
-    (heteroscedastic precision, var_dtc.py:78-86,126-129,224-226,240-256,267-269; Dy = 1) and R = Y - mean_function.f(X)
-    (var_dtc.py:73-76,88-89).  Returns dict(lml, dtheta (concatenated in part order), dnoise (scalar, or the N-vector dL_dR),
+    parts = [(kind, ARD, variance, lengthscale, active_dims[, term])] as in gp_oracle.sum_kern_K; parts sharing a non-zero
+    term id are the factors of one `Prod`, prod.py:58-99: every factor sees dL_dK times the other factors' K, its
+    gradients_X likewise, and its update_gradients_diag dL_dKdiag times the other factors' Kdiag), per-point noise variances
+    (heteroscedastic precision, var_dtc.py:78-86,126-129,224-226,240-256,267-269; any Dy) and R = Y - mean_function.f(X)
+    (var_dtc.py:73-76,88-89).  Returns dict(lml, dtheta (concatenated in part order), dnoise (scalar, or dL_dR: N-vector / N x Dy),
     dZ, woodbury_vector, woodbury_inv, dL_dKmm, dL_dKnm, dL_dm)."""
     N, Dy = R.shape
     M = Z.shape[0]
     noise = np.atleast_1d(np.asarray(noise, dtype=float)).ravel()
     het = noise.size > 1
-    assert not het or Dy == 1
     beta = 1.0 / np.fmax(noise, CONST_JITTER)                                # (1,) or (N,)
     bcol = beta[:, None] if het else beta[0]
     VVT = bcol * R
@@ -160,7 +161,7 @@ def vardtc_general(parts, X, Z, R, noise):
         dL_dR += 0.5 * np.sum((LBi.T @ LBi @ Lmi_psi1) * Lmi_psi1, 0)[:, None] * b2
         dL_dR += -(c.T @ LBi_Lmi_psi1).T * R * b2
         dL_dR += 0.5 * (c.T @ LBi_Lmi_psi1).T ** 2 * b2
-        dnoise = dL_dR[:, 0]
+        dnoise = dL_dR[:, 0] if Dy == 1 else dL_dR
     else:
         b = beta[0]
         trYYT = float(np.sum(np.square(R)))
@@ -171,28 +172,37 @@ def vardtc_general(parts, X, Z, R, noise):
     Bi = np.tril(Bi) + np.tril(Bi, -1).T
     Bi[np.arange(M), np.arange(M)] += 1.0
     woodbury_inv = backsub_both_sides(Lm, Bi)
-    # SparseGP._update_gradients (sparse_gp.py:108-118) part by part (add.py:81-84: every part sees the same dL_dK)
-    grads, dZ = [], np.zeros(Z.shape)
-    for part in parts:
-        kind, ARD, var, ls, dims = part[:5]
-        if kind in ("white", "bias"):
-            g = float(np.sum(dL_dpsi0))                                      # update_gradients_diag (static.py:95-96,172-173)
-            if kind == "bias":
-                g += float(np.sum(dL_dpsi1)) + float(np.sum(dL_dKmm))        # static.py:169-170
-            else:
-                g += float(np.trace(dL_dKmm))                                # White: K(X, Z) = 0, trace for the symmetric call
-            grads.append(np.array([g]))
-            continue
-        Xp, Zp = X[:, dims], Z[:, dims]
-        dv = float(np.sum(dL_dpsi0))
-        dl = 0.0
-        for G_, A_, B_ in ((dL_dpsi1, Xp, Zp), (dL_dKmm, Zp, None)):
-            a, b_ = O.update_gradients_full(kind, G_, A_, B_, var, ls, ARD)
-            dv += float(a)
-            dl = dl + np.atleast_1d(np.asarray(b_, float))
-        grads.append(np.concatenate([[dv], dl]))
-        gz = gradients_X(kind, dL_dKmm, Zp, None, var, ls, ARD) + gradients_X(kind, dL_dpsi1.T, Zp, Xp, var, ls, ARD)
-        dZ[:, dims] += gz
+    # SparseGP._update_gradients (sparse_gp.py:108-118) part by part (add.py:81-84: every part of a sum sees the same dL_dK;
+    # prod.py:86-99,101-113: a factor of a product sees it times the other factors' covariance)
+    grads, dZ = [None] * len(parts), np.zeros(Z.shape)
+    for grp in O._terms(parts):
+        for i in grp:
+            part = parts[i]
+            kind, ARD, var, ls, dims = part[:5]
+            Wnm, Wmm, wdiag = dL_dpsi1, dL_dKmm, 1.0
+            for j in grp:
+                if j != i:
+                    Wnm = Wnm * O._part_K(parts[j], X, Z)
+                    Wmm = Wmm * O._part_K(parts[j], Z)
+                    wdiag *= float(parts[j][2])
+            if kind in ("white", "bias"):
+                g = float(np.sum(dL_dpsi0)) * wdiag                          # update_gradients_diag (static.py:95-96,172-173)
+                if kind == "bias":
+                    g += float(np.sum(Wnm)) + float(np.sum(Wmm))             # static.py:169-170
+                else:
+                    g += float(np.trace(Wmm))                                # White: K(X, Z) = 0, trace for the symmetric call
+                grads[i] = np.array([g])
+                continue
+            Xp, Zp = X[:, dims], Z[:, dims]
+            dv = float(np.sum(dL_dpsi0)) * wdiag
+            dl = 0.0
+            for G_, A_, B_ in ((Wnm, Xp, Zp), (Wmm, Zp, None)):
+                a, b_ = O.update_gradients_full(kind, G_, A_, B_, var, ls, ARD)
+                dv += float(a)
+                dl = dl + np.atleast_1d(np.asarray(b_, float))
+            grads[i] = np.concatenate([[dv], dl])
+            gz = gradients_X(kind, Wmm, Zp, None, var, ls, ARD) + gradients_X(kind, Wnm.T, Zp, Xp, var, ls, ARD)
+            dZ[:, dims] += gz
     return dict(lml=float(lml), dtheta=np.concatenate(grads), dnoise=dnoise, dZ=dZ, woodbury_vector=Cpsi1Vf,
                 woodbury_inv=woodbury_inv, dL_dKmm=dL_dKmm, dL_dKnm=dL_dpsi1, dL_dm=dL_dm, Kmm=Kmm, Lm=Lm)
 

@@ -20,7 +20,7 @@ def golden_names():
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
     # sparse_* fixtures: tests/test_oracle_sparse.py; sum_* / prod_*: tests/test_oracle_sum.py
     # baseline_* (full BASELINE.json sizes, inputs regenerated from the seed): tests/test_gpu_baseline.py
-    return [n for n in names if not n.startswith(("sparse_", "sparse2_", "sum_", "studentt_", "prod_", "baseline_", "predict_", "predsparse_"))]
+    return [n for n in names if not n.startswith(("sparse_", "sparse2_", "sparse3_", "sum_", "studentt_", "prod_", "baseline_", "predict_", "predsparse_"))]
 
 
 def load_golden(name):

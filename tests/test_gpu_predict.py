@@ -118,6 +118,27 @@ def test_predictive_gradients_entry_point_at_a_larger_size():
     assert np.abs(dvar - vj).max() <= 1e-7 * np.abs(vj).max()
 
 
+def test_predictive_gradients_with_more_than_32_input_dimensions():
+    """D = 40: the n-reductions of `GP.predictive_gradients` (core/gp.py:418-474) in two groups of input dimensions."""
+    D = 40
+    X, Y = O.synthetic(900, D, seed=6)
+    var, ls, noise = O.default_theta(D, True)
+    th = L.theta_vec(var, ls, True, D)
+    Xs = np.random.default_rng(2).standard_normal((70, D))
+    c = L.Context(0)
+    try:
+        c.set_data(X, Y)
+        info, r = c.exact_inference("rbf", True, th, noise)
+        assert info == 0
+        dmu, dvar = c.predictive_gradients([("rbf", True, th, None)], Xs)
+    finally:
+        c.close()
+    ref = O.exact_inference(O.kern_K("rbf", X, None, var, ls, True), Y, noise)
+    mj, vj = O.predictive_gradients("rbf", X, Xs, ref["alpha"], ref["Wi"], var, ls, True)
+    assert np.abs(dmu - mj).max() <= 1e-8 * np.abs(mj).max()
+    assert np.abs(dvar - vj).max() <= 1e-7 * np.abs(vj).max()
+
+
 def _sparse_names():
     import glob
     import os

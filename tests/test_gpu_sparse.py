@@ -73,6 +73,34 @@ def test_gradients_X_through_the_c_abi():
         assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
 
 
+def test_more_than_32_input_dimensions_in_gradients_X_and_the_sparse_path(sctx):
+    """`stationary.py:245-252,330-358` has no limit on the input dimension; round 2 had D <= 32 in
+    `mi355gp_gradients_X` and the sparse path (the column reductions H^T [x~ | 1] now run in groups of 32 dimensions).
+    D = 40 (two groups, a ragged second one), D = 64 (the all-ones column in a launch of its own) and D = 33."""
+    rng = np.random.default_rng(11)
+    for kind, ARD, N, M, D in (("rbf", True, 120, 90, 40), ("matern32", True, 70, 100, 64), ("matern52", False, 80, 60, 33)):
+        X, X2 = rng.standard_normal((N, D)), rng.standard_normal((M, D))
+        var, ls, _ = O.default_theta(D, ARD)
+        th = L.theta_vec(var, ls, ARD, D)
+        G = rng.standard_normal((N, M))
+        ref = S.gradients_X(kind, G, X, X2, var, ls, ARD)
+        got = L.gradients_X(kind, ARD, th, G, X, X2)
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+        Gs = rng.standard_normal((N, N))
+        ref = S.gradients_X(kind, Gs, X, None, var, ls, ARD)
+        got = L.gradients_X(kind, ARD, th, Gs, X, None)
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+    for kind, ARD, N, M, D, Dy in (("rbf", True, 3000, 70, 40, 1), ("matern52", True, 1500, 45, 64, 2)):
+        X, Y = O.synthetic(N, D, seed=D, Dy=Dy)
+        Z = S.synthetic_Z(X, M, 3)
+        var, ls, noise = O.default_theta(D, ARD)
+        ref = S.vardtc(kind, X, Z, Y, var, ls, ARD, noise)
+        sctx.set_data(X, Y)
+        info, r = sctx.vardtc(kind, ARD, L.theta_vec(var, ls, ARD, D), Z, noise)
+        assert info == 0
+        check_sparse(r, ref)
+
+
 def test_sparse_gp_regression_host_classes_and_checkgrad():
     import gpy_amd
     X, Y = O.synthetic(600, 2, seed=8)
@@ -123,14 +151,15 @@ from test_oracle_sparse import check_sparse2, load_sparse2_golden, sparse2_golde
 
 
 def _specs_of(g):
-    return [(k, a, L.theta_vec(v, ls, a, len(d)) if ls is not None else np.array([v]), np.asarray(d, np.int32), 0)
-            for k, a, v, ls, d in g["parts"]]
+    return [(p[0], p[1], L.theta_vec(p[2], p[3], p[1], len(p[4])) if p[3] is not None else np.array([p[2]]),
+             np.asarray(p[4], np.int32), p[5] if len(p) > 5 else 0) for p in g["parts"]]
 
 
 @pytest.mark.parametrize("name", sparse2_golden_names())
 def test_sparse_sum_hetero_meanfn_golden_through_the_c_abi(name, sctx):
     """`mi355gp_vardtc_inference_sum` / `mi355gp_sparse_predict` / `mi355gp_sparse_fetch_dLdKnm` against outputs of the
-    reference's own VarDTC + SparseGP._update_gradients + Posterior._raw_predict (oracle/make_golden_sparse2.py)."""
+    reference's own VarDTC + SparseGP._update_gradients + Posterior._raw_predict (oracle/make_golden_sparse2.py; round 3,
+    oracle/make_golden_sparse3.py: per-point noise with several output columns, D = 40, product kernels)."""
     g = load_sparse2_golden(name)
     specs = _specs_of(g)
     sctx.set_data(g["X"], g["R"])

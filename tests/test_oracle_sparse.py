@@ -61,7 +61,10 @@ def test_sparse_oracle_gradients_by_finite_differences():
 
 # ---- sum kernels, heteroscedastic noise, mean function (tests/golden/sparse2_*.npz, oracle/make_golden_sparse2.py) ----------
 def sparse2_golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "sparse2_*.npz")))
+    # sparse2_*: oracle/make_golden_sparse2.py; sparse3_* (per-point noise with several output columns, D = 40):
+    # oracle/make_golden_sparse3.py
+    return sorted(os.path.splitext(os.path.basename(p))[0] for pat in ("sparse2_*.npz", "sparse3_*.npz")
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, pat)))
 
 
 def load_sparse2_golden(name):
@@ -70,7 +73,7 @@ def load_sparse2_golden(name):
     for i, kind in enumerate(d["kinds"]):
         ls = d["ls%d" % i]
         parts.append((str(kind), bool(d["ARDs"][i]), float(d["variances"][i]), ls if ls.size else None,
-                      [int(v) for v in d["dims%d" % i]]))
+                      [int(v) for v in d["dims%d" % i]]) + ((int(d["terms"][i]),) if "terms" in d else ()))
     d["parts"] = parts
     d["R"] = d["Y"] - (d["X"] @ d["mean_w"] if d["mean_w"].size else 0.0)
     return d
@@ -79,7 +82,7 @@ def load_sparse2_golden(name):
 def check_sparse2(res, g, tol_lml=1e-9, tol_g=1e-6):
     assert abs(res["lml"] - g["lml"]) <= tol_lml * abs(g["lml"])
     assert np.abs(res["dtheta"] - g["dtheta"]).max() <= tol_g * np.abs(g["dtheta"]).max()
-    assert np.abs(np.atleast_1d(res["dnoise"]) - g["dnoise"]).max() <= tol_g * np.abs(g["dnoise"]).max()
+    assert np.abs(np.atleast_1d(res["dnoise"]).ravel() - g["dnoise"]).max() <= tol_g * np.abs(g["dnoise"]).max()   # N x Dy, row-major
     assert np.abs(res["dZ"] - g["dZ"]).max() <= tol_g * np.abs(g["dZ"]).max()
     assert np.linalg.norm(res["woodbury_vector"] - g["woodbury_vector"]) <= 1e-5 * np.linalg.norm(g["woodbury_vector"])
 

@@ -222,6 +222,30 @@ def test_sparse_host_classes_with_add_kernel_hetero_noise_and_mean_function():
     assert np.abs(k2.gradient - ref2["dtheta"]).max() <= 1e-6 * np.abs(ref2["dtheta"]).max()
 
 
+def test_sparse_host_classes_with_a_product_kernel():
+    """`SparseGP` with `Prod` (reference prod.py:58-113) + White through the drop-in classes: LML, every gradient (Z, both
+    factors, White, noise), prediction -- against the oracle (pinned to the reference's own VarDTC on product kernels by the
+    sparse3_prod_* fixtures) and by a finite-difference check."""
+    import gpy_amd
+    X, Y = O.synthetic(420, 3, seed=9)
+    Z = S.synthetic_Z(X, 24, 9)
+    k = gpy_amd.RBF(2, variance=1.3, lengthscale=0.9, active_dims=[0, 1]) * gpy_amd.Matern32(1, variance=0.8, lengthscale=1.4,
+                                                                                           active_dims=[2])
+    k = k + gpy_amd.White(3, variance=0.03)
+    m = gpy_amd.SparseGP(X, Y, Z, k, gpy_amd.Gaussian(0.1))
+    parts = [("rbf", False, 1.3, np.array([0.9]), [0, 1], 1), ("matern32", False, 0.8, np.array([1.4]), [2], 1),
+             ("white", False, 0.03, None, [0, 1, 2], 0)]
+    ref = S.vardtc_general(parts, X, Z, Y, 0.1)
+    assert abs(m.log_likelihood() - ref["lml"]) <= 1e-9 * abs(ref["lml"])
+    gref = np.concatenate([ref["dZ"].ravel(), ref["dtheta"], [ref["dnoise"]]])
+    assert np.abs(m.gradient - gref).max() <= 1e-6 * np.abs(gref).max()
+    Xs = np.random.default_rng(4).standard_normal((30, 3))
+    mu, var = m.predict(Xs, include_likelihood=False)
+    mur, varr = S.sparse_predict(parts, Z, Xs, ref["woodbury_vector"], ref["woodbury_inv"])
+    assert np.abs(mu - mur).max() <= 1e-6 * np.abs(mur).max() and np.abs(var - varr).max() <= 1e-5 * np.abs(varr).max()
+    assert m.checkgrad()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_row_sharded_mode_over_the_loopback_transport(world):
     """world > 1 on ONE GPU: `world` contexts, one host thread each, meet at the in-process rendezvous for both exchange

@@ -128,6 +128,9 @@ def lib():
     L.mi355gp_grid_set_data.argtypes = [vp, _dp, i64, ci, _dp, ci]
     L.mi355gp_grid_exact_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_grid_fetch.argtypes = [vp, ci, _dp]
+    L.mi355gp_grid_set_option.argtypes = [vp, ci, ci]
+    L.mi355gp_dbg_grid_multi.argtypes = [ci, ci, ci, ci, _dp]
+    L.mi355gp_grid_get_option.argtypes = [vp, ci, ctypes.POINTER(ci)]
     L.mi355gp_sparse_create.argtypes = [ci, ctypes.POINTER(vp)]
     L.mi355gp_sparse_destroy.argtypes = [vp]
     L.mi355gp_sparse_set_data.argtypes = [vp, _dp, i64, ci, _dp, ci]
@@ -150,12 +153,13 @@ def lib():
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
-                 "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "sparse_create",
+                 "grid_create", "grid_destroy", "grid_set_data", "grid_exact_inference", "grid_fetch", "grid_set_option",
+                 "grid_get_option", "sparse_create",
                  "sparse_destroy", "sparse_set_data", "vardtc_inference", "sparse_fetch", "gradients_X", "sparse_attach_comm", "exact_inference_sum",
                  "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum", "dbg_mask_probe",
                  "vardtc_inference_sum", "sparse_predict", "sparse_fetch_dLdKnm", "sparse_attach_loopback",
                  "predictive_gradients_sum", "dbg_pipe_share", "pdinv_full", "dbg_graph_factor", "get_option",
-                 "sparse_get_profile", "dbg_persist"):
+                 "sparse_get_profile", "dbg_persist", "dbg_grid_multi"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -167,6 +171,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_fetch", "mi355gp_predict", "mi355gp_potrf", "mi355gp_pdinv", "mi355gp_bench_factor",
             "mi355gp_set_option", "mi355gp_get_profile", "mi355gp_grid_unique_id", "mi355gp_grid_create",
             "mi355gp_grid_destroy", "mi355gp_grid_set_data", "mi355gp_grid_exact_inference", "mi355gp_grid_fetch",
+            "mi355gp_grid_set_option", "mi355gp_grid_get_option",
             "mi355gp_sparse_create", "mi355gp_sparse_destroy", "mi355gp_sparse_set_data", "mi355gp_vardtc_inference",
             "mi355gp_sparse_fetch", "mi355gp_gradients_X", "mi355gp_sparse_attach_comm",
             "mi355gp_exact_inference_sum", "mi355gp_predict_sum", "mi355gp_dbg_gemm_clock",
@@ -174,7 +179,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_sparse_predict", "mi355gp_sparse_fetch_dLdKnm", "mi355gp_sparse_attach_loopback",
             "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share", "mi355gp_pdinv_full", "mi355gp_dbg_graph_factor",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe", "mi355gp_get_option",
-            "mi355gp_sparse_get_profile", "mi355gp_dbg_persist")
+            "mi355gp_sparse_get_profile", "mi355gp_dbg_persist", "mi355gp_dbg_grid_multi")
 
 
 # mi355gp_set_option / mi355gp_get_option ids (include/mi355gp.h, MI355GP_OPT_*)
@@ -658,3 +663,12 @@ def dbg_peaks(device=0):
     return dict(mfma_f64_tflops=out[0], valu_f64_tflops=out[1], hbm_copy_gbs=out[2], hbm_fill_gbs=out[3],
                 mfma_cycles_per_inst_1wave=out[4], shader_mhz_under_load=out[5], mfma_1wave_tflops=out[6],
                 mfma_cycles_per_inst_loaded=out[7])
+
+
+def dbg_grid_multi(T, nb=512, reps=3, device=0):
+    """ms of the deep-K X^T X pass: [k_lauum row-major, grid kernel on two panel stores, on one panel store, grid kernel
+    on the row-major matrix] (mi355gp_dbg_grid_multi)."""
+    require_device(device)
+    out = np.zeros(5)
+    check(lib().mi355gp_dbg_grid_multi(device, int(T), int(nb), int(reps), out), "mi355gp_dbg_grid_multi")
+    return out

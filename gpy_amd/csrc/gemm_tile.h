@@ -336,6 +336,80 @@ __device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, l
     }
 }
 
+// The same pipeline with the K dimension running over a LIST of operand panels (grid.hip: the aggregated updates of the
+// block-cyclic mode apply panels k0 .. k1-1 of `slabs` 16-wide slabs each in ONE pass over C).  Atab[k] / Btab[k] are the
+// panels' base pointers (workgroup-uniform: scalar loads), aoff / boff this tile's offset inside every panel.  The two
+// LDS stages roll across panel boundaries: no pipeline drain between panels.
+template <bool AK, bool BK, bool NEGA>
+__device__ __forceinline__ void gemm_tile_128_v3_multi(const double* const* __restrict__ Atab, long aoff, long lda,
+                                                       const double* const* __restrict__ Btab, long boff, long ldb,
+                                                       int k0, int k1, int slabs, d4 (&acc)[4][4], double* smem) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+    const int nk = (k1 - k0) * slabs;
+    const int arow = wr * 64 + (lane & 15), bcol = wc * 64 + (lane & 15), kq = lane >> 4;
+    auto rsrc = [](const double* p) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000);
+    };
+    int va[4], vb[4];
+    gt3_src_offsets<AK>(lda, lane, w, va);
+    gt3_src_offsets<BK>(ldb, lane, w, vb);
+    const long sa = AK ? 16 : 16 * lda, sb = BK ? 16 : 16 * ldb;
+    int fa0[4], fb0[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int r = arow + mi * 16, c = bcol + mi * 16;
+        fa0[mi] = AK ? r * 16 : r;
+        fb0[mi] = BK ? c * 16 : c;
+    }
+    const int ha = gt3_h(arow), hb = gt3_h(bcol);
+    int pk = k0, ps = 0;                                     // panel / slab-in-panel of the NEXT slab to fetch
+    const double* Ab = Atab[pk] + aoff;
+    const double* Bb = Btab[pk] + boff;
+    gt3_issue<AK>(rsrc(Ab), va, 0, smem, w);
+    gt3_issue<BK>(rsrc(Bb), vb, 0, smem + GT3_OP, w);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            if (++ps == slabs) {
+                ps = 0;
+                ++pk;
+                Ab = Atab[pk] + aoff;
+                Bb = Btab[pk] + boff;
+            }
+            double* nxt = smem + (cur ^ 1) * 2 * GT3_OP;
+            gt3_issue<AK>(rsrc(Ab + ps * sa), va, 0, nxt, w);
+            gt3_issue<BK>(rsrc(Bb + ps * sb), vb, 0, nxt + GT3_OP, w);
+        }
+        const double* a_s = smem + cur * 2 * GT3_OP;
+        const double* b_s = a_s + GT3_OP;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            d2 af[4], bf[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                if (AK) af[mi] = *reinterpret_cast<const d2*>(a_s + fa0[mi] + 2 * ((2 * kq + e) ^ ha));
+                else af[mi] = (d2){a_s[(4 * kq + 2 * e) * GT3_SMN + fa0[mi]], a_s[(4 * kq + 2 * e + 1) * GT3_SMN + fa0[mi]]};
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                if (BK) bf[ni] = *reinterpret_cast<const d2*>(b_s + fb0[ni] + 2 * ((2 * kq + e) ^ hb));
+                else bf[ni] = (d2){b_s[(4 * kq + 2 * e) * GT3_SMN + fb0[ni]], b_s[(4 * kq + 2 * e + 1) * GT3_SMN + fb0[ni]]};
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = mfma_f64(NEGA ? -af[mi][s] : af[mi][s], bf[ni][s], acc[mi][ni]);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+}
+
 // =====================================================================================================================
 // 64 x 64 output tiles on the v3 (LDS-DMA) pipeline, for launches with FEWER 128-tiles than the chip has CUs.
 // fp64 MFMA peak is per CU (4 SIMDs x one 16x16x4 MFMA per 64 cycles = 0.31 TFLOP/s): a 128x128 tile confined to one

@@ -171,6 +171,120 @@ static void grid_gemm_t(hipStream_t st, double* C, long ldc, int c_tm, GOp a, GO
                        a.p, a.ld, a.tm, b.p, b.ld, b.tm, (int)K, ntc, (int)(nb / NB), nb, mode, pd);
 }
 
+// The aggregated updates: C (op)= sum over the panels k in [ks, k1) of A_k * B_k on the 128x128 tiles of a local region,
+// ONE pass over C for the whole panel list (the tile pipeline rolls across panels: gemm_tile_128_v3_multi).
+//   MODE 0: C = acc,  1: C += acc,  2: C -= acc   (1 / 2 read C before the k-loop: its latency hides behind the prologue)
+//   Atab[k] / Btab[k]: base of panel k such that LOCAL nb-tile l of the operand starts at base + l * nb * nb
+//       AK / BK = true : the panel is a tall [rows][nb] matrix (k contiguous): L_ik row panels / L_jk column panels
+//       AK / BK = false: the panel is a sequence of [nb(k)][nb] tiles (m/n contiguous): X_ki / X_kj row panels
+//   ti0 / tj0: first local 128-tile row / column of the region.   pd: keep tiles with I >= J (global nb-tile indices).
+//   kpred: the first panel that touches tile (I, J):  0: k0;  1: max(k0, J) (B -= L X: X_kj = 0 for j > k);
+//          2: max(k0, I, J) (W += X^T X).  A tile with no panel left keeps its C (MODE 0: stores zeros).
+// Live-tile enumeration of a region under the lower predicate: pre[i] = number of live nb-tile pairs in the region's
+// rows before row i (host-computed per launch, passed BY VALUE in the kernel arguments: <= 4 KB).  Consecutive
+// workgroups then are consecutive LIVE tiles: a plain rows x columns grid whose dead half exits at once runs the same
+// tiles 30 % slower (N=16384 X^T X: 48 vs 69 TF/s, mi355gp_dbg_grid_multi) -- workgroups go to the 8 XCDs round-robin
+// by index, dead ones included, and the XCDs drift out of balance.
+#define GRID_ROWTAB_MAX 960
+struct GridRowTab {
+    int n;                                    // rows in the table; 0 = plain rows x columns enumeration
+    int pre[GRID_ROWTAB_MAX + 1];
+};
+template <bool AK, bool BK, int MODE>
+__global__ __launch_bounds__(256, 2) void k_grid_gemm_multi(double* __restrict__ C, long ldc,
+                                                            const double* const* __restrict__ Atab,
+                                                            const double* const* __restrict__ Btab, int k0, int k1,
+                                                            int ti0, int tj0, int ntc, int q, long nb, int kpred,
+                                                            GridPred pd, long ldo, int tm, GridRowTab rt) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int ti, tj;
+    if (tm == 2) {                                           // experiment: triangular enumeration of a square region at (0, 0)
+        const int bid = blockIdx.x;
+        ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+        while ((long)ti * (ti + 1) / 2 > bid) --ti;
+        while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+        tj = bid - (int)((long)ti * (ti + 1) / 2);
+    } else if (rt.n > 0) {                                   // live nb-tile pairs in row order, q x q tiles per pair
+        const int qq = q * q, p = (int)(blockIdx.x / qq), sub = (int)(blockIdx.x % qq);
+        int lo = 0, hi = rt.n - 1;                           // last row with pre[row] <= p
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (rt.pre[mid] <= p) lo = mid;
+            else hi = mid - 1;
+        }
+        ti = ti0 + lo * q + sub / q;
+        tj = tj0 + (p - rt.pre[lo]) * q + sub % q;
+    } else {
+        ti = ti0 + blockIdx.x / ntc;
+        tj = tj0 + blockIdx.x % ntc;
+    }
+    const int I = (ti / q) * pd.Pr + pd.pr, J = (tj / q) * pd.Pc + pd.pc;
+    if (pd.on && J > I) return;
+    int ks = k0;
+    if (kpred >= 1 && J > ks) ks = J;
+    if (kpred >= 2 && I > ks) ks = I;
+    double* Ct = C + (long)ti * NB * ldc + (long)tj * NB;
+    d4 acc[4][4];
+    if (ks >= k1) {
+        if (MODE == 0) {
+            gt_zero<4>(acc);
+            gt_store<0, 4>(Ct, ldc, acc);
+        }
+        return;
+    }
+    if (MODE == 0) gt_zero<4>(acc);
+    else gt_load_buf<4>(Ct, ldc, acc);
+    // ldo / tm: operand row stride and tile-major flag (the panel stores: ldo = nb, tm = 1; the microbenchmark also reads a
+    // plain row-major matrix: ldo = its leading dimension, tm = 0)
+    const long aoff = AK ? (long)ti * NB * ldo : (tm == 1 ? (long)(ti / q) * nb * nb + (long)(ti % q) * NB : (long)ti * NB);
+    const long boff = BK ? (long)tj * NB * ldo : (tm == 1 ? (long)(tj / q) * nb * nb + (long)(tj % q) * NB : (long)tj * NB);
+    gemm_tile_128_v3_multi<AK, BK, MODE == 2>(Atab, aoff, ldo, Btab, boff, ldo, ks, k1, (int)(nb / 16), acc, smem);
+    gt_store<0, 4>(Ct, ldc, acc);
+}
+
+// region [ti0, ti1) x [tj0, tj1) in local nb-tiles
+template <bool AK, bool BK, int MODE>
+static void grid_gemm_multi(hipStream_t st, double* C, long ldc, const double* const* Atab, const double* const* Btab,
+                            int k0, int k1, int ti0, int ti1, int tj0, int tj1, long nb, int kpred, GridPred pd,
+                            long ldo = 0, int tm = 1) {
+    if (ti1 <= ti0 || tj1 <= tj0 || k1 <= k0) return;
+    static bool opted = false;
+    if (!opted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_gemm_multi<AK, BK, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
+        opted = true;
+    }
+    const int q = (int)(nb / NB), ntr = (ti1 - ti0) * q, ntc = (tj1 - tj0) * q;
+    long nblk = (tm == 2) ? (long)ntr * (ntr + 1) / 2 : (long)ntr * ntc;
+    GridRowTab rt;
+    rt.n = 0;
+    if (pd.on && tm != 2 && ti1 - ti0 <= GRID_ROWTAB_MAX) {
+        // live columns of local row li: lj with lj * Pc + pc <= li * Pr + pr, clipped to [tj0, tj1) (a prefix of the range)
+        long tot = 0;
+        int first = -1, last = -1;
+        for (int li = ti0; li < ti1; ++li) {
+            const long I = (long)li * pd.Pr + pd.pr;
+            long m = (I >= pd.pc) ? (I - pd.pc) / pd.Pc + 1 : 0;             // local columns with J <= I
+            long c = m - tj0;
+            if (c < 0) c = 0;
+            if (c > tj1 - tj0) c = tj1 - tj0;
+            if (c > 0) {
+                if (first < 0) first = li;
+                last = li;
+            }
+            if (first >= 0) rt.pre[li - first] = (int)tot;
+            tot += c;
+        }
+        if (tot == 0) return;
+        rt.n = last - first + 1;
+        rt.pre[rt.n] = (int)tot;
+        ti0 = first;
+        nblk = tot * q * q;
+    }
+    hipLaunchKernelGGL((k_grid_gemm_multi<AK, BK, MODE>), dim3((unsigned)nblk), dim3(256), GT_LDS_BYTES, st, C, ldc,
+                       Atab, Btab, k0, k1, ti0 * q, tj0 * q, ntc, q, nb, kpred, pd, ldo ? ldo : nb, tm, rt);
+}
+
 // local diagonal fix-up after the cross-covariance build: entries with equal global index get noise + jitter
 // (real points) or 1 (padding); one thread per element of every diagonal nb-tile this rank owns.
 __global__ void k_grid_fix_diag(double* __restrict__ A, long ld, long nb, long n, int ndiag,
@@ -221,16 +335,22 @@ __global__ __launch_bounds__(256) void k_grid_row_reduce(const double* __restric
     if (lane == 0) y[i] = s;
 }
 
-// out[j] = sum_i M[i][j] * (v ? v[g(i)][d] : M[i][j])   (64 columns per block, fixed-order combine)
-__global__ __launch_bounds__(256) void k_grid_col_reduce(const double* __restrict__ M, long ld, long rows, long cols,
-                                                         const long* __restrict__ gr, const double* __restrict__ v,
-                                                         int Dy, int d, long n, double* __restrict__ out) {
+// out[j] = sum_i M[i][j] * (v ? v[g(i)][d] : M[i][j]) in two fixed-order stages: partials per chunk of CR_ROWS rows (64
+// columns x CR_ROWS rows per block), then the sum over chunks.  M = X = L^-1 is lower block triangular in GLOBAL nb-tiles:
+// a chunk whose tile row lies above the column's tile contributes exact zeros and is not read.
+#define CR_ROWS 128
+__global__ __launch_bounds__(256) void k_grid_col_reduce_part(const double* __restrict__ M, long ld, long rows, long cols,
+                                                              const long* __restrict__ gr, const double* __restrict__ v,
+                                                              int Dy, int d, long n, double* __restrict__ part, long nb,
+                                                              int Pr, int pr, int Pc, int pc) {
     __shared__ double red[4][64];
     const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const long j = (long)blockIdx.x * 64 + tx;
+    const long j = (long)blockIdx.x * 64 + tx, i0 = (long)blockIdx.y * CR_ROWS;
+    const long I = (i0 / nb) * Pr + pr, J = (((long)blockIdx.x * 64) / nb) * Pc + pc;
     double s = 0.0;
-    if (j < cols) {
-        for (long i = g; i < rows; i += 4) {
+    if (j < cols && I >= J) {
+        const long i1 = (i0 + CR_ROWS < rows) ? i0 + CR_ROWS : rows;
+        for (long i = i0 + g; i < i1; i += 4) {
             const double x = M[i * ld + j];
             if (v) {
                 const long gi = gr[i];
@@ -242,7 +362,14 @@ __global__ __launch_bounds__(256) void k_grid_col_reduce(const double* __restric
     }
     red[g][tx] = s;
     __syncthreads();
-    if (g == 0 && j < cols) out[j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (g == 0 && j < cols) part[(long)blockIdx.y * cols + j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+__global__ void k_grid_col_combine(const double* __restrict__ part, long nchunks, long cols, double* __restrict__ out) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    double s = 0.0;
+    for (long c = 0; c < nchunks; ++c) s += part[c * cols + j];
+    out[j] = s;
 }
 
 // gvec[g(l)*stride + d] = loc[l]  for g(l) < n
@@ -279,9 +406,16 @@ struct GridRank {
     long LR = 0, LC = 0;             // allocated local rows / cols (uniform over ranks)
     long nvr = 0, nvc = 0;           // local rows / cols whose global index is < n (a prefix of the local order)
     double *A = nullptr, *X = nullptr, *W = nullptr;
-    // panel buffers, double-buffered by step parity: step k+1's panels are produced on the communication stream while the
-    // bulk updates of step k still read step k's
-    double *RP2[2] = {nullptr, nullptr}, *CP2[2] = {nullptr, nullptr}, *XR2[2] = {nullptr, nullptr}, *XRr2[2] = {nullptr, nullptr};
+    // Panel stores: EVERY step's four panels are kept for the whole evaluation (written once by the step's critical path,
+    // read by the aggregated updates of its group and, for the X panels, by the deferred W = X^T X), packed back to back:
+    //   RPs: L_ik for the local row tiles with I > k          CPs: L_jk for the local column tiles with J > k
+    //   XRs: X_kj for the local column tiles with J <= k      XRrs: X_ki for the local row tiles with I <= k
+    // hRP[k] .. are the panels' VIRTUAL bases (local tile l of panel k at base + l * nb * nb; only the tiles the panel holds
+    // are ever addressed), dRP .. the same tables in device memory for k_grid_gemm_multi.
+    double *RPs = nullptr, *CPs = nullptr, *XRs = nullptr, *XRrs = nullptr;
+    std::vector<double*> hRP, hCP, hXR, hXRr;
+    const double **dRP = nullptr, **dCP = nullptr, **dXR = nullptr, **dXRr = nullptr;
+    double* cpart = nullptr;         // column-reduction partials [row chunk][LC]
     double *Dt = nullptr, *Dv = nullptr, *Ds = nullptr;
     double *XtR = nullptr, *XtC = nullptr, *XsR = nullptr, *XsC = nullptr;   // scaled dimension-major / raw row-major
     long *gR = nullptr, *gC = nullptr;                                       // global index of every local row / col
@@ -293,6 +427,7 @@ struct GridRank {
     FactorWs ws;
     hipStream_t st = nullptr;        // bulk updates and everything outside the factorisation loop
     hipStream_t sc = nullptr;        // the critical path of a step: diagonal tile, panel solves, all panel broadcasts
+    hipStream_t sw = nullptr;        // W = X^T X updates
 };
 
 struct mi355gp_grid {
@@ -303,8 +438,12 @@ struct mi355gp_grid {
     ncclComm_t comm_world = nullptr, comm_row = nullptr, comm_col = nullptr;
     hipStream_t st = nullptr;        // loopback: shared by all logical ranks
     hipStream_t sc = nullptr;        // second stream (high priority): panel factorisation + broadcasts, one step ahead
+    hipStream_t sw = nullptr;        // third stream (low priority): the W = X^T X updates, which nothing waits for until the end
+    hipEvent_t ev_w = nullptr;
     std::vector<hipEvent_t> ev_cr, ev_p1;   // [k]: panels of step k are in place / the part-1 updates of step k are done
     int lookahead = 1;               // MI355GP_GRID_LOOKAHEAD=0: everything in order on one stream
+    int G = 1;                       // MI355GP_GRID_G: steps per group of the two-level blocked factorisation (K = G * nb updates)
+    int GW = 4;                      // MI355GP_GRID_GW: steps per W = X^T X update; 0 = one deep-K pass after the last step
     long n = 0, npad = 0, T = 0;
     int D = 0, Dy = 0;
     hipEvent_t ev[6] = {};
@@ -315,11 +454,25 @@ struct mi355gp_grid {
     mi355gp_ctx* single = nullptr;
 };
 
+// process defaults of the schedule options: environment, else built-in
+static void grid_default_option(mi355gp_grid* g, int o) {
+    if (o == MI355GP_GRID_OPT_LOOKAHEAD) {
+        const char* e = getenv("MI355GP_GRID_LOOKAHEAD");
+        g->lookahead = (e && *e) ? (atoi(e) ? 1 : 0) : 1;
+    } else if (o == MI355GP_GRID_OPT_G) {
+        const char* e = getenv("MI355GP_GRID_G");
+        g->G = (e && *e && atoi(e) >= 1) ? atoi(e) : 1;
+    } else if (o == MI355GP_GRID_OPT_GW) {
+        const char* e = getenv("MI355GP_GRID_GW");
+        g->GW = (e && *e && atoi(e) >= 0) ? atoi(e) : 4;
+    }
+}
+
 static int cnt_le(long k, int p, int P) { return (k >= p) ? (int)((k - p) / P + 1) : 0; }   // tiles t <= k with t % P == p
 static int cnt_lt(long k, int p, int P) { return (k > 0) ? cnt_le(k - 1, p, P) : 0; }
 
 static void free_rank(GridRank& r) {
-    void* ptrs[] = {r.A, r.X, r.W, r.RP2[0], r.RP2[1], r.CP2[0], r.CP2[1], r.XR2[0], r.XR2[1], r.XRr2[0], r.XRr2[1], r.Dt, r.Dv, r.Ds, r.XtR, r.XtC, r.XsR, r.XsC, r.gR, r.gC,
+    void* ptrs[] = {r.A, r.X, r.W, r.RPs, r.CPs, r.XRs, r.XRrs, (void*)r.dRP, (void*)r.dCP, (void*)r.dXR, (void*)r.dXRr, r.cpart, r.Dt, r.Dv, r.Ds, r.XtR, r.XtC, r.XsR, r.XsC, r.gR, r.gC,
                     r.dl_r, r.dl_c, r.dg, r.vloc, r.gvec, r.gvec2, r.alpha, r.ybuf, r.Rg, r.scal, r.gradPart,
                     r.gradOut, r.invls, r.noise, r.info_g};
     for (void* p : ptrs)
@@ -432,8 +585,9 @@ int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb,
         int least = 0, greatest = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_CHECK(hipStreamCreateWithPriority(&g->sc, hipStreamNonBlocking, greatest));
-        const char* envl = getenv("MI355GP_GRID_LOOKAHEAD");
-        if (envl && *envl) g->lookahead = atoi(envl) ? 1 : 0;
+        HIP_CHECK(hipStreamCreateWithPriority(&g->sw, hipStreamNonBlocking, least));
+        HIP_CHECK(hipEventCreateWithFlags(&g->ev_w, hipEventDisableTiming));
+        for (int o = 0; o < MI355GP_GRID_OPT_NUM; ++o) grid_default_option(g, o);
     }
     for (auto& e : g->ev) HIP_CHECK(hipEventCreate(&e));
     if (g->loopback) {
@@ -444,6 +598,7 @@ int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb,
             g->ranks[r].pc = r % Pc;
             g->ranks[r].st = g->st;
             g->ranks[r].sc = g->sc;
+            g->ranks[r].sw = g->sw;
         }
     } else {
         if (!g_rccl.load()) return -20;
@@ -454,6 +609,7 @@ int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb,
         r.pc = rank % Pc;
         r.st = g->st;
         r.sc = g->sc;
+        r.sw = g->sw;
         ncclUniqueId id;
         memcpy(&id, id128, sizeof(id));
         NCCL_CHECK(g_rccl.CommInitRank(&g->comm_world, world, id, rank));
@@ -485,6 +641,11 @@ int mi355gp_grid_destroy(mi355gp_grid* g) {
         (void)hipStreamSynchronize(g->sc);
         (void)hipStreamDestroy(g->sc);
     }
+    if (g->sw) {
+        (void)hipStreamSynchronize(g->sw);
+        (void)hipStreamDestroy(g->sw);
+    }
+    if (g->ev_w) (void)hipEventDestroy(g->ev_w);
     if (g->st) (void)hipStreamDestroy(g->st);
     delete g;
     return 0;
@@ -500,6 +661,7 @@ int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, co
     HIP_CHECK(hipSetDevice(g->device));
     HIP_CHECK(hipStreamSynchronize(g->st));
     HIP_CHECK(hipStreamSynchronize(g->sc));
+    HIP_CHECK(hipStreamSynchronize(g->sw));
     const long nb = g->nb;
     g->n = N;
     g->T = (N + nb - 1) / nb;
@@ -518,9 +680,9 @@ int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, co
     const int groups = (D + 31) / 32;
     for (GridRank& r : g->ranks) {
         const int rank = r.rank, pr = r.pr, pc = r.pc;
-        hipStream_t st = r.st, sc = r.sc;
+        hipStream_t st = r.st, sc = r.sc, sw = r.sw;
         free_rank(r);
-        r.rank = rank; r.pr = pr; r.pc = pc; r.st = st; r.sc = sc;
+        r.rank = rank; r.pr = pr; r.pc = pc; r.st = st; r.sc = sc; r.sw = sw;
         r.TLr = cnt_le(T - 1, pr, g->Pr);
         r.TLc = cnt_le(T - 1, pc, g->Pc);
         r.LR = TLrM * nb;
@@ -529,11 +691,36 @@ int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, co
         HIP_CHECK(hipMalloc(&r.A, mat));
         HIP_CHECK(hipMalloc(&r.X, mat));
         HIP_CHECK(hipMalloc(&r.W, mat));
-        for (int b = 0; b < 2; ++b) {
-            HIP_CHECK(hipMalloc(&r.RP2[b], sizeof(double) * r.LR * nb));
-            HIP_CHECK(hipMalloc(&r.CP2[b], sizeof(double) * r.LC * nb));
-            HIP_CHECK(hipMalloc(&r.XR2[b], sizeof(double) * r.LC * nb));
-            HIP_CHECK(hipMalloc(&r.XRr2[b], sizeof(double) * r.LR * nb));
+        {
+            const size_t tile = (size_t)nb * nb;
+            std::vector<long> oRP((size_t)T + 1, 0), oCP((size_t)T + 1, 0), oXR((size_t)T + 1, 0), oXRr((size_t)T + 1, 0);
+            for (long k = 0; k < T; ++k) {
+                oRP[k + 1] = oRP[k] + (r.TLr - cnt_le(k, pr, g->Pr));
+                oCP[k + 1] = oCP[k] + (r.TLc - cnt_le(k, pc, g->Pc));
+                oXR[k + 1] = oXR[k] + cnt_le(k, pc, g->Pc);
+                oXRr[k + 1] = oXRr[k] + cnt_le(k, pr, g->Pr);
+            }
+            HIP_CHECK(hipMalloc(&r.RPs, sizeof(double) * tile * (size_t)(oRP[T] + 1)));
+            HIP_CHECK(hipMalloc(&r.CPs, sizeof(double) * tile * (size_t)(oCP[T] + 1)));
+            HIP_CHECK(hipMalloc(&r.XRs, sizeof(double) * tile * (size_t)(oXR[T] + 1)));
+            HIP_CHECK(hipMalloc(&r.XRrs, sizeof(double) * tile * (size_t)(oXRr[T] + 1)));
+            r.hRP.resize((size_t)T); r.hCP.resize((size_t)T); r.hXR.resize((size_t)T); r.hXRr.resize((size_t)T);
+            for (long k = 0; k < T; ++k) {
+                r.hRP[k] = r.RPs + (oRP[k] - cnt_le(k, pr, g->Pr)) * (long)tile;
+                r.hCP[k] = r.CPs + (oCP[k] - cnt_le(k, pc, g->Pc)) * (long)tile;
+                r.hXR[k] = r.XRs + oXR[k] * (long)tile;
+                r.hXRr[k] = r.XRrs + oXRr[k] * (long)tile;
+            }
+            const size_t tb = sizeof(double*) * (size_t)T;
+            HIP_CHECK(hipMalloc((void**)&r.dRP, tb));
+            HIP_CHECK(hipMalloc((void**)&r.dCP, tb));
+            HIP_CHECK(hipMalloc((void**)&r.dXR, tb));
+            HIP_CHECK(hipMalloc((void**)&r.dXRr, tb));
+            HIP_CHECK(hipMemcpy((void*)r.dRP, r.hRP.data(), tb, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy((void*)r.dCP, r.hCP.data(), tb, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy((void*)r.dXR, r.hXR.data(), tb, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy((void*)r.dXRr, r.hXRr.data(), tb, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMalloc(&r.cpart, sizeof(double) * (size_t)(r.LR / CR_ROWS + 1) * r.LC));
         }
         HIP_CHECK(hipMalloc(&r.Dt, sizeof(double) * nb * nb));
         HIP_CHECK(hipMalloc(&r.Dv, sizeof(double) * nb * nb));
@@ -632,24 +819,34 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
         }
     }
     HIP_CHECK(hipEventRecord(g->ev[1], g->st));
-    // ---- the one-pass factorisation / inversion ------------------------------------------------------------
-    // Two streams per rank, one step of look-ahead:
-    //   sc (high priority)  crit(k):  diagonal tile k, D = L_kk^-1, its broadcasts, the panel solves of step k and ALL panel
-    //                                 broadcasts (RCCL); panels land in the buffers of parity k & 1
-    //   st                  part1(k): the updates of step k that step k+1's critical path reads -- tile column k+1 of A,
-    //                                 tile row k+1 of B;  then bulk(k): the rest of the three rank-nb updates
-    // crit(k+1) starts after part1(k) and runs underneath bulk(k); bulk(k+1) waits for crit(k+1).  crit(k+1) reads and
-    // writes only column k+1 of A and row k+1 of X, which bulk(k) does not touch; crit(k+2) overwrites the parity-k panel
-    // buffers only after part1(k+1), which is behind bulk(k) on st.  Every rank enqueues the same sequence of
-    // collectives on sc, so their order is consistent across the grid.
+    // ---- the one-pass factorisation / inversion, two-level blocked -----------------------------------------------
+    // Steps are taken in GROUPS of G (MI355GP_GRID_G).  Every step k runs its critical path crit(k) -- diagonal tile k,
+    // D = L_kk^-1, the panel solves, row k of X and ALL panel broadcasts -- and then brings only the REST OF ITS GROUP up to
+    // date with K = nb updates (near(k): tile columns k+1 .. ge-1 of A, tile rows k+1 .. ge-1 of B; ge = first step of the
+    // next group).  Everything beyond the group receives the group's G panels in ONE pass over C with K = G * nb
+    // (k_grid_gemm_multi): first the next group's columns / rows (part1(g), on the critical path), then the bulk.  W = X^T X is
+    // not read by anything before the end: its updates are aggregated over GW steps (MI355GP_GRID_GW; 0 = one deep-K pass
+    // after the last step, the distributed lauum).  The three read-modify-write passes per step of the one-level form
+    // become one pass per G (A, B) and per GW (W) steps: the C traffic of the updates drops accordingly and the tile
+    // pipeline runs K = G * nb deep (k_grid_gemm at K = 512: 0.61 of the fp64 peak; lauum-deep: 0.87).
+    // Two streams per rank, one group of look-ahead:
+    //   sc (high priority): crit(k), near(k) for the steps of group g, then part1(g) [after bulk(g-1): both write the
+    //                       columns / rows of group g+1], then group g+1
+    //   st                : bulk(g) [after crit of the group's last step]
+    //   sw (low priority) : the W updates [after crit of the last step they read]; st joins it after the loop
+    // bulk(g) touches columns / rows >= the start of group g+2 only, the critical path of group g+1 stays inside group
+    // g+1's columns / rows: they run concurrently.  Every panel has its own buffer for the whole evaluation (no reuse
+    // hazards).  Every rank enqueues the same sequence of collectives on sc, so their order is consistent across the grid.
     const bool la = g->lookahead != 0;
     hipStream_t scs = la ? g->sc : g->st;
+    const long G = g->G < 1 ? 1 : g->G, GW = g->GW;
     if (la) {
-        HIP_CHECK(hipEventRecord(g->ev[5], g->st));          // the covariance tiles precede everything on sc
+        HIP_CHECK(hipEventRecord(g->ev[5], g->st));          // the covariance tiles precede everything on sc / sw
         HIP_CHECK(hipStreamWaitEvent(g->sc, g->ev[5], 0));
+        HIP_CHECK(hipStreamWaitEvent(g->sw, g->ev[5], 0));
     }
     auto crit = [&](long k) -> int {
-        const int opr = (int)(k % Pr), opc = (int)(k % Pc), pb = (int)(k & 1);
+        const int opr = (int)(k % Pr), opc = (int)(k % Pc);
         const long lkr = k / Pr, lkc = k / Pc;
         // (a) diagonal tile: L_kk and D = L_kk^-1 on its owner
         for (GridRank& r : g->ranks) {
@@ -677,9 +874,9 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
             const long rows = (long)(r.TLr - lr0) * nb;
             if (rows <= 0) continue;
             double* Acol = r.A + (long)lr0 * nb * r.LC + lkc * nb;
-            grid_gemm_t<true, true>(s, r.RP2[pb] + (long)lr0 * tile, nb, 0, GOp{Acol, r.LC, 0}, GOp{r.Dv, nb, 0}, rows, nb,
+            grid_gemm_t<true, true>(s, r.hRP[k] + (long)lr0 * tile, nb, 0, GOp{Acol, r.LC, 0}, GOp{r.Dv, nb, 0}, rows, nb,
                                     nb, nb, 0, nopred);
-            HIP_CHECK(hipMemcpy2DAsync(Acol, sizeof(double) * r.LC, r.RP2[pb] + (long)lr0 * tile, sizeof(double) * nb,
+            HIP_CHECK(hipMemcpy2DAsync(Acol, sizeof(double) * r.LC, r.hRP[k] + (long)lr0 * tile, sizeof(double) * nb,
                                        sizeof(double) * nb, rows, hipMemcpyDeviceToDevice, s));
         }
         // (d) row panel along every process row
@@ -687,7 +884,7 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
             const int lr0 = cnt_le(k, pr, Pr), TLr = cnt_le(T - 1, pr, Pr);
             const size_t cnt = (size_t)(TLr - lr0) * tile;
             if (int rc = grid_bcast(g, GROUP_ROW, pr, opc, cnt,
-                                    [&](GridRank& r, bool) { return r.RP2[pb] + (long)lr0 * tile; }))
+                                    [&](GridRank& r, bool) { return r.hRP[k] + (long)lr0 * tile; }))
                 return rc;
         }
         // (e) column panel: L_jk for the local columns j > k comes from process row j % Pr
@@ -696,7 +893,7 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
             const int pc = (int)(j % Pc), root = (int)(j % Pr);
             const long lj = j / Pc, li = j / Pr;
             if (int rc = grid_bcast(g, GROUP_COL, pc, root, tile, [&](GridRank& r, bool is_root) {
-                    return is_root ? r.RP2[pb] + li * tile : r.CP2[pb] + lj * tile;
+                    return is_root ? r.hRP[k] + li * tile : r.hCP[k] + lj * tile;
                 }))
                 return rc;
         }
@@ -707,20 +904,20 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
             hipStream_t s = la ? r.sc : r.st;
             const int lcB = cnt_lt(k, r.pc, Pc);                      // local columns with J < k
             const double* Brow = r.X + lkr * nb * r.LC;
-            grid_gemm_t<true, false>(s, r.XR2[pb], nb, 1, GOp{r.Dv, nb, 0}, GOp{Brow, r.LC, 0}, nb, (long)lcB * nb, nb, nb,
+            grid_gemm_t<true, false>(s, r.hXR[k], nb, 1, GOp{r.Dv, nb, 0}, GOp{Brow, r.LC, 0}, nb, (long)lcB * nb, nb, nb,
                                      0, nopred);
-            if (r.pc == opc) HIP_CHECK(hipMemcpyAsync(r.XR2[pb] + (long)lcB * tile, r.Dv, sizeof(double) * tile,
+            if (r.pc == opc) HIP_CHECK(hipMemcpyAsync(r.hXR[k] + (long)lcB * tile, r.Dv, sizeof(double) * tile,
                                                       hipMemcpyDeviceToDevice, s));
             const int lc0 = cnt_le(k, r.pc, Pc);
             for (int lj = 0; lj < lc0; ++lj)                           // final X row block back into the local matrix
                 HIP_CHECK(hipMemcpy2DAsync(r.X + lkr * nb * r.LC + (long)lj * nb, sizeof(double) * r.LC,
-                                           r.XR2[pb] + (long)lj * tile, sizeof(double) * nb, sizeof(double) * nb, nb,
+                                           r.hXR[k] + (long)lj * tile, sizeof(double) * nb, sizeof(double) * nb, nb,
                                            hipMemcpyDeviceToDevice, s));
         }
         // (h) X row panel down every process column
         for (int pc = 0; pc < Pc; ++pc) {
             const size_t cnt = (size_t)cnt_le(k, pc, Pc) * tile;
-            if (int rc = grid_bcast(g, GROUP_COL, pc, opr, cnt, [&](GridRank& r, bool) { return r.XR2[pb]; })) return rc;
+            if (int rc = grid_bcast(g, GROUP_COL, pc, opr, cnt, [&](GridRank& r, bool) { return r.hXR[k]; })) return rc;
         }
         // (i) X_ki for the local rows i <= k comes from process column i % Pc
         if (int rc = grid_group_start(g)) return rc;
@@ -728,59 +925,58 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
             const int pr = (int)(i % Pr), root = (int)(i % Pc);
             const long li = i / Pr, lj = i / Pc;
             if (int rc = grid_bcast(g, GROUP_ROW, pr, root, tile, [&](GridRank& r, bool is_root) {
-                    return is_root ? r.XR2[pb] + lj * tile : r.XRr2[pb] + li * tile;
+                    return is_root ? r.hXR[k] + lj * tile : r.hXRr[k] + li * tile;
                 }))
                 return rc;
         }
         if (int rc = grid_group_end(g)) return rc;
         return 0;
     };
-    if (int rc = crit(0)) return rc;
-    if (la) HIP_CHECK(hipEventRecord(g->ev_cr[0], scs));
-    for (long k = 0; k < T; ++k) {
-        const int pb = (int)(k & 1);
-        if (la) HIP_CHECK(hipStreamWaitEvent(g->st, g->ev_cr[k], 0));
-        // (f1) part 1: what crit(k+1) reads -- tile column k+1 of A (I >= k+1), tile row k+1 of B (J <= k)
-        const int npr = (int)((k + 1) % Pr), npc = (int)((k + 1) % Pc);
-        if (k + 1 < T) {
-            for (GridRank& r : g->ranks) {
-                const int lr0 = cnt_le(k, r.pr, Pr), lc0 = cnt_le(k, r.pc, Pc);
-                const long rows_hi = (long)(r.TLr - lr0) * nb;
-                if (r.pc == npc && rows_hi > 0) {        // local tile column lc0 is global column k+1
-                    const GridPred lower{1, Pr, r.pr, Pc, r.pc, lr0, lc0};
-                    grid_gemm_t<true, true>(r.st, r.A + (long)lr0 * nb * r.LC + (long)lc0 * nb, r.LC, 0,
-                                            GOp{r.RP2[pb] + (long)lr0 * tile, nb, 0}, GOp{r.CP2[pb] + (long)lc0 * tile, nb, 0},
-                                            rows_hi, nb, nb, nb, 2, lower);
-                }
-                if (r.pr == npr && lc0 > 0)              // local tile row lr0 is global row k+1
-                    grid_gemm_t<true, false>(r.st, r.X + (long)lr0 * nb * r.LC, r.LC, 0, GOp{r.RP2[pb] + (long)lr0 * tile, nb, 0},
-                                             GOp{r.XR2[pb], nb, 1}, nb, (long)lc0 * nb, nb, nb, 2, nopred);
-            }
-            if (la) {
-                HIP_CHECK(hipEventRecord(g->ev_p1[k], g->st));
-                HIP_CHECK(hipStreamWaitEvent(g->sc, g->ev_p1[k], 0));
-            }
-            if (int rc = crit(k + 1)) return rc;
-            if (la) HIP_CHECK(hipEventRecord(g->ev_cr[k + 1], scs));
-        }
-        // (f2) bulk: the rest of the three rank-nb updates on the local tiles
+    // updates of A and B by the panels [k0, k1) on local tile columns J in [ca, cb) (A, rows I >= ca) and tile rows I in
+    // [ca, cb) (B, columns J < k1; panel k reaches the columns J <= k)
+    auto update_AB = [&](hipStream_t (*pick)(GridRank&, bool), long k0, long k1, long ca, long cb) {
         for (GridRank& r : g->ranks) {
-            const int lr0 = cnt_le(k, r.pr, Pr), lc0 = cnt_le(k, r.pc, Pc);
-            const int lr1 = cnt_le(k + 1, r.pr, Pr), lc1 = cnt_le(k + 1, r.pc, Pc);     // first local tile with I, J > k+1
-            const long rows_hi1 = (long)(r.TLr - lr1) * nb, cols_hi1 = (long)(r.TLc - lc1) * nb;
-            const long rows_lo = (long)lr0 * nb, cols_lo = (long)lc0 * nb;
-            const GridPred lower_hi{1, Pr, r.pr, Pc, r.pc, lr1, lc1}, lower_lo{1, Pr, r.pr, Pc, r.pc, 0, 0};
-            // A_ij -= L_ik L_jk^T,  i >= j > k+1
-            grid_gemm_t<true, true>(r.st, r.A + (long)lr1 * nb * r.LC + (long)lc1 * nb, r.LC, 0,
-                                    GOp{r.RP2[pb] + (long)lr1 * tile, nb, 0}, GOp{r.CP2[pb] + (long)lc1 * tile, nb, 0}, rows_hi1,
-                                    cols_hi1, nb, nb, 2, lower_hi);
-            // B_ij -= L_ik X_kj,    i > k+1, k >= j
-            grid_gemm_t<true, false>(r.st, r.X + (long)lr1 * nb * r.LC, r.LC, 0, GOp{r.RP2[pb] + (long)lr1 * tile, nb, 0},
-                                     GOp{r.XR2[pb], nb, 1}, rows_hi1, cols_lo, nb, nb, 2, nopred);
-            // W_ij += X_ki^T X_kj,  k >= i >= j
-            grid_gemm_t<false, false>(r.st, r.W, r.LC, 0, GOp{r.XRr2[pb], nb, 1}, GOp{r.XR2[pb], nb, 1}, rows_lo, cols_lo, nb, nb,
-                                      1, lower_lo);
+            hipStream_t s = pick(r, la);
+            const GridPred lower{1, Pr, r.pr, Pc, r.pc, 0, 0}, all{0, Pr, r.pr, Pc, r.pc, 0, 0};
+            grid_gemm_multi<true, true, 2>(s, r.A, r.LC, r.dRP, r.dCP, (int)k0, (int)k1, cnt_lt(ca, r.pr, Pr), r.TLr,
+                                           cnt_lt(ca, r.pc, Pc), cnt_lt(cb, r.pc, Pc), nb, 0, lower);
+            grid_gemm_multi<true, false, 2>(s, r.X, r.LC, r.dRP, r.dXR, (int)k0, (int)k1, cnt_lt(ca, r.pr, Pr),
+                                            cnt_lt(cb, r.pr, Pr), 0, cnt_lt(k1, r.pc, Pc), nb, 1, all);
         }
+    };
+    auto on_sc = [](GridRank& r, bool la_) -> hipStream_t { return la_ ? r.sc : r.st; };
+    auto on_st = [](GridRank& r, bool) -> hipStream_t { return r.st; };
+    long kw0 = 0;                                            // first step whose X panels W has not received yet
+    const long ngroups = (T + G - 1) / G;
+    for (long gi = 0; gi < ngroups; ++gi) {
+        const long kb = gi * G, ge = (kb + G < T) ? kb + G : T, ge2 = (ge + G < T) ? ge + G : T;
+        for (long k = kb; k < ge; ++k) {
+            if (int rc = crit(k)) return rc;
+            if (k + 1 < ge) update_AB(on_sc, k, k + 1, k + 1, ge);                 // near(k)
+        }
+        if (la) HIP_CHECK(hipEventRecord(g->ev_cr[gi], scs));
+        if (ge < T) {                                                              // part1(g): the next group's columns / rows
+            if (la && gi > 0) HIP_CHECK(hipStreamWaitEvent(g->sc, g->ev_p1[gi - 1], 0));
+            update_AB(on_sc, kb, ge, ge, ge2);
+        }
+        if (la) HIP_CHECK(hipStreamWaitEvent(g->st, g->ev_cr[gi], 0));
+        if (ge2 < T) update_AB(on_st, kb, ge, ge2, T);                             // bulk(g)
+        if (la) HIP_CHECK(hipEventRecord(g->ev_p1[gi], g->st));
+        // W_ij += sum_k X_ki^T X_kj over the finished steps, k >= i >= j
+        const bool flush = (ge == T) || (GW > 0 && ge - kw0 >= GW);
+        if (flush) {                                          // on the low-priority stream: fills whatever the other two leave idle
+            if (la) HIP_CHECK(hipStreamWaitEvent(g->sw, g->ev_cr[gi], 0));
+            for (GridRank& r : g->ranks) {
+                const GridPred lower{1, Pr, r.pr, Pc, r.pc, 0, 0};
+                grid_gemm_multi<false, false, 1>(la ? r.sw : r.st, r.W, r.LC, r.dXRr, r.dXR, (int)kw0, (int)ge, 0,
+                                                 cnt_lt(ge, r.pr, Pr), 0, cnt_lt(ge, r.pc, Pc), nb, 2, lower);
+            }
+            kw0 = ge;
+        }
+    }
+    if (la) {
+        HIP_CHECK(hipEventRecord(g->ev_w, g->sw));
+        HIP_CHECK(hipStreamWaitEvent(g->st, g->ev_w, 0));
     }
     HIP_CHECK(hipEventRecord(g->ev[2], g->st));
     // ---- alpha = X^T (X R), diag W, logdet ------------------------------------------------------------------
@@ -797,17 +993,22 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
     // NB: a rank's partial y covers only its local columns, and ranks of one process row write the same global
     // rows: the scatter above must not overwrite -- every rank owns a private ybuf, and the all-reduce sums them.
     if (int rc = grid_allreduce(g, (size_t)n * Dy, [](GridRank& r) { return r.ybuf; })) return rc;
+    auto col_reduce = [&](GridRank& r, const double* v, int d) {    // vloc[j] = sum_i X_ij * (v ? v[g(i)][d] : X_ij)
+        const long nch = (r.LR + CR_ROWS - 1) / CR_ROWS;
+        hipLaunchKernelGGL(k_grid_col_reduce_part, dim3((unsigned)((r.LC + 63) / 64), (unsigned)nch), dim3(256), 0, r.st, r.X,
+                           r.LC, r.LR, r.LC, r.gR, v, v ? Dy : 1, d, n, r.cpart, nb, Pr, r.pr, Pc, r.pc);
+        hipLaunchKernelGGL(k_grid_col_combine, dim3((unsigned)((r.LC + 255) / 256)), dim3(256), 0, r.st, r.cpart, nch, r.LC,
+                           r.vloc);
+    };
     for (GridRank& r : g->ranks) {                       // alpha = X^T y (partial over the local rows), diag W
         HIP_CHECK(hipMemsetAsync(r.alpha, 0, sizeof(double) * n * Dy, r.st));
         HIP_CHECK(hipMemsetAsync(r.gvec2, 0, sizeof(double) * n, r.st));
         for (int d = 0; d < Dy; ++d) {
-            hipLaunchKernelGGL(k_grid_col_reduce, dim3((unsigned)((r.LC + 63) / 64)), dim3(256), 0, r.st, r.X, r.LC, r.LR,
-                               r.LC, r.gR, r.ybuf, Dy, d, n, r.vloc);
+            col_reduce(r, r.ybuf, d);
             hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)((r.LC + 255) / 256)), dim3(256), 0, r.st, r.vloc, r.LC,
                                r.gC, n, Dy, d, r.alpha);
         }
-        hipLaunchKernelGGL(k_grid_col_reduce, dim3((unsigned)((r.LC + 63) / 64)), dim3(256), 0, r.st, r.X, r.LC, r.LR,
-                           r.LC, r.gR, (const double*)nullptr, 1, 0, n, r.vloc);
+        col_reduce(r, nullptr, 0);
         hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)((r.LC + 255) / 256)), dim3(256), 0, r.st, r.vloc, r.LC, r.gC,
                            n, 1, 0, r.gvec2);
     }
@@ -940,6 +1141,28 @@ int mi355gp_grid_exact_inference(mi355gp_grid* g, int kind, int ard, const doubl
                     diag_dLdK_out, stage_ms);
 }
 
+int mi355gp_grid_set_option(mi355gp_grid* g, int option, int value) {
+    ARGCHK(g && option >= 0 && option < MI355GP_GRID_OPT_NUM, "mi355gp_grid_set_option: unknown option");
+    ARGCHK(value >= -1, "mi355gp_grid_set_option: value must be >= 0 (or -1 for the default)");
+    if (g->single) return 0;                              // the degenerate 1 x 1 grid runs the single-GPU pipeline
+    if (value < 0) {
+        grid_default_option(g, option);
+        return 0;
+    }
+    if (option == MI355GP_GRID_OPT_LOOKAHEAD) g->lookahead = value ? 1 : 0;
+    else if (option == MI355GP_GRID_OPT_G) {
+        ARGCHK(value >= 1, "mi355gp_grid_set_option: G >= 1");
+        g->G = value;
+    } else g->GW = value;
+    return 0;
+}
+
+int mi355gp_grid_get_option(mi355gp_grid* g, int option, int* value) {
+    ARGCHK(g && value && option >= 0 && option < MI355GP_GRID_OPT_NUM, "mi355gp_grid_get_option: unknown option");
+    *value = option == MI355GP_GRID_OPT_LOOKAHEAD ? g->lookahead : option == MI355GP_GRID_OPT_G ? g->G : g->GW;
+    return 0;
+}
+
 // Host copy of the tiles owned by this process's ranks, placed at their global position in an N x N row-major array
 // (entries owned by other processes are left untouched: callers zero `out` first and sum over ranks).
 // which: MI355GP_FETCH_L (lower tiles of L), MI355GP_FETCH_KINV is not available after the gradient pass consumed W;
@@ -970,6 +1193,76 @@ int mi355gp_grid_fetch(mi355gp_grid* g, int which, double* out) {
                 }
             }
     }
+    return 0;
+}
+
+// Microbenchmark of the deep-K W = X^T X pass on ONE device (1 x 1 layout, T tiles of nb): out_ms[v] for
+//   v = 0: k_lauum on the row-major matrix (the single-GPU path's kernel)
+//   v = 1: k_grid_gemm_multi on the tile-major panel stores (two copies: XRr and XR), as the grid mode runs it
+//   v = 2: the same with ONE panel store for both operands
+//   v = 3: k_grid_gemm_multi reading the row-major matrix (panel k = rows k*nb ..)
+int mi355gp_dbg_grid_multi(int device, int T, int nb, int reps, double* out_ms) {
+    ARGCHK(T >= 1 && nb >= NB && nb % NB == 0 && reps >= 1 && out_ms, "mi355gp_dbg_grid_multi: bad arguments");
+    HIP_CHECK(hipSetDevice(device));
+    const long N = (long)T * nb;
+    const size_t tile = (size_t)nb * nb;
+    double *X = nullptr, *W = nullptr, *P1 = nullptr, *P2 = nullptr;
+    const double **t1 = nullptr, **t2 = nullptr, **t3 = nullptr;
+    HIP_CHECK(hipMalloc(&X, sizeof(double) * N * N));
+    HIP_CHECK(hipMalloc(&W, sizeof(double) * N * N));
+    const long ntl = (long)T * (T + 1) / 2;
+    HIP_CHECK(hipMalloc(&P1, sizeof(double) * tile * ntl));
+    HIP_CHECK(hipMalloc(&P2, sizeof(double) * tile * ntl));
+    {
+        std::vector<double> h((size_t)N * 64);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = 1e-3 * (double)((i * 2654435761u) % 1024) - 0.5;
+        for (long r = 0; r < N; r += 64) HIP_CHECK(hipMemcpy(X + r * N, h.data(), sizeof(double) * N * 64, hipMemcpyHostToDevice));
+    }
+    std::vector<const double*> h1((size_t)T), h2((size_t)T), h3((size_t)T);
+    long off = 0;
+    for (long k = 0; k < T; ++k) {
+        h1[k] = P1 + off * tile;
+        h2[k] = P2 + off * tile;
+        h3[k] = X + k * nb * N;
+        for (long j = 0; j <= k; ++j) {
+            HIP_CHECK(hipMemcpy2D(P1 + (off + j) * tile, sizeof(double) * nb, X + k * nb * N + j * nb, sizeof(double) * N,
+                                  sizeof(double) * nb, nb, hipMemcpyDeviceToDevice));
+        }
+        off += k + 1;
+    }
+    HIP_CHECK(hipMemcpy(P2, P1, sizeof(double) * tile * ntl, hipMemcpyDeviceToDevice));
+    const size_t tb = sizeof(double*) * (size_t)T;
+    HIP_CHECK(hipMalloc((void**)&t1, tb));
+    HIP_CHECK(hipMalloc((void**)&t2, tb));
+    HIP_CHECK(hipMalloc((void**)&t3, tb));
+    HIP_CHECK(hipMemcpy((void*)t1, h1.data(), tb, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy((void*)t2, h2.data(), tb, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy((void*)t3, h3.data(), tb, hipMemcpyHostToDevice));
+    hipStream_t st;
+    HIP_CHECK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    const GridPred lower{1, 1, 0, 1, 0, 0, 0};
+    for (int v = 0; v < 5; ++v) {
+        for (int rep = -1; rep < reps; ++rep) {
+            if (rep == 0) HIP_CHECK(hipEventRecord(e0, st));
+            if (v == 0) launch_lauum(st, X, W, N, (int)(N / NB));
+            else if (v == 1) grid_gemm_multi<false, false, 0>(st, W, N, t1, t2, 0, T, 0, T, 0, T, nb, 2, lower);
+            else if (v == 2) grid_gemm_multi<false, false, 0>(st, W, N, t1, t1, 0, T, 0, T, 0, T, nb, 2, lower);
+            else if (v == 3) grid_gemm_multi<false, false, 0>(st, W, N, t3, t3, 0, T, 0, T, 0, T, nb, 2, lower, N, 0);
+            else grid_gemm_multi<false, false, 0>(st, W, N, t3, t3, 0, T, 0, T, 0, T, nb, 2, lower, N, 2);
+        }
+        HIP_CHECK(hipEventRecord(e1, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        out_ms[v] = ms / reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(st);
+    for (void* p : {(void*)X, (void*)W, (void*)P1, (void*)P2, (void*)t1, (void*)t2, (void*)t3}) (void)hipFree(p);
     return 0;
 }
 

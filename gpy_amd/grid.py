@@ -224,6 +224,18 @@ class GridContext(object):
                 idb = exchange(idb, rank)
         return cls(local, rank, world, Pr, Pc, nb, idb)
 
+    OPTIONS = {"lookahead": 0, "G": 1, "GW": 2}
+
+    def set_option(self, name, value):
+        """Schedule option of this grid (include/mi355gp.h MI355GP_GRID_OPT_*; -1 = process default); every rank must set
+        the same value."""
+        check(_lib.lib().mi355gp_grid_set_option(self._h, self.OPTIONS[name], int(value)), "mi355gp_grid_set_option")
+
+    def get_option(self, name):
+        v = ctypes.c_int(0)
+        check(_lib.lib().mi355gp_grid_get_option(self._h, self.OPTIONS[name], ctypes.byref(v)), "mi355gp_grid_get_option")
+        return v.value
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             _lib.lib().mi355gp_grid_destroy(self._h)

@@ -228,6 +228,17 @@ int mi355gp_grid_exact_inference(mi355gp_grid* g, int kind, int ard, const doubl
  * which = MI355GP_FETCH_L or MI355GP_FETCH_LINV */
 #define MI355GP_FETCH_LINV 100
 int mi355gp_grid_fetch(mi355gp_grid* g, int which, double* out);
+/* Schedule options of one grid (every rank must set the same values; takes effect at the next inference call).
+ *   MI355GP_GRID_OPT_LOOKAHEAD: 1 = critical path one group ahead on a second stream (default), 0 = in order on one stream
+ *   MI355GP_GRID_OPT_G        : steps per group of the two-level blocked factorisation: tiles beyond the group receive the
+ *                               group's panels in ONE pass with K = G * nb (default 1 = one rank-nb update per step; measured best on the loopback grid)
+ *   MI355GP_GRID_OPT_GW       : steps per update of Kinv = X^T X; default 4; 0 = one deep-K pass after the last step
+ * value -1 restores the process default (environment MI355GP_GRID_LOOKAHEAD / _G / _GW, else the built-in one). */
+enum { MI355GP_GRID_OPT_LOOKAHEAD = 0, MI355GP_GRID_OPT_G = 1, MI355GP_GRID_OPT_GW = 2, MI355GP_GRID_OPT_NUM = 3 };
+int mi355gp_grid_set_option(mi355gp_grid* g, int option, int value);
+int mi355gp_grid_get_option(mi355gp_grid* g, int option, int* value);
+/* diagnostics: the deep-K X^T X pass of the grid mode against the single-GPU lauum kernel */
+int mi355gp_dbg_grid_multi(int device, int T, int nb, int reps, double* out_ms4);
 
 /* ---- sparse GP (VarDTC) path: BASELINE config 5 -----------------------------------------------------------------
  * One SparseGP.parameters_changed (core/sparse_gp.py:76-119) for certain inputs and a homoscedastic Gaussian likelihood:

@@ -67,6 +67,46 @@ def test_loopback_grid_matches_oracle(kind, ARD, N, D, Dy, Pr, Pc, nb):
         g.close()
 
 
+@pytest.mark.parametrize("Pr,Pc,nb,N", [(2, 4, 128, 1150), (3, 2, 128, 900), (1, 1, 128, 700), (2, 2, 256, 2000)])
+def test_two_level_blocking_options(Pr, Pc, nb, N):
+    """The group size G of the two-level blocked factorisation, the W = X^T X aggregation GW and the look-ahead switch
+    (mi355gp_grid_set_option) change the schedule, never the result beyond rounding: every combination against the oracle,
+    including groups that do not divide the number of steps and G larger than the number of steps."""
+    import os
+    kind, ARD, D = "matern52", True, 4
+    X, Y = O.synthetic(N, D, seed=N + 3, Dy=2)
+    var, ls, noise = O.default_theta(D, ARD)
+    ref = O.parameters_changed(kind, X, Y, var, ls, ARD, noise)
+    os.environ["MI355GP_GRID_FORCE_GENERIC"] = "1"
+    try:
+        g = G.GridContext.loopback(Pr, Pc, nb)
+    finally:
+        os.environ.pop("MI355GP_GRID_FORCE_GENERIC", None)
+    try:
+        assert g.get_option("G") == 1 and g.get_option("GW") == 4 and g.get_option("lookahead") == 1
+        g.set_data(X, Y)
+        th = L.theta_vec(var, ls, ARD, D)
+        for Gs, GW, la in [(1, 1, 1), (1, 0, 0), (2, 0, 1), (2, 3, 1), (3, 2, 0), (4, 0, 1), (4, 4, 1), (5, 1, 1), (64, 0, 1),
+                           (64, 7, 0)]:
+            g.set_option("G", Gs)
+            g.set_option("GW", GW)
+            g.set_option("lookahead", la)
+            assert (g.get_option("G"), g.get_option("GW"), g.get_option("lookahead")) == (Gs, GW, la)
+            info, res = g.exact_inference(kind, ARD, th, noise, want_diag=True)
+            assert info == 0, (Gs, GW, la)
+            _check(res, ref)
+            dref = np.diag(ref["dL_dK"])
+            assert np.abs(res["diag_dL_dK"] - dref).max() <= TOL_GRAD * np.abs(dref).max()
+            Lg = g.fetch(G.FETCH_L)
+            assert np.linalg.norm(Lg - ref["L"]) <= 1e-11 * np.linalg.norm(ref["L"])
+            Xg = g.fetch(G.FETCH_LINV)
+            assert np.abs(Xg @ ref["L"] - np.eye(N)).max() <= 1e-9
+        g.set_option("G", -1)
+        assert g.get_option("G") == 1
+    finally:
+        g.close()
+
+
 def test_grid_agrees_with_single_gpu_path_and_heteroscedastic_noise():
     N, D = 1100, 6
     X, Y = O.synthetic(N, D, seed=5)

@@ -109,6 +109,7 @@ static void apply_options(mi355gp_ctx* c) {
     set(MI355GP_OPT_SOLVE_OVERLAP, &w.solve_overlap);
     set(MI355GP_OPT_DIAG_EXCL_FIRST, &w.diag_excl_first);
     set(MI355GP_OPT_PERSIST, &w.persist);
+    set(MI355GP_OPT_AGG2, &w.agg2);
     if (c->opt[MI355GP_OPT_GRAPH] != INT_MIN) c->graph_enabled = c->opt[MI355GP_OPT_GRAPH] ? 1 : 0;
 }
 
@@ -1160,6 +1161,7 @@ int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
             case MI355GP_OPT_SOLVE_OVERLAP: c->ws.solve_overlap = env("MI355GP_SOLVE_OVERLAP", d.solve_overlap) ? 1 : 0; break;
             case MI355GP_OPT_DIAG_EXCL_FIRST: c->ws.diag_excl_first = env("MI355GP_DIAG_EXCL_FIRST", d.diag_excl_first) ? 1 : 0; break;
             case MI355GP_OPT_PERSIST: c->ws.persist = env("MI355GP_PERSIST", d.persist); break;
+            case MI355GP_OPT_AGG2: c->ws.agg2 = env("MI355GP_AGG2", d.agg2) ? 1 : 0; break;
             case MI355GP_OPT_GRAPH: c->graph_enabled = env("MI355GP_GRAPH", 1) ? 1 : 0; break;
             default: break;
         }
@@ -1174,7 +1176,7 @@ int mi355gp_get_option(mi355gp_ctx* c, int option, int* value) {
     const FactorWs& w = c->ws;
     const int v[MI355GP_OPT_NUM] = {0, w.lookahead, w.tri_overlap, w.tri_min_nt, w.tri_h_override, w.tri_wgs, w.tri_half_ok,
                                     w.part1_on_panel, w.nbo_override, w.solve_overlap, w.diag_excl_first, c->graph_enabled,
-                                    w.persist};
+                                    w.persist, w.agg2};
     *value = v[option];
     return 0;
 }

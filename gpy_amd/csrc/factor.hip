@@ -146,6 +146,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     }
     const char* envp1 = getenv("MI355GP_PART1_ON_PANEL");
     if (envp1 && *envp1) ws->part1_on_panel = atoi(envp1) ? 1 : 0;
+    const char* envag = getenv("MI355GP_AGG2");
+    if (envag && *envag) ws->agg2 = atoi(envag) ? 1 : 0;
     const char* envnbo = getenv("MI355GP_NBO");
     if (envnbo && *envnbo) ws->nbo_override = atoi(envnbo);
     const char* envso = getenv("MI355GP_SOLVE_OVERLAP");
@@ -346,8 +348,32 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
             update_cols(sp, A, npad, K0, W, pcol(p + 1), pcol(p + 2), ws);
             factor_panel(sp, A, npad, pcol(p + 1), pcol(p + 2) - pcol(p + 1), ws);
             (void)hipStreamWaitEvent(su, ws->ev_panel[p], 0);
-            update_cols(su, A, npad, K0, W, pcol(p + 2), npad, ws);          // part 2: everything to the right
-            (void)hipEventRecord(ws->ev_cols[p + 1], su);
+            if (!ws->agg2) {
+                update_cols(su, A, npad, K0, W, pcol(p + 2), npad, ws);      // part 2: everything to the right
+                (void)hipEventRecord(ws->ev_cols[p + 1], su);
+                continue;
+            }
+            // Part 2 in PAIRS of panels (e, e+1), e even: the far columns receive both panels in ONE pass over C with K = 2 nbo
+            // (the two panels are adjacent columns of L), C is read and written once per two panels.  ev_cols[p+1] keeps its
+            // meaning "the columns of panel p+2 are up to date through panel p":
+            //   p even: only panel p+2's columns now (K = nbo); everything further waits for the partner panel
+            //   p odd : panel p+2's columns with K = 2 nbo first (event), then all columns from panel p+3 on with K = 2 nbo,
+            //           underneath which part 1 / chain of the next two steps run
+            // Every tile still receives its panels in ascending order with the accumulator carried in fp64 through C: the
+            // factor is bit-identical to the one-panel-per-pass schedule.
+            if ((p & 1) == 0) {
+                if (p + 2 < P) {                                             // a partner panel follows inside the loop
+                    update_cols(su, A, npad, K0, W, pcol(p + 2), pcol(p + 3), ws);
+                } else {
+                    update_cols(su, A, npad, K0, W, pcol(p + 2), npad, ws);
+                }
+                (void)hipEventRecord(ws->ev_cols[p + 1], su);
+            } else {
+                const long K1 = pcol(p - 1), W2 = pcol(p + 1) - K1;
+                update_cols(su, A, npad, K1, W2, pcol(p + 2), pcol(p + 3), ws);
+                (void)hipEventRecord(ws->ev_cols[p + 1], su);
+                update_cols(su, A, npad, K1, W2, pcol(p + 3), npad, ws);
+            }
             continue;
         }
         (void)hipStreamWaitEvent(su, ws->ev_panel[p], 0);

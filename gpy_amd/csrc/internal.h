@@ -66,6 +66,7 @@ struct FactorWs {
     std::vector<hipEvent_t> ev_panel;        // [p]: outer panel p is factored
     std::vector<hipEvent_t> ev_cols;         // [p]: every update of panel p's columns has been issued (-> its factorisation)
     hipEvent_t ev_fork = nullptr;
+    int agg2 = 0;               // MI355GP_AGG2: part 2 of the look-ahead schedule in pairs of panels (K = 2 nbo far updates; N >= 6144); measured: no gain
     int part1_on_panel = 1;     // MI355GP_PART1_ON_PANEL: part 1 of a step on the panel stream (no cross-stream hop before the next chain)
     int lookahead = 1;          // 1: panel p+1 factored on st_panel while the big update of step p runs; 0: serial reference schedule
     // outer panel width of the two-level right-looking Cholesky: NBO (512) keeps the big trailing update at 64 flop per

@@ -61,6 +61,31 @@ def test_persistent_dataflow_cholesky_is_bit_identical_to_the_launch_per_step_sc
     assert r["ms_persist"] < 2.0 * r["ms_steps"] + 0.05
 
 
+@pytest.mark.parametrize("N", [6400, 7300, 8192])
+def test_paired_far_updates_are_bit_identical_to_one_panel_per_pass(N):
+    """Option "agg2": from N = 6144 the look-ahead schedule applies two adjacent panels to the far columns in ONE pass over C
+    (K = 1024).  Every tile still receives its panels in ascending order with the accumulator carried in fp64 through C, so the
+    result has the same BITS as the one-panel-per-pass schedule and as the in-order schedule (look-ahead off); an even and
+    an odd number of panels and a ragged last panel are covered."""
+    X, Y = O.synthetic(N, 4, seed=N)
+    var, ls, noise = O.default_theta(4, True)
+    th = L.theta_vec(var, ls, True, 4)
+    c = L.Context(0)
+    try:
+        c.set_data(X, Y)
+        assert c.get_option("agg2") == 0
+        outs = []
+        for agg, la in ((1, 1), (0, 1), (1, 0), (1, 1)):
+            c.set_option("agg2", agg)
+            c.set_option("lookahead", la)
+            info, r = c.exact_inference("matern52", True, th, noise)
+            assert info == 0
+            outs.append((r["lml"], r["dtheta"].tobytes(), r["alpha"].tobytes()))
+        assert outs[0] == outs[1] == outs[2] == outs[3]
+    finally:
+        c.close()
+
+
 def test_persistent_cholesky_option_reports_non_pd_and_can_be_switched_off_per_context():
     """The product path takes the persistent launch below N = 4608 (`FACTOR_PERSIST_MAX_NT`); option "persist" = 0 returns a
     context to the launch-per-step schedule; both give the same bits, the same LAPACK-style info on a non-PD matrix."""

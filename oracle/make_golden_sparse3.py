@@ -79,6 +79,14 @@ def main():
     case_prod(ns, "sparse3_prod_rbfard_x_m52_plus_white_plus_rbf_n460_m36_d4_dy2",
               [("rbf", True, 1.1, [0.7, 1.3], [0, 2], 1), ("matern52", False, 0.7, [1.6], [1, 3], 1),
                ("white", False, 0.05, None, [0, 1, 2, 3], 0), ("rbf", False, 0.5, [1.1], [0, 1, 2, 3], 0)], 460, 36, 4, 0.15, Dy=2, seed=10)
+    # everything round 3 added at once: a product of two ARD factors on 20 + 20 of 40 input dimensions plus a White term,
+    # per-point noise, two output columns
+    rng2 = np.random.default_rng(12)
+    D2 = 40
+    case_prod(ns, "sparse3_combo_prod_ard_d40_white_hetero_dy2_n520_m44",
+              [("rbf", True, 1.2, list(np.linspace(0.9, 2.2, 20) * np.sqrt(20 / 6.0)), list(range(0, 20)), 1),
+               ("matern32", True, 0.8, list(np.linspace(1.1, 2.6, 20) * np.sqrt(20 / 6.0)), list(range(20, 40)), 1),
+               ("white", False, 0.03, None, list(range(D2)), 0)], 520, 44, D2, 0.05 + 0.1 * rng2.random(520), Dy=2, seed=12)
     case_prod(ns, "sparse3_prod_three_factors_bias_hetero_n350_m25_d3",
               [("rbf", False, 0.9, [1.2], [0], 2), ("exponential", False, 1.2, [2.5], [1], 2), ("bias", False, 0.6, None, [0, 1, 2], 2),
                ("matern52", True, 0.5, [0.8, 1.0, 1.7], [0, 1, 2], 0)], 350, 25, 3, 0.05 + 0.1 * rng.random(350), seed=11)

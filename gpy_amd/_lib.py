@@ -130,6 +130,8 @@ def lib():
     L.mi355gp_grid_fetch.argtypes = [vp, ci, _dp]
     L.mi355gp_grid_set_option.argtypes = [vp, ci, ci]
     L.mi355gp_dbg_grid_multi.argtypes = [ci, ci, ci, ci, _dp]
+    L.mi355gp_dbg_update_nt.argtypes = [ci, ci, ctypes.POINTER(ci), ci, ci, _dp]
+    L.mi355gp_dbg_update_rect.argtypes = [ci, ci, ci, ctypes.POINTER(ci), ci, ci, _dp]
     L.mi355gp_grid_get_option.argtypes = [vp, ci, ctypes.POINTER(ci)]
     L.mi355gp_sparse_create.argtypes = [ci, ctypes.POINTER(vp)]
     L.mi355gp_sparse_destroy.argtypes = [vp]
@@ -159,7 +161,7 @@ def lib():
                  "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum", "dbg_mask_probe",
                  "vardtc_inference_sum", "sparse_predict", "sparse_fetch_dLdKnm", "sparse_attach_loopback",
                  "predictive_gradients_sum", "dbg_pipe_share", "pdinv_full", "dbg_graph_factor", "get_option",
-                 "sparse_get_profile", "dbg_persist", "dbg_grid_multi"):
+                 "sparse_get_profile", "dbg_persist", "dbg_grid_multi", "dbg_update_nt", "dbg_update_rect"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -179,7 +181,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_sparse_predict", "mi355gp_sparse_fetch_dLdKnm", "mi355gp_sparse_attach_loopback",
             "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share", "mi355gp_pdinv_full", "mi355gp_dbg_graph_factor",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe", "mi355gp_get_option",
-            "mi355gp_sparse_get_profile", "mi355gp_dbg_persist", "mi355gp_dbg_grid_multi")
+            "mi355gp_sparse_get_profile", "mi355gp_dbg_persist", "mi355gp_dbg_grid_multi", "mi355gp_dbg_update_nt", "mi355gp_dbg_update_rect")
 
 
 # mi355gp_set_option / mi355gp_get_option ids (include/mi355gp.h, MI355GP_OPT_*)
@@ -671,4 +673,22 @@ def dbg_grid_multi(T, nb=512, reps=3, device=0):
     require_device(device)
     out = np.zeros(5)
     check(lib().mi355gp_dbg_grid_multi(device, int(T), int(nb), int(reps), out), "mi355gp_dbg_grid_multi")
+    return out
+
+
+def dbg_update_nt(nt, ks, reps=5, device=0):
+    """ms per launch of the trailing-update kernel alone on the lower triangle of nt x nt tiles, one entry per panel depth."""
+    require_device(device)
+    ka = (ctypes.c_int * len(ks))(*[int(k) for k in ks])
+    out = np.zeros(len(ks))
+    check(lib().mi355gp_dbg_update_nt(device, int(nt), ka, len(ks), int(reps), out), "mi355gp_dbg_update_nt")
+    return out
+
+
+def dbg_update_rect(ntr, ntc, ks, reps=5, device=0):
+    """the same for rows [ntc, ntr) x columns [0, ntc) of tiles (part 1 of a step: the next panel's columns)"""
+    require_device(device)
+    ka = (ctypes.c_int * len(ks))(*[int(k) for k in ks])
+    out = np.zeros(len(ks))
+    check(lib().mi355gp_dbg_update_rect(device, int(ntr), int(ntc), ka, len(ks), int(reps), out), "mi355gp_dbg_update_rect")
     return out

@@ -1475,6 +1475,56 @@ int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_
     return 0;
 }
 
+int mi355gp_dbg_update_rect(int device, int ntr, int ntc, const int* ks, int nk, int reps, double* out_ms);
+// Diagnostics: the trailing-update kernel of the blocked Cholesky ALONE on a resident matrix: C (lower triangle of nt x nt
+// 128-tiles) -= P P^T with a K-column panel, for each K in ks[0..nk): out_ms[i] = average launch time.  What a deeper panel
+// (fewer passes over C) would buy the kernel itself, without any schedule around it.
+int mi355gp_dbg_update_nt(int device, int nt, const int* ks, int nk, int reps, double* out_ms) {
+    return mi355gp_dbg_update_rect(device, nt, nt, ks, nk, reps, out_ms);
+}
+
+// the same for a rectangular region of ntr x ntc tiles below the diagonal (ntc < ntr: "part 1" of a step, the next panel's
+// columns; ntc == ntr: the lower triangle)
+int mi355gp_dbg_update_rect(int device, int ntr, int ntc, const int* ks, int nk, int reps, double* out_ms) {
+    ARG_CHECK(ntr >= 1 && ntc >= 1 && ntc <= ntr && ks && nk >= 1 && reps >= 1 && out_ms, "mi355gp_dbg_update_rect: bad arguments");
+    HIP_CHECK(hipSetDevice(device));
+    const int nt = ntr;
+    const long n = (long)nt * NB;
+    long kmax = 0;
+    for (int i = 0; i < nk; ++i) {
+        ARG_CHECK(ks[i] >= 16 && ks[i] % 16 == 0, "mi355gp_dbg_update_nt: K % 16");
+        if (ks[i] > kmax) kmax = ks[i];
+    }
+    DevBuf C, P;
+    HIP_CHECK(C.alloc(n * n));
+    HIP_CHECK(P.alloc(n * kmax));
+    HIP_CHECK(hipMemset(C, 0, sizeof(double) * n * n));
+    HIP_CHECK(hipMemset(P, 0, sizeof(double) * n * kmax));
+    hipStream_t st;
+    HIP_CHECK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < nk; ++i) {
+        // rectangular case: rows [ntc, ntr) x columns [0, ntc) -- no tile above the diagonal
+        const int r0 = (ntc == ntr) ? 0 : ntc, nr = (ntc == ntr) ? ntr : ntr - ntc;
+        launch_update_nt(st, C + (long)r0 * NB * n, n, P + (long)r0 * NB * kmax, kmax, P, kmax, ks[i], nr, ntc, r0, 0);
+        HIP_CHECK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r)
+            launch_update_nt(st, C + (long)r0 * NB * n, n, P + (long)r0 * NB * kmax, kmax, P, kmax, ks[i], nr, ntc, r0, 0);
+        HIP_CHECK(hipEventRecord(e1, st));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float t;
+        HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+        out_ms[i] = t / reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(st);
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int mi355gp_dbg_peaks(int device, double* out4) { return run_peaks(device, out4); }
 
 int mi355gp_dbg_gemm_clock(double* mhz, double* cycles) { return gemm_last_clock(mhz, cycles); }

@@ -239,6 +239,9 @@ int mi355gp_grid_set_option(mi355gp_grid* g, int option, int value);
 int mi355gp_grid_get_option(mi355gp_grid* g, int option, int* value);
 /* diagnostics: the deep-K X^T X pass of the grid mode against the single-GPU lauum kernel */
 int mi355gp_dbg_grid_multi(int device, int T, int nb, int reps, double* out_ms4);
+/* diagnostics: the trailing-update kernel alone, lower triangle of nt x nt tiles, panel depths ks[0..nk) */
+int mi355gp_dbg_update_nt(int device, int nt, const int* ks, int nk, int reps, double* out_ms);
+int mi355gp_dbg_update_rect(int device, int ntr, int ntc, const int* ks, int nk, int reps, double* out_ms);
 
 /* ---- sparse GP (VarDTC) path: BASELINE config 5 -----------------------------------------------------------------
  * One SparseGP.parameters_changed (core/sparse_gp.py:76-119) for certain inputs and a homoscedastic Gaussian likelihood:

@@ -1,5 +1,6 @@
 // api.hip -- the extern "C" boundary of libmi355gp.so (declared in include/mi355gp.h) and the
 // orchestration of one exact-GP objective+gradient evaluation with everything N x N resident in HBM.
+#include <functional>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -277,9 +278,10 @@ static void finish_dtheta(const KernParams& kp, const double* theta, const doubl
 }
 
 // Shared tail: given Ky (lower) in c->A: factor, invert, alpha, scalars [, kernel gradients].
+// rebuild(): re-enqueues the construction of Ky in c->A (needed only after a DIRTY abort of the persistent factorisation).
 static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_grads, const double* theta,
                         double* out_scalars, double* alpha_out, double* dtheta_out, double* diag_out, double* stage_ms,
-                        double studentt_nu = 0.0) {
+                        const std::function<int()>& rebuild, double studentt_nu = 0.0, int attempt = 0) {
     hipStream_t st = c->st;
     const long n = c->n, np = c->npad;
     c->ws.prof.reset();
@@ -309,7 +311,7 @@ static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_gra
     // hipGraph replay when nothing in the region needs a CU-masked stream (sizes below the overlapped-inverse threshold), no
     // stage timing was asked for and launch bracketing is off; the first evaluation of a context runs plain (one-time
     // function attributes), the second captures, every later one replays.
-    const bool structural = c->graph_enabled && !c->ws.prof.on && c->ws.lookahead == 1 &&
+    const bool structural = c->graph_enabled && !c->ws.prof.on && c->ws.lookahead == 1 && c->ws.persist_skip == 0 &&
                             (!c->ws.tri_overlap || (int)(np / NB) < c->ws.tri_min_nt);
     if (c->fgraph && !structural) drop_graph(c);
     const bool graphable = structural && !stage_ms;          // a call that wants the stage timings runs plain, the graph stays
@@ -324,23 +326,27 @@ static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_gra
         // them would be recorded into this graph instead of executed.  Entry points hold the engine gate shared;
         // the capture window takes it exclusively (nothing inside the window waits for another thread).
         hipGraph_t g = nullptr;
-        gate->exclusive();
-        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
-        if (ok) {
-            const int rc = region(false);
-            ok = (hipStreamEndCapture(st, &g) == hipSuccess) && rc == 0 && g != nullptr;
-        }
-        gate->share();
-        if (ok) ok = hipGraphInstantiate(&c->fgraph, g, nullptr, nullptr, 0) == hipSuccess;
-        if (g) (void)hipGraphDestroy(g);
-        if (!ok) {                                            // capture not possible here: stay on plain launches
-            (void)hipGetLastError();
-            c->fgraph = nullptr;
-            c->graph_enabled = 0;
+        if (!gate->try_exclusive()) {                         // another thread is inside an entry point: capture next time
+            --c->fgraph_calls;
             if (int rc = region(false)) return rc;
         } else {
-            c->fgraph_lookahead = c->ws.lookahead;
-            HIP_CHECK(hipGraphLaunch(c->fgraph, st));
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                const int rc = region(false);
+                ok = (hipStreamEndCapture(st, &g) == hipSuccess) && rc == 0 && g != nullptr;
+            }
+            gate->share();
+            if (ok) ok = hipGraphInstantiate(&c->fgraph, g, nullptr, nullptr, 0) == hipSuccess;
+            if (g) (void)hipGraphDestroy(g);
+            if (!ok) {                                        // capture not possible here: stay on plain launches
+                (void)hipGetLastError();
+                c->fgraph = nullptr;
+                c->graph_enabled = 0;
+                if (int rc = region(false)) return rc;
+            } else {
+                c->fgraph_lookahead = c->ws.lookahead;
+                HIP_CHECK(hipGraphLaunch(c->fgraph, st));
+            }
         }
     }
     launch_scalars(st, c->dAlpha, c->dR, c->C, np, n, c->Dy, c->ws.logsum, c->ws.nblk, c->dScal, c->dDiag, c->ws.info);
@@ -395,12 +401,21 @@ static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_gra
         HIP_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[6]));
         stage_ms[MI355GP_T_TOTAL] = ms;
     }
-    if (info[0] >= (1 << 30)) {                                // a wait inside the persistent factorisation timed out
+    bool clean = false;
+    if (potrf_persist_aborted(info[0], &c->ws, &clean)) {
+        // The persistent factorisation did not run: called off at its co-residency gate (something else held CUs: the matrix
+        // is untouched) or, never seen in a sane run, aborted on a wait timeout (the matrix is rebuilt).  Redo the evaluation
+        // here with the launch-per-step schedule (same bits); the caller never sees it, the jitter ladder never hears of it.
         c->have_factor = false;
-        c->ws.persist = 0;                                     // fall back to the launch-per-step schedule from now on
         drop_graph(c);
-        mi355gp_set_error("the persistent factorisation aborted on a wait timeout (another process holding CUs?); this "
-                          "context continues with the launch-per-step schedule -- repeat the call");
+        if (attempt == 0 && (clean || rebuild)) {
+            if (!clean)
+                if (int rc = rebuild()) return rc;
+            return run_pipeline(c, gate, with_kernel_grads, theta, out_scalars, alpha_out, dtheta_out, diag_out, stage_ms,
+                                rebuild, studentt_nu, attempt + 1);
+        }
+        mi355gp_set_error("the persistent factorisation aborted and could not be redone (info %d); this context continues "
+                          "with the launch-per-step schedule -- repeat the call", info[0]);
         return -6;
     }
     if (info[0] > 0) {
@@ -564,11 +579,15 @@ int mi355gp_exact_inference_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* 
     HIP_CHECK(hipEventRecord(c->ev[0], st));
     if (int rc = scale_parts(c)) return rc;
     // Ky = sum_t prod_f K_f + (noise + jitter) I   (add.py:58-72, prod.py:58-65)
-    build_expression(c, c->A, c->Mbuf, false, [&](int p, double* dst, const double* mul, int acc, bool first) {
-        launch_kbuild_sym(st, c->parts[(size_t)p].kp, c->parts[(size_t)p].dXt, c->npad, c->n, c->npad, dst, c->dNoise,
-                          noise_len, jitter + extra_jitter, /*lower_only=*/1, /*add_diag=*/first, acc, mul);
-    });
-    return run_pipeline(c, &gate, true, nullptr, out_scalars, alpha_out, dtheta_out, diag_dLdK_out, stage_ms);
+    auto build = [&]() -> int {
+        build_expression(c, c->A, c->Mbuf, false, [&](int p, double* dst, const double* mul, int acc, bool first) {
+            launch_kbuild_sym(st, c->parts[(size_t)p].kp, c->parts[(size_t)p].dXt, c->npad, c->n, c->npad, dst, c->dNoise,
+                              noise_len, jitter + extra_jitter, /*lower_only=*/1, /*add_diag=*/first, acc, mul);
+        });
+        return 0;
+    };
+    build();
+    return run_pipeline(c, &gate, true, nullptr, out_scalars, alpha_out, dtheta_out, diag_dLdK_out, stage_ms, build);
 }
 
 // Student-t PROCESS inference (ExactStudentTInference.inference, exact_studentt_inference.py:20-52): the same pdinv +
@@ -590,11 +609,15 @@ int mi355gp_exact_studentt_sum(mi355gp_ctx* c, int nparts, const mi355gp_part* p
     c->have_kernel = true;
     HIP_CHECK(hipEventRecord(c->ev[0], st));
     if (int rc = scale_parts(c)) return rc;
-    build_expression(c, c->A, c->Mbuf, false, [&](int p, double* dst, const double* mul, int acc, bool first) {
-        launch_kbuild_sym(st, c->parts[(size_t)p].kp, c->parts[(size_t)p].dXt, c->npad, c->n, c->npad, dst, c->dNoise, 1,
-                          jitter + extra_jitter, 1, first, acc, mul);
-    });
-    return run_pipeline(c, &gate, true, nullptr, out_scalars, alpha_out, dtheta_out, nullptr, stage_ms, nu);
+    auto build = [&]() -> int {
+        build_expression(c, c->A, c->Mbuf, false, [&](int p, double* dst, const double* mul, int acc, bool first) {
+            launch_kbuild_sym(st, c->parts[(size_t)p].kp, c->parts[(size_t)p].dXt, c->npad, c->n, c->npad, dst, c->dNoise, 1,
+                              jitter + extra_jitter, 1, first, acc, mul);
+        });
+        return 0;
+    };
+    build();
+    return run_pipeline(c, &gate, true, nullptr, out_scalars, alpha_out, dtheta_out, nullptr, stage_ms, build, nu);
 }
 
 int mi355gp_exact_inference(mi355gp_ctx* c, int kind, int ard, const double* theta, const double* noise,
@@ -617,10 +640,14 @@ int mi355gp_inference_given_K(mi355gp_ctx* c, const double* K_host, const double
     hipStream_t st = c->st;
     c->have_kernel = false;
     // stage the dense n x n matrix in C (free until lauum), then pad + add the diagonal into A
-    HIP_CHECK(hipMemcpyAsync(c->C, K_host, sizeof(double) * c->n * c->n, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipEventRecord(c->ev[0], st));
-    launch_pad_from_dense(st, c->C, c->n, c->A, c->npad, c->dNoise, noise_len, jitter + extra_jitter);
-    return run_pipeline(c, &gate, false, nullptr, out_scalars, alpha_out, nullptr, diag_dLdK_out, stage_ms);
+    auto build = [&]() -> int {
+        HIP_CHECK(hipMemcpyAsync(c->C, K_host, sizeof(double) * c->n * c->n, hipMemcpyHostToDevice, st));
+        launch_pad_from_dense(st, c->C, c->n, c->A, c->npad, c->dNoise, noise_len, jitter + extra_jitter);
+        return 0;
+    };
+    if (int rc = build()) return rc;
+    return run_pipeline(c, &gate, false, nullptr, out_scalars, alpha_out, nullptr, diag_dLdK_out, stage_ms, build);
 }
 
 int mi355gp_fetch(mi355gp_ctx* c, int which, double* out, int fortran_order) {
@@ -834,17 +861,29 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
     HIP_CHECK(hipEventCreate(&guard.e1));
     hipEvent_t e0 = guard.e0, e1 = guard.e1;
     HIP_CHECK(hipMemcpy(tmp, A_host, sizeof(double) * N * N, hipMemcpyHostToDevice));
-    launch_pad_from_dense(0, tmp, N, A, np, nullptr, 0, 0.0);
-    HIP_CHECK(hipEventRecord(e0, 0));
-    potrf_device(0, A, np, &ws);
-    if (invert) {
-        trtri_device(0, A, B, C, np, &ws);
-        lauum_device(0, B, C, np, &ws);
+    {
+        const char* et = getenv("MI355GP_DENSE_PERSIST_TEST");   // fault injection for the tests (see MI355GP_OPT_PERSIST_TEST)
+        if (et && *et) ws.persist_test = atoi(et);
     }
-    HIP_CHECK(hipEventRecord(e1, 0));
     int info = 0;
-    HIP_CHECK(hipMemcpy(&info, ws.info, sizeof(int), hipMemcpyDeviceToHost));
-    HIP_CHECK(hipGetLastError());
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        launch_pad_from_dense(0, tmp, N, A, np, nullptr, 0, 0.0);
+        HIP_CHECK(hipEventRecord(e0, 0));
+        potrf_device(0, A, np, &ws);
+        if (invert) {
+            trtri_device(0, A, B, C, np, &ws);
+            lauum_device(0, B, C, np, &ws);
+        }
+        HIP_CHECK(hipEventRecord(e1, 0));
+        HIP_CHECK(hipMemcpy(&info, ws.info, sizeof(int), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipGetLastError());
+        bool clean = false;
+        if (!potrf_persist_aborted(info, &ws, &clean)) break;  // else: the persistent launch did not run -- redo on launches
+        if (attempt == 1) {
+            mi355gp_set_error("dense_factor: the factorisation aborted twice (info %d)", info);
+            return -6;
+        }
+    }
     if (ms) {
         float t;
         HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
@@ -1135,8 +1174,14 @@ int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
         c->ws.prof.mask = (value == 1) ? 0xffu : (unsigned)value >> 1;
         return 0;
     }
-    if (option < 0 || option >= MI355GP_OPT_NUM) {
-        mi355gp_set_error("mi355gp_set_option: unknown option %d", option);
+    if (option == MI355GP_OPT_PERSIST_TEST) {
+        c->ws.persist_test = value;
+        if (value) c->ws.persist_skip = 0;
+        drop_graph(c);
+        return 0;
+    }
+    if (option < 0 || option >= MI355GP_OPT_NUM || option == MI355GP_OPT_PERSIST_ABORTS || option == MI355GP_OPT_PERSIST_SKIP) {
+        mi355gp_set_error("mi355gp_set_option: unknown or read-only option %d", option);
         return -1;
     }
     if (option == MI355GP_OPT_LOOKAHEAD) value = (value == 0) ? 0 : 1;
@@ -1176,7 +1221,7 @@ int mi355gp_get_option(mi355gp_ctx* c, int option, int* value) {
     const FactorWs& w = c->ws;
     const int v[MI355GP_OPT_NUM] = {0, w.lookahead, w.tri_overlap, w.tri_min_nt, w.tri_h_override, w.tri_wgs, w.tri_half_ok,
                                     w.part1_on_panel, w.nbo_override, w.solve_overlap, w.diag_excl_first, c->graph_enabled,
-                                    w.persist, w.agg2};
+                                    w.persist, w.agg2, w.persist_test, w.persist_aborts, w.persist_skip};
     *value = v[option];
     return 0;
 }

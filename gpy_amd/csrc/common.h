@@ -15,6 +15,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define FACTOR_PERSIST_MAX_NT 36        // ... up to this many 128-tiles per dimension (N <= 4608): measured A/B on one box, whole
                                         // evaluation N=2048 -3.2 %, N=4096 -4.4 % (potrf stage -16 %), N=5120 +4 % (the far-tile
                                         // owners saturate and starve the near tiles); MI355GP_PERSIST_MAX_NT overrides
+// info[0] codes of a persistent launch that did not complete (far above any column index):
+//   PS_ABORT_INFO : a wait inside the dataflow timed out -- the matrix is partly overwritten, the caller rebuilds it
+//   PS_ABORT_CLEAN: the launch was called off at its co-residency gate before anything was written -- the matrix is intact
+// Either way the factorisation is redone with the launch-per-step schedule inside the same C-ABI call (never mapped to a
+// LAPACK info, never surfaced to the jitter ladder).
+#define PS_ABORT_INFO (1 << 30)
+#define PS_ABORT_CLEAN ((1 << 30) + 1)
+#define PS_SKIP_AFTER_CLEAN 16          // evaluations that stay on the launch-per-step schedule after a called-off launch
 #define FACTOR_DEFAULT_DIAG_EXCL_FIRST 1   // small factorisations only (N < 6144): from N = 8192 on it measured slower
 #define GEMM_DEFAULT_TRI64_MAX 512    // levels of the triangular inverse with at most this many 128-tiles per stage run as 64 x 64 quadrants
 #define GEMM_DEFAULT_LAUUM64_MAX 528  // X^T X of at most this many lower 128-tiles (nt <= 32) runs as 64 x 64 quadrants

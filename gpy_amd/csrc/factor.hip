@@ -275,9 +275,15 @@ static void potrf_serial(hipStream_t st, double* A, long npad, FactorWs* ws) {
 // trailing updates stay in order on `st`: their launch durations are not inflated by overlapping each other.
 void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     ws->ovl_h = 0;
+    ws->persist_used = 0;
     if (potrf_persist_eligible(npad, ws)) {                     // small factorisation: one persistent dataflow launch
-        launch_potrf_persist(st, A, npad, ws);
-        return;
+        if (launch_potrf_persist(st, A, npad, ws)) {
+            ws->persist_used = 1;
+            return;
+        }
+        ws->persist = 0;                                        // the launch cannot be made on this device: never try again
+    } else if (ws->persist_skip > 0 && ws->persist_skip != 0x7fffffff) {
+        --ws->persist_skip;                                     // a called-off launch is retried after a number of evaluations
     }
     if (ws->lookahead != 1) {
         potrf_serial(st, A, npad, ws);

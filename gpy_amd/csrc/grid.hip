@@ -393,7 +393,9 @@ __global__ void k_grid_tile_stats(const double* __restrict__ logsum, int q, cons
     double s = 0.0;
     for (int i = 0; i < q; ++i) s += logsum[i];
     scal[0] += s;
-    if (info_tile[0] != 0) {
+    if (info_tile[0] >= PS_ABORT_INFO) {
+        scal[2] += 1.0;                                  // a persistent tile factorisation did not run: every rank redoes the evaluation
+    } else if (info_tile[0] != 0) {
         scal[1] += 1.0;                                  // summed over ranks: "some tile failed" is known everywhere
         if (info_g[0] == 0) info_g[0] = (int)(col0 + info_tile[0]);
     }
@@ -793,7 +795,7 @@ int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, co
 // one evaluation on all local ranks
 static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const std::vector<double>& inv_ls,
                     const double* noise, int64_t noise_len, double jit, double* out_scalars, double* alpha_out,
-                    double* dtheta_out, double* diag_out, double* stage_ms) {
+                    double* dtheta_out, double* diag_out, double* stage_ms, int attempt = 0) {
     const long nb = g->nb, T = g->T, n = g->n;
     const int Pr = g->Pr, Pc = g->Pc, Dy = g->Dy, D = g->D, q = (int)(nb / NB);
     const size_t tile = (size_t)nb * nb;
@@ -1057,6 +1059,19 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
     }
     if (scal[1] > 0.0 && info == 0) info = (int)n;
     HIP_CHECK(hipGetLastError());
+    if (scal[2] > 0.0) {
+        // A persistent factorisation of a diagonal tile was called off (co-residency gate) or aborted on some rank: the count
+        // travels in the all-reduced scal[2], so EVERY rank takes this branch and the collectives of the redone evaluation
+        // line up.  The tile factorisations stay on the launch-per-step schedule from here on.
+        for (GridRank& r : g->ranks) {
+            r.ws.persist_aborts += 1;
+            r.ws.persist = 0;
+        }
+        if (attempt == 0)
+            return grid_run(g, kp, theta, inv_ls, noise, noise_len, jit, out_scalars, alpha_out, dtheta_out, diag_out, stage_ms, 1);
+        mi355gp_set_error("mi355gp_grid_exact_inference: a tile factorisation aborted twice");
+        return -6;
+    }
     if (stage_ms) {
         for (int i = 0; i < MI355GP_NUM_T; ++i) stage_ms[i] = 0.0;
         float ms;

@@ -95,6 +95,10 @@ struct FactorWs {
     int solve_overlap = 1;           // MI355GP_SOLVE_OVERLAP: alpha = X^T (X R) on st_tri underneath lauum
     // MI355GP_PERSIST: the single-launch dataflow Cholesky of persist.hip for factorisations of at most persist_max_nt tiles
     int persist = FACTOR_DEFAULT_PERSIST, persist_max_nt = FACTOR_PERSIST_MAX_NT, persist_kcap = 2, persist_cus = 0;
+    // persist_skip: calls of potrf_device that stay on the launch-per-step schedule (set after a called-off / aborted persistent
+    // launch: PS_SKIP_AFTER_CLEAN, or INT_MAX after a dirty abort); persist_aborts counts them (MI355GP_OPT_PERSIST_ABORTS)
+    int persist_skip = 0, persist_aborts = 0, persist_used = 0;
+    int persist_test = 0;            // MI355GP_OPT_PERSIST_TEST: fault injection for the NEXT persistent launch (1 clean, 2 dirty)
     int* persist_sync = nullptr;     // progress words of the persistent launch (zeroed before every launch)
     double* persist_hs = nullptr;    // [min(nblk, 64)][128 x 128]: sub-diagonal tile of every row, handed to the chain in ITS load order
     KernelProf prof;
@@ -113,10 +117,17 @@ struct EngineShared {
         if (shared) m->unlock_shared();
         else m->unlock();
     }
-    void exclusive() {
+    // Upgrade for a capture window WITHOUT blocking: other shared holders may be loopback ranks parked in a rendezvous whose
+    // peer thread still has to take lock_shared() -- behind a pending writer (a writer-preferring shared_mutex is allowed by
+    // the standard) that would never be granted.  false: somebody else is inside; the caller skips the capture this time.
+    bool try_exclusive() {
         m->unlock_shared();
-        m->lock();
-        shared = false;
+        if (m->try_lock()) {
+            shared = false;
+            return true;
+        }
+        m->lock_shared();
+        return false;
     }
     void share() {
         m->unlock();
@@ -137,9 +148,14 @@ void lauum_device(hipStream_t st, const double* X, double* W, long npad, FactorW
 
 // ---- persist.hip : the whole factorisation of a small matrix as one persistent dataflow launch ------------------------
 bool potrf_persist_eligible(long npad, const FactorWs* ws);
+// bookkeeping after the host has read info[0] of a factorisation: true if it is one of the PS_ABORT codes (then persist_skip /
+// persist_aborts are updated and the caller redoes the factorisation -- on the untouched matrix if *clean, after
+// rebuilding it otherwise)
+bool potrf_persist_aborted(int info, FactorWs* ws, bool* clean);
 int potrf_persist_sync_ints();
 // dbg (optional, 8 * nt wall-clock stamps): per chain step [factor start, factor end, sub tile seen, solve end, diag tile seen, update end]
-void launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg = nullptr);
+// false: the launch could not be made (no large-LDS opt-in on this device, launch error): nothing was enqueued that writes A
+bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg = nullptr);
 
 // ---- kern.hip : covariance assembly, reductions, solves, fetch helpers ----------------------------
 struct KernParams {

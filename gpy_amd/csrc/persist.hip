@@ -34,12 +34,14 @@
 #define PS_MAXNT 64                        // tiles per dimension the sync block is laid out for
 #define PS_MAXT 48                         // tiles one worker can own
 #define PS_LDS_BYTES (64 * TSZ * 8)        // 147,456 B: the chain's Y image (64 tiles); one workgroup per CU
-#define PS_ABORT_INFO (1 << 30)            // written to info[0] when a wait timed out (results are garbage)
 #define PS_TIMEOUT_TICKS 50000000LL        // 0.5 s of the 100 MHz wall clock: no wait of a sane run comes near it
+#define PS_ARRIVE_TICKS 100000LL           // 1 ms: every workgroup of the launch must be resident by then (see ps_arrive)
+#define PS_ARRIVE_ABORT (1 << 30)          // bit of the arrival word: the launch was called off before anything was written
 
 // sync block (ints, zeroed before every launch)
 #define PS_DCNT 0                          // diagonal blocks factored (L_jj and dinv(j) final for j < dcnt)
 #define PS_ABORT 1
+#define PS_ARRIVE 2                        // arrival word: workgroups that have started (+ PS_ARRIVE_ABORT)
 #define PS_CNT 16                          // [nt] cnt[i]: L(i, 0 .. cnt[i]-1) final
 #define PS_SUB (16 + PS_MAXNT)             // [nt] tile (i, i-1) holds columns 0 .. i-2, published for the chain
 #define PS_DIA (16 + 2 * PS_MAXNT)         // [nt] tile (i, i)   holds columns 0 .. i-2, published for the chain
@@ -64,6 +66,49 @@ __device__ __forceinline__ bool wait_ge(const int* p, int target, int* sync) {
             }
         }
     }
+}
+
+// Co-residency gate.  The dataflow below spin-waits on tiles owned by OTHER workgroups, so every workgroup of the launch has
+// to be resident at the same time.  The host sizes the grid from the occupancy query, but it cannot know what else holds
+// CUs right now (another process, another stream's kernel, a CU mask): every workgroup therefore checks in on ONE word
+// before it touches anything and waits (at most PS_ARRIVE_TICKS) until all have.  The word decides atomically between
+//   "all gridDim.x workgroups arrived"  -> the launch runs: all are resident, and the tile DAG cannot deadlock, or
+//   "called off" (PS_ARRIVE_ABORT set by compare-and-swap while the count was still short): every workgroup -- those
+//   waiting and those that start later -- returns at once and A has not been written: info[0] = PS_ABORT_CLEAN, and the
+//   host redoes the factorisation with the launch-per-step schedule on the untouched matrix.
+// A count that reached gridDim.x can no longer be called off (the CAS expects a short count), and a called-off word never
+// reads as complete (the bit stays set under further increments): no workgroup can start working while another gives up.
+__device__ __forceinline__ bool ps_arrive(int* sync, int* info, int extra) {
+    __shared__ int s_go;
+    if (threadIdx.x == 0) {
+        const int n = (int)gridDim.x + extra;                 // extra > 0: fault injection (a workgroup that never comes)
+        int* word = sync + PS_ARRIVE;
+        int v = __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        int go = -1;
+        const long long t0 = wall_clock64();
+        for (int it = 1; go < 0; ++it) {
+            if (v & PS_ARRIVE_ABORT) go = 0;
+            else if (v >= n) go = 1;
+            else {
+                if ((it & 7) == 0 && wall_clock64() - t0 > PS_ARRIVE_TICKS) {
+                    int expect = v;
+                    if (__hip_atomic_compare_exchange_strong(word, &expect, v | PS_ARRIVE_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)) {
+                        go = 0;
+                        break;
+                    }
+                    v = expect;
+                    continue;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                v = ld_flag(word);
+            }
+        }
+        if (go == 0) atomicMax(info, PS_ABORT_CLEAN);
+        s_go = go;
+    }
+    __syncthreads();
+    return s_go != 0;
 }
 
 // Static tile ownership.  NEAR tiles (i - k <= 2: the diagonal, the sub-diagonal and the one below it) feed the chain within
@@ -570,11 +615,19 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
 __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A, long ld, int nt,
                                                           double* __restrict__ dinv_all, double* __restrict__ logsum,
                                                           int* __restrict__ info, int* __restrict__ sync, int kcap,
-                                                          double* __restrict__ hs, long long* __restrict__ dbg) {
+                                                          double* __restrict__ hs, long long* __restrict__ dbg, int test) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (!ps_arrive(sync, info, test == 1 ? 1 : 0)) return;    // not all workgroups resident: called off, A untouched
+    if (test == 2 && blockIdx.x == 0) {                       // fault injection: the chain gives up, the workers time out on it
+        if (threadIdx.x == 0) {
+            st_flag(sync + PS_ABORT, 1);
+            atomicMax(info, PS_ABORT_INFO);
+        }
+        return;
+    }
     if (blockIdx.x == 0) {
         chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, hs, dbg, sm);
-        if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicExch(info, PS_ABORT_INFO);
+        if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
     } else {
         worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, sm);
     }
@@ -583,29 +636,63 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
 // ---- host side --------------------------------------------------------------------------------------------------------
 bool potrf_persist_eligible(long npad, const FactorWs* ws) {
     const long nt = npad / NB;
-    if (!ws->persist || !ws->persist_sync || !ws->persist_hs || ws->lookahead != 1) return false;
+    if (!ws->persist || ws->persist_skip > 0 || !ws->persist_sync || !ws->persist_hs || ws->lookahead != 1) return false;
     if (nt < 2 || nt > PS_MAXNT || nt > ws->persist_max_nt) return false;
     // tiles per worker: near 3 nt / (cus / 2) <= 2, far (nt-3)(nt-2)/2 / (cus / 2)
     return ws->persist_cus >= 16 && (nt - 3) * (nt - 2) / 2 / (ws->persist_cus / 2 - 1) + 2 <= PS_MAXT;
 }
 
+bool potrf_persist_aborted(int info, FactorWs* ws, bool* clean) {
+    if (info < PS_ABORT_INFO) return false;
+    *clean = (info == PS_ABORT_CLEAN);
+    ws->persist_aborts += 1;
+    ws->persist_skip = *clean ? PS_SKIP_AFTER_CLEAN : 0x7fffffff;
+    return true;
+}
+
 int potrf_persist_sync_ints() { return PS_SYNC_INTS; }
 
-void launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg) {
-    static bool opted = false;
-    if (!opted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_persist), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  PS_LDS_BYTES);
-        opted = true;
+// Workgroups the launch may have: one per CU, and never more than the occupancy query says can be resident at once (the
+// kernel asks for 147 KB of LDS: one workgroup per CU).  What ELSE holds CUs at launch time is only known to the GPU:
+// ps_arrive() settles that.  The large-LDS opt-in is a per-device function attribute.
+static int persist_max_grid(int cus) {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (cached[dev] == 0) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_persist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                PS_LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            cached[dev] = -1;
+        } else {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_potrf_persist, 64 * PS_CHAIN_WAVES, PS_LDS_BYTES) != hipSuccess) {
+                (void)hipGetLastError();
+                per_cu = 0;
+            }
+            hipDeviceProp_t prop;
+            int ncu = 0;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+            cached[dev] = per_cu > 0 ? per_cu * ncu : -1;
+        }
     }
+    if (cached[dev] < 0) return 0;
+    return cached[dev] < cus ? cached[dev] : cus;
+}
+
+bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg) {
     const int nt = (int)(npad / NB);
     const long ntl = (long)nt * (nt + 1) / 2;
-    long grid = ws->persist_cus;                               // one workgroup per CU: all resident
+    long grid = persist_max_grid(ws->persist_cus);             // one workgroup per CU: all resident
+    if (grid < 16) return false;
     if (grid > ntl + 1) grid = ntl + 1;
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
     (void)hipMemsetAsync(ws->persist_sync, 0, sizeof(int) * PS_SYNC_INTS, st);
     ws->prof.begin(st, PF_PERSIST, (double)npad * npad * npad / 3.0);
     hipLaunchKernelGGL(k_potrf_persist, dim3((unsigned)grid), dim3(64 * PS_CHAIN_WAVES), PS_LDS_BYTES, st, A, npad, nt, ws->dinv, ws->logsum,
-                       ws->info, ws->persist_sync, ws->persist_kcap, ws->persist_hs, dbg);
+                       ws->info, ws->persist_sync, ws->persist_kcap, ws->persist_hs, dbg, ws->persist_test);
+    ws->persist_test = 0;
+    const bool ok = hipGetLastError() == hipSuccess;
     ws->prof.end(st);
+    return ok;
 }

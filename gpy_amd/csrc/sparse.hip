@@ -11,6 +11,7 @@
 //                                  theta reductions + H = dL_dKnm * dK/dr / r, then H^T [X~ | 1] for dL/dZ
 // Larger N streams through bounded chunk buffers (<= 262144 rows: 2 x 4.3 GB at M = 2048); up to that size the Kfu
 // chunk of pass 1 is still resident in pass 2 and is not rebuilt.
+#include <functional>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -614,6 +615,37 @@ int mi355gp_sparse_attach_loopback(mi355gp_sparse* s, int rank, int world, int g
     return 0;
 }
 
+// Cholesky of an M x M matrix of the sparse path with the persistent launch's "did not run" outcomes handled in place: when the
+// single-launch schedule was taken, the host reads info[0] right away (one stream sync, twice per evaluation: ~0.1 % of
+// configuration 5) and, if the launch was called off at its co-residency gate or aborted, redoes the factorisation with the
+// launch-per-step schedule -- on the untouched matrix, or after rebuild() if it was partly overwritten.  Doing it HERE (and not
+// by repeating the evaluation) keeps a row-sharded run in step: the redo involves no collective.  info_host receives the
+// LAPACK-style info (0 or the first non-positive pivot), never an abort code.
+static int potrf_checked(hipStream_t st, double* A, long mp, FactorWs* ws, int* info_host,
+                         const std::function<void()>& rebuild) {
+    potrf_device(st, A, mp, ws);
+    if (!ws->persist_used) {
+        HIP_CHECK(hipMemcpyAsync(info_host, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
+        return 0;
+    }
+    int info = 0;
+    HIP_CHECK(hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    bool clean = false;
+    if (potrf_persist_aborted(info, ws, &clean)) {
+        if (!clean) rebuild();
+        potrf_device(st, A, mp, ws);                           // persist_skip > 0: the launch-per-step schedule
+        HIP_CHECK(hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (info >= PS_ABORT_INFO) {
+            mi355gp_set_error("sparse path: the M x M factorisation aborted twice (info %d)", info);
+            return -6;
+        }
+    }
+    *info_host = info;
+    return 0;
+}
+
 // One SparseGP.parameters_changed for a SUM of kernels, scalar or per-point noise and R = Y - mean (see mi355gp.h).
 // out_scalars: [0] log marginal likelihood, [1] dL/d(noise variance) (homoscedastic; 0 otherwise), [2] trace(A),
 //              [3] data_fit, [4] sum(log diag LB), [5] beta (homoscedastic)
@@ -662,9 +694,16 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     if (int rc = scale_for_parts(s, s->dZ, m, mp, true)) return rc;
     // Kmm + 1e-8 I (var_dtc.py:93-94) = sum of the parts' K(Z) (White on the diagonal), Lm = chol (jitchol, :95), Xm = Lm^-1
     build_kmm(s, s->Lm, s->T1, 1e-8 + extra_jitter, /*lower_only=*/1);
-    potrf_device(st, s->Lm, mp, &s->ws);
     s->h_info[0] = s->h_info[1] = 0;
-    HIP_CHECK(hipMemcpyAsync(&s->h_info[0], s->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    int inject = 0;                                            // fault injection for the tests: 1 / 2 hit Kmm's launch, 11 / 12 B's
+    {
+        const char* et = getenv("MI355GP_SPARSE_PERSIST_TEST");
+        if (et && *et) inject = atoi(et);
+    }
+    if (inject == 1 || inject == 2) s->ws.persist_test = inject, s->ws.persist_skip = 0;
+    if (int rc = potrf_checked(st, s->Lm, mp, &s->ws, &s->h_info[0],
+                               [&]() { build_kmm(s, s->Lm, s->T1, 1e-8 + extra_jitter, /*lower_only=*/1); }))
+        return rc;
     HIP_CHECK(hipMemsetAsync(s->Xm, 0, sizeof(double) * mp * mp, st));
     trtri_device(st, s->Lm, s->Xm, s->Tm, mp, &s->ws);
     // ---- pass 1: psi2 = sum_n beta_n k_n k_n^T (heteroscedastic) or Kuf Kfu (then A carries beta), psi1V = Kuf V -------
@@ -702,10 +741,13 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     // A = Lm^-1 psi2_beta Lm^-T (var_dtc.py:129-134), B = I + A (:137), LB = chol(B) (:138), XB = LB^-1
     launch_gemm(st, 0, 1, mp, mp, mp, s->Xm, mp, s->psi2, mp, s->T1, mp, 1.0, 0.0);
     launch_gemm(st, 0, 0, mp, mp, mp, s->T1, mp, s->Xm, mp, s->Amat, mp, het ? 1.0 : beta, 0.0);
-    hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->Amat, 1.0, (const double*)nullptr, 0.0, 1.0, mp,
-                       s->LB);
-    potrf_device(st, s->LB, mp, &s->ws);
-    HIP_CHECK(hipMemcpyAsync(&s->h_info[1], s->ws.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    auto build_B = [&]() {
+        hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->Amat, 1.0, (const double*)nullptr, 0.0, 1.0, mp,
+                           s->LB);
+    };
+    build_B();
+    if (inject == 11 || inject == 12) s->ws.persist_test = inject - 10, s->ws.persist_skip = 0;
+    if (int rc = potrf_checked(st, s->LB, mp, &s->ws, &s->h_info[1], build_B)) return rc;
     HIP_CHECK(hipMemsetAsync(s->XB, 0, sizeof(double) * mp * mp, st));
     trtri_device(st, s->LB, s->XB, s->Tm, mp, &s->ws);
     // c = LB^-1 Lm^-1 psi1 V (:141-143), w = LB^-T c (:144), v = Lm^-T w = woodbury_vector (:145)

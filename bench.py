@@ -23,6 +23,10 @@ line carries one sub-record per other GPU configuration of BASELINE.json, each m
                                  RCCL over all ranks of the launch otherwise
     "c5"             configs[4]  VarDTC N=200000 (per GPU) M=2048 D=16 (rows sharded over the ranks of the launch; roofline of
                                  its dominant MFMA GEMM + cpu_baseline from the sparse oracle)
+    "c4_single"      configs[3]'s problem (RBF N=32768 D=8) on the dedicated SINGLE-GPU path (rank 0's GPU): the N = 1 anchor
+                                 of the strong-scaling series, parity against the N=32768 golden
+Every `cpu_baseline` of the line is measured by one background thread of rank 0 while those child legs run (the host cores are
+idle then): the headline configuration DIRECTLY at N=16384, configs[1] directly at N=4096, the sparse oracle at two sizes.
 """
 import argparse
 import json
@@ -140,12 +144,12 @@ def committed_cpu_record(kind, ARD, D, n_full):
     return out or None
 
 
-def cpu_baseline(kind, ARD, D, n_small, n_full, full=False):
+def cpu_baseline(kind, ARD, D, n_small, n_full, full=False, fit=True):
     """The oracle (NumPy/SciPy restatement of GPy's CPU path, oracle/gp_oracle.py; kind "port") on the host cores.
-    Default: a bounded sample -- one full iteration at TWO sizes (n_small, 2 n_small), the model t(N) = a N^2 + b N^3
-    fitted through both (the path is ~N^2 at these sizes: a dozen single-threaded N x N NumPy passes and the serial ARD
-    gradient loop; only dpotrf / dtrtri / dpotri are N^3 and multi-threaded) and evaluated at n_full.
-    full=True times n_full directly (minutes)."""
+    full=True (the default run): ONE full iteration timed DIRECTLY at n_full -- `value` is that measurement; the two-point
+    model t(N) = a N^2 + b N^3 through (n_small, 2 n_small) is kept as `fit_cross_check` only (its cubic coefficient wanders from
+    run to run: the path is ~N^2 at the sample sizes -- a dozen single-threaded N x N NumPy passes and the serial ARD gradient
+    loop; only dpotrf / dtrtri / dpotri are N^3 and multi-threaded).  full=False: the fit alone (quick runs)."""
     from oracle import gp_oracle as O
     try:
         import subprocess
@@ -155,12 +159,15 @@ def cpu_baseline(kind, ARD, D, n_small, n_full, full=False):
     _oracle_seconds(kind, ARD, D, 512)                                         # warm BLAS threads
     threads = _cpu_threads()
     rec = {"unit": "iters/s", "cores": int(threads), "kind": "port", "host_cores": os.cpu_count() or 1}
-    if full or 2 * n_small >= n_full:
+    direct = full or 2 * n_small >= n_full
+    if direct:
         dt = _oracle_seconds(kind, ARD, D, n_full)
         rec.update(value=1.0 / dt, measured_seconds=dt, sample_N=n_full,
                    sample="one full iteration of the NumPy/SciPy oracle (GPy's CPU algorithm, paramz-style K/r caching) "
-                          "timed directly at N=%d D=%d: %.1f s on %d BLAS threads" % (n_full, D, dt, threads))
-    else:
+                          "timed directly at N=%d D=%d: %.1f s on %d BLAS threads of %d host cores, while the GPU legs of the "
+                          "other configurations run (they leave the host cores idle)" % (
+                              n_full, D, dt, threads, os.cpu_count() or 1))
+    if (fit or not direct) and 2 * n_small < n_full:
         n1, n2 = n_small, 2 * n_small
         t1, t2 = _oracle_seconds(kind, ARD, D, n1), _oracle_seconds(kind, ARD, D, n2)
         # t = a N^2 + b N^3 through (n1, t1), (n2, t2)
@@ -171,16 +178,45 @@ def cpu_baseline(kind, ARD, D, n_small, n_full, full=False):
         if a < 0.0:
             a, b = 0.0, t2 / n2 ** 3
         est = a * n_full ** 2 + b * n_full ** 3
-        rec.update(value=1.0 / est, estimated_seconds=est, fit={"a_N2": a, "b_N3": b, "n": [n1, n2], "seconds": [t1, t2]},
-                   sample="one full iteration of the NumPy/SciPy oracle (GPy's CPU algorithm, paramz-style K/r caching) "
-                          "at N=%d (%.2f s) and N=%d (%.2f s), D=%d, on %d BLAS threads of %d host cores; "
-                          "t = a N^2 + b N^3 fitted through both and evaluated at N=%d (%.0f s); the ARD gradient "
-                          "loop and the N x N NumPy passes are single-threaded as in GPy" % (
-                              n1, t1, n2, t2, D, threads, os.cpu_count() or 1, n_full, est))
+        fitrec = {"estimated_seconds": est, "a_N2": a, "b_N3": b, "n": [n1, n2], "seconds": [t1, t2]}
+        if direct:
+            rec["fit_cross_check"] = fitrec
+        else:
+            rec.update(value=1.0 / est, estimated_seconds=est, fit=fitrec,
+                       sample="one full iteration of the NumPy/SciPy oracle at N=%d (%.2f s) and N=%d (%.2f s), D=%d, on %d "
+                              "BLAS threads of %d host cores; t = a N^2 + b N^3 fitted through both and evaluated at N=%d "
+                              "(%.0f s)" % (n1, t1, n2, t2, D, threads, os.cpu_count() or 1, n_full, est))
     committed = committed_cpu_record(kind, ARD, D, n_full)
     if committed:
         rec["committed_full_size"] = committed
     return rec
+
+
+class CpuBaselines(object):
+    """All CPU baselines of the default run, measured by ONE background thread of the parent process while the GPU legs
+    (child processes, host cores idle) run: the headline configuration timed directly at its full N, configs[1] directly at
+    N = 4096, and the sparse oracle at two bounded sizes.  Sequential, so that they do not compete with each other."""
+
+    def __init__(self, jobs):
+        import threading
+        self.results, self.errors = {}, {}
+        self._t = threading.Thread(target=self._run, args=(jobs,), daemon=True)
+        self._t.start()
+
+    def _run(self, jobs):
+        for name, fn in jobs:
+            t0 = time.perf_counter()
+            try:
+                self.results[name] = fn()
+                self.results[name]["baseline_wall_s"] = round(time.perf_counter() - t0, 1)
+            except Exception as e:                        # noqa: BLE001 -- a failed baseline must not take the line down
+                self.errors[name] = repr(e)[-300:]
+
+    def get(self, name, timeout=900.0):
+        self._t.join(timeout)
+        if name in self.results:
+            return self.results[name]
+        return {"error": self.errors.get(name, "not finished within %.0f s" % timeout)}
 
 
 def profiled_traffic(kernel_prefix, with_source=False):
@@ -200,6 +236,20 @@ def profiled_traffic(kernel_prefix, with_source=False):
     except Exception:
         pass
     return (None, None) if with_source else None
+
+
+def profiled_c2_traffic(kernel_prefix):
+    """HBM-side bytes per launch of a kernel of configs[1] (N=4096) from the committed PMC summary (profiles/*_c2_traffic.json);
+    (bytes, file) or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c2_traffic.json")))
+    try:
+        for name, v in json.load(open(files[-1]))["kernels"].items():
+            if name.startswith(kernel_prefix):
+                return v["hbm_bytes_per_launch"], os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
 
 
 def profiled_sparse_traffic(kernel_prefix):
@@ -283,15 +333,23 @@ def run_child(argv, timeout, env=None, single=True):
 
 
 C2_KEEP = ("ms_per_step", "value", "unit", "steps", "warmup", "config", "stage_ms", "iteration_tflops",
-           "iteration_frac_of_fp64_peak", "cholesky_stage_gflops", "cholesky_stage_frac_of_fp64_peak", "cholesky_gflops",
-           "cholesky_frac_of_fp64_peak", "roofline", "families", "parity_checked", "parity", "cpu_baseline", "host_path", "lml",
-           "leg_wall_s", "error")
+           "iteration_frac_of_fp64_peak", "cholesky_gflops", "cholesky_frac_of_fp64_peak", "roofline", "roofline_k_lauum",
+           "families", "parity_checked", "parity", "cpu_baseline", "host_path", "lml", "leg_wall_s", "error")
 
 
 def c2_leg(comm, args):
     """BASELINE configs[1]: RBF iso, N=4096, D=8 on ONE GPU (rank 0's), through the drop-in classes."""
     rec = run_child(["--n", "4096", "--d", "8", "--kind", "rbf", "--iso", "--steps", "300", "--warmup", "20", "--no-legs",
-                     "--device", str(comm.local_rank), "--cpu-sample-n", "2048"], timeout=240.0)
+                     "--device", str(comm.local_rank), "--no-cpu-baseline"], timeout=240.0)
+    return {k: rec[k] for k in C2_KEEP if k in rec}
+
+
+def c4_single_leg(comm, args):
+    """BASELINE configs[3]'s problem (RBF iso, N=32768, D=8) on the DEDICATED single-GPU path: the N = 1 anchor of the
+    strong-scaling series north_star asks for (N in {4k, 16k, 32k} at 1/2/4/8 GPUs), next to `grid` (the same problem on the
+    block-cyclic code).  26 GB resident; parity against the N=32768 golden."""
+    rec = run_child(["--n", str(args.grid_n), "--d", "8", "--kind", "rbf", "--iso", "--steps", "4", "--warmup", "1", "--no-legs",
+                     "--device", str(comm.local_rank), "--no-cpu-baseline"], timeout=420.0)
     return {k: rec[k] for k in C2_KEEP if k in rec}
 
 
@@ -300,7 +358,7 @@ def sparse_leg(comm, args, timeout=300.0):
     child with its rank variables, like the grid leg."""
     env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 29))
     env.pop("TORCHELASTIC_RUN_ID", None)
-    argv = ["--sparse", "--steps", "12", "--warmup", "3"]
+    argv = ["--sparse", "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
     if comm.world == 1:
         argv += ["--device", str(comm.local_rank)]
     rec = run_child(argv, timeout, env=env, single=comm.world == 1)
@@ -359,7 +417,8 @@ def main():
     ap.add_argument("--kind", default=WORKLOAD["kind"])
     ap.add_argument("--iso", action="store_true", help="single lengthscale instead of ARD")
     ap.add_argument("--cpu-sample-n", type=int, default=3072, help="the CPU baseline is timed at this N and at twice it")
-    ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline directly at the full N (minutes)")
+    ap.add_argument("--cpu-full", action="store_true", help="(default since round 4) time the CPU baseline directly at the full N")
+    ap.add_argument("--cpu-fit-only", action="store_true", help="quick runs: CPU baseline from the two-point fit only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     ap.add_argument("--no-grid-leg", action="store_true", help="skip the block-cyclic sub-record (configs[3])")
@@ -437,6 +496,16 @@ def main():
         # k_diag128 / k_trsm128 run on the panel stream underneath the updates: their sum is not wall time)
         families = {k: {"ms": round(v[0], 4), "launches": v[2], "flops": v[1],
                         "tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else 0.0} for k, v in pf.items() if v[2] > 0}
+        if "trtri" in families:
+            # the triangular inverse runs partly UNDERNEATH potrf (leading block + its share of T21 on the CU-masked side
+            # stream: "trtri_early", elapsed on that stream) and partly after it ("exposed"): N^3/3 flops over BOTH, so that no
+            # family is billed more flops than the time it was given (round 3 divided all of them by the exposed part only)
+            early = families.pop("trtri_early", None)
+            t = families["trtri"]
+            ov_ms = early["ms"] if early else 0.0
+            t.update(exposed_ms=t["ms"], overlapped_ms=round(ov_ms, 4), ms=round(t["ms"] + ov_ms, 4),
+                     tflops=t["flops"] / ((t["ms"] + ov_ms) * 1e-3) / 1e12 if t["ms"] + ov_ms > 0 else 0.0,
+                     note="ms = exposed_ms (after potrf, main stream) + overlapped_ms (side stream underneath potrf)")
         upd_ms, upd_flops, upd_n = pf["update_nt"]
         roof_kernel = ("k_update_nt<4, true> (fp64 MFMA trailing update of the blocked Cholesky, 128 x 128 tiles; in the pipeline "
                        "it shares the CUs with the chain kernels and the overlapped inverse)")
@@ -447,6 +516,12 @@ def main():
             roof_kernel = ("k_potrf_persist (the whole Cholesky as one persistent dataflow launch: chain workgroup + static tile "
                            "owners; N^3/3 algorithmic flops)")
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        traffic = traffic_source = None
+        if (N, D, args.kind) == (16384, 32, "matern52"):
+            traffic, traffic_source = profiled_traffic("k_update_nt<", True)
+        elif (N, D, args.kind) == (4096, 8, "rbf"):
+            traffic, traffic_source = profiled_c2_traffic("k_potrf_persist" if pf.get("update_nt", (0, 0, 0))[2] == 0 else "k_update_nt<")
+        traffic_source = ("profiles/%s" % traffic_source) if traffic_source else None
         out = {
             "metric": "exact-GP log_lik+grad iters/sec", "value": its, "unit": "iters/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -456,10 +531,8 @@ def main():
                        "N": N, "D": D, "kernel": args.kind, "ARD": ARD, "parallelism": "replicas x%d" % n_gpus,
                        "path": "C-ABI only" if args.abi_only else "drop-in classes (gpy_amd.GPRegression: param_array "
                                "write -> parameters_changed -> log_likelihood + gradient)"},
-            # N^3/3 over the pipeline's potrf STAGE, which also hosts the overlapped inverse kernels (~16 ms of them at
-            # N = 16384); "cholesky_gflops" (the metric's Cholesky GF/s) is the factorisation timed alone, below
-            "cholesky_stage_gflops": (N ** 3 / 3.0) / (st["potrf"] * 1e-3) / 1e9,
-            "cholesky_stage_frac_of_fp64_peak": (N ** 3 / 3.0) / (st["potrf"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+            # "cholesky_gflops" (the metric's Cholesky GF/s, filled in below) is the factorisation timed ALONE on a resident
+            # matrix; the pipeline's potrf stage also hosts the overlapped inverse kernels and is only reported as stage_ms
             "iteration_tflops": float(N) ** 3 / (st["total"] * 1e-3) / 1e12,
             "iteration_frac_of_fp64_peak": float(N) ** 3 / (st["total"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
             "stage_ms": {k: round(float(v), 4) for k, v in st.items()},
@@ -468,10 +541,7 @@ def main():
                          "frac": achieved / PEAK_FP64_TFLOPS,
                          # HBM-side bytes per launch from the PMC passes of THIS command (rocprofv3 cannot run inside the
                          # timed process): the committed summary of the shipped schedule, named in traffic_source
-                         "traffic": profiled_traffic("k_update_nt<") if (N, D, args.kind) == (16384, 32, "matern52")
-                         else None,
-                         "traffic_source": ("profiles/%s" % profiled_traffic("k_update_nt<", True)[1])
-                         if (N, D, args.kind) == (16384, 32, "matern52") else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "launches_per_step": upd_n, "avg_launch_ms": upd_ms / max(upd_n, 1),
                          "algorithmic_flops_per_step": upd_flops,
                          "k_update_nt64": {"launches_per_step": pf["update_nt64"][2],
@@ -523,6 +593,15 @@ def main():
                     out["parity"]["timed_config_vs_reference"] = g
     ctx.close()
     del m
+    cpu = None
+    if comm.rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        # every CPU baseline of the line in ONE background thread, while the GPU legs below run in child processes
+        jobs = [("headline", lambda: cpu_baseline(args.kind, ARD, D, min(args.cpu_sample_n, N // 2), N,
+                                                  full=not args.cpu_fit_only))]
+        if not args.no_legs:
+            jobs.append(("c2", lambda: cpu_baseline("rbf", False, 8, 2048, 4096, full=True, fit=False)))
+            jobs.append(("c5", lambda: sparse_cpu_baseline(16, args.m, 200000)))
+        cpu = CpuBaselines(jobs)
     if not args.no_legs:
         comm.barrier()
         if comm.rank == 0:
@@ -538,9 +617,18 @@ def main():
         rec = sparse_leg(comm, args)                          # configs[4], rows sharded over all ranks of the launch
         if out is not None:
             out["c5"] = rec
+    if not args.no_legs:
+        comm.barrier()
+        if comm.rank == 0:
+            out["c4_single"] = c4_single_leg(comm, args)      # configs[3]'s problem on the dedicated single-GPU path (rank 0's GPU)
+        comm.barrier()
     if comm.rank == 0:
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.kind, ARD, D, min(args.cpu_sample_n, N // 2), N, full=args.cpu_full)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu.get("headline")
+            if not args.no_legs:
+                for leg in ("c2", "c5"):
+                    if isinstance(out.get(leg), dict) and "error" not in out[leg]:
+                        out[leg]["cpu_baseline"] = cpu.get(leg)
         print(json.dumps(out), flush=True)
     comm.close()
 

@@ -52,7 +52,7 @@ FETCH_L, FETCH_KINV, FETCH_DLDK, FETCH_K = 0, 1, 2, 3
 OUT_LML, OUT_LOGDET, OUT_DATAFIT, OUT_DNOISE, OUT_TRKINV, NUM_OUT = 0, 1, 2, 3, 4, 8
 STAGE_NAMES = ("kbuild", "potrf", "trtri", "lauum", "solve", "grad", "total")
 NUM_T = 8
-PROFILE_FAMILIES = ("update_nt", "trtri", "lauum", "diag128", "trsm128", "update_nt64", "potrf_persist")
+PROFILE_FAMILIES = ("update_nt", "trtri", "lauum", "diag128", "trsm128", "update_nt64", "potrf_persist", "trtri_early")
 
 _lib = None
 

@@ -334,6 +334,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
             hipStream_t sq = ws->st_tri_cur ? ws->st_tri_cur : ws->st_tri;
             (void)hipStreamWaitEvent(sq, ws->ev_panel[p], 0);
             (void)hipMemsetAsync(ws->tri_counter, 0, sizeof(int) * 4, sq);
+            ws->prof.begin(sq, PF_TRTRI_EARLY, 0.0);            // elapsed on the side stream; the flops are billed to PF_TRTRI
             launch_inv128(sq, A, ws->scratchX, npad, ovl_h, ws->dinv);
             int level = 0;
             for (; (1 << level) < ovl_h; ++level) launch_trtri_level(sq, A, ws->scratchX, ws->scratchT, npad, ovl_h, level);
@@ -343,6 +344,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
             const int nt_pair = ntl < 2 * ovl_h ? ntl : 2 * ovl_h;
             launch_trtri_stage1_steal(sq, A, ws->scratchX, ws->scratchT, npad, nt_pair, level, ws->tri_counter,
                                       ws->tri_wgs > 0 ? ws->tri_wgs : 512 * ws->tri_cur_pct / 100);
+            ws->prof.end(sq);
             (void)hipEventRecord(ws->ev_tri, sq);
             ws->ovl_h = ovl_h;
         }

@@ -19,13 +19,6 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
-// every tile kernel runs 4-wave workgroups on the LDS-DMA pipeline (the 8-wave arrangement measured within +-1 %)
-#define NW_DISPATCH(CALL4, CALL8) \
-    do {                          \
-        CALL4;                    \
-    } while (0)
-static int gemm_variant_nw() { return 4; }
-
 #define LB(NW) __launch_bounds__((NW) * 64, (NW) / 2)
 
 // ------------------------------------------------------------------------------------------------
@@ -126,7 +119,7 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
 // stage 2: X21 = -X22 * T21  (X22 lower triangular -> k from the start of the right block to ti)
 template <int STAGE, int NW>
 __device__ __forceinline__ void trtri_stage_tile(int bid, const double* __restrict__ L, double* __restrict__ X,
-                                                 double* __restrict__ T, long ld, int nt, int nbt, int rev, double* smem) {
+                                                 double* __restrict__ T, long ld, int nt, int nbt, double* smem) {
     const int per = nbt * nbt;
     const int p = bid / per;
     const int rem = bid - p * per;
@@ -146,7 +139,7 @@ __device__ __forceinline__ void trtri_stage_tile(int bid, const double* __restri
     if (STAGE == 1) {
         const int K = (right0 - tj) * NB;
         gemm_tile_128<true, false, NW>(L + (long)ti * NB * ld + (long)tj * NB, ld,
-                                   X + (long)tj * NB * ld + (long)tj * NB, ld, K, acc, smem, 0, rev);
+                                   X + (long)tj * NB * ld + (long)tj * NB, ld, K, acc, smem);
         gt_store<0, NW>(T + (long)ti * NB * ld + (long)tj * NB, ld, acc);
     } else {
         const int K = (ti - right0 + 1) * NB;
@@ -192,9 +185,9 @@ __global__ __launch_bounds__(256) void k_trtri_stage64(const double* __restrict_
 
 template <int STAGE, int NW>
 __global__ LB(NW) void k_trtri_stage(const double* __restrict__ L, double* __restrict__ X,
-                                                        double* __restrict__ T, long ld, int nt, int nbt, int rev) {
+                                                        double* __restrict__ T, long ld, int nt, int nbt) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    trtri_stage_tile<STAGE, NW>((int)blockIdx.x, L, X, T, ld, nt, nbt, rev, smem);
+    trtri_stage_tile<STAGE, NW>((int)blockIdx.x, L, X, T, ld, nt, nbt, smem);
 }
 
 // Stage 1 with a shared tile counter: several launches of this kernel (on different streams, with different grids) drain
@@ -202,7 +195,7 @@ __global__ LB(NW) void k_trtri_stage(const double* __restrict__ L, double* __res
 // still runs and a second, machine-wide instance on the main stream afterwards: whatever the first one did not get to is
 // picked up at full speed, nothing is left behind on the masked stream.
 __global__ LB(4) void k_trtri_stage1_steal(const double* __restrict__ L, double* __restrict__ X, double* __restrict__ T,
-                                           long ld, int nt, int nbt, int rev, int* __restrict__ counter, int nblocks) {
+                                           long ld, int nt, int nbt, int* __restrict__ counter, int nblocks) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_bid;
     for (;;) {
@@ -211,7 +204,7 @@ __global__ LB(4) void k_trtri_stage1_steal(const double* __restrict__ L, double*
         const int bid = s_bid;
         __syncthreads();
         if (bid >= nblocks) return;
-        trtri_stage_tile<1, 4>(bid, L, X, T, ld, nt, nbt, rev, smem);
+        trtri_stage_tile<1, 4>(bid, L, X, T, ld, nt, nbt, smem);
     }
 }
 
@@ -221,23 +214,21 @@ void launch_trtri_stage1_steal(hipStream_t st, const double* L, double* X, doubl
     if (nbt >= nt) return;
     const int pairs = (nt + 2 * nbt - 1) / (2 * nbt);
     const int nblocks = pairs * nbt * nbt;
-    const int rev = 0;
     LDS_OPT_IN(k_trtri_stage1_steal);
     if (grid > nblocks) grid = nblocks;
-    hipLaunchKernelGGL(k_trtri_stage1_steal, dim3((unsigned)grid), dim3(256), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev,
+    hipLaunchKernelGGL(k_trtri_stage1_steal, dim3((unsigned)grid), dim3(256), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt,
                        counter, nblocks);
 }
 
 template <int NW>
 static void launch_trtri_level_t(hipStream_t st, long nblocks, const double* L, double* X, double* T, long ld, int nt,
                                  int nbt, int stages) {
-    const int rev = 0;
     LDS_OPT_IN((k_trtri_stage<1, NW>));
     LDS_OPT_IN((k_trtri_stage<2, NW>));
     if (stages & 1)
-        hipLaunchKernelGGL((k_trtri_stage<1, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev);
+        hipLaunchKernelGGL((k_trtri_stage<1, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt);
     if (stages & 2)
-        hipLaunchKernelGGL((k_trtri_stage<2, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt, rev);
+        hipLaunchKernelGGL((k_trtri_stage<2, NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt);
 }
 
 // stages: bit 0 = T21 = L21 X11, bit 1 = X21 = -X22 T21 (3 = the whole level)
@@ -247,22 +238,20 @@ void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, l
     const int pairs = (nt + 2 * nbt - 1) / (2 * nbt);
     const long nblocks = (long)pairs * nbt * nbt;
     static const int tri64_max = env_int("MI355GP_TRI64_MAX", GEMM_DEFAULT_TRI64_MAX);
-    if (nblocks <= tri64_max && gemm_variant_nw() == 4) {
+    if (nblocks <= tri64_max) {
         if (stages & 1)
             hipLaunchKernelGGL((k_trtri_stage64<1>), dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, L, X, T, ld, nt, nbt);
         if (stages & 2)
             hipLaunchKernelGGL((k_trtri_stage64<2>), dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, L, X, T, ld, nt, nbt);
         return;
     }
-    NW_DISPATCH((launch_trtri_level_t<4>(st, nblocks, L, X, T, ld, nt, nbt, stages)),
-                (launch_trtri_level_t<8>(st, nblocks, L, X, T, ld, nt, nbt, stages)));
+    launch_trtri_level_t<4>(st, nblocks, L, X, T, ld, nt, nbt, stages);
 }
 
 // ------------------------------------------------------------------------------------------------
 // W = X^T X for lower-triangular X (the dlauum half of LAPACK dpotri): W[ti,tj] = sum_{tk>=ti} X[tk,ti]^T X[tk,tj].
 template <int NW>
-__global__ LB(NW) void k_lauum(const double* __restrict__ X, double* __restrict__ W, long ld,
-                                                  int nt, int rev) {
+__global__ LB(NW) void k_lauum(const double* __restrict__ X, double* __restrict__ W, long ld, int nt) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int bid = blockIdx.x;
     int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
@@ -273,7 +262,7 @@ __global__ LB(NW) void k_lauum(const double* __restrict__ X, double* __restrict_
     gt_zero<NW>(acc);
     const int K = (nt - ti) * NB;
     gemm_tile_128<false, false, NW>(X + (long)ti * NB * ld + (long)ti * NB, ld, X + (long)ti * NB * ld + (long)tj * NB, ld,
-                                K, acc, smem, 0, rev);
+                                K, acc, smem);
     gt_store<0, NW>(W + (long)ti * NB * ld + (long)tj * NB, ld, acc);
 }
 
@@ -294,19 +283,18 @@ __global__ __launch_bounds__(256) void k_lauum64(const double* __restrict__ X, d
 
 template <int NW>
 static void launch_lauum_t(hipStream_t st, long nblocks, const double* X, double* W, long ld, int nt) {
-    const int rev = 0;
     LDS_OPT_IN((k_lauum<NW>));
-    hipLaunchKernelGGL((k_lauum<NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, X, W, ld, nt, rev);
+    hipLaunchKernelGGL((k_lauum<NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, X, W, ld, nt);
 }
 
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt) {
     const long nblocks = (long)nt * (nt + 1) / 2;
     static const int lauum64_max = env_int("MI355GP_LAUUM64_MAX", GEMM_DEFAULT_LAUUM64_MAX);
-    if (nblocks <= lauum64_max && gemm_variant_nw() == 4) {
+    if (nblocks <= lauum64_max) {
         hipLaunchKernelGGL(k_lauum64, dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, X, W, ld, nt);
         return;
     }
-    NW_DISPATCH((launch_lauum_t<4>(st, nblocks, X, W, ld, nt)), (launch_lauum_t<8>(st, nblocks, X, W, ld, nt)));
+    launch_lauum_t<4>(st, nblocks, X, W, ld, nt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,8 +343,7 @@ static void launch_trmm_lower_t(hipStream_t st, const double* X, long ldx, const
 
 void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
                        int ntr, int ntc) {
-    NW_DISPATCH((launch_trmm_lower_t<4>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc)),
-                (launch_trmm_lower_t<8>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc)));
+    launch_trmm_lower_t<4>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc);
 }
 
 // C (mpad x mpad, ldc) = alpha * A^T A + beta * C with A (K x mpad): the K** - tmp^T tmp of full_cov prediction
@@ -387,7 +374,7 @@ __global__ LB(NW) void k_gemm_full(const double* __restrict__ A, long lda,
     const double* Ap = AK ? A + (long)ti * NB * lda : A + (long)ti * NB;
     const double* Bp = BK ? B + (long)tj * NB * ldb : B + (long)tj * NB;
     const long long c0 = clock64(), w0 = wall_clock64();
-    gemm_tile_128<AK, BK, NW>(Ap, lda, Bp, ldb, K, acc, smem, swz >> 1);
+    gemm_tile_128<AK, BK, NW>(Ap, lda, Bp, ldb, K, acc, smem);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         g_gemm_clk[0] = clock64() - c0;
         g_gemm_clk[1] = wall_clock64() - w0;
@@ -409,21 +396,13 @@ static void launch_gemm_full(hipStream_t st, unsigned nblocks, const double* A, 
                              double* C, long ldc, int K, int ntc, double alpha, double beta) {
     static const int dbg_ld0 = env_int("MI355GP_DBG_LD0", 0), dbg_swz = env_int("MI355GP_DBG_SWZ", 0);
     if (dbg_ld0) lda = ldb = 0;                           // every operand row aliases row 0: cache-resident loads
-    static const int dbg_nosync = env_int("MI355GP_DBG_NOSYNC", 0), dbg_1wg = env_int("MI355GP_DBG_1WG", 0);
-    // MI355GP_DBG_NOSYNC: 1 = no staging and no barrier in the k-loop, 2 = staging but no barrier (racy; timing only)
-    const int swz = ((dbg_swz && (ntc % 8 == 0) && ((nblocks / ntc) % 8 == 0)) ? 1 : 0) | ((dbg_nosync & 3) << 1);
+    static const int dbg_1wg = env_int("MI355GP_DBG_1WG", 0);
+    const int swz = (dbg_swz && (ntc % 8 == 0) && ((nblocks / ntc) % 8 == 0)) ? 1 : 0;
     const size_t lds = dbg_1wg ? 100 * 1024 : GT_LDS_BYTES;
-    if (gemm_variant_nw() == 8) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_full<AK, BK, 8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gemm_full<AK, BK, 8>), dim3(nblocks), dim3(512), lds, st, A, lda, B, ldb, C, ldc, K,
-                           ntc, alpha, beta, swz);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_full<AK, BK, 4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gemm_full<AK, BK, 4>), dim3(nblocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, K,
-                           ntc, alpha, beta, swz);
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_full<AK, BK, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_gemm_full<AK, BK, 4>), dim3(nblocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, K,
+                       ntc, alpha, beta, swz);
 }
 
 void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A,

@@ -1,90 +1,30 @@
 // gemm_tile.h -- the fp64 MFMA workhorse: one 128x128 output tile per workgroup.
 //
-// Geometry (MI355X / gfx950), two wave arrangements selected by the template parameter NW:
-//   NW = 4 (256 threads): waves 2x2, each owns a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators
-//                         (128 accumulator VGPRs; 2 workgroups per CU = 2 waves per SIMD)
-//   NW = 8 (512 threads): waves 2x4, each owns a 64x32 sub-tile = 4x2 accumulators (64 VGPRs;
-//                         2 workgroups per CU = 4 waves per SIMD, so the matrix pipe always finds a ready wave)
-// K is consumed in slabs of 16 (four MFMA k-slices); slabs are double-buffered in LDS
-// (2 x (A 18 KB + B 18 KB) = 72 KB, two workgroups per CU) and the next slab's global loads are issued
-// before the current slab's MFMAs.
+// Geometry (MI355X / gfx950): 256 threads = 4 waves arranged 2x2, each owns a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64
+// accumulators (128 accumulator VGPRs; 2 workgroups per CU = 2 waves per SIMD).  K is consumed in slabs of 16 (four MFMA
+// k-slices); slabs are double-buffered in LDS and move global -> LDS by LDS-DMA (the pipeline is described at
+// gemm_tile_128_v3 below; the register-staged and 8-wave pipelines of rounds 1-2 measured within +-4 % of it and are gone,
+// DESIGN.md 6e).
 //
 // Operand storage (row-major buffers with leading dimension ld):
-//   k-contiguous  : element (i, k) at P[i*ld + k]   -> LDS image [128][18]  (stride 18 = 2*odd: the
-//                   fragment read row*18+k is bank-conflict free for ds_read_b64)
-//   m/n-contiguous: element (k, i) at P[k*ld + i]   -> LDS image [16][144] (stride 144 = 16 mod 32)
+//   k-contiguous  : element (i, k) at P[i*ld + k]
+//   m/n-contiguous: element (k, i) at P[k*ld + i]
 // NT = (A k-contig, B k-contig), NN = (A k-contig, B n-contig), TN = (A m-contig, B n-contig).
 #pragma once
 #include "common.h"
 
-#define GT_BK 16
-#ifndef GT_USE_V3
-#define GT_USE_V3 1                       // 4-wave tile kernels take the LDS-DMA pipeline (v3); 0 = register-staged v1
-#endif
-#define GT_SKC 18
-#define GT_SMN 144
-#define GT_TILE 2304                      // doubles per staged operand slab (128*18 == 16*144)
-#define GT_LDS_BYTES (4 * GT_TILE * 8)    // 73,728 B
+// dynamic LDS asked for by the 128-tile kernels: the pipeline uses GT3_LDS_BYTES (69,632 B); the request stays at the 72 KiB
+// every measured schedule ran with (two workgroups per CU either way)
+#define GT_LDS_BYTES 73728
 
 template <int NW>
 struct GTCfg {
+    static_assert(NW == 4, "the tile kernels run 4-wave workgroups");
     static constexpr int NTHR = NW * 64;
-    static constexpr int NLD = 1024 / NTHR;          // 16-byte loads per operand slab per thread
-    static constexpr int NI = (NW == 8) ? 2 : 4;     // 16-column accumulator blocks per wave
+    static constexpr int NI = 4;                     // 16-column accumulator blocks per wave
     static constexpr int WCOLS = NI * 16;            // columns of the wave's sub-tile
     static constexpr int WPR = 128 / WCOLS;          // waves per tile row
 };
-
-// k-contiguous staging: which (row, 16-byte chunk c of the 16-wide slab row) thread t moves in trip `it`.
-// ds_write_b128 is serviced in 16-lane groups {0-3,12-15,20-27},{4-11,16-19,28-31} (+32); with row stride 18
-// doubles a group is conflict-free iff its four lane-quads hit rows = 0,4,8,12 (mod 16) with the same chunk
-// half, hence the row/chunk permutation below (global reads stay 128 B contiguous per 8 lanes).
-// Trip `it` of the staging loops moves row0 + it*NW*8.
-template <int NW>
-__device__ __forceinline__ void gt_kc_map(int t, int& row0, int& c) {
-    const int l = t & 63, w = t >> 6, o = l >> 3, m = o & 3;
-    const int e = w * 2 + (o >> 2);                      // trip `it` adds NW*2 to e, i.e. NW*8 rows
-    row0 = 16 * (e >> 2) + 4 * m + (e & 3);
-    c = (l & 7) ^ ((m == 1 || m == 2) ? 4 : 0);
-}
-#define GT_KC_RSTEP(NW) ((NW) * 8)
-
-template <bool KC, int NW>
-__device__ __forceinline__ void gt_g2r(const double* __restrict__ P, long ld, int k0, d2 (&r)[GTCfg<NW>::NLD], int t) {
-    if (KC) {
-        int row0, c;
-        gt_kc_map<NW>(t, row0, c);
-        const double* p = P + (long)row0 * ld + k0 + 2 * c;
-#pragma unroll
-        for (int it = 0; it < GTCfg<NW>::NLD; ++it) r[it] = *reinterpret_cast<const d2*>(p + (long)(it * GT_KC_RSTEP(NW)) * ld);
-    } else {
-        const int k = t >> 6, cp = (t & 63) * 2;
-#pragma unroll
-        for (int it = 0; it < GTCfg<NW>::NLD; ++it)
-            r[it] = *reinterpret_cast<const d2*>(P + (long)(k0 + k + NW * it) * ld + cp);
-    }
-}
-
-template <bool KC, int NW>
-__device__ __forceinline__ void gt_r2s(double* s, const d2 (&r)[GTCfg<NW>::NLD], int t) {
-    if (KC) {
-        int row0, c;
-        gt_kc_map<NW>(t, row0, c);
-#pragma unroll
-        for (int it = 0; it < GTCfg<NW>::NLD; ++it)
-            *reinterpret_cast<d2*>(s + (row0 + it * GT_KC_RSTEP(NW)) * GT_SKC + 2 * c) = r[it];
-    } else {
-        const int k = t >> 6, cp = (t & 63) * 2;
-#pragma unroll
-        for (int it = 0; it < GTCfg<NW>::NLD; ++it)
-            *reinterpret_cast<d2*>(s + (k + NW * it) * GT_SMN + cp) = r[it];
-    }
-}
-
-template <bool KC>
-__device__ __forceinline__ double gt_frag(const double* s, int idx, int kk) {
-    return KC ? s[idx * GT_SKC + kk] : s[kk * GT_SMN + idx];
-}
 
 template <bool AK, bool BK, bool NEGA = false>
 __device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, long lda, const double* __restrict__ B,
@@ -95,57 +35,8 @@ __device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, l
 template <bool AK, bool BK, int NW, bool NEGA = false>
 __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long lda,
                                               const double* __restrict__ B, long ldb, int K,
-                                              d4 (&acc)[4][GTCfg<NW>::NI], double* smem, int dbg_nosync = 0,
-                                              int reverse_k = 0) {
-    constexpr int NI = GTCfg<NW>::NI;
-    if constexpr (GT_USE_V3 && NW == 4) {                    // LDS-DMA pipeline (see the v3 block at the end of this file)
-        if (!dbg_nosync && !reverse_k) {
-            gemm_tile_128_v3<AK, BK, NEGA>(A, lda, B, ldb, K, acc, smem);
-            return;
-        }
-    }
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / GTCfg<NW>::WPR, wc = w % GTCfg<NW>::WPR;
-    d2 ra[GTCfg<NW>::NLD], rb[GTCfg<NW>::NLD];
-    const int nk = K / GT_BK;
-    // reverse_k: walk the slabs from k = K-16 down to 0.  Tiles of one launch whose k-ranges END at a common point
-    // (lauum, trtri stage 1) then sweep the same operand slabs at the same time, which is what keeps them in L2.
-    const int kbeg = reverse_k ? K - GT_BK : 0, kinc = reverse_k ? -GT_BK : GT_BK;
-    gt_g2r<AK, NW>(A, lda, kbeg, ra, t);
-    gt_g2r<BK, NW>(B, ldb, kbeg, rb, t);
-    gt_r2s<AK, NW>(smem, ra, t);
-    gt_r2s<BK, NW>(smem + GT_TILE, rb, t);
-    __syncthreads();
-    const int arow = wr * 64 + (lane & 15), bcol = wc * GTCfg<NW>::WCOLS + (lane & 15), kq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            gt_g2r<AK, NW>(A, lda, kbeg + (kt + 1) * kinc, ra, t);
-            gt_g2r<BK, NW>(B, ldb, kbeg + (kt + 1) * kinc, rb, t);
-        }
-        const double* a_s = smem + cur * 2 * GT_TILE;
-        const double* b_s = a_s + GT_TILE;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int kk = 4 * s + kq;
-            double af[4], bf[NI];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[mi] = NEGA ? -gt_frag<AK>(a_s, arow + mi * 16, kk) : gt_frag<AK>(a_s, arow + mi * 16, kk);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bf[ni] = gt_frag<BK>(b_s, bcol + ni * 16, kk);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma_f64(af[mi], bf[ni], acc[mi][ni]);
-        }
-        if (dbg_nosync & 1) continue;   // diagnostics only: MFMA + LDS-read steady state without staging / barriers
-        if (kt + 1 < nk) {
-            double* nxt = smem + (cur ^ 1) * 2 * GT_TILE;
-            gt_r2s<AK, NW>(nxt, ra, t);
-            gt_r2s<BK, NW>(nxt + GT_TILE, rb, t);
-        }
-        if (dbg_nosync & 2) continue;   // diagnostics only (racy, wrong results): staging but no barrier
-        __syncthreads();
-    }
+                                              d4 (&acc)[4][GTCfg<NW>::NI], double* smem) {
+    gemm_tile_128_v3<AK, BK, NEGA>(A, lda, B, ldb, K, acc, smem);
 }
 
 template <int NW>
@@ -232,7 +123,7 @@ __device__ __forceinline__ void gt_store(double* __restrict__ C, long ldc, const
 }
 
 // =====================================================================================================================
-// v3 pipeline (the shipping one for 4-wave workgroups): operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
+// The tile pipeline: operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
 // VGPRs, no ds_write pass.  The DMA destination is wave-uniform base + lane*16 B (linear), so the bank-conflict-free
 // layout is obtained by permuting the per-lane SOURCE address:
 //   k-contiguous operand : [128][16] unpadded; one DMA moves 8 rows x 128 B; lane l = (row l>>3, slot l&7) fetches the

@@ -41,7 +41,7 @@ void launch_dbg_mfma(hipStream_t st, const double* a, const double* b, double* d
 
 // ---- factor.hip : blocked drivers -------------------------------------------------------------------
 // per-kernel-family device timing (hipEvent pairs on the launching stream) + algorithmic flop counts
-enum { PF_UPDATE = 0, PF_TRTRI = 1, PF_LAUUM = 2, PF_DIAG = 3, PF_TRSM = 4, PF_UPDATE64 = 5, PF_PERSIST = 6, PF_NUM = 7 };
+enum { PF_UPDATE = 0, PF_TRTRI = 1, PF_LAUUM = 2, PF_DIAG = 3, PF_TRSM = 4, PF_UPDATE64 = 5, PF_PERSIST = 6, PF_TRTRI_EARLY = 7, PF_NUM = 8 };
 struct KernelProf {
     unsigned mask = 0;          // bit f set: family f is timed
     bool on = false;

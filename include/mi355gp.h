@@ -203,7 +203,10 @@ enum { MI355GP_PF_UPDATE = 0 /* k_update_nt<4,true>: trailing update of potrf on
        MI355GP_PF_DIAG = 3 /* k_diag128 */, MI355GP_PF_TRSM = 4 /* k_trsm128 */,
        MI355GP_PF_UPDATE64 = 5 /* k_update_nt64: the same update on 64 x 64 tiles (launches of few tiles) */,
        MI355GP_PF_PERSIST = 6 /* k_potrf_persist: the whole factorisation of a small matrix as one persistent launch */,
-       MI355GP_PF_NUM = 7 };
+       MI355GP_PF_TRTRI_EARLY = 7 /* the part of the triangular inverse that runs on the CU-masked side stream UNDERNEATH potrf
+                                     (inverse of the leading block + its share of T21 = L21 X11): elapsed time on that stream;
+                                     MI355GP_PF_TRTRI is the part exposed after potrf, and carries the flops of both */,
+       MI355GP_PF_NUM = 8 };
 /* Per family, for the last inference call made with PROFILE on: summed launch durations (ms), summed ALGORITHMIC
  * flops of those launches, launch count.  Arrays of MI355GP_PF_NUM. */
 int mi355gp_get_profile(mi355gp_ctx* ctx, double* ms, double* flops, int* launches);

@@ -408,13 +408,18 @@ struct GridRank {
     long LR = 0, LC = 0;             // allocated local rows / cols (uniform over ranks)
     long nvr = 0, nvc = 0;           // local rows / cols whose global index is < n (a prefix of the local order)
     double *A = nullptr, *X = nullptr, *W = nullptr;
-    // Panel stores: EVERY step's four panels are kept for the whole evaluation (written once by the step's critical path,
-    // read by the aggregated updates of its group and, for the X panels, by the deferred W = X^T X), packed back to back:
+    // Panel stores (alloc_panel_stores):
     //   RPs: L_ik for the local row tiles with I > k          CPs: L_jk for the local column tiles with J > k
     //   XRs: X_kj for the local column tiles with J <= k      XRrs: X_ki for the local row tiles with I <= k
+    // The L panels of a step are read only by the updates of its own group (near, part 1 on sc; bulk on st), and the
+    // critical path of group g+2 starts after sc has waited for bulk(g): they live in a RING of 2 G full-height slots (panel
+    // k in slot k % 2G), 2 G (N/Pr + N/Pc) nb doubles instead of ~N^2/2 (1/Pr + 1/Pc).  The X panels are also read by the
+    // deferred W = X^T X on the low-priority stream, which may trail by any number of steps (all of them with GW = 0): every
+    // step keeps its own, packed back to back.
     // hRP[k] .. are the panels' VIRTUAL bases (local tile l of panel k at base + l * nb * nb; only the tiles the panel holds
     // are ever addressed), dRP .. the same tables in device memory for k_grid_gemm_multi.
     double *RPs = nullptr, *CPs = nullptr, *XRs = nullptr, *XRrs = nullptr;
+    long ring_slots = 0;             // L-panel ring slots the stores were sized for (2 G at allocation time)
     std::vector<double*> hRP, hCP, hXR, hXRr;
     const double **dRP = nullptr, **dCP = nullptr, **dXR = nullptr, **dXRr = nullptr;
     double* cpart = nullptr;         // column-reduction partials [row chunk][LC]
@@ -540,6 +545,56 @@ static int grid_allreduce(mi355gp_grid* g, size_t count, const std::function<dou
     }
     GridRank& r = g->ranks[0];
     NCCL_CHECK(g_rccl.AllReduce(pick(r), pick(r), count, ncclFloat64, ncclSum, g->comm_world, r.st));
+    return 0;
+}
+
+// (Re)allocates the four panel stores of a rank and their pointer tables for the current group size G (see GridRank).
+static int alloc_panel_stores(mi355gp_grid* g, GridRank& r) {
+    const long nb = g->nb, T = g->T;
+    const size_t tile = (size_t)nb * nb;
+    void* old[] = {r.RPs, r.CPs, r.XRs, r.XRrs, (void*)r.dRP, (void*)r.dCP, (void*)r.dXR, (void*)r.dXRr};
+    for (void* p : old)
+        if (p) (void)hipFree(p);
+    r.RPs = r.CPs = r.XRs = r.XRrs = nullptr;
+    r.dRP = r.dCP = r.dXR = r.dXRr = nullptr;
+    const long G = g->G < 1 ? 1 : g->G;
+    long slots = 2 * G;
+    if (slots > T) slots = T;
+    r.ring_slots = slots;
+    std::vector<long> oXR((size_t)T + 1, 0), oXRr((size_t)T + 1, 0);
+    for (long k = 0; k < T; ++k) {
+        oXR[k + 1] = oXR[k] + cnt_le(k, r.pc, g->Pc);
+        oXRr[k + 1] = oXRr[k] + cnt_le(k, r.pr, g->Pr);
+    }
+    const size_t bytes[4] = {sizeof(double) * tile * (size_t)(slots * r.TLr + 1), sizeof(double) * tile * (size_t)(slots * r.TLc + 1),
+                             sizeof(double) * tile * (size_t)(oXR[T] + 1), sizeof(double) * tile * (size_t)(oXRr[T] + 1)};
+    double** dst[4] = {&r.RPs, &r.CPs, &r.XRs, &r.XRrs};
+    for (int i = 0; i < 4; ++i)
+        if (hipMalloc(dst[i], bytes[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            mi355gp_set_error("grid mode: out of device memory for the panel stores of rank %d (N=%ld on %dx%d, nb=%ld: L-panel ring "
+                              "%.2f + %.2f GB for G=%ld, X panels %.2f + %.2f GB, next to 3 x %.2f GB of local matrices); use more "
+                              "GPUs or a smaller G",
+                              r.rank, g->n, g->Pr, g->Pc, nb, bytes[0] / 1e9, bytes[1] / 1e9, G, bytes[2] / 1e9, bytes[3] / 1e9,
+                              sizeof(double) * (double)r.LR * (double)r.LC / 1e9);
+            return -4;
+        }
+    r.hRP.resize((size_t)T); r.hCP.resize((size_t)T); r.hXR.resize((size_t)T); r.hXRr.resize((size_t)T);
+    for (long k = 0; k < T; ++k) {
+        r.hRP[k] = r.RPs + (k % slots) * (long)r.TLr * (long)tile;       // full-height slot: local tile l at base + l * tile
+        r.hCP[k] = r.CPs + (k % slots) * (long)r.TLc * (long)tile;
+        r.hXR[k] = r.XRs + oXR[k] * (long)tile;
+        r.hXRr[k] = r.XRrs + oXRr[k] * (long)tile;
+    }
+    const size_t tb = sizeof(double*) * (size_t)T;
+    HIP_CHECK(hipMalloc((void**)&r.dRP, tb));
+    HIP_CHECK(hipMalloc((void**)&r.dCP, tb));
+    HIP_CHECK(hipMalloc((void**)&r.dXR, tb));
+    HIP_CHECK(hipMalloc((void**)&r.dXRr, tb));
+    HIP_CHECK(hipMemcpy((void*)r.dRP, r.hRP.data(), tb, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy((void*)r.dCP, r.hCP.data(), tb, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy((void*)r.dXR, r.hXR.data(), tb, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy((void*)r.dXRr, r.hXRr.data(), tb, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -693,37 +748,8 @@ int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, co
         HIP_CHECK(hipMalloc(&r.A, mat));
         HIP_CHECK(hipMalloc(&r.X, mat));
         HIP_CHECK(hipMalloc(&r.W, mat));
-        {
-            const size_t tile = (size_t)nb * nb;
-            std::vector<long> oRP((size_t)T + 1, 0), oCP((size_t)T + 1, 0), oXR((size_t)T + 1, 0), oXRr((size_t)T + 1, 0);
-            for (long k = 0; k < T; ++k) {
-                oRP[k + 1] = oRP[k] + (r.TLr - cnt_le(k, pr, g->Pr));
-                oCP[k + 1] = oCP[k] + (r.TLc - cnt_le(k, pc, g->Pc));
-                oXR[k + 1] = oXR[k] + cnt_le(k, pc, g->Pc);
-                oXRr[k + 1] = oXRr[k] + cnt_le(k, pr, g->Pr);
-            }
-            HIP_CHECK(hipMalloc(&r.RPs, sizeof(double) * tile * (size_t)(oRP[T] + 1)));
-            HIP_CHECK(hipMalloc(&r.CPs, sizeof(double) * tile * (size_t)(oCP[T] + 1)));
-            HIP_CHECK(hipMalloc(&r.XRs, sizeof(double) * tile * (size_t)(oXR[T] + 1)));
-            HIP_CHECK(hipMalloc(&r.XRrs, sizeof(double) * tile * (size_t)(oXRr[T] + 1)));
-            r.hRP.resize((size_t)T); r.hCP.resize((size_t)T); r.hXR.resize((size_t)T); r.hXRr.resize((size_t)T);
-            for (long k = 0; k < T; ++k) {
-                r.hRP[k] = r.RPs + (oRP[k] - cnt_le(k, pr, g->Pr)) * (long)tile;
-                r.hCP[k] = r.CPs + (oCP[k] - cnt_le(k, pc, g->Pc)) * (long)tile;
-                r.hXR[k] = r.XRs + oXR[k] * (long)tile;
-                r.hXRr[k] = r.XRrs + oXRr[k] * (long)tile;
-            }
-            const size_t tb = sizeof(double*) * (size_t)T;
-            HIP_CHECK(hipMalloc((void**)&r.dRP, tb));
-            HIP_CHECK(hipMalloc((void**)&r.dCP, tb));
-            HIP_CHECK(hipMalloc((void**)&r.dXR, tb));
-            HIP_CHECK(hipMalloc((void**)&r.dXRr, tb));
-            HIP_CHECK(hipMemcpy((void*)r.dRP, r.hRP.data(), tb, hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemcpy((void*)r.dCP, r.hCP.data(), tb, hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemcpy((void*)r.dXR, r.hXR.data(), tb, hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemcpy((void*)r.dXRr, r.hXRr.data(), tb, hipMemcpyHostToDevice));
-            HIP_CHECK(hipMalloc(&r.cpart, sizeof(double) * (size_t)(r.LR / CR_ROWS + 1) * r.LC));
-        }
+        if (int rc = alloc_panel_stores(g, r)) return rc;
+        HIP_CHECK(hipMalloc(&r.cpart, sizeof(double) * (size_t)(r.LR / CR_ROWS + 1) * r.LC));
         HIP_CHECK(hipMalloc(&r.Dt, sizeof(double) * nb * nb));
         HIP_CHECK(hipMalloc(&r.Dv, sizeof(double) * nb * nb));
         HIP_CHECK(hipMalloc(&r.Ds, sizeof(double) * nb * nb));
@@ -800,6 +826,15 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
     const int Pr = g->Pr, Pc = g->Pc, Dy = g->Dy, D = g->D, q = (int)(nb / NB);
     const size_t tile = (size_t)nb * nb;
     const GridPred nopred{0, 1, 0, 1, 0, 0, 0};
+    {   // the L-panel ring is sized for the group size in effect when the data was set: follow a later change of G
+        long want = 2 * (g->G < 1 ? 1 : g->G);
+        if (want > T) want = T;
+        for (GridRank& r : g->ranks)
+            if (r.ring_slots != want) {
+                HIP_CHECK(hipDeviceSynchronize());
+                if (int rc = alloc_panel_stores(g, r)) return rc;
+            }
+    }
     HIP_CHECK(hipEventRecord(g->ev[0], g->st));
     // ---- covariance tiles: K(X_rows, X_cols) + diagonal fix-up -------------------------------------------
     for (GridRank& r : g->ranks) {

@@ -339,7 +339,8 @@ C2_KEEP = ("ms_per_step", "value", "unit", "steps", "warmup", "config", "stage_m
 
 def c2_leg(comm, args):
     """BASELINE configs[1]: RBF iso, N=4096, D=8 on ONE GPU (rank 0's), through the drop-in classes."""
-    rec = run_child(["--n", "4096", "--d", "8", "--kind", "rbf", "--iso", "--steps", "300", "--warmup", "20", "--no-legs",
+    steps = ["--steps", "20", "--warmup", "5"] if args.dry_run_sizes else ["--steps", "300", "--warmup", "20"]
+    rec = run_child(["--n", "4096", "--d", "8", "--kind", "rbf", "--iso"] + steps + ["--no-legs",
                      "--device", str(comm.local_rank), "--no-cpu-baseline"], timeout=240.0)
     return {k: rec[k] for k in C2_KEEP if k in rec}
 
@@ -359,6 +360,8 @@ def sparse_leg(comm, args, timeout=300.0):
     env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 29))
     env.pop("TORCHELASTIC_RUN_ID", None)
     argv = ["--sparse", "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
+    if args.dry_run_sizes:
+        argv = ["--sparse", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--n", "20000", "--m", "512"]
     if comm.world == 1:
         argv += ["--device", str(comm.local_rank)]
     rec = run_child(argv, timeout, env=env, single=comm.world == 1)
@@ -426,6 +429,8 @@ def main():
     ap.add_argument("--device", type=int, default=-1, help="HIP device of a one-process run (default: LOCAL_RANK)")
     ap.add_argument("--grid-n", type=int, default=32768)
     ap.add_argument("--grid-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run-sizes", action="store_true", help="small child legs (c2 20 steps, c5 20000 rows x 512 inducing "
+                    "points, grid / c4_single at --grid-n): the multi-rank dry run of tools/multiproc_dryrun.sh on one GPU")
     ap.add_argument("--abi-only", action="store_true", help="time the bare C-ABI call instead of the drop-in classes")
     ap.add_argument("--grid", default="", help="PrxPc: ONE problem on a 2D block-cyclic process grid (RCCL panel "
                     "broadcasts, strong scaling) instead of the default independent replicas; with one process the "
@@ -629,6 +634,8 @@ def main():
                 for leg in ("c2", "c5"):
                     if isinstance(out.get(leg), dict) and "error" not in out[leg]:
                         out[leg]["cpu_baseline"] = cpu.get(leg)
+        if args.dry_run_sizes:
+            out["dry_run_sizes"] = True
         print(json.dumps(out), flush=True)
     comm.close()
 

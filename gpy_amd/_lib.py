@@ -129,6 +129,8 @@ def lib():
     L.mi355gp_grid_exact_inference.argtypes = [vp, ci, ci, _dp, _dp, i64, cd, cd, _dp, _c_dp, _c_dp, _c_dp, _c_dp]
     L.mi355gp_grid_fetch.argtypes = [vp, ci, _dp]
     L.mi355gp_grid_set_option.argtypes = [vp, ci, ci]
+    L.mi355gp_grid_coll_log.argtypes = [vp, ci, _dp]
+    L.mi355gp_grid_coll_log.restype = ci
     L.mi355gp_dbg_grid_multi.argtypes = [ci, ci, ci, ci, _dp]
     L.mi355gp_dbg_update_nt.argtypes = [ci, ci, ctypes.POINTER(ci), ci, ci, _dp]
     L.mi355gp_dbg_update_rect.argtypes = [ci, ci, ci, ctypes.POINTER(ci), ci, ci, _dp]
@@ -152,6 +154,7 @@ def lib():
     L.mi355gp_dbg_gemm_clock.argtypes = [_c_dp, _c_dp]
     L.mi355gp_dbg_mask_probe.argtypes = [ci, ci, ci, _dp]
     L.mi355gp_dbg_persist.argtypes = [ci, i64, ci, ci, _dp]
+    L.mi355gp_dbg_ipc_selftest.argtypes = [ctypes.c_char_p, ci, ci, ci, ci, i64, _dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
                  "pdinv", "dbg_mfma", "dbg_gemm", "dbg_peaks", "set_option", "get_profile", "grid_unique_id",
@@ -161,7 +164,8 @@ def lib():
                  "predict_sum", "dbg_gemm_clock", "covariance_between_points", "exact_studentt_sum", "dbg_mask_probe",
                  "vardtc_inference_sum", "sparse_predict", "sparse_fetch_dLdKnm", "sparse_attach_loopback",
                  "predictive_gradients_sum", "dbg_pipe_share", "pdinv_full", "dbg_graph_factor", "get_option",
-                 "sparse_get_profile", "dbg_persist", "dbg_grid_multi", "dbg_update_nt", "dbg_update_rect"):
+                 "sparse_get_profile", "dbg_persist", "dbg_grid_multi", "dbg_update_nt", "dbg_update_rect",
+                 "dbg_ipc_selftest"):
         getattr(L, "mi355gp_" + name).restype = ci
     _lib = L
     return L
@@ -181,7 +185,8 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_sparse_predict", "mi355gp_sparse_fetch_dLdKnm", "mi355gp_sparse_attach_loopback",
             "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share", "mi355gp_pdinv_full", "mi355gp_dbg_graph_factor",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe", "mi355gp_get_option",
-            "mi355gp_sparse_get_profile", "mi355gp_dbg_persist", "mi355gp_dbg_grid_multi", "mi355gp_dbg_update_nt", "mi355gp_dbg_update_rect")
+            "mi355gp_sparse_get_profile", "mi355gp_dbg_persist", "mi355gp_dbg_grid_multi", "mi355gp_dbg_update_nt", "mi355gp_dbg_update_rect",
+            "mi355gp_dbg_ipc_selftest", "mi355gp_grid_coll_log")
 
 
 # mi355gp_set_option / mi355gp_get_option ids (include/mi355gp.h, MI355GP_OPT_*)

@@ -47,8 +47,20 @@
 // signature change in RCCL is a compile error here, not silent ABI drift.
 #include <rccl/rccl.h>
 static_assert(sizeof(ncclUniqueId) == 128, "mi355gp_grid_unique_id hands out 128-byte ids");
+// the second provider of the same entry points (ipc_comm.hip): ranks = processes sharing ONE GPU, MI355GP_TRANSPORT=ipc
+ncclResult_t ipcGetUniqueId(ncclUniqueId* id);
+ncclResult_t ipcCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int rank);
+ncclResult_t ipcCommSplit(ncclComm_t parent, int color, int key, ncclComm_t* out, ncclConfig_t* cfg);
+ncclResult_t ipcCommDestroy(ncclComm_t comm);
+ncclResult_t ipcBroadcast(const void* send, void* recv, size_t count, ncclDataType_t type, int root, ncclComm_t comm, hipStream_t st);
+ncclResult_t ipcAllReduce(const void* send, void* recv, size_t count, ncclDataType_t type, ncclRedOp_t op, ncclComm_t comm, hipStream_t st);
+ncclResult_t ipcGroupStart();
+ncclResult_t ipcGroupEnd();
+const char* ipcGetErrorString(ncclResult_t r);
+
 struct Rccl {
     void* h = nullptr;
+    bool ipc = false;
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommSplit) CommSplit = nullptr;
@@ -60,6 +72,23 @@ struct Rccl {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool load() {
         if (h) return true;
+        {
+            const char* t = getenv("MI355GP_TRANSPORT");
+            if (t && strcmp(t, "ipc") == 0) {                // multi-process transport over hipIpc + shared memory (ipc_comm.hip)
+                GetUniqueId = ipcGetUniqueId;
+                CommInitRank = ipcCommInitRank;
+                CommSplit = ipcCommSplit;
+                CommDestroy = ipcCommDestroy;
+                Broadcast = ipcBroadcast;
+                AllReduce = ipcAllReduce;
+                GroupStart = ipcGroupStart;
+                GroupEnd = ipcGroupEnd;
+                GetErrorString = ipcGetErrorString;
+                ipc = true;
+                h = (void*)this;
+                return true;
+            }
+        }
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
             h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -431,6 +460,13 @@ struct GridRank {
     double *vloc = nullptr, *gvec = nullptr, *gvec2 = nullptr, *alpha = nullptr, *ybuf = nullptr, *Rg = nullptr;
     double *scal = nullptr, *gradPart = nullptr, *gradOut = nullptr, *invls = nullptr, *noise = nullptr;
     int* info_g = nullptr;
+    // Log of the collectives this rank took part in during the current evaluation, per communicator (0 world, 1 process row,
+    // 2 process column): count and an FNV-1a hash over (operation, root, doubles).  RCCL matches collectives by ORDER: two members
+    // of a communicator that enqueue different sequences dead-lock or, worse, exchange the wrong panels.  check_seq compares
+    // the logs of all members after every evaluation (mi355gp_grid_coll_log reads them).
+    uint64_t coll_hash[3] = {0, 0, 0};
+    long coll_count[3] = {0, 0, 0};
+    double* seqbuf = nullptr;        // 2 * world doubles: the exchange buffer of the check
     FactorWs ws;
     hipStream_t st = nullptr;        // bulk updates and everything outside the factorisation loop
     hipStream_t sc = nullptr;        // the critical path of a step: diagonal tile, panel solves, all panel broadcasts
@@ -449,6 +485,7 @@ struct mi355gp_grid {
     hipEvent_t ev_w = nullptr;
     std::vector<hipEvent_t> ev_cr, ev_p1;   // [k]: panels of step k are in place / the part-1 updates of step k are done
     int lookahead = 1;               // MI355GP_GRID_LOOKAHEAD=0: everything in order on one stream
+    int check_seq = 0;               // MI355GP_GRID_CHECK_SEQ=1: compare the collective logs of all ranks after every evaluation
     int G = 1;                       // MI355GP_GRID_G: steps per group of the two-level blocked factorisation (K = G * nb updates)
     int GW = 4;                      // MI355GP_GRID_GW: steps per W = X^T X update; 0 = one deep-K pass after the last step
     long n = 0, npad = 0, T = 0;
@@ -472,7 +509,22 @@ static void grid_default_option(mi355gp_grid* g, int o) {
     } else if (o == MI355GP_GRID_OPT_GW) {
         const char* e = getenv("MI355GP_GRID_GW");
         g->GW = (e && *e && atoi(e) >= 0) ? atoi(e) : 4;
+    } else if (o == MI355GP_GRID_OPT_CHECK_SEQ) {
+        const char* e = getenv("MI355GP_GRID_CHECK_SEQ");
+        g->check_seq = (e && *e && atoi(e)) ? 1 : 0;
     }
+}
+
+static void coll_log(GridRank& r, int comm, int op, int root, size_t count) {
+    uint64_t h = r.coll_hash[comm];
+    const uint64_t words[3] = {(uint64_t)op, (uint64_t)(unsigned)root, (uint64_t)count};
+    for (uint64_t w : words)
+        for (int b = 0; b < 8; ++b) {
+            h ^= (w >> (8 * b)) & 0xffu;
+            h *= 1099511628211ull;
+        }
+    r.coll_hash[comm] = h;
+    r.coll_count[comm] += 1;
 }
 
 static int cnt_le(long k, int p, int P) { return (k >= p) ? (int)((k - p) / P + 1) : 0; }   // tiles t <= k with t % P == p
@@ -481,7 +533,7 @@ static int cnt_lt(long k, int p, int P) { return (k > 0) ? cnt_le(k - 1, p, P) :
 static void free_rank(GridRank& r) {
     void* ptrs[] = {r.A, r.X, r.W, r.RPs, r.CPs, r.XRs, r.XRrs, (void*)r.dRP, (void*)r.dCP, (void*)r.dXR, (void*)r.dXRr, r.cpart, r.Dt, r.Dv, r.Ds, r.XtR, r.XtC, r.XsR, r.XsC, r.gR, r.gC,
                     r.dl_r, r.dl_c, r.dg, r.vloc, r.gvec, r.gvec2, r.alpha, r.ybuf, r.Rg, r.scal, r.gradPart,
-                    r.gradOut, r.invls, r.noise, r.info_g};
+                    r.gradOut, r.invls, r.noise, r.info_g, r.seqbuf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     factor_ws_free(&r.ws);
@@ -509,6 +561,7 @@ static int grid_bcast(mi355gp_grid* g, int group, int index, int root_coord, siz
         for (GridRank& r : g->ranks) {
             const bool in = (group == GROUP_ROW) ? (r.pr == index) : (r.pc == index);
             if (!in) continue;
+            coll_log(r, group == GROUP_ROW ? 1 : 2, 1, root_coord, count);
             double* dst = buf(r, false);
             if (dst != src) HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, lst));
         }
@@ -520,6 +573,7 @@ static int grid_bcast(mi355gp_grid* g, int group, int index, int root_coord, siz
     const int coord = (group == GROUP_ROW) ? r.pc : r.pr;
     const bool is_root = coord == root_coord;
     const double* send = is_root ? buf(r, true) : buf(r, false);
+    coll_log(r, group == GROUP_ROW ? 1 : 2, 1, root_coord, count);
     NCCL_CHECK(g_rccl.Broadcast(send, buf(r, false), count, ncclFloat64, root_coord,
                                 group == GROUP_ROW ? g->comm_row : g->comm_col, lst));
     return 0;
@@ -534,6 +588,7 @@ static int grid_group_end(mi355gp_grid* g) {
 }
 // sum `count` doubles at `pick(rank)` over all ranks, result everywhere
 static int grid_allreduce(mi355gp_grid* g, size_t count, const std::function<double*(GridRank&)>& pick) {
+    for (GridRank& r : g->ranks) coll_log(r, 0, 2, 0, count);
     if (g->loopback) {
         double* acc = pick(g->ranks[0]);
         const unsigned nblk = (unsigned)((count + 255) / 256);
@@ -595,6 +650,50 @@ static int alloc_panel_stores(mi355gp_grid* g, GridRank& r) {
     HIP_CHECK(hipMemcpy((void*)r.dCP, r.hCP.data(), tb, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy((void*)r.dXR, r.hXR.data(), tb, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy((void*)r.dXRr, r.hXRr.data(), tb, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Debug mode (MI355GP_GRID_CHECK_SEQ=1 / MI355GP_GRID_OPT_CHECK_SEQ): after an evaluation, every member of a communicator must
+// have logged the SAME sequence of collectives on it.  Loopback: the logical ranks are compared on the host.  One rank per
+// process: every member contributes (hash high, hash low, count) at its own position of a vector that is sum-all-reduced inside
+// the communicator (the three numbers are integers below 2^32: exact in fp64), then compares all positions with its own.
+static int grid_check_sequences(mi355gp_grid* g) {
+    if (g->loopback) {
+        for (const GridRank& a : g->ranks)
+            for (const GridRank& b : g->ranks) {
+                const bool same[3] = {true, a.pr == b.pr, a.pc == b.pc};
+                for (int c = 0; c < 3; ++c)
+                    if (same[c] && (a.coll_hash[c] != b.coll_hash[c] || a.coll_count[c] != b.coll_count[c])) {
+                        mi355gp_set_error("grid mode: ranks %d and %d logged different collective sequences on communicator %d "
+                                          "(%ld vs %ld collectives)", a.rank, b.rank, c, a.coll_count[c], b.coll_count[c]);
+                        return -7;
+                    }
+            }
+        return 0;
+    }
+    GridRank& r = g->ranks[0];
+    if (!r.seqbuf) HIP_CHECK(hipMalloc(&r.seqbuf, sizeof(double) * 3 * 64));
+    const ncclComm_t comms[3] = {g->comm_world, g->comm_row, g->comm_col};
+    const int sizes[3] = {g->world, g->Pc, g->Pr}, me[3] = {r.rank, r.pc, r.pr};
+    const uint64_t hash[3] = {r.coll_hash[0], r.coll_hash[1], r.coll_hash[2]};       // before the check's own collectives
+    const long cnt[3] = {r.coll_count[0], r.coll_count[1], r.coll_count[2]};
+    for (int c = 0; c < 3; ++c) {
+        std::vector<double> v((size_t)3 * sizes[c], 0.0);
+        v[(size_t)3 * me[c]] = (double)(hash[c] >> 32);
+        v[(size_t)3 * me[c] + 1] = (double)(hash[c] & 0xffffffffull);
+        v[(size_t)3 * me[c] + 2] = (double)cnt[c];
+        HIP_CHECK(hipMemcpyAsync(r.seqbuf, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, r.st));
+        NCCL_CHECK(g_rccl.AllReduce(r.seqbuf, r.seqbuf, v.size(), ncclFloat64, ncclSum, comms[c], r.st));
+        HIP_CHECK(hipMemcpyAsync(v.data(), r.seqbuf, sizeof(double) * v.size(), hipMemcpyDeviceToHost, r.st));
+        HIP_CHECK(hipStreamSynchronize(r.st));
+        for (int m = 0; m < sizes[c]; ++m)
+            for (int q = 0; q < 3; ++q)
+                if (v[(size_t)3 * m + q] != v[(size_t)3 * me[c] + q]) {
+                    mi355gp_set_error("grid mode: rank %d and member %d of communicator %d logged different collective sequences "
+                                      "(%.0f vs %ld collectives)", r.rank, m, c, v[(size_t)3 * m + 2], cnt[c]);
+                    return -7;
+                }
+    }
     return 0;
 }
 
@@ -835,6 +934,11 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
                 if (int rc = alloc_panel_stores(g, r)) return rc;
             }
     }
+    for (GridRank& r : g->ranks)
+        for (int c = 0; c < 3; ++c) {
+            r.coll_hash[c] = 14695981039346656037ull;
+            r.coll_count[c] = 0;
+        }
     HIP_CHECK(hipEventRecord(g->ev[0], g->st));
     // ---- covariance tiles: K(X_rows, X_cols) + diagonal fix-up -------------------------------------------
     for (GridRank& r : g->ranks) {
@@ -1094,6 +1198,8 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
     }
     if (scal[1] > 0.0 && info == 0) info = (int)n;
     HIP_CHECK(hipGetLastError());
+    if (g->check_seq)
+        if (int rc = grid_check_sequences(g)) return rc;
     if (scal[2] > 0.0) {
         // A persistent factorisation of a diagonal tile was called off (co-residency gate) or aborted on some rank: the count
         // travels in the all-reduced scal[2], so EVERY rank takes this branch and the collectives of the redone evaluation
@@ -1203,13 +1309,32 @@ int mi355gp_grid_set_option(mi355gp_grid* g, int option, int value) {
     else if (option == MI355GP_GRID_OPT_G) {
         ARGCHK(value >= 1, "mi355gp_grid_set_option: G >= 1");
         g->G = value;
-    } else g->GW = value;
+    } else if (option == MI355GP_GRID_OPT_CHECK_SEQ) g->check_seq = value ? 1 : 0;
+    else g->GW = value;
     return 0;
 }
 
 int mi355gp_grid_get_option(mi355gp_grid* g, int option, int* value) {
     ARGCHK(g && value && option >= 0 && option < MI355GP_GRID_OPT_NUM, "mi355gp_grid_get_option: unknown option");
-    *value = option == MI355GP_GRID_OPT_LOOKAHEAD ? g->lookahead : option == MI355GP_GRID_OPT_G ? g->G : g->GW;
+    *value = option == MI355GP_GRID_OPT_LOOKAHEAD ? g->lookahead : option == MI355GP_GRID_OPT_G ? g->G
+             : option == MI355GP_GRID_OPT_CHECK_SEQ ? g->check_seq : g->GW;
+    return 0;
+}
+
+// Collective log of logical rank `rank` of this process (loopback: any rank of the grid; one rank per process: its own, rank is
+// ignored) for the LAST evaluation: out9 = [count world, row, column, then per communicator the hash as (high 32 bits, low 32 bits)].
+int mi355gp_grid_coll_log(mi355gp_grid* g, int rank, double* out9) {
+    ARGCHK(g && out9 && !g->single, "mi355gp_grid_coll_log: not available on the degenerate 1 x 1 grid");
+    const GridRank* r = &g->ranks[0];
+    if (g->loopback) {
+        ARGCHK(rank >= 0 && rank < (int)g->ranks.size(), "mi355gp_grid_coll_log: bad rank");
+        r = &g->ranks[(size_t)rank];
+    }
+    for (int c = 0; c < 3; ++c) {
+        out9[c] = (double)r->coll_count[c];
+        out9[3 + 2 * c] = (double)(r->coll_hash[c] >> 32);
+        out9[4 + 2 * c] = (double)(r->coll_hash[c] & 0xffffffffull);
+    }
     return 0;
 }
 

@@ -13,6 +13,7 @@ can be unit-tested without a GPU; csrc/grid.hip implements the same maps.
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -84,6 +85,25 @@ def step_traffic_bytes(N, nb, Pr, Pc):
         diag += tile * (Pr - 1 + Pc - 1)
     return dict(row_panel=row_panel, col_panel=col_panel, x_row=xrow, x_row_t=xrowT, diag=diag,
                 total=row_panel + col_panel + xrow + xrowT + diag)
+
+
+def expected_collectives(N, nb, Pr, Pc, rank, Dy=1, D=1):
+    """Number of collectives ONE evaluation enqueues on the world / process-row / process-column communicator of grid rank
+    `rank` (csrc/grid.hip, crit(k): the diagonal inverse down its column and along its row, the row panel along every process
+    row, the column-panel tiles, the X row panel down every process column, the transposed X tiles; then five all-reduces).
+    Independent of the look-ahead / grouping options: only the ORDER of compute changes with them, never the collectives."""
+    T = -(-N // nb)
+    pr, pc = rank // Pc, rank % Pc
+    row = col = 0
+    for k in range(T):
+        opr, opc = k % Pr, k % Pc
+        col += 1 if pc == opc else 0                                   # (b) D down process column opc
+        row += 1 if pr == opr else 0                                   # (b) D along process row opr
+        row += 1 if count_le(T - 1, pr, Pr) - count_le(k, pr, Pr) > 0 else 0     # (d) row panel (skipped when empty)
+        col += sum(1 for j in range(k + 1, T) if j % Pc == pc)         # (e) column-panel tiles
+        col += 1 if count_le(k, pc, Pc) > 0 else 0                     # (h) X row panel down process column pc
+        row += sum(1 for i in range(k + 1) if i % Pr == pr)            # (i) transposed X tiles
+    return {"world": 5, "row": row, "col": col}
 
 
 def shard_rows(N, rank, world):
@@ -205,9 +225,11 @@ class GridContext(object):
         idb = unique_id() if rank == 0 else b"\0" * ID_BYTES
         if world > 1:
             if exchange is None:
+                # torch is never imported from here: the id travels over torch.distributed only if the CALLER already set a
+                # process group up (bench.py under torch.distributed.run does); the file exchange is the default channel
+                dist = sys.modules.get("torch.distributed")
                 try:
-                    import torch.distributed as dist
-                    use_torch = dist.is_available() and dist.is_initialized()
+                    use_torch = dist is not None and dist.is_available() and dist.is_initialized()
                 except Exception:
                     use_torch = False
                 if use_torch:
@@ -224,7 +246,7 @@ class GridContext(object):
                 idb = exchange(idb, rank)
         return cls(local, rank, world, Pr, Pc, nb, idb)
 
-    OPTIONS = {"lookahead": 0, "G": 1, "GW": 2}
+    OPTIONS = {"lookahead": 0, "G": 1, "GW": 2, "check_seq": 3}
 
     def set_option(self, name, value):
         """Schedule option of this grid (include/mi355gp.h MI355GP_GRID_OPT_*; -1 = process default); every rank must set
@@ -235,6 +257,14 @@ class GridContext(object):
         v = ctypes.c_int(0)
         check(_lib.lib().mi355gp_grid_get_option(self._h, self.OPTIONS[name], ctypes.byref(v)), "mi355gp_grid_get_option")
         return v.value
+
+    def coll_log(self, rank=0):
+        """Collectives of the LAST evaluation as logical rank `rank` logged them (loopback: any rank; one rank per process:
+        this process's own): {"world" | "row" | "col": (count, 64-bit hash over (operation, root, doubles) in order)}."""
+        out = np.zeros(9)
+        check(_lib.lib().mi355gp_grid_coll_log(self._h, int(rank), out), "mi355gp_grid_coll_log")
+        return {name: (int(out[c]), (int(out[3 + 2 * c]) << 32) | int(out[4 + 2 * c]))
+                for c, name in enumerate(("world", "row", "col"))}
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -242,10 +242,24 @@ int mi355gp_grid_fetch(mi355gp_grid* g, int which, double* out);
  *   MI355GP_GRID_OPT_G        : steps per group of the two-level blocked factorisation: tiles beyond the group receive the
  *                               group's panels in ONE pass with K = G * nb (default 1 = one rank-nb update per step; measured best on the loopback grid)
  *   MI355GP_GRID_OPT_GW       : steps per update of Kinv = X^T X; default 4; 0 = one deep-K pass after the last step
- * value -1 restores the process default (environment MI355GP_GRID_LOOKAHEAD / _G / _GW, else the built-in one). */
-enum { MI355GP_GRID_OPT_LOOKAHEAD = 0, MI355GP_GRID_OPT_G = 1, MI355GP_GRID_OPT_GW = 2, MI355GP_GRID_OPT_NUM = 3 };
+ *   MI355GP_GRID_OPT_CHECK_SEQ: 1 = after every evaluation compare, inside every communicator, the members' logs of the
+ *                               collectives they enqueued (operation, root, size, in order): RCCL matches collectives by order,
+ *                               so a divergence is a dead-lock or a wrong panel in waiting; error -7 names the ranks
+ * value -1 restores the process default (environment MI355GP_GRID_LOOKAHEAD / _G / _GW / _CHECK_SEQ, else the built-in one). */
+enum { MI355GP_GRID_OPT_LOOKAHEAD = 0, MI355GP_GRID_OPT_G = 1, MI355GP_GRID_OPT_GW = 2, MI355GP_GRID_OPT_CHECK_SEQ = 3,
+       MI355GP_GRID_OPT_NUM = 4 };
 int mi355gp_grid_set_option(mi355gp_grid* g, int option, int value);
 int mi355gp_grid_get_option(mi355gp_grid* g, int option, int* value);
+/* The collective log of the LAST evaluation of logical rank `rank` (loopback transport: any rank of the grid; one rank per
+ * process: the caller's own): out9 = [collectives on the world / row / column communicator, then per communicator an FNV-1a hash
+ * over (operation, root, doubles) as (high 32 bits, low 32 bits)]. */
+int mi355gp_grid_coll_log(mi355gp_grid* g, int rank, double* out9);
+/* Self-test of the multi-PROCESS transport (csrc/ipc_comm.hip; MI355GP_TRANSPORT=ipc binds it in place of RCCL for ranks that
+ * are processes sharing one GPU): communicator set-up as in mi355gp_grid_create, then broadcasts / all-reduces of `count` doubles
+ * on the world, row and column communicators.  With MI355GP_IPC_HOST=1 every buffer is host memory (no HIP call): the protocol
+ * is testable without a GPU.  out4 = [mismatching doubles, checksum, rank inside the row communicator, inside the column one].
+ * id128: from mi355gp_grid_unique_id under MI355GP_TRANSPORT=ipc. */
+int mi355gp_dbg_ipc_selftest(const void* id128, int rank, int world, int Pr, int Pc, int64_t count, double* out4);
 /* diagnostics: the deep-K X^T X pass of the grid mode against the single-GPU lauum kernel */
 int mi355gp_dbg_grid_multi(int device, int T, int nb, int reps, double* out_ms4);
 /* diagnostics: the trailing-update kernel alone, lower triangle of nt x nt tiles, panel depths ks[0..nk) */

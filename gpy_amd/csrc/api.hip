@@ -290,6 +290,14 @@ static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_gra
     // The factorisation region: potrf -> trtri -> (alpha solve on the side stream) || lauum.  `timing`: record the stage events.
     auto region = [&](bool timing) -> int {
         if (timing) HIP_CHECK(hipEventRecord(c->ev[1], st));
+        // small N: ONE persistent dataflow launch for the factorisation, the inverse and X^T X (persist.hip, "folded launch")
+        if (pdinv_device(st, c->A, c->B, c->C, np, &c->ws)) {
+            if (timing) HIP_CHECK(hipEventRecord(c->ev[2], st));
+            HIP_CHECK(hipEventRecord(c->ev[3], st));
+            if (timing) HIP_CHECK(hipEventRecord(c->ev[4], st));
+            launch_tri_matvec(st, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
+            return 0;
+        }
         potrf_device(st, c->A, np, &c->ws);
         if (timing) HIP_CHECK(hipEventRecord(c->ev[2], st));
         trtri_device(st, c->A, c->B, c->C, np, &c->ws);
@@ -869,10 +877,12 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
     for (int attempt = 0; attempt < 2; ++attempt) {
         launch_pad_from_dense(0, tmp, N, A, np, nullptr, 0, 0.0);
         HIP_CHECK(hipEventRecord(e0, 0));
-        potrf_device(0, A, np, &ws);
-        if (invert) {
-            trtri_device(0, A, B, C, np, &ws);
-            lauum_device(0, B, C, np, &ws);
+        if (!(invert && pdinv_device(0, A, B, C, np, &ws))) {     // small N: the folded persistent launch does all three
+            potrf_device(0, A, np, &ws);
+            if (invert) {
+                trtri_device(0, A, B, C, np, &ws);
+                lauum_device(0, B, C, np, &ws);
+            }
         }
         HIP_CHECK(hipEventRecord(e1, 0));
         HIP_CHECK(hipMemcpy(&info, ws.info, sizeof(int), hipMemcpyDeviceToHost));

@@ -155,7 +155,14 @@ bool potrf_persist_aborted(int info, FactorWs* ws, bool* clean);
 int potrf_persist_sync_ints();
 // dbg (optional, 8 * nt wall-clock stamps): per chain step [factor start, factor end, sub tile seen, solve end, diag tile seen, update end]
 // false: the launch could not be made (no large-LDS opt-in on this device, launch error): nothing was enqueued that writes A
-bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg = nullptr);
+// X != NULL: the FOLDED launch -- the same dataflow goes on to X = L^-1 (by rows, into X) and, with W != NULL, to the lower tiles
+// of W = X^T X (dtrtri + dlauum of dpotri, GPy/util/linalg.py:127-145) inside the one launch
+bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg = nullptr, double* X = nullptr,
+                          double* W = nullptr);
+bool pdinv_persist_eligible(long npad, FactorWs* ws, int want_w);
+// A -> L in place, X = L^-1, W = X^T X (W may be NULL): the folded persistent launch when eligible (returns true; ws->persist_used
+// = 2), else false and NOTHING was enqueued: the caller takes potrf_device / trtri_device / lauum_device
+bool pdinv_device(hipStream_t st, double* A, double* X, double* W, long npad, FactorWs* ws);
 
 // ---- kern.hip : covariance assembly, reductions, solves, fetch helpers ----------------------------
 struct KernParams {

@@ -621,9 +621,17 @@ int mi355gp_sparse_attach_loopback(mi355gp_sparse* s, int rank, int world, int g
 // launch-per-step schedule -- on the untouched matrix, or after rebuild() if it was partly overwritten.  Doing it HERE (and not
 // by repeating the evaluation) keeps a row-sharded run in step: the redo involves no collective.  info_host receives the
 // LAPACK-style info (0 or the first non-positive pivot), never an abort code.
-static int potrf_checked(hipStream_t st, double* A, long mp, FactorWs* ws, int* info_host,
+static int potrf_checked(hipStream_t st, double* A, double* X, double* T, double* W, long mp, FactorWs* ws, int* info_host,
                          const std::function<void()>& rebuild) {
-    potrf_device(st, A, mp, ws);
+    // A -> L (in place), X = L^-1 (T: scratch of the launch-per-step inverse), W = X^T X if W != NULL.  X is used as a FULL
+    // matrix by the GEMMs of the M x M phase: its strictly upper tiles are zeroed here (no schedule writes them).
+    HIP_CHECK(hipMemsetAsync(X, 0, sizeof(double) * mp * mp, st));
+    auto stepwise = [&]() {
+        potrf_device(st, A, mp, ws);
+        trtri_device(st, A, X, T, mp, ws);
+        if (W) lauum_device(st, X, W, mp, ws);
+    };
+    if (!pdinv_device(st, A, X, W, mp, ws)) stepwise();
     if (!ws->persist_used) {
         HIP_CHECK(hipMemcpyAsync(info_host, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
         return 0;
@@ -634,7 +642,7 @@ static int potrf_checked(hipStream_t st, double* A, long mp, FactorWs* ws, int* 
     bool clean = false;
     if (potrf_persist_aborted(info, ws, &clean)) {
         if (!clean) rebuild();
-        potrf_device(st, A, mp, ws);                           // persist_skip > 0: the launch-per-step schedule
+        stepwise();                                            // persist_skip > 0: the launch-per-step schedule
         HIP_CHECK(hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (info >= PS_ABORT_INFO) {
@@ -701,11 +709,9 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
         if (et && *et) inject = atoi(et);
     }
     if (inject == 1 || inject == 2) s->ws.persist_test = inject, s->ws.persist_skip = 0;
-    if (int rc = potrf_checked(st, s->Lm, mp, &s->ws, &s->h_info[0],
+    if (int rc = potrf_checked(st, s->Lm, s->Xm, s->Tm, nullptr, mp, &s->ws, &s->h_info[0],
                                [&]() { build_kmm(s, s->Lm, s->T1, 1e-8 + extra_jitter, /*lower_only=*/1); }))
         return rc;
-    HIP_CHECK(hipMemsetAsync(s->Xm, 0, sizeof(double) * mp * mp, st));
-    trtri_device(st, s->Lm, s->Xm, s->Tm, mp, &s->ws);
     // ---- pass 1: psi2 = sum_n beta_n k_n k_n^T (heteroscedastic) or Kuf Kfu (then A carries beta), psi1V = Kuf V -------
     HIP_CHECK(hipMemsetAsync(s->psi1Y, 0, sizeof(double) * mp * Dy, st));
     int nch = 0;
@@ -747,16 +753,14 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     };
     build_B();
     if (inject == 11 || inject == 12) s->ws.persist_test = inject - 10, s->ws.persist_skip = 0;
-    if (int rc = potrf_checked(st, s->LB, mp, &s->ws, &s->h_info[1], build_B)) return rc;
-    HIP_CHECK(hipMemsetAsync(s->XB, 0, sizeof(double) * mp * mp, st));
-    trtri_device(st, s->LB, s->XB, s->Tm, mp, &s->ws);
+    // LB = chol(B), XB = LB^-1 and B^-1 = XB^T XB (lower tiles; :150) in one go
+    if (int rc = potrf_checked(st, s->LB, s->XB, s->Tm, s->Bi, mp, &s->ws, &s->h_info[1], build_B)) return rc;
     // c = LB^-1 Lm^-1 psi1 V (:141-143), w = LB^-T c (:144), v = Lm^-T w = woodbury_vector (:145)
     launch_trmv_lower(st, s->Xm, mp, mp, s->psi1Y, Dy, s->vecA);
     launch_trmv_lower(st, s->XB, mp, mp, s->vecA, Dy, s->cvec);
     launch_trmv_lower_T(st, s->XB, mp, mp, s->cvec, Dy, s->wvec, s->trmvPart);
     launch_trmv_lower_T(st, s->Xm, mp, mp, s->wvec, Dy, s->vvec, s->trmvPart);
-    // B^-1 = XB^T XB (lower tiles), P = Dy B^-1 + w w^T = DBi_plus_BiPBi (:150-152)
-    lauum_device(st, s->XB, s->Bi, mp, &s->ws);
+    // B^-1 = XB^T XB (lower tiles: computed with the factorisation above), P = Dy B^-1 + w w^T = DBi_plus_BiPBi (:150-152)
     hipLaunchKernelGGL(k_form_P, grid2d(mp, mp), dim3(256), 0, st, s->Bi, s->wvec, Dy, mp, m, s->P);
     // dL_dKmm = Lm^-T (-0.5 P - 0.5 Dy B + Dy I) Lm^-1 (:153-158);  -0.5 Dy (I + A) + Dy I = -0.5 Dy A + 0.5 Dy I
     hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->P, -0.5, s->Amat, -0.5 * Dy, 0.5 * Dy, mp, s->E);

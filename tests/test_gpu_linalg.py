@@ -87,15 +87,19 @@ def test_paired_far_updates_are_bit_identical_to_one_panel_per_pass(N):
 
 
 def test_persistent_cholesky_option_reports_non_pd_and_can_be_switched_off_per_context():
-    """The product path takes the persistent launch below N = 4608 (`FACTOR_PERSIST_MAX_NT`); option "persist" = 0 returns a
-    context to the launch-per-step schedule; both give the same bits, the same LAPACK-style info on a non-PD matrix."""
+    """The product path takes the persistent launch below N = 4608 (`FACTOR_PERSIST_MAX_NT`): option "persist" = 2 (default)
+    folds the inverse and X^T X into it, 1 runs the factorisation alone as one launch, 0 returns a context to the
+    launch-per-step schedule.  1 and 0 give the same bits; 2 agrees to rounding (another summation order of L^-1 / Ky^-1); all
+    report the same LAPACK-style info on a non-PD matrix."""
     X, Y = O.synthetic(1500, 3, seed=5)
     var, ls, noise = O.default_theta(3, False)
     th = L.theta_vec(var, ls, False, 3)
     c = L.Context(0)
     try:
         c.set_data(X, Y)
-        assert c.get_option("persist") == 1
+        assert c.get_option("persist") == 2
+        info, rf = c.exact_inference("rbf", False, th, noise)
+        assert info == 0 and c.get_option("persist_aborts") == 0        # the folded launch ran to completion (no silent redo)
         outs = []
         for p in (1, 0, 1):
             c.set_option("persist", p)
@@ -103,14 +107,17 @@ def test_persistent_cholesky_option_reports_non_pd_and_can_be_switched_off_per_c
             assert info == 0
             outs.append((r["lml"], r["dtheta"].tobytes(), r["alpha"].tobytes()))
         assert outs[0] == outs[1] == outs[2]
+        assert abs(rf["lml"] - r["lml"]) <= 1e-12 * abs(r["lml"])
+        assert np.abs(rf["alpha"] - r["alpha"]).max() <= 1e-11 * np.abs(r["alpha"]).max()
+        assert np.abs(rf["dtheta"] - r["dtheta"]).max() <= 1e-10 * np.abs(r["dtheta"]).max()
         # duplicated inputs, no noise, negative jitter: the Gram matrix is not positive definite -> same info either way
         Xd = np.vstack([X[:700], X[:700], X[:100]])
         c.set_data(Xd, Y)
         infos = []
-        for p in (1, 0):
+        for p in (2, 1, 0):
             c.set_option("persist", p)
             info, _ = c.exact_inference("rbf", False, th, 0.0, jitter=-1e-3)
             infos.append(info)
-        assert infos[0] == infos[1] and infos[0] > 0
+        assert infos[0] == infos[1] == infos[2] and infos[0] > 0
     finally:
         c.close()

@@ -26,6 +26,14 @@ def _key(r):
     return (r["lml"], r["dtheta"].tobytes(), r["alpha"].tobytes())
 
 
+def _close(r, r0):
+    """the folded persistent launch (default) and the launch-per-step schedule it falls back to sum L^-1 / Ky^-1 in different
+    orders: equal to rounding, not to the bit"""
+    return (abs(r["lml"] - r0["lml"]) <= 1e-12 * abs(r0["lml"]) and
+            np.abs(r["alpha"] - r0["alpha"]).max() <= 1e-11 * np.abs(r0["alpha"]).max() and
+            np.abs(r["dtheta"] - r0["dtheta"]).max() <= 1e-10 * np.abs(r0["dtheta"]).max())
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_called_off_or_aborted_persistent_launch_is_redone_inside_the_call(mode):
     """mode 1: the launch waits for a workgroup that never comes -> called off after 1 ms, matrix untouched; mode 2: the chain
@@ -45,20 +53,20 @@ def test_called_off_or_aborted_persistent_launch_is_redone_inside_the_call(mode)
             info, r = c.exact_inference("matern52", True, th, noise)
             assert info == 0 and _key(r) == _key(r0)
         c.set_option("persist_test", mode)
-        info, r = c.exact_inference("matern52", True, th, noise)
-        assert info == 0 and _key(r) == _key(r0)
+        info, rs = c.exact_inference("matern52", True, th, noise)       # redone on launches inside the call
+        assert info == 0 and _close(rs, r0)
         assert c.get_option("persist_aborts") == 1
         skip = c.get_option("persist_skip")
         assert skip > 0
         if mode == 1:
-            for _ in range(skip + 4):                         # back on the persistent schedule (and its graph) afterwards
+            for it in range(skip + 4):                        # launches while the skip lasts, then the persistent schedule again
                 info, r = c.exact_inference("matern52", True, th, noise)
-                assert info == 0 and _key(r) == _key(r0)
+                assert info == 0 and _key(r) == (_key(rs) if it < skip else _key(r0)), it
             assert c.get_option("persist_skip") == 0 and c.get_option("persist_aborts") == 1
         else:
             for _ in range(3):
                 info, r = c.exact_inference("matern52", True, th, noise)
-                assert info == 0 and _key(r) == _key(r0)
+                assert info == 0 and _key(r) == _key(rs)
             assert c.get_option("persist_skip") == skip       # stays off
         # a genuinely non-PD matrix still reports its LAPACK info through the redone factorisation
         Xd = np.vstack([X[:900], X[:900], X[:248]])
@@ -79,9 +87,9 @@ def test_dense_pdinv_redoes_a_called_off_launch(mode, monkeypatch):
     ref = gpy_amd.linalg.pdinv(A)
     monkeypatch.setenv("MI355GP_DENSE_PERSIST_TEST", str(mode))
     got = gpy_amd.linalg.pdinv(A)
-    for a, b in zip(ref[:3], got[:3]):
-        assert np.array_equal(a, b)
-    assert ref[3] == got[3]
+    assert np.array_equal(ref[1], got[1]) and ref[3] == got[3]            # L and logdet: the same bits on every schedule
+    for a, b in ((ref[0], got[0]), (ref[2], got[2])):                      # Ky^-1, L^-1: another summation order
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
     Lj = gpy_amd.linalg.jitchol(A)
     assert np.array_equal(Lj, ref[1])
 
@@ -104,16 +112,17 @@ def test_vardtc_redoes_either_m_by_m_factorisation_in_place(inject, monkeypatch)
         info, r1 = c.vardtc("rbf", False, th, Z, noise)
         monkeypatch.delenv("MI355GP_SPARSE_PERSIST_TEST")
         assert info == 0
-        assert r1["lml"] == r0["lml"] and np.array_equal(r1["dtheta"], r0["dtheta"]) and np.array_equal(r1["dZ"], r0["dZ"])
-        info, r2 = c.vardtc("rbf", False, th, Z, noise)
-        assert info == 0 and r2["lml"] == r0["lml"]
+        assert abs(r1["lml"] - r0["lml"]) <= 1e-11 * abs(r0["lml"])
+        assert np.abs(r1["dtheta"] - r0["dtheta"]).max() <= 1e-8 * np.abs(r0["dtheta"]).max()
+        assert np.abs(r1["dZ"] - r0["dZ"]).max() <= 1e-8 * np.abs(r0["dZ"]).max()
     finally:
         c.close()
 
 
 def test_two_host_threads_with_a_context_each_at_n4096():
     """Two Python threads, one context each, 50 evaluations of configs[1]'s size each, concurrently (ctypes releases the GIL
-    inside the C-ABI call): no error, every evaluation has the bits of the single-threaded one."""
+    inside the C-ABI call): no error, every evaluation has the bits of a single-threaded one (of the persistent schedule, or
+    of the launch-per-step schedule if a launch was called off)."""
     N, D = 4096, 8
     var, ls, noise = O.default_theta(D, False)
     th = L.theta_vec(var, ls, False, D)
@@ -122,9 +131,13 @@ def test_two_host_threads_with_a_context_each_at_n4096():
     for X, Y in data:
         c = L.Context(0)
         c.set_data(X, Y)
-        info, r = c.exact_inference("rbf", False, th, noise)
-        assert info == 0
-        refs.append(_key(r))
+        both = set()
+        for p in (2, 0):                                      # the bits of the persistent schedule and of its fall-back
+            c.set_option("persist", p)
+            info, r = c.exact_inference("rbf", False, th, noise)
+            assert info == 0
+            both.add(_key(r))
+        refs.append(both)
         c.close()
     errors, aborts = [], [0, 0]
 
@@ -134,7 +147,7 @@ def test_two_host_threads_with_a_context_each_at_n4096():
             c.set_data(*data[i])
             for _ in range(50):
                 info, r = c.exact_inference("rbf", False, th, noise)
-                if info != 0 or _key(r) != refs[i]:
+                if info != 0 or _key(r) not in refs[i]:
                     errors.append((i, info))
             aborts[i] = c.get_option("persist_aborts")
             c.close()
@@ -175,8 +188,8 @@ c.close()
 def test_two_processes_sharing_one_gpu_at_n4096():
     """Two PROCESSES on the one GPU, each 50 evaluations at N = 4096 on the default (persistent) schedule.  Their persistent
     launches cannot be co-resident (147 KB of LDS per workgroup, one per CU): whichever comes second waits at the gate, and if
-    the two interleave both are called off and redo on launches.  No error, no -6, and both processes report the bits of
-    a process that has the GPU to itself."""
+    the two interleave both are called off and redo on launches.  No error, no -6, and every evaluation of both processes has
+    the bits a process that has the GPU to itself produces (on the persistent schedule or on its fall-back)."""
     import json
     from gpy_amd.datasets import default_theta, synthetic
     N, D = 4096, 8
@@ -187,9 +200,12 @@ def test_two_processes_sharing_one_gpu_at_n4096():
         X, Y = synthetic(N, D, seed=seed)
         c = L.Context(0)
         c.set_data(X, Y)
-        info, r = c.exact_inference("rbf", False, th, noise)
-        assert info == 0
-        solo[seed] = (float(r["lml"]).hex(), r["dtheta"].tobytes().hex())
+        solo[seed] = set()
+        for p in (2, 0):
+            c.set_option("persist", p)
+            info, r = c.exact_inference("rbf", False, th, noise)
+            assert info == 0
+            solo[seed].add((float(r["lml"]).hex(), r["dtheta"].tobytes().hex()))
         c.close()
     code = _CHILD % {"root": ROOT}
     procs = [subprocess.Popen([sys.executable, "-c", code, str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -198,5 +214,5 @@ def test_two_processes_sharing_one_gpu_at_n4096():
     for seed, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, se[-2000:]
         rec = json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1])
-        assert rec["keys"] == 1, "results changed between evaluations"
-        assert (rec["lml"], rec["dtheta"]) == solo[seed]
+        assert rec["keys"] <= 2, "more than the two schedules' bit patterns"
+        assert (rec["lml"], rec["dtheta"]) in solo[seed]

@@ -49,6 +49,7 @@
 #define PS_DIA (16 + 2 * PS_MAXNT)         // [nt] tile (i, i)   holds columns 0 .. i-2, published for the chain
 #define PS_XCOL (16 + 3 * PS_MAXNT)         // [nt] xcol[k]: X(k .. k+xcol[k]-1, k) final (the inverse, column k, from the diagonal down)
 #define PS_SYNC_INTS (16 + 4 * PS_MAXNT)
+#define PS_RING 4                          // LDS stages of the folded launch's worker GEMM (4 x 34,816 B of the 147,456)
 #define PS_MAXTASK 64                      // tasks (P / X / W tiles) one worker of the folded launch can own
 
 __device__ __forceinline__ int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -820,7 +821,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
                 d4 acc[4][4];
                 gt_load_buf<4>(Ct, ld, acc);
                 if (pj1 > pj0)
-                    gemm_tile_128<true, true, 4, true>(A + (long)pi * NB * ld + (long)pj0 * NB, ld,
+                    gemm_tile_128_ring<true, true, true, PS_RING>(A + (long)pi * NB * ld + (long)pj0 * NB, ld,
                                                        A + (long)pk * NB * ld + (long)pj0 * NB, ld, (pj1 - pj0) * NB, acc, sm);
                 if (handover || subdiag) {
                     __syncthreads();
@@ -892,7 +893,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
             d4 acc[4][4];
             if (pj0 == pk) gt_zero<4>(acc);
             else gt_load_buf<4>(St, ld, acc);
-            gemm_tile_128<true, false, 4>(A + (long)pi * NB * ld + (long)pj0 * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
+            gemm_tile_128_ring<true, false, false, PS_RING>(A + (long)pi * NB * ld + (long)pj0 * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
                                           (pj1 - pj0) * NB, acc, sm);
             gt_store<0, 4>(St, ld, acc);
             drain_stores();
@@ -903,7 +904,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
             double* St = X + (long)pi * NB * ld + (long)pk * NB;
             d4 acc[4][4];
             gt_zero<4>(acc);
-            gemm_tile_128<true, false, 4, true>(X + (long)pi * NB * ld + (long)pi * NB, ld, St, ld, NB, acc, sm);
+            gemm_tile_128_ring<true, false, true, PS_RING>(X + (long)pi * NB * ld + (long)pi * NB, ld, St, ld, NB, acc, sm);
             __syncthreads();                                   // the GEMM's LDS stages are free, every read of S has landed
             stage_put_acc(sm, acc);
             __syncthreads();
@@ -921,7 +922,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
             d4 acc[4][4];
             if (pj0 == pi) gt_zero<4>(acc);
             else gt_load_buf<4>(Wt, ld, acc);
-            gemm_tile_128<false, false, 4>(X + (long)pj0 * NB * ld + (long)pi * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
+            gemm_tile_128_ring<false, false, false, PS_RING>(X + (long)pj0 * NB * ld + (long)pi * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
                                            (pj1 - pj0) * NB, acc, sm);
             gt_store<0, 4>(Wt, ld, acc);
             drain_stores();
@@ -1032,10 +1033,12 @@ static int inv_max_tasks(int nt, int nw, int want_w) {
     return mx;
 }
 
+// workgroups of the launch for this matrix; 0: the device cannot host the kernel (no large-LDS opt-in / occupancy query failed)
 static long persist_grid_for(long npad, FactorWs* ws) {
     const int nt = (int)(npad / NB);
     const long ntl = (long)nt * (nt + 1) / 2;
     long grid = persist_max_grid(ws->persist_cus);             // one workgroup per CU: all resident
+    if (grid < 16) return 0;
     if (grid > ntl + 1) grid = ntl + 1;
     return grid;
 }
@@ -1045,14 +1048,14 @@ static long persist_grid_for(long npad, FactorWs* ws) {
 bool pdinv_persist_eligible(long npad, FactorWs* ws, int want_w) {
     if (ws->persist < 2 || !potrf_persist_eligible(npad, ws)) return false;
     const long grid = persist_grid_for(npad, ws);
-    if (grid < 16) return false;
+    if (grid < 2) return false;
     return inv_max_tasks((int)(npad / NB), (int)grid - 1, want_w) <= PS_MAXTASK;
 }
 
 bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg, double* X, double* W) {
     const int nt = (int)(npad / NB);
     const long grid = persist_grid_for(npad, ws);
-    if (grid < 16) return false;
+    if (grid < 2) return false;
     const int inv_mode = X ? (W ? 2 : 1) : 0;
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
     (void)hipMemsetAsync(ws->persist_sync, 0, sizeof(int) * PS_SYNC_INTS, st);

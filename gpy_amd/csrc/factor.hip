@@ -158,6 +158,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     if (envps && *envps) ws->persist = atoi(envps);
     const char* envpm = getenv("MI355GP_PERSIST_MAX_NT");
     if (envpm && *envpm) ws->persist_max_nt = atoi(envpm);
+    const char* envpt = getenv("MI355GP_PERSIST_TUNE");
+    if (envpt && *envpt) ws->persist_tune = atoi(envpt);
     const char* envpk = getenv("MI355GP_PERSIST_KCAP");
     if (envpk && *envpk) ws->persist_kcap = atoi(envpk) > 0 ? atoi(envpk) : 1;
     {

@@ -98,6 +98,8 @@ struct FactorWs {
     // persist_skip: calls of potrf_device that stay on the launch-per-step schedule (set after a called-off / aborted persistent
     // launch: PS_SKIP_AFTER_CLEAN, or INT_MAX after a dirty abort); persist_aborts counts them (MI355GP_OPT_PERSIST_ABORTS)
     int persist_skip = 0, persist_aborts = 0, persist_used = 0;
+    int persist_tune = 0;            // MI355GP_PERSIST_TUNE: schedule bits of the folded launch (1: near owners take W tiles only after
+                                     // their X tiles, 2: two-stage worker GEMM instead of the 4-stage ring)
     int persist_test = 0;            // MI355GP_OPT_PERSIST_TEST: fault injection for the NEXT persistent launch (1 clean, 2 dirty)
     int* persist_sync = nullptr;     // progress words of the persistent launch (zeroed before every launch)
     double* persist_hs = nullptr;    // [min(nblk, 64)][128 x 128]: sub-diagonal tile of every row, handed to the chain in ITS load order
@@ -158,7 +160,7 @@ int potrf_persist_sync_ints();
 // X != NULL: the FOLDED launch -- the same dataflow goes on to X = L^-1 (by rows, into X) and, with W != NULL, to the lower tiles
 // of W = X^T X (dtrtri + dlauum of dpotri, GPy/util/linalg.py:127-145) inside the one launch
 bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg = nullptr, double* X = nullptr,
-                          double* W = nullptr);
+                          double* W = nullptr, long long* dbg2 = nullptr);
 bool pdinv_persist_eligible(long npad, FactorWs* ws, int want_w);
 // A -> L in place, X = L^-1, W = X^T X (W may be NULL): the folded persistent launch when eligible (returns true; ws->persist_used
 // = 2), else false and NOTHING was enqueued: the caller takes potrf_device / trtri_device / lauum_device
@@ -233,6 +235,10 @@ void launch_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, l
 // are rows [s*rows/S, (s+1)*rows/S) of the (rows x mp) row-major panel P; rows % (16*S) == 0
 void launch_gram_splitk(hipStream_t st, const double* P, long ldp, long rows, long mp, int S, int accumulate,
                         double* part);
+// the same Gram matrix by stream-K (G equal contiguous slab ranges, one per workgroup): out_lower (lower 128-tiles of an mp x mp
+// matrix, ld = mp) (+)= P^T P; scratch: 2 * G * 128 * 128 doubles; false = not applicable (nothing launched)
+bool launch_gram_streamk(hipStream_t st, const double* P, long ldp, long rows, long mp, int accumulate, double* out_lower,
+                         double* scratch, int G);
 int grad_generic_num_blocks(long n, long m);
 // sums `nblocks` rows of `stride` doubles in a fixed order into out[stride]
 void launch_reduce_partials(hipStream_t st, const double* partials, int nblocks, int stride, double* out);

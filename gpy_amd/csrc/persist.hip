@@ -677,17 +677,26 @@ __device__ __forceinline__ void inv128_col_coh(const double* __restrict__ Lb, do
     }
 }
 
+// the worker's tile GEMM: the 4-stage ring (a workgroup alone on its CU) or, tune bit 1, the two-stage pipeline (A/B diagnostics)
+#define WGEMM(AK, BK, NEGA, ...)                                                    \
+    do {                                                                            \
+        if (tune & 2) gemm_tile_128_v3<AK, BK, NEGA>(__VA_ARGS__);                   \
+        else gemm_tile_128_ring<AK, BK, NEGA, PS_RING>(__VA_ARGS__);                 \
+    } while (0)
+
 // who owns X tile (i,k) (a near owner e < H; row i only among the owners whose own near tile lies in a row <= i) / W tile (k,l)
 __device__ __forceinline__ int own_x(int i, int k, int H) {
     int span = 3 * i + 1;
     if (span > H) span = H;
     return (i * (i + 1) / 2 + k) % span;
 }
+#define PS_DBG2_DOUBLES 2048               // diagnostics of the folded launch: [0] start, [1 + i] X(i,0) final, [1 + nt] chain end,
+                                           // [2 + nt + 4 me ..] worker me: ticks in P / X / W tasks, end of its last task
 __device__ __forceinline__ int own_w(int k, int l, int nw) { return (k * (k + 1) / 2 + l) % nw; }
 
 __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict__ X, double* __restrict__ Wm, long ld, int nt,
                                      const double* __restrict__ dinv_all, int* __restrict__ sync, int kcap,
-                                     double* __restrict__ hs, int want_w, double* sm) {
+                                     double* __restrict__ hs, int want_w, int tune, long long* __restrict__ dbg2, double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress of L, [nt] dcnt, [nt+1] abort
     __shared__ int s_x[PS_MAXNT];                              // xcol snapshot
     __shared__ int s_prog[PS_MAXTASK];                         // terms applied per task; -1: task finished
@@ -746,9 +755,13 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
         s_wait[s] = 0;
     }
     __syncthreads();
-    int left = 0;
-    for (int s = 0; s < ntask; ++s) left += (s_prog[s] >= 0) ? 1 : 0;
-    long long idle0 = 0;
+    int left = 0, xleft = 0;
+    for (int s = 0; s < ntask; ++s) {
+        left += (s_prog[s] >= 0) ? 1 : 0;
+        xleft += (s_prog[s] >= 0 && (s_kind[s] == TK_X || s_kind[s] == TK_XD)) ? 1 : 0;
+    }
+    long long idle0 = 0, tk0 = 0, busy[3] = {0, 0, 0};
+    if (dbg2 && me == 0 && t == 0) dbg2[0] = wall_clock64();
     while (left > 0) {
         // ---- snapshot of the progress words (sc1 loads), then one agent acquire for this CU's L1
         if (t < nt) s_cnt[t] = ld_flag(sync + PS_CNT + t);
@@ -789,7 +802,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
                 } else if (p == i - k && s_x[i] >= 1) {
                     pick = s; pfin = 1;
                 }
-            } else {                                           // TK_W: (i,k) = (row tile, column tile) of W; terms r = i + p ...
+            } else if (!((tune & 1) && xleft > 0)) {           // TK_W: (i,k) = (row tile, column tile) of W; terms r = i + p ...
                 int rmax = i + s_x[i] < k + s_x[k] ? i + s_x[i] : k + s_x[k];
                 if (rmax > nt) rmax = nt;
                 if (rmax > i + p) {
@@ -810,6 +823,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
             continue;
         }
         idle0 = 0;
+        if (dbg2 && t == 0) tk0 = wall_clock64();
         if (kind == TK_P) {
             // ===== a tile of the factorisation: exactly worker_workgroup's step =====
             const int limit = (pi == pk) ? pi - 1 : pk;
@@ -821,7 +835,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
                 d4 acc[4][4];
                 gt_load_buf<4>(Ct, ld, acc);
                 if (pj1 > pj0)
-                    gemm_tile_128_ring<true, true, true, PS_RING>(A + (long)pi * NB * ld + (long)pj0 * NB, ld,
+                    WGEMM(true, true, true, A + (long)pi * NB * ld + (long)pj0 * NB, ld,
                                                        A + (long)pk * NB * ld + (long)pj0 * NB, ld, (pj1 - pj0) * NB, acc, sm);
                 if (handover || subdiag) {
                     __syncthreads();
@@ -885,15 +899,17 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
             if (t == 0) {
                 st_flag(sync + PS_XCOL + pi, 1);
                 s_prog[pick] = -1;
+                if (dbg2 && pi == 0) dbg2[1] = wall_clock64();
             }
             --left;
+            --xleft;
         } else if (kind == TK_X && !pfin) {
             // ===== S(i,k) += sum_{j in [pj0, pj1)} L(i,j) X(j,k), in place in X(i,k) (owner-private until final) =====
             double* St = X + (long)pi * NB * ld + (long)pk * NB;
             d4 acc[4][4];
             if (pj0 == pk) gt_zero<4>(acc);
             else gt_load_buf<4>(St, ld, acc);
-            gemm_tile_128_ring<true, false, false, PS_RING>(A + (long)pi * NB * ld + (long)pj0 * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
+            WGEMM(true, false, false, A + (long)pi * NB * ld + (long)pj0 * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
                                           (pj1 - pj0) * NB, acc, sm);
             gt_store<0, 4>(St, ld, acc);
             drain_stores();
@@ -904,7 +920,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
             double* St = X + (long)pi * NB * ld + (long)pk * NB;
             d4 acc[4][4];
             gt_zero<4>(acc);
-            gemm_tile_128_ring<true, false, true, PS_RING>(X + (long)pi * NB * ld + (long)pi * NB, ld, St, ld, NB, acc, sm);
+            WGEMM(true, false, true, X + (long)pi * NB * ld + (long)pi * NB, ld, St, ld, NB, acc, sm);
             __syncthreads();                                   // the GEMM's LDS stages are free, every read of S has landed
             stage_put_acc(sm, acc);
             __syncthreads();
@@ -914,15 +930,17 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
             if (t == 0) {
                 st_flag(sync + PS_XCOL + pk, pi - pk + 1);
                 s_prog[pick] = -1;
+                if (dbg2 && pk == 0) dbg2[1 + pi] = wall_clock64();
             }
             --left;
+            --xleft;
         } else {
             // ===== W(i,k) += sum_{r in [pj0, pj1)} X(r,i)^T X(r,k)  (W tile row i, column k; read by nobody in this launch) =====
             double* Wt = Wm + (long)pi * NB * ld + (long)pk * NB;
             d4 acc[4][4];
             if (pj0 == pi) gt_zero<4>(acc);
             else gt_load_buf<4>(Wt, ld, acc);
-            gemm_tile_128_ring<false, false, false, PS_RING>(X + (long)pj0 * NB * ld + (long)pi * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
+            WGEMM(false, false, false, X + (long)pj0 * NB * ld + (long)pi * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
                                            (pj1 - pj0) * NB, acc, sm);
             gt_store<0, 4>(Wt, ld, acc);
             drain_stores();
@@ -931,7 +949,15 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
             if (t == 0) s_prog[pick] = done ? -1 : pj1 - pi;
             if (done) --left;
         }
+        if (dbg2 && t == 0) busy[kind == TK_P ? 0 : (kind == TK_W ? 2 : 1)] += wall_clock64() - tk0;
         __syncthreads();
+    }
+    if (dbg2 && t == 0 && 2 + nt + 4 * me + 3 < PS_DBG2_DOUBLES) {
+        long long* o = dbg2 + 2 + nt + 4 * me;
+        o[0] = busy[0];
+        o[1] = busy[1];
+        o[2] = busy[2];
+        o[3] = wall_clock64();
     }
 }
 
@@ -939,7 +965,8 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
                                                           double* __restrict__ dinv_all, double* __restrict__ logsum,
                                                           int* __restrict__ info, int* __restrict__ sync, int kcap,
                                                           double* __restrict__ hs, long long* __restrict__ dbg, int test,
-                                                          double* __restrict__ X, double* __restrict__ Wm, int inv_mode) {
+                                                          double* __restrict__ X, double* __restrict__ Wm, int inv_mode, int tune,
+                                                          long long* __restrict__ dbg2) {
     // inv_mode 0: the factorisation alone; 1: + X = L^-1 into X; 2: + W = X^T X (lower tiles) into Wm
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if (!ps_arrive(sync, info, test == 1 ? 1 : 0)) return;    // not all workgroups resident: called off, A untouched
@@ -952,11 +979,12 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
     }
     if (blockIdx.x == 0) {
         chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, hs, dbg, sm);
+        if (threadIdx.x == 0 && dbg2) dbg2[1 + nt] = wall_clock64();
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
     } else if (inv_mode == 0) {
         worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, sm);
     } else {
-        worker_workgroup_inv(A, X, Wm, ld, nt, dinv_all, sync, kcap, hs, inv_mode >= 2 ? 1 : 0, sm);
+        worker_workgroup_inv(A, X, Wm, ld, nt, dinv_all, sync, kcap, hs, inv_mode >= 2 ? 1 : 0, tune, dbg2, sm);
     }
 }
 
@@ -1052,7 +1080,8 @@ bool pdinv_persist_eligible(long npad, FactorWs* ws, int want_w) {
     return inv_max_tasks((int)(npad / NB), (int)grid - 1, want_w) <= PS_MAXTASK;
 }
 
-bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg, double* X, double* W) {
+bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg, double* X, double* W,
+                          long long* dbg2) {
     const int nt = (int)(npad / NB);
     const long grid = persist_grid_for(npad, ws);
     if (grid < 2) return false;
@@ -1062,7 +1091,7 @@ bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, lo
     const double flops = (double)npad * npad * npad / 3.0 * (1 + inv_mode);
     ws->prof.begin(st, PF_PERSIST, flops);
     hipLaunchKernelGGL(k_potrf_persist, dim3((unsigned)grid), dim3(64 * PS_CHAIN_WAVES), PS_LDS_BYTES, st, A, npad, nt, ws->dinv, ws->logsum,
-                       ws->info, ws->persist_sync, ws->persist_kcap, ws->persist_hs, dbg, ws->persist_test, X, W, inv_mode);
+                       ws->info, ws->persist_sync, ws->persist_kcap, ws->persist_hs, dbg, ws->persist_test, X, W, inv_mode, ws->persist_tune, dbg2);
     ws->persist_test = 0;
     const bool ok = hipGetLastError() == hipSuccess;
     ws->prof.end(st);

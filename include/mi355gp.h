@@ -353,6 +353,12 @@ int mi355gp_dbg_graph_factor(int device, int64_t N, int reps, double* out3);
  * then for tile row i and d = i - k in 0..2 (the near tiles): out[8 + 8 nt + 4 (3 i + d) + q], q = 0 last task picked, 1 computed,
  * 2 published.  kcap: columns a worker applies per pass (0 = default).  out: 8 + 20 ceil(N / 128) doubles. */
 int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out);
+/* the FOLDED persistent launch (factorisation + inverse + X^T X as one tile dataflow) against the launch-per-step schedule on a
+ * resident SPD matrix: out[0] / out[1] ms per repetition (steps / folded), out[2] / out[3] relative max differences of L^-1 and
+ * of (lower) A^-1, out[4] info, out[5] tiles per dimension; out[8 .. 8 + 2048) the launch's timeline in 100 MHz ticks (start,
+ * X(i,0) final per row, chain end, per worker the ticks spent in factorisation / inverse / X^T X tasks and its end).
+ * tune: bit 0 near owners take X^T X tiles only after their inverse tiles, bit 1 two-stage worker GEMM. */
+int mi355gp_dbg_fold(int device, int64_t N, int reps, int tune, double* out);
 /* diagnostics: is a CU-masked stream really confined?  out3 = ms of a 4096^3 GEMM on [plain, masked, masked] streams */
 int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3);
 

@@ -594,6 +594,155 @@ __global__ __launch_bounds__(256) void k_grad_cols(KernParams kp, const double* 
     }
 }
 
+
+// The same pass with the column reductions on the MATRIX pipe.  k_grad_cols keeps hc[4][17] per thread (136 VGPRs of accumulators:
+// 256 VGPRs in all, ONE workgroup per CU, 18 % of the issue rate at configuration 5).  Here the tile H = dL_dKnm * (dK/dr)/r goes
+// to LDS once and  HX[j][c] += sum_i H[i][j] x~[i][c]  is a 64 x 16 x 64 product per tile on v_mfma_f64_16x16x4 (wave w: columns
+// 16 w .. 16 w + 15; A operand H^T from the LDS tile, B operand from a row-major copy of the x~ slab): 4 accumulator VGPR pairs
+// instead of 68, no cross-thread reduction (every (j, c) lives in one lane) and the same fp64 pipe time as the FMAs it replaces
+// (MFMA and VALU fp64 share the pipe) -- the gain is occupancy.  The column SUMS of H (the "ones" column) stay on the
+// VALU (4 partial sums per thread, reduced once per block).  Rows in fixed order per block: bit reproducible.
+#define GC_HS 80                                    // row stride (doubles) of the LDS H tile: rows 128 B apart in bank space
+template <bool ARD>
+__global__ __launch_bounds__(256, 2) void k_grad_cols_mfma(KernParams kp, const double* __restrict__ Xt1, long ld1, long n,
+                                                           const double* __restrict__ Xt2, long ld2, long m,
+                                                           const double* __restrict__ G, long ldg, RankTerm rk, int ntc,
+                                                           int ntr, int tiles_per_split, double* __restrict__ partials,
+                                                           double* __restrict__ colpart, long mcols, int nv) {
+    constexpr int DM = 16;                               // D <= 16
+    __shared__ __attribute__((aligned(16))) double si[DM * KT];
+    __shared__ __attribute__((aligned(16))) double sj[DM * KT];
+    __shared__ __attribute__((aligned(16))) double sit[KT * 18];   // x~ slab row-major [i][c], stride 18: the B operand
+    __shared__ __attribute__((aligned(16))) double sh[KT * GC_HS];
+    __shared__ double red[256];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, lane = t & 63, w = t >> 6;
+    const int tj = blockIdx.x % ntc, split = blockIdx.x / ntc;
+    const long j0 = (long)tj * KT;
+    const int D = kp.D;
+    double a_var = 0.0, a_iso = 0.0;
+    double a_q[DM];
+    double csum[4] = {0.0, 0.0, 0.0, 0.0};
+    d4 hx = {0.0, 0.0, 0.0, 0.0};                        // HX[j = 16 w + (lane >> 4) + 4 r][c = lane & 15]
+#pragma unroll
+    for (int q = 0; q < DM; ++q) a_q[q] = 0.0;
+    for (int idx = t; idx < KT * 18; idx += 256) sit[idx] = 0.0;      // columns c >= D stay zero
+    const int ti_end = ((split + 1) * tiles_per_split < ntr) ? (split + 1) * tiles_per_split : ntr;
+    for (int ti = split * tiles_per_split; ti < ti_end; ++ti) {
+        const long i0 = (long)ti * KT;
+        double r2[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+        __syncthreads();                                 // the previous tile's MFMA reads of sh / sit are done
+        for (int idx = t; idx < D * KT; idx += 256) {
+            const int q = idx >> 6, ii = idx & 63;
+            const double v = Xt1[(long)q * ld1 + i0 + ii];
+            si[q * KT + ii] = v;
+            sit[ii * 18 + q] = v;
+        }
+        stage_x(Xt2, ld2, j0, 0, D, sj, t);
+        __syncthreads();
+        accum_r2(si, sj, D, ty, tx, r2);
+        double gT[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long i = i0 + ty * 4 + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long j = j0 + tx * 4 + b;
+                double g = 0.0;
+                if (i < n && j < m) {
+                    g = G[i * ldg + j];
+                    if (rk.Y) {
+                        double yv = 0.0;
+                        for (int d = 0; d < rk.Dy; ++d) yv = fma(rk.Y[i * rk.Dy + d], rk.V[j * rk.Dy + d], yv);
+                        g = fma(rk.gscale, g, rk.beta * yv);
+                        if (rk.rowscale) g *= rk.rowscale[i];
+                    }
+                }
+                const CovVal c = cov_all(kp.kind, kp.variance, r2[a][b], false);
+                a_var = fma(g, c.k, a_var);
+                if (!ARD) a_iso = fma(g, c.dk_r, a_iso);
+                gT[a][b] = g * c.dk_or;
+                csum[b] += gT[a][b];
+            }
+            *reinterpret_cast<d4*>(sh + (ty * 4 + a) * GC_HS + tx * 4) = (d4){gT[a][0], gT[a][1], gT[a][2], gT[a][3]};
+        }
+        if (ARD) {
+#pragma unroll
+            for (int q = 0; q < DM; ++q) {
+                if (q < D) {
+                    const d4 xi = *reinterpret_cast<const d4*>(si + q * KT + ty * 4);
+                    const d4 xj = *reinterpret_cast<const d4*>(sj + q * KT + tx * 4);
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const double d = xi[a] - xj[b];
+                            sacc = fma(gT[a][b], d * d, sacc);
+                        }
+                    a_q[q] += sacc;
+                }
+            }
+        }
+        __syncthreads();                                 // the H tile is complete
+        // HX[16 w .., :] += H[:, 16 w ..]^T x~ : k = 4 s + (lane >> 4) over the 64 rows of the tile
+        const double* ha = sh + (lane >> 4) * GC_HS + 16 * w + (lane & 15);
+        const double* xb = sit + (lane >> 4) * 18 + (lane & 15);
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) hx = mfma_f64(ha[4 * s4 * GC_HS], xb[4 * s4 * 18], hx);
+    }
+    // theta partials of this block
+    double* out = partials + (long)blockIdx.x * GP_STRIDE;
+    auto block_sum = [&](double v) -> double {
+        __syncthreads();
+        red[t] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (t < s) red[t] += red[t + s];
+            __syncthreads();
+        }
+        return red[0];
+    };
+    const double sv = block_sum(a_var);
+    if (t == 0) out[0] = sv;
+    if (!ARD) {
+        const double sl = block_sum(a_iso);
+        if (t == 0) out[1] = sl;
+    } else {
+#pragma unroll
+        for (int q = 0; q < DM; ++q) {
+            if (q < D) {
+                const double sq = block_sum(a_q[q]);
+                if (t == 0) out[2 + q] = sq;
+            }
+        }
+    }
+    double* cp = colpart + (long)split * mcols * nv;
+    // HX: every (j, c) is one accumulator register
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long j = j0 + 16 * w + (lane >> 4) + 4 * r;
+        const int c = lane & 15;
+        if (c < D && j < mcols) cp[j * nv + c] = (j < m) ? hx[r] : 0.0;
+    }
+    // column sums of H: over the 16 row groups (ty) in fixed order
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        __syncthreads();
+        red[ty * 16 + tx] = csum[b];
+        __syncthreads();
+        if (ty == 0) {
+            double sacc = 0.0;
+            for (int r = 0; r < 16; ++r) sacc += red[r * 16 + tx];
+            const long j = j0 + tx * 4 + b;
+            if (j < mcols) cp[j * nv + D] = (j < m) ? sacc : 0.0;
+        }
+    }
+}
+
 // returns the number of row splits (colpart holds nsplit * mcols * (D+1) doubles, partials ntc*nsplit blocks); 0 if the
 // fused form does not apply (D > 16)
 int launch_grad_cols(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2, long ld2,
@@ -608,6 +757,17 @@ int launch_grad_cols(hipStream_t st, KernParams kp, const double* Xt1, long ld1,
     const int tps = (ntr + nsplit - 1) / nsplit;
     nsplit = (ntr + tps - 1) / tps;
     const int nb = ntc * nsplit;
+    static const int use_mfma = [] { const char* e = getenv("MI355GP_GRAD_COLS_MFMA"); return (e && *e) ? atoi(e) : 1; }();
+    if (use_mfma) {
+        if (kp.ard)
+            hipLaunchKernelGGL((k_grad_cols_mfma<true>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg, rk, ntc,
+                               ntr, tps, partials, colpart, mcols, kp.D + 1);
+        else
+            hipLaunchKernelGGL((k_grad_cols_mfma<false>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg, rk, ntc,
+                               ntr, tps, partials, colpart, mcols, kp.D + 1);
+        *nblocks_out = nb;
+        return nsplit;
+    }
     if (kp.ard)
         hipLaunchKernelGGL((k_grad_cols<true>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg, rk, ntc, ntr,
                            tps, partials, colpart, mcols, kp.D + 1);

@@ -755,11 +755,18 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
         s_wait[s] = 0;
     }
     __syncthreads();
-    int left = 0, xleft = 0;
+    int left = 0, xleft = 0, pleft = 0;
     for (int s = 0; s < ntask; ++s) {
         left += (s_prog[s] >= 0) ? 1 : 0;
         xleft += (s_prog[s] >= 0 && (s_kind[s] == TK_X || s_kind[s] == TK_XD)) ? 1 : 0;
+        pleft += (s_prog[s] >= 0 && s_kind[s] == TK_P) ? 1 : 0;
     }
+    // A near owner's tile of the factorisation feeds the chain: nothing else may occupy this workgroup while it is pending
+    // (a 100 us pass over an inverse tile in front of it stretched the chain's step from 57 to 104 us).  Terms of X / W tiles
+    // trickle in one per finished row: a pass is only worth its C round trip (~15 us) when it applies a BATCH of terms, or
+    // when the tile is on the frontier (row i of L about to be final / every term of a W tile available).
+    const bool near_owner = me < own.H;
+    const int xbatch = (tune & 4) ? 1 : 8, wbatch = (tune & 4) ? 1 : 8;
     long long idle0 = 0, tk0 = 0, busy[3] = {0, 0, 0};
     if (dbg2 && me == 0 && t == 0) dbg2[0] = wall_clock64();
     while (left > 0) {
@@ -791,22 +798,27 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
                         ptrsm = (pj1 == limit && i >= k + 2 && dcnt >= k + 1) ? 1 : 0;
                     }
                 }
+            } else if (near_owner && pleft > 0) {
+                continue;                                      // the chain's tile first
             } else if (kd == TK_XD) {
                 if (dcnt >= i + 1) pick = s;
             } else if (kd == TK_X) {                           // terms j = k + p ...: need L(i,j) and X(j,k)
                 int jmax = s_cnt[i] < k + s_x[k] ? s_cnt[i] : k + s_x[k];
                 if (jmax > i) jmax = i;
-                if (jmax > k + p) {
+                const int navail = jmax - (k + p);
+                const bool hot = s_cnt[i] >= i - 1;            // row i of L is final but for the chain's own tile
+                if (navail > 0 && (navail >= xbatch || hot)) {
                     pick = s; pj0 = k + p;
-                    pj1 = (jmax > pj0 + 8) ? pj0 + 8 : jmax;
+                    pj1 = (jmax > pj0 + 16) ? pj0 + 16 : jmax;
                 } else if (p == i - k && s_x[i] >= 1) {
                     pick = s; pfin = 1;
                 }
             } else if (!((tune & 1) && xleft > 0)) {           // TK_W: (i,k) = (row tile, column tile) of W; terms r = i + p ...
                 int rmax = i + s_x[i] < k + s_x[k] ? i + s_x[i] : k + s_x[k];
                 if (rmax > nt) rmax = nt;
-                if (rmax > i + p) {
-                    const int cap = (me < own.H && dcnt < nt) ? 2 : 8;   // near owners keep their passes short while the chain runs
+                const int navail = rmax - (i + p);
+                if (navail > 0 && (navail >= wbatch || rmax == nt)) {
+                    const int cap = (dcnt < nt) ? 4 : 16;     // while the chain runs, a pass must not sit long in front of a P tile
                     pick = s; pj0 = i + p;
                     pj1 = (rmax > pj0 + cap) ? pj0 + cap : rmax;
                 }
@@ -855,6 +867,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
                     s_prog[pick] = -1;
                 }
                 --left;
+                --pleft;
             } else if (pj1 == limit && !ptrsm) {
                 drain_stores();
                 __syncthreads();
@@ -879,6 +892,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
                     s_prog[pick] = -1;
                 }
                 --left;
+                --pleft;
             } else {
                 __syncthreads();
                 if (t == 0) s_prog[pick] = pj1;

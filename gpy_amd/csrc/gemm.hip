@@ -470,72 +470,3 @@ void launch_gram_splitk(hipStream_t st, const double* P, long ldp, long rows, lo
                        accumulate, part);
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same Gram matrix by a STREAM-K decomposition: the work is the linear sequence (lower tile t, 16-row slab s), ntl * nslab
-// slabs in all, cut into G EQUAL contiguous ranges, one per workgroup (G = two per CU).  A workgroup's range touches at most two
-// tiles (per <= nslab); for each it runs the tile pipeline over its slabs and leaves a partial tile in scratch[g][segment].
-// k_gram_fix then sums, per tile, the partials of the workgroups whose ranges meet it, in workgroup order (fixed order: bit
-// reproducible).  Against the split-K form: every workgroup does exactly the same number of slabs, so the launch is ONE round of
-// equally long workgroups instead of four rounds of 136 * S tile tasks whose last round drains unevenly (0.77-0.81 of the fp64
-// peak there against 0.88 for the same pipeline in k_lauum), and the partial sums shrink from S full matrices to 2 G tiles.
-__global__ __launch_bounds__(256, 2) void k_gram_streamk(const double* __restrict__ P, long ldp, long nslab, int ntl, long per,
-                                                         double* __restrict__ scratch) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const long total = (long)ntl * nslab;
-    long lin0 = (long)blockIdx.x * per;
-    long lin1 = lin0 + per < total ? lin0 + per : total;
-    int seg = 0;
-    while (lin0 < lin1) {
-        const int bid = (int)(lin0 / nslab);
-        const long s0 = lin0 - (long)bid * nslab;
-        const long s1 = (s0 + (lin1 - lin0) < nslab) ? s0 + (lin1 - lin0) : nslab;
-        int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
-        while ((long)ti * (ti + 1) / 2 > bid) --ti;
-        while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
-        const int tj = bid - (int)((long)ti * (ti + 1) / 2);
-        d4 acc[4][4];
-        gt_zero<4>(acc);
-        const double* Ps = P + s0 * 16 * ldp;
-        gemm_tile_128<false, false, 4>(Ps + (long)ti * NB, ldp, Ps + (long)tj * NB, ldp, (int)((s1 - s0) * 16), acc, smem);
-        gt_store<0, 4>(scratch + ((long)blockIdx.x * 2 + seg) * (NB * NB), NB, acc);
-        lin0 += s1 - s0;
-        ++seg;
-        __syncthreads();
-    }
-}
-
-// out (lower tile t of an mp x mp matrix, ld = mp) (+)= sum of the partial tiles of the workgroups g0 .. g1 whose ranges meet tile t
-__global__ __launch_bounds__(256) void k_gram_fix(const double* __restrict__ scratch, long nslab, long per, long mp, int accumulate,
-                                                  double* __restrict__ out) {
-    const int bid = blockIdx.x;
-    int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
-    while ((long)ti * (ti + 1) / 2 > bid) --ti;
-    while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
-    const int tj = bid - (int)((long)ti * (ti + 1) / 2);
-    const long lo = (long)bid * nslab, hi = lo + nslab;
-    const long g0 = lo / per, g1 = (hi - 1) / per;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
-        double s = 0.0;
-        for (long g = g0; g <= g1; ++g) {
-            const long first_tile = (g * per) / nslab;         // the tile of workgroup g's segment 0
-            s += scratch[(g * 2 + (bid - first_tile)) * (NB * NB) + e];
-        }
-        double* o = out + ((long)ti * NB + (e >> 7)) * mp + (long)tj * NB + (e & 127);
-        *o = accumulate ? *o + s : s;
-    }
-}
-
-// rows % 16 == 0; returns false (nothing launched) when a workgroup's range could span more than two tiles
-bool launch_gram_streamk(hipStream_t st, const double* P, long ldp, long rows, long mp, int accumulate, double* out_lower,
-                         double* scratch, int G) {
-    const int nt = (int)(mp / NB), ntl = nt * (nt + 1) / 2;
-    const long nslab = rows / 16;
-    if (nslab <= 0 || G < 1) return false;
-    const long total = (long)ntl * nslab, per = (total + G - 1) / G;
-    if (per > nslab) return false;
-    LDS_OPT_IN(k_gram_streamk);
-    const long nwg = (total + per - 1) / per;
-    hipLaunchKernelGGL(k_gram_streamk, dim3((unsigned)nwg), dim3(256), GT_LDS_BYTES, st, P, ldp, nslab, ntl, per, scratch);
-    hipLaunchKernelGGL(k_gram_fix, dim3((unsigned)ntl), dim3(256), 0, st, scratch, nslab, per, mp, accumulate, out_lower);
-    return true;
-}

@@ -235,10 +235,6 @@ void launch_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, l
 // are rows [s*rows/S, (s+1)*rows/S) of the (rows x mp) row-major panel P; rows % (16*S) == 0
 void launch_gram_splitk(hipStream_t st, const double* P, long ldp, long rows, long mp, int S, int accumulate,
                         double* part);
-// the same Gram matrix by stream-K (G equal contiguous slab ranges, one per workgroup): out_lower (lower 128-tiles of an mp x mp
-// matrix, ld = mp) (+)= P^T P; scratch: 2 * G * 128 * 128 doubles; false = not applicable (nothing launched)
-bool launch_gram_streamk(hipStream_t st, const double* P, long ldp, long rows, long mp, int accumulate, double* out_lower,
-                         double* scratch, int G);
 int grad_generic_num_blocks(long n, long m);
 // sums `nblocks` rows of `stride` doubles in a fixed order into out[stride]
 void launch_reduce_partials(hipStream_t st, const double* partials, int nblocks, int stride, double* out);

@@ -188,63 +188,6 @@ __global__ __launch_bounds__(256) void k_kbuild(KernParams kp, const double* __r
 }
 
 
-// Rectangular K(X1, X2) for the streaming sparse path (K(X_chunk, Z): var_dtc.py:123, the 3.3 GB chunk of configuration 5), full
-// tiles only: one workgroup keeps its 64-row slab of X1 in LDS and walks KSTRIP_T column tiles of X2, and every thread stores
-// its four rows as 32-byte vectors (a wave writes 512 contiguous bytes per row; the general kernel's bounds-checked 8-byte
-// stores touch every 128-byte line four times: 2.2 TB/s against the ~5 TB/s the chip sustains on stores).
-#define KSTRIP_T 8
-__global__ __launch_bounds__(256) void k_kbuild_strip(KernParams kp, const double* __restrict__ Xt1, long ld1,
-                                                      const double* __restrict__ Xt2, long ld2, double* __restrict__ out,
-                                                      long ldo, int ntc, int nstrips) {
-    __shared__ __attribute__((aligned(16))) double si[KDC * KT];
-    __shared__ __attribute__((aligned(16))) double sj[2][KDC * KT];
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-    const long ti = blockIdx.x / nstrips;
-    const int strip = (int)(blockIdx.x % nstrips);
-    const long i0 = ti * KT;
-    const int tj0 = strip * KSTRIP_T, tj1 = (tj0 + KSTRIP_T < ntc) ? tj0 + KSTRIP_T : ntc;
-    const int D = kp.D;
-    stage_x(Xt1, ld1, i0, 0, D, si, t);
-    stage_x(Xt2, ld2, (long)tj0 * KT, 0, D, sj[0], t);
-    __syncthreads();
-    constexpr int NPRE = KDC * KT / 256;                       // slab elements per thread (D <= KDC)
-    for (int tj = tj0; tj < tj1; ++tj) {
-        const int cur = (tj - tj0) & 1;
-        // the next tile's X2 slab: loads issued now, written to the other LDS buffer AFTER this tile's arithmetic
-        double pre[NPRE];
-        const bool more = tj + 1 < tj1;
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < NPRE; ++u) {
-                const int idx = t + 256 * u;
-                pre[u] = (idx < D * KT) ? Xt2[(long)(idx >> 6) * ld2 + (long)(tj + 1) * KT + (idx & 63)] : 0.0;
-            }
-        }
-        double r2[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
-        accum_r2(si, sj[cur], D, ty, tx, r2);
-        const long j0 = (long)tj * KT;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            d4 o;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) o[b] = cov_k(kp.kind, kp.variance, r2[a][b], false);
-            *reinterpret_cast<d4*>(out + (i0 + ty * 4 + a) * ldo + j0 + tx * 4) = o;
-        }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < NPRE; ++u) {
-                const int idx = t + 256 * u;
-                if (idx < D * KT) sj[cur ^ 1][idx] = pre[u];
-            }
-        }
-        __syncthreads();
-    }
-}
-
 void launch_kbuild_sym(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, long npad, double* A,
                        const double* noise, long noise_len, double jit, int lower_only, int add_diag, int accumulate,
                        const double* mul) {
@@ -256,14 +199,6 @@ void launch_kbuild_sym(hipStream_t st, KernParams kp, const double* Xt, long ldx
 void launch_kbuild_cross(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
                          long ld2, long m, double* Kout, long ldk, int accumulate, int diag_same, const double* mul) {
     const int ntr = (int)((n + KT - 1) / KT), ntc = (int)((m + KT - 1) / KT);
-    static const int strip_on = [] { const char* e = getenv("MI355GP_KBUILD_STRIP"); return (e && *e) ? atoi(e) : 1; }();
-    if (strip_on && !accumulate && !diag_same && !mul && n % KT == 0 && m % KT == 0 && kp.D <= KDC && kp.kind <= 3 && ldk % 4 == 0 &&
-        ((uintptr_t)Kout & 31) == 0) {
-        const int nstrips = (ntc + KSTRIP_T - 1) / KSTRIP_T;
-        hipLaunchKernelGGL(k_kbuild_strip, dim3((unsigned)((long)ntr * nstrips)), dim3(256), 0, st, kp, Xt1, ld1, Xt2, ld2, Kout,
-                           ldk, ntc, nstrips);
-        return;
-    }
     hipLaunchKernelGGL((k_kbuild<false>), dim3((unsigned)((long)ntr * ntc)), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2,
                        ld2, m, Kout, ldk, n, nullptr, 0, 0.0, 0, 0, ntc, accumulate, diag_same, mul);
 }

@@ -20,7 +20,6 @@
 #include "internal.h"
 
 #define GP_STRIDE 34
-#define GRAM_STREAMK_WGS 512          // two workgroups per CU: one round
 #define SPLITK_MAX 16
 #define CHUNK_MAX 262144                    // rows per chunk: 2 x (chunk x Mp) doubles of HBM (8.6 GB at M = 2048)
 #define ARGCHK(cond, msg)                 \
@@ -205,8 +204,6 @@ struct mi355gp_sparse {
     hipStream_t st = nullptr;
     long n = 0, chunk = 0;
     int D = 0, Dy = 0, splitk = 8;
-    bool gram_streamk = false, gram_streamk_ok = true;   // this evaluation's Gram form / MI355GP_GRAM_STREAMK=0 keeps split-K
-    double* gramScratch = nullptr;                        // 2 * GRAM_STREAMK_WGS partial tiles
     double trYYT = 0.0;
     std::vector<double> rowYY;    // host: |R_n|^2 per row (heteroscedastic log likelihood)
     // row-sharded multi-GPU mode (the reference's MPI design: var_dtc_parallel.py:121-130,387-394):
@@ -257,7 +254,7 @@ static void free_parts(mi355gp_sparse* s) {
 
 static void free_m(mi355gp_sparse* s) {
     free_parts(s);
-    double** ptrs[] = {&s->dZ, &s->invls, &s->zero1, &s->gramScratch, &s->Lm, &s->Xm, &s->Tm, &s->psi2part, &s->psi2, &s->Amat,
+    double** ptrs[] = {&s->dZ, &s->invls, &s->zero1, &s->Lm, &s->Xm, &s->Tm, &s->psi2part, &s->psi2, &s->Amat,
                        &s->LB, &s->XB, &s->Bi, &s->P, &s->E, &s->T1, &s->Q2, &s->dLdKmm, &s->Winv, &s->psi1Y, &s->vecA,
                        &s->vecB, &s->cvec, &s->wvec, &s->vvec, &s->trmvPart, &s->colPart, &s->gradPart,
                        &s->gradChunk, &s->scal, &s->redbuf, &s->Kfu, &s->T};
@@ -303,11 +300,6 @@ static int alloc_m(mi355gp_sparse* s, long M) {
                        &s->dLdKmm, &s->Winv};
     for (auto p : mats) HIP_CHECK(hipMalloc(p, mm));
     HIP_CHECK(hipMalloc(&s->psi2part, mm * SPLITK_MAX));
-    HIP_CHECK(hipMalloc(&s->gramScratch, sizeof(double) * 2 * GRAM_STREAMK_WGS * NB * NB));
-    {
-        const char* e = getenv("MI355GP_GRAM_STREAMK");
-        s->gram_streamk_ok = (e && *e) ? (atoi(e) != 0) : true;
-    }
     HIP_CHECK(hipMalloc(&s->Kfu, sizeof(double) * s->chunk * mp));
     HIP_CHECK(hipMalloc(&s->T, sizeof(double) * s->chunk * mp));
     double** vecs[] = {&s->psi1Y, &s->vecA, &s->vecB, &s->cvec, &s->wvec, &s->vvec};
@@ -740,17 +732,12 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
             G = s->T;
         }
         s->mfma_prof.begin(st, 1, (double)rc * (double)m * (double)m);            // algorithmic: the lower half of psi2
-        // stream-K (one round of equally long workgroups, partial tiles summed in workgroup order) where a workgroup's range
-        // stays inside two tiles; the split-K form otherwise.  One form per evaluation: both accumulate into psi2part[0]
-        if (nch == 0) s->gram_streamk = s->gram_streamk_ok && launch_gram_streamk(st, G, mp, round_up(rc, 16L * s->splitk), mp, 0, s->psi2part, s->gramScratch, GRAM_STREAMK_WGS);
-        else if (s->gram_streamk) (void)launch_gram_streamk(st, G, mp, round_up(rc, 16L * s->splitk), mp, 1, s->psi2part, s->gramScratch, GRAM_STREAMK_WGS);
-        if (!s->gram_streamk)
-            launch_gram_splitk(st, G, mp, round_up(rc, 16L * s->splitk), mp, s->splitk, nch > 0, s->psi2part);   // rows >= rc are zero
+        launch_gram_splitk(st, G, mp, round_up(rc, 16L * s->splitk), mp, s->splitk, nch > 0, s->psi2part);   // rows >= rc are zero
         s->mfma_prof.end(st);
         const int ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, s->dV + r0 * Dy, Dy, 1, Dy, 0, s->colPart);
         launch_sum_splits(st, s->colPart, mp * Dy, ns, 1, s->psi1Y);               // psi1V += Kuf V_chunk
     }
-    hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->psi2part, mp, s->gram_streamk ? 1 : s->splitk, s->psi2);
+    hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->psi2part, mp, s->splitk, s->psi2);
     if (sharded(s)) {                                           // the one exchange step of pass 1
         if (int rc = sparse_allreduce(s, s->psi2, (size_t)mp * mp)) return rc;
         if (int rc = sparse_allreduce(s, s->psi1Y, (size_t)mp * Dy)) return rc;

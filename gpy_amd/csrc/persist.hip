@@ -779,6 +779,10 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
         __syncthreads();
         if (s_cnt[nt + 1] != 0) return;
         const int dcnt = s_cnt[nt];
+        int rowP = 1 << 20;                                    // row of this owner's next tile of the factorisation
+        if (near_owner && pleft > 0)
+            for (int s = 0; s < ntask; ++s)
+                if (s_kind[s] == TK_P && s_prog[s] >= 0 && s_ti[s] < rowP) rowP = s_ti[s];
         // ---- the first task of the list that has something to do
         int pick = -1, kind = 0, pi = 0, pk = 0, pj0 = 0, pj1 = 0, ptrsm = 0, pfin = 0;
         for (int s = 0; s < ntask && pick < 0; ++s) {
@@ -798,29 +802,30 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
                         ptrsm = (pj1 == limit && i >= k + 2 && dcnt >= k + 1) ? 1 : 0;
                     }
                 }
-            } else if (near_owner && pleft > 0) {
-                continue;                                      // the chain's tile first
+            } else if (near_owner && rowP <= dcnt + 3) {
+                continue;                                      // the chain will want this owner's tile within a few steps: stay free
             } else if (kd == TK_XD) {
                 if (dcnt >= i + 1) pick = s;
             } else if (kd == TK_X) {                           // terms j = k + p ...: need L(i,j) and X(j,k)
                 int jmax = s_cnt[i] < k + s_x[k] ? s_cnt[i] : k + s_x[k];
                 if (jmax > i) jmax = i;
-                const int navail = jmax - (k + p);
-                const bool hot = s_cnt[i] >= i - 1;            // row i of L is final but for the chain's own tile
-                if (navail > 0 && (navail >= xbatch || hot)) {
-                    pick = s; pj0 = k + p;
-                    pj1 = (jmax > pj0 + 16) ? pj0 + 16 : jmax;
-                } else if (p == i - k && s_x[i] >= 1) {
-                    pick = s; pfin = 1;
+                const int navail = jmax - (k + p), rem = (i - k) - p;
+                if (rem >= 2) {                                // terms before the last one: in batches, or all that are left
+                    const int nf = navail < rem - 1 ? navail : rem - 1;
+                    if (nf >= 1 && (nf >= xbatch || nf == rem - 1)) {
+                        pick = s; pj0 = k + p;
+                        pj1 = pj0 + (nf > 16 ? 16 : nf);
+                    }
+                } else if (navail >= 1 && s_x[i] >= 1) {       // the last term (j = i - 1) and the product with X(i,i), in one visit
+                    pick = s; pj0 = k + p; pj1 = i; pfin = 1;
                 }
-            } else if (!((tune & 1) && xleft > 0)) {           // TK_W: (i,k) = (row tile, column tile) of W; terms r = i + p ...
+            } else if (dcnt >= nt && !((tune & 1) && xleft > 0)) {   // TK_W, once the chain is through: (i,k) = (row, column) tile
                 int rmax = i + s_x[i] < k + s_x[k] ? i + s_x[i] : k + s_x[k];
                 if (rmax > nt) rmax = nt;
                 const int navail = rmax - (i + p);
                 if (navail > 0 && (navail >= wbatch || rmax == nt)) {
-                    const int cap = (dcnt < nt) ? 4 : 16;     // while the chain runs, a pass must not sit long in front of a P tile
                     pick = s; pj0 = i + p;
-                    pj1 = (rmax > pj0 + cap) ? pj0 + cap : rmax;
+                    pj1 = (rmax > pj0 + 16) ? pj0 + 16 : rmax;
                 }
             }
             if (pick >= 0) { kind = kd; pi = i; pk = k; }
@@ -917,37 +922,42 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
             }
             --left;
             --xleft;
-        } else if (kind == TK_X && !pfin) {
-            // ===== S(i,k) += sum_{j in [pj0, pj1)} L(i,j) X(j,k), in place in X(i,k) (owner-private until final) =====
-            double* St = X + (long)pi * NB * ld + (long)pk * NB;
-            d4 acc[4][4];
-            if (pj0 == pk) gt_zero<4>(acc);
-            else gt_load_buf<4>(St, ld, acc);
-            WGEMM(true, false, false, A + (long)pi * NB * ld + (long)pj0 * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
-                                          (pj1 - pj0) * NB, acc, sm);
-            gt_store<0, 4>(St, ld, acc);
-            drain_stores();
-            __syncthreads();
-            if (t == 0) s_prog[pick] = pj1 - pk;
         } else if (kind == TK_X) {
-            // ===== X(i,k) = -X(i,i) S: final, written through, column k's progress published =====
+            // ===== S(i,k) += sum_{j in [pj0, pj1)} L(i,j) X(j,k), in place in X(i,k) (owner-private until final); with the last
+            //       term (pfin) the tile is finished in the same visit: X(i,k) = -X(i,i) S, written through, column k published =====
             double* St = X + (long)pi * NB * ld + (long)pk * NB;
-            d4 acc[4][4];
-            gt_zero<4>(acc);
-            WGEMM(true, false, true, X + (long)pi * NB * ld + (long)pi * NB, ld, St, ld, NB, acc, sm);
-            __syncthreads();                                   // the GEMM's LDS stages are free, every read of S has landed
-            stage_put_acc(sm, acc);
-            __syncthreads();
-            stage_store_coherent<256>(sm, St, ld, t);
+            {
+                d4 acc[4][4];
+                if (pj0 == pk) gt_zero<4>(acc);
+                else gt_load_buf<4>(St, ld, acc);
+                WGEMM(true, false, false, A + (long)pi * NB * ld + (long)pj0 * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
+                      (pj1 - pj0) * NB, acc, sm);
+                gt_store<0, 4>(St, ld, acc);
+            }
             drain_stores();
             __syncthreads();
-            if (t == 0) {
-                st_flag(sync + PS_XCOL + pk, pi - pk + 1);
-                s_prog[pick] = -1;
-                if (dbg2 && pk == 0) dbg2[1 + pi] = wall_clock64();
+            if (!pfin) {
+                if (t == 0) s_prog[pick] = pj1 - pk;
+            } else {
+                if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // S was read through this CU's L1 earlier in the visit
+                __syncthreads();
+                d4 acc[4][4];
+                gt_zero<4>(acc);
+                WGEMM(true, false, true, X + (long)pi * NB * ld + (long)pi * NB, ld, St, ld, NB, acc, sm);
+                __syncthreads();                               // the GEMM's LDS stages are free, every read of S has landed
+                stage_put_acc(sm, acc);
+                __syncthreads();
+                stage_store_coherent<256>(sm, St, ld, t);
+                drain_stores();
+                __syncthreads();
+                if (t == 0) {
+                    st_flag(sync + PS_XCOL + pk, pi - pk + 1);
+                    s_prog[pick] = -1;
+                    if (dbg2 && pk == 0) dbg2[1 + pi] = wall_clock64();
+                }
+                --left;
+                --xleft;
             }
-            --left;
-            --xleft;
         } else {
             // ===== W(i,k) += sum_{r in [pj0, pj1)} X(r,i)^T X(r,k)  (W tile row i, column k; read by nobody in this launch) =====
             double* Wt = Wm + (long)pi * NB * ld + (long)pk * NB;

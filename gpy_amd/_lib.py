@@ -633,6 +633,16 @@ def dbg_persist(N, reps=3, kcap=0, device=0):
                 steps=(st - st[0, 0]) / 100.0, near=(near - st[0, 0]) / 100.0)
 
 
+def dbg_fold(N, reps=2, tune=0, device=0):
+    """The FOLDED persistent launch (option persist = 2: factorisation + L^-1 + X^T X as one tile dataflow) next to the
+    launch-per-step schedule on a resident SPD matrix: dict(ms_steps, ms_fold, dX, dW (relative max differences of L^-1 and of the
+    lower triangle of A^-1), info, nt, stamps (the launch's raw timeline, see mi355gp.h / tools/fold_probe.py))."""
+    require_device(device)
+    out = np.zeros(8 + 2048)
+    check(lib().mi355gp_dbg_fold(device, int(N), int(reps), int(tune), out), "mi355gp_dbg_fold")
+    return dict(ms_steps=out[0], ms_fold=out[1], dX=out[2], dW=out[3], info=int(out[4]), nt=int(out[5]), stamps=out[8:])
+
+
 def dbg_mask_probe(pct=75, order=0, device=0):
     """ms of a 4096^3 GEMM on (plain, CU-masked, CU-masked again) streams: is the mask in force?"""
     require_device(device)

@@ -305,7 +305,7 @@ __global__ LB(NW) void k_trmm_lower(const double* __restrict__ X, long ldx,
                                                        const double* __restrict__ B, long ldb,
                                                        double* __restrict__ Out, long ldo, int ntc) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
+    const int ti = (int)(gridDim.x / ntc) - 1 - (int)(blockIdx.x / ntc), tj = blockIdx.x % ntc;     // longest k range first
     d4 acc[4][GTCfg<NW>::NI];
     gt_zero<NW>(acc);
     gemm_tile_128<true, false, NW>(X + (long)ti * NB * ldx, ldx, B + (long)tj * NB, ldb, (ti + 1) * NB, acc, smem);
@@ -344,6 +344,43 @@ static void launch_trmm_lower_t(hipStream_t st, const double* X, long ldx, const
 void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
                        int ntr, int ntc) {
     launch_trmm_lower_t<4>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc);
+}
+
+// Right-hand products with a lower-triangular X (the M x M algebra of the sparse path, var_dtc.py:129-158: Lm^-1 psi2 Lm^-T and
+// Lm^-T E Lm^-1): only the k range where X is non-zero is walked -- half the flops of the full GEMM; tiles with the longest
+// range first.   MODE 0: Out = alpha * B X^T  (Out[i,j] = sum_{k <= j} B[i,k] X[j,k])
+//                MODE 1: Out = alpha * B X    (Out[i,j] = sum_{k >= j} B[i,k] X[k,j])
+template <int MODE>
+__global__ LB(4) void k_trmm_right(const double* __restrict__ B, long ldb, const double* __restrict__ X, long ldx,
+                                   double* __restrict__ Out, long ldo, int ntr, int ntc, double alpha) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ti = blockIdx.x % ntr;
+    const int tj = (MODE == 0) ? ntc - 1 - (int)(blockIdx.x / ntr) : (int)(blockIdx.x / ntr);     // heavy column tiles first
+    d4 acc[4][4];
+    gt_zero<4>(acc);
+    if (MODE == 0)
+        gemm_tile_128<true, true, 4>(B + (long)ti * NB * ldb, ldb, X + (long)tj * NB * ldx, ldx, (tj + 1) * NB, acc, smem);
+    else
+        gemm_tile_128<true, false, 4>(B + (long)ti * NB * ldb + (long)tj * NB, ldb, X + (long)tj * NB * ldx + (long)tj * NB, ldx,
+                                      (ntc - tj) * NB, acc, smem);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] *= alpha;
+    gt_store<0, 4>(Out + (long)ti * NB * ldo + (long)tj * NB, ldo, acc);
+}
+
+void launch_trmm_right(hipStream_t st, int transposed, const double* B, long ldb, const double* X, long ldx, double* Out, long ldo,
+                       int ntr, int ntc, double alpha) {
+    if (transposed) {
+        LDS_OPT_IN((k_trmm_right<0>));
+        hipLaunchKernelGGL((k_trmm_right<0>), dim3((unsigned)(ntr * ntc)), dim3(256), GT_LDS_BYTES, st, B, ldb, X, ldx, Out, ldo, ntr,
+                           ntc, alpha);
+    } else {
+        LDS_OPT_IN((k_trmm_right<1>));
+        hipLaunchKernelGGL((k_trmm_right<1>), dim3((unsigned)(ntr * ntc)), dim3(256), GT_LDS_BYTES, st, B, ldb, X, ldx, Out, ldo, ntr,
+                           ntc, alpha);
+    }
 }
 
 // C (mpad x mpad, ldc) = alpha * A^T A + beta * C with A (K x mpad): the K** - tmp^T tmp of full_cov prediction

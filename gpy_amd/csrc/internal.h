@@ -20,6 +20,10 @@ void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* 
 // Out = X^T B (X lower triangular npad x npad, B npad x mpad)
 void launch_trmm_lower_T(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
                          int ntr, int ntc);
+// Out = alpha * B X^T (transposed != 0) or alpha * B X for a lower-triangular X (ntc x ntc tiles), B of ntr x ntc tiles: only the
+// non-zero k range of X is walked
+void launch_trmm_right(hipStream_t st, int transposed, const double* B, long ldb, const double* X, long ldx, double* Out, long ldo,
+                       int ntr, int ntc, double alpha);
 void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
                        double beta);
 void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A,

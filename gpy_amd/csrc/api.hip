@@ -1356,6 +1356,7 @@ int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out) 
     if (kcap > 0) ws.persist_kcap = kcap;
     ws.persist_max_nt = 64;
     hipEvent_t e[2];
+    ws.persist = 1;
     for (auto& ev : e) HIP_CHECK(hipEventCreate(&ev));
     const KernParams kp{MI355GP_RBF, 0, D, 1.0};
     launch_scale_inputs(st, dX, N, D, dIl, 0, dXt, np);

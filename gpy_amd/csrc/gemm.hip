@@ -346,40 +346,44 @@ void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* 
     launch_trmm_lower_t<4>(st, X, ldx, B, ldb, Out, ldo, ntr, ntc);
 }
 
-// Right-hand products with a lower-triangular X (the M x M algebra of the sparse path, var_dtc.py:129-158: Lm^-1 psi2 Lm^-T and
-// Lm^-T E Lm^-1): only the k range where X is non-zero is walked -- half the flops of the full GEMM; tiles with the longest
-// range first.   MODE 0: Out = alpha * B X^T  (Out[i,j] = sum_{k <= j} B[i,k] X[j,k])
-//                MODE 1: Out = alpha * B X    (Out[i,j] = sum_{k >= j} B[i,k] X[k,j])
+// The four triangular products of the M x M algebra on 64 x 64 quadrants: a 2048^2 output has only 256 128-tiles -- one per CU, so
+// the launch lasts as long as its LONGEST k range and skipping the zero half of X buys nothing; 1024 quadrants with the long
+// ranges first balance (the full product is 0.27 ms at M = 2048, the triangular one half the flops).
+//   MODE 0: Out = X B      (k <  (ti+1) 128)     MODE 1: Out = X^T B   (k >= ti 128)
+//   MODE 2: Out = B X^T    (k <  (tj+1) 128)     MODE 3: Out = B X     (k >= tj 128)          X lower triangular, nt x nt tiles
 template <int MODE>
-__global__ LB(4) void k_trmm_right(const double* __restrict__ B, long ldb, const double* __restrict__ X, long ldx,
-                                   double* __restrict__ Out, long ldo, int ntr, int ntc, double alpha) {
+__global__ __launch_bounds__(256) void k_trmm64(const double* __restrict__ X, long ldx, const double* __restrict__ B, long ldb,
+                                                double* __restrict__ Out, long ldo, int nt, int ntother, double alpha) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int ti = blockIdx.x % ntr;
-    const int tj = (MODE == 0) ? ntc - 1 - (int)(blockIdx.x / ntr) : (int)(blockIdx.x / ntr);     // heavy column tiles first
-    d4 acc[4][4];
-    gt_zero<4>(acc);
-    if (MODE == 0)
-        gemm_tile_128<true, true, 4>(B + (long)ti * NB * ldb, ldb, X + (long)tj * NB * ldx, ldx, (tj + 1) * NB, acc, smem);
-    else
-        gemm_tile_128<true, false, 4>(B + (long)ti * NB * ldb + (long)tj * NB, ldb, X + (long)tj * NB * ldx + (long)tj * NB, ldx,
-                                      (ntc - tj) * NB, acc, smem);
+    const int q = blockIdx.x & 3, qi = q >> 1, qj = q & 1, bid = blockIdx.x >> 2;
+    int ti, tj;                                                // heavy tiles first
+    if (MODE == 0) { ti = nt - 1 - bid / ntother; tj = bid % ntother; }
+    else if (MODE == 1) { ti = bid / ntother; tj = bid % ntother; }
+    else if (MODE == 2) { tj = nt - 1 - bid / ntother; ti = bid % ntother; }
+    else { tj = bid / ntother; ti = bid % ntother; }
+    const long r0 = (long)ti * NB + qi * 64, c0 = (long)tj * NB + qj * 64;
+    d4 acc[2][2];
+    gt64_zero(acc);
+    if (MODE == 0) gemm_tile_64_v3<true, false>(X + r0 * ldx, ldx, B + c0, ldb, (ti + 1) * NB, acc, smem);
+    else if (MODE == 1) gemm_tile_64_v3<false, false>(X + (long)ti * NB * ldx + r0, ldx, B + (long)ti * NB * ldb + c0, ldb, (nt - ti) * NB, acc, smem);
+    else if (MODE == 2) gemm_tile_64_v3<true, true>(B + r0 * ldb, ldb, X + c0 * ldx, ldx, (tj + 1) * NB, acc, smem);
+    else gemm_tile_64_v3<true, false>(B + r0 * ldb + (long)tj * NB, ldb, X + (long)tj * NB * ldx + c0, ldx, (nt - tj) * NB, acc, smem);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] *= alpha;
-    gt_store<0, 4>(Out + (long)ti * NB * ldo + (long)tj * NB, ldo, acc);
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] *= alpha;
+    gt64_store<0>(Out + r0 * ldo + c0, ldo, acc);
 }
 
-void launch_trmm_right(hipStream_t st, int transposed, const double* B, long ldb, const double* X, long ldx, double* Out, long ldo,
-                       int ntr, int ntc, double alpha) {
-    if (transposed) {
-        LDS_OPT_IN((k_trmm_right<0>));
-        hipLaunchKernelGGL((k_trmm_right<0>), dim3((unsigned)(ntr * ntc)), dim3(256), GT_LDS_BYTES, st, B, ldb, X, ldx, Out, ldo, ntr,
-                           ntc, alpha);
-    } else {
-        LDS_OPT_IN((k_trmm_right<1>));
-        hipLaunchKernelGGL((k_trmm_right<1>), dim3((unsigned)(ntr * ntc)), dim3(256), GT_LDS_BYTES, st, B, ldb, X, ldx, Out, ldo, ntr,
-                           ntc, alpha);
+// mode: 0 X B, 1 X^T B, 2 B X^T, 3 B X; X: nt x nt tiles (lower triangular), the other dimension of B / Out: ntother tiles
+void launch_trmm64(hipStream_t st, int mode, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo, int nt,
+                   int ntother, double alpha) {
+    const unsigned grid = (unsigned)(4 * nt * ntother);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_trmm64<0>), dim3(grid), dim3(256), GT64_LDS_BYTES, st, X, ldx, B, ldb, Out, ldo, nt, ntother, alpha); break;
+        case 1: hipLaunchKernelGGL((k_trmm64<1>), dim3(grid), dim3(256), GT64_LDS_BYTES, st, X, ldx, B, ldb, Out, ldo, nt, ntother, alpha); break;
+        case 2: hipLaunchKernelGGL((k_trmm64<2>), dim3(grid), dim3(256), GT64_LDS_BYTES, st, X, ldx, B, ldb, Out, ldo, nt, ntother, alpha); break;
+        default: hipLaunchKernelGGL((k_trmm64<3>), dim3(grid), dim3(256), GT64_LDS_BYTES, st, X, ldx, B, ldb, Out, ldo, nt, ntother, alpha); break;
     }
 }
 

@@ -20,10 +20,10 @@ void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* 
 // Out = X^T B (X lower triangular npad x npad, B npad x mpad)
 void launch_trmm_lower_T(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
                          int ntr, int ntc);
-// Out = alpha * B X^T (transposed != 0) or alpha * B X for a lower-triangular X (ntc x ntc tiles), B of ntr x ntc tiles: only the
-// non-zero k range of X is walked
-void launch_trmm_right(hipStream_t st, int transposed, const double* B, long ldb, const double* X, long ldx, double* Out, long ldo,
-                       int ntr, int ntc, double alpha);
+// triangular products on 64 x 64 quadrants (X lower triangular, nt x nt tiles; the other dimension of B / Out: ntother tiles):
+// mode 0 Out = alpha X B, 1 alpha X^T B, 2 alpha B X^T, 3 alpha B X -- only the non-zero k range of X is walked
+void launch_trmm64(hipStream_t st, int mode, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo, int nt,
+                   int ntother, double alpha);
 void launch_gemm_tn_sq(hipStream_t st, const double* A, long lda, long K, double* C, long ldc, int nt, double alpha,
                        double beta);
 void launch_dbg_gemm(hipStream_t st, int a_mcontig, int b_ncontig, long M, long N, long K, const double* A,
@@ -189,6 +189,10 @@ void launch_kbuild_sym(hipStream_t st, KernParams kp, const double* Xt, long ldx
 void launch_kbuild_cross(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2,
                          long ld2, long m, double* Kout, long ldk, int accumulate = 0, int diag_same = 0,
                          const double* mul = nullptr);
+// K(X1, X2) into Kout AND the column partials of psi1^T V = sum_i K[i][j] V[i][d] in one pass (one plain stationary part);
+// returns the number of row splits in colpart ([split][mcols][Dy]; combine with launch_sum_splits), 0 = not applicable
+int launch_kbuild_cols(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2, long ld2, long m,
+                       long mcols, double* Kout, long ldk, const double* V, int Dy, double* colpart);
 // y = X r (lower-triangular X, n x n within npad), then a = X^T y   (Dy right-hand sides, row-major n x Dy)
 void launch_tri_matvec(hipStream_t st, const double* X, long ld, long n, const double* R, int Dy, double* tmp,
                        double* alpha, double* partials);

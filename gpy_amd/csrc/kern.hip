@@ -188,6 +188,109 @@ __global__ __launch_bounds__(256) void k_kbuild(KernParams kp, const double* __r
 }
 
 
+
+// K(X_chunk, Z) of the streaming sparse path (var_dtc.py:123) WITH the column reduction psi1^T V = sum_i K[i][j] V[i][d]
+// (var_dtc_parallel.py:91-116) fused in: block = (column tile, row split) as in k_grad_cols; the Z slab of the column tile is
+// staged once per block, every 64 x 64 tile of K is stored as 32-byte row vectors and its contribution to the column sums stays
+// in registers across the block's row tiles.  The separate pass re-read the whole 3.3 GB chunk for it (k_colreduce_multi: 0.58 ms
+// at configuration 5).  One plain stationary part only (no accumulation, no product): sums of kernels keep the two-pass form.
+// Partials [split][column][d] are combined in fixed order by launch_sum_splits: bit reproducible.
+#define KBC_DY 4
+__global__ __launch_bounds__(256) void k_kbuild_cols(KernParams kp, const double* __restrict__ Xt1, long ld1, long n,
+                                                     const double* __restrict__ Xt2, long ld2, long m, double* __restrict__ out,
+                                                     long ldo, const double* __restrict__ V, int Dy, int ntc, int ntr,
+                                                     int tiles_per_split, double* __restrict__ colpart, long mcols) {
+    __shared__ __attribute__((aligned(16))) double si[KDC * KT];
+    __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
+    __shared__ double sv[KT * KBC_DY];
+    __shared__ double red[256];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int tj = blockIdx.x % ntc, split = blockIdx.x / ntc;
+    const long j0 = (long)tj * KT;
+    const int D = kp.D;                                   // <= KDC
+    double csum[4][KBC_DY];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int d = 0; d < KBC_DY; ++d) csum[b][d] = 0.0;
+    stage_x(Xt2, ld2, j0, 0, D, sj, t);
+    const bool fullcols = j0 + KT <= m;
+    const int ti_end = ((split + 1) * tiles_per_split < ntr) ? (split + 1) * tiles_per_split : ntr;
+    for (int ti = split * tiles_per_split; ti < ti_end; ++ti) {
+        const long i0 = (long)ti * KT;
+        __syncthreads();                                  // the previous tile's reads of si / sv are done
+        stage_x(Xt1, ld1, i0, 0, D, si, t);
+        if (t < KT * Dy) {
+            const long i = i0 + t / Dy;
+            sv[(t / Dy) * KBC_DY + t % Dy] = (i < n) ? V[i * Dy + t % Dy] : 0.0;
+        }
+        __syncthreads();
+        double r2[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+        accum_r2(si, sj, D, ty, tx, r2);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long i = i0 + ty * 4 + a;
+            d4 o;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) o[b] = (i < n && j0 + tx * 4 + b < m) ? cov_k(kp.kind, kp.variance, r2[a][b], false) : 0.0;
+            if (i < n) {
+                if (fullcols) *reinterpret_cast<d4*>(out + i * ldo + j0 + tx * 4) = o;
+                else
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (j0 + tx * 4 + b < m) out[i * ldo + j0 + tx * 4 + b] = o[b];
+            }
+#pragma unroll
+            for (int d = 0; d < KBC_DY; ++d) {
+                if (d < Dy) {
+                    const double v = sv[(ty * 4 + a) * KBC_DY + d];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) csum[b][d] = fma(o[b], v, csum[b][d]);
+                }
+            }
+        }
+    }
+    // column partials of this block: over the 16 row groups (ty) in fixed order
+    double* cp = colpart + (long)split * mcols * Dy;
+#pragma unroll
+    for (int d = 0; d < KBC_DY; ++d) {
+        if (d < Dy) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                __syncthreads();
+                red[ty * 16 + tx] = csum[b][d];
+                __syncthreads();
+                if (ty == 0) {
+                    double sacc = 0.0;
+                    for (int r = 0; r < 16; ++r) sacc += red[r * 16 + tx];
+                    const long j = j0 + tx * 4 + b;
+                    if (j < mcols) cp[j * Dy + d] = sacc;
+                }
+            }
+        }
+    }
+}
+
+// returns the number of row splits (colpart: nsplit * mcols * Dy doubles), 0 if the fused form does not apply
+int launch_kbuild_cols(hipStream_t st, KernParams kp, const double* Xt1, long ld1, long n, const double* Xt2, long ld2, long m,
+                       long mcols, double* Kout, long ldk, const double* V, int Dy, double* colpart) {
+    if (kp.D > KDC || kp.kind > 3 || Dy > KBC_DY || Dy < 1 || ldk % 4 != 0 || ((uintptr_t)Kout & 31) != 0) return 0;
+    const int ntr = (int)((n + KT - 1) / KT), ntc = (int)((mcols + KT - 1) / KT);
+    int nsplit = 2048 / ntc;
+    if (nsplit > 64) nsplit = 64;
+    if (nsplit > ntr) nsplit = ntr;
+    if (nsplit < 1) nsplit = 1;
+    const int tps = (ntr + nsplit - 1) / nsplit;
+    nsplit = (ntr + tps - 1) / tps;
+    hipLaunchKernelGGL(k_kbuild_cols, dim3((unsigned)(ntc * nsplit)), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, Kout, ldk, V, Dy,
+                       ntc, ntr, tps, colpart, mcols);
+    return nsplit;
+}
+
 void launch_kbuild_sym(hipStream_t st, KernParams kp, const double* Xt, long ldx, long n, long npad, double* A,
                        const double* noise, long noise_len, double jit, int lower_only, int add_diag, int accumulate,
                        const double* mul) {

@@ -724,7 +724,14 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
         } else if (rc < chunk) {
             HIP_CHECK(hipMemsetAsync(s->Kfu + rc * mp, 0, sizeof(double) * (chunk - rc) * mp, st));
         }
-        build_cross_chunk(s, rc, s->Kfu, s->T);
+        // one plain stationary part: K(X_chunk, Z) and the column sums of psi1^T V in ONE pass over the chunk; otherwise the
+        // expression is accumulated part by part and reduced by a second pass
+        int ns_fused = 0;
+        if (s->parts.size() == 1 && s->parts[0].stationary() && s->fuse_cols) {
+            const SPart& pt = s->parts[0];
+            ns_fused = launch_kbuild_cols(st, pt.kp, pt.XtC, chunk, rc, pt.XtZ, mp, m, mp, s->Kfu, mp, s->dV + r0 * Dy, Dy, s->colPart);
+        }
+        if (ns_fused == 0) build_cross_chunk(s, rc, s->Kfu, s->T);
         const double* G = s->Kfu;
         if (het) {                                            // rows scaled by sqrt(beta_n) (var_dtc.py:126-129) into T
             HIP_CHECK(hipMemsetAsync(s->T + rc * mp, 0, sizeof(double) * (round_up(rc, 16L * s->splitk) - rc) * mp, st));
@@ -734,7 +741,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
         s->mfma_prof.begin(st, 1, (double)rc * (double)m * (double)m);            // algorithmic: the lower half of psi2
         launch_gram_splitk(st, G, mp, round_up(rc, 16L * s->splitk), mp, s->splitk, nch > 0, s->psi2part);   // rows >= rc are zero
         s->mfma_prof.end(st);
-        const int ns = launch_colreduce_multi(st, s->Kfu, mp, rc, mp, s->dV + r0 * Dy, Dy, 1, Dy, 0, s->colPart);
+        const int ns = ns_fused > 0 ? ns_fused : launch_colreduce_multi(st, s->Kfu, mp, rc, mp, s->dV + r0 * Dy, Dy, 1, Dy, 0, s->colPart);
         launch_sum_splits(st, s->colPart, mp * Dy, ns, 1, s->psi1Y);               // psi1V += Kuf V_chunk
     }
     hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->psi2part, mp, s->splitk, s->psi2);
@@ -747,8 +754,8 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     // A = Lm^-1 psi2_beta Lm^-T (var_dtc.py:129-134), B = I + A (:137), LB = chol(B) (:138), XB = LB^-1
     // (Xm = Lm^-1 is lower triangular: the four products below walk only its non-zero k range, half the flops of full GEMMs)
     const int ntm = (int)(mp / NB);
-    launch_trmm_lower(st, s->Xm, mp, s->psi2, mp, s->T1, mp, ntm, ntm);
-    launch_trmm_right(st, 1, s->T1, mp, s->Xm, mp, s->Amat, mp, ntm, ntm, het ? 1.0 : beta);
+    launch_trmm64(st, 0, s->Xm, mp, s->psi2, mp, s->T1, mp, ntm, ntm, 1.0);
+    launch_trmm64(st, 2, s->Xm, mp, s->T1, mp, s->Amat, mp, ntm, ntm, het ? 1.0 : beta);
     auto build_B = [&]() {
         hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->Amat, 1.0, (const double*)nullptr, 0.0, 1.0, mp,
                            s->LB);
@@ -766,20 +773,20 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     hipLaunchKernelGGL(k_form_P, grid2d(mp, mp), dim3(256), 0, st, s->Bi, s->wvec, Dy, mp, m, s->P);
     // dL_dKmm = Lm^-T (-0.5 P - 0.5 Dy B + Dy I) Lm^-1 (:153-158);  -0.5 Dy (I + A) + Dy I = -0.5 Dy A + 0.5 Dy I
     hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->P, -0.5, s->Amat, -0.5 * Dy, 0.5 * Dy, mp, s->E);
-    launch_trmm_lower_T(st, s->Xm, mp, s->E, mp, s->T1, mp, ntm, ntm);                   // Xm^T E
-    launch_trmm_right(st, 0, s->T1, mp, s->Xm, mp, s->dLdKmm, mp, ntm, ntm, 1.0);        // (Xm^T E) Xm
+    launch_trmm64(st, 1, s->Xm, mp, s->E, mp, s->T1, mp, ntm, ntm, 1.0);                 // Xm^T E
+    launch_trmm64(st, 3, s->Xm, mp, s->T1, mp, s->dLdKmm, mp, ntm, ntm, 1.0);            // (Xm^T E) Xm
     // Q2 = dL_dpsi2_beta = 0.5 Lm^-T (Dy I - P) Lm^-1 (:220); the precision enters per row in pass 2 (:224-226,231)
     hipLaunchKernelGGL(k_mm_axpby, grid2d(mp, mp), dim3(256), 0, st, s->P, -0.5, (const double*)nullptr, 0.0, 0.5 * Dy, mp,
                        s->E);
-    launch_trmm_lower_T(st, s->Xm, mp, s->E, mp, s->T1, mp, ntm, ntm);
-    launch_trmm_right(st, 0, s->T1, mp, s->Xm, mp, s->Q2, mp, ntm, ntm, 1.0);
+    launch_trmm64(st, 1, s->Xm, mp, s->E, mp, s->T1, mp, ntm, ntm, 1.0);
+    launch_trmm64(st, 3, s->Xm, mp, s->T1, mp, s->Q2, mp, ntm, ntm, 1.0);
     const bool het_multi = het && Dy > 1;
     if (het_multi) {
         // several output columns with per-point noise: dL_dR (var_dtc.py:240-256) needs r_n = |LB^-1 Lm^-1 k_n|^2 on its own
         // (for Dy = 1 it folds into t_n and s_n); r_n = k_n^T Gr k_n with Gr = Lm^-T B^-1 Lm^-1, built in the Winv buffer
         hipLaunchKernelGGL(k_sym_from_lower, grid2d(mp, mp), dim3(256), 0, st, s->Bi, mp, 1, s->E);
-        launch_trmm_lower_T(st, s->Xm, mp, s->E, mp, s->T1, mp, ntm, ntm);
-        launch_trmm_right(st, 0, s->T1, mp, s->Xm, mp, s->Winv, mp, ntm, ntm, 1.0);
+        launch_trmm64(st, 1, s->Xm, mp, s->E, mp, s->T1, mp, ntm, ntm, 1.0);
+        launch_trmm64(st, 3, s->Xm, mp, s->T1, mp, s->Winv, mp, ntm, ntm, 1.0);
     }
     hipLaunchKernelGGL(k_sparse_scalars_rows, dim3((unsigned)m), dim3(256), 0, st, s->Amat, s->P, s->LB, s->cvec, Dy, mp, m,
                        s->colPart);

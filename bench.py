@@ -415,8 +415,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=70, help="timed steps (default: >= 5 s of timed work at the default workload)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=WORKLOAD["N"])
-    ap.add_argument("--d", type=int, default=WORKLOAD["D"])
+    # (--size / --dims: aliases that are no prefix of a torch.distributed.run option -- its argparse rejects "--n" as ambiguous)
+    ap.add_argument("--n", "--size", dest="n", type=int, default=WORKLOAD["N"])
+    ap.add_argument("--d", "--dims", dest="d", type=int, default=WORKLOAD["D"])
     ap.add_argument("--kind", default=WORKLOAD["kind"])
     ap.add_argument("--iso", action="store_true", help="single lengthscale instead of ARD")
     ap.add_argument("--cpu-sample-n", type=int, default=3072, help="the CPU baseline is timed at this N and at twice it")

@@ -17,7 +17,7 @@ mkdir -p gpurun_out
 if [ "$MODE" = full ]; then
     ARGS="--gpus $N --steps 3 --warmup 1"
 else
-    ARGS="--gpus $N --steps 2 --warmup 1 --n 4096 --d 8 --kind rbf --iso --grid-n 8192 --dry-run-sizes"
+    ARGS="--gpus $N --steps 2 --warmup 1 --size 4096 --dims 8 --kind rbf --iso --grid-n 8192 --dry-run-sizes"
 fi
 echo "== default bench line with $N ranks on one GPU ($MODE legs)"
 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port "$PORT" \
@@ -26,4 +26,4 @@ echo
 echo "== --grid mode with $N ranks: one problem on the block-cyclic grid"
 case "$N" in 2) SHAPE=1x2 ;; 4) SHAPE=2x2 ;; 8) SHAPE=2x4 ;; *) SHAPE=1x$N ;; esac
 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((PORT + 50)) \
-    bench.py --grid "$SHAPE" --gpus "$N" --n 8192 --d 8 --kind rbf --iso --steps 2 --warmup 1 | tee gpurun_out/dryrun_grid_${N}.json | tail -c 1500
+    bench.py --grid "$SHAPE" --gpus "$N" --size 8192 --dims 8 --kind rbf --iso --steps 2 --warmup 1 | tee gpurun_out/dryrun_grid_${N}.json | tail -c 1500

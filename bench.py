@@ -319,8 +319,9 @@ def run_child(argv, timeout, env=None, single=True):
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, capture_output=True, text=True,
                            timeout=timeout)
-    except subprocess.TimeoutExpired:
-        return {"error": "timed out after %.0f s" % timeout}
+    except subprocess.TimeoutExpired as e:
+        tail = e.stderr if isinstance(e.stderr, str) else (e.stderr or b"").decode("utf-8", "replace")
+        return {"error": "timed out after %.0f s" % timeout, "stderr_tail": tail[-600:]}
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": ("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-400:]}
@@ -398,8 +399,9 @@ def grid_leg(comm, args, timeout=180.0):
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
         ok = r.returncode == 0
         err = (r.stderr or r.stdout)[-400:]
-    except subprocess.TimeoutExpired:
-        ok, err = False, "timed out after %.0f s" % timeout
+    except subprocess.TimeoutExpired as e:
+        tail = e.stderr if isinstance(e.stderr, str) else (e.stderr or b"").decode("utf-8", "replace")
+        ok, err = False, "timed out after %.0f s; stderr: %s" % (timeout, tail[-500:])
     if comm.rank != 0:
         return None
     if ok and os.path.exists(out_path):
@@ -787,7 +789,7 @@ def main_grid(args):
     theta = L.theta_vec(var, ls, ARD, D)
     if comm.world > 1:
         assert comm.world == Pr * Pc, "--grid PrxPc must match the number of processes"
-        g = G.GridContext.from_env(Pr, Pc, args.nb)
+        g = G.GridContext.from_env(Pr, Pc, args.nb, device=comm.local_rank)
     else:
         g = G.GridContext.loopback(Pr, Pc, args.nb, device=comm.local_rank)
     g.set_data(X, Y)

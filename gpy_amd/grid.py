@@ -213,12 +213,16 @@ class GridContext(object):
         return cls(device, 0, Pr * Pc, Pr, Pc, nb, None)
 
     @classmethod
-    def from_env(cls, Pr=None, Pc=None, nb=512, exchange=None):
+    def from_env(cls, Pr=None, Pc=None, nb=512, exchange=None, device=None):
         """One process per GPU: RANK / WORLD_SIZE / LOCAL_RANK from the launcher; `exchange(id_bytes, rank)` ships
-        rank 0's id (default: torch.distributed if initialised, else a file under $MI355GP_ID_DIR or /tmp)."""
+        rank 0's id (default: torch.distributed if initialised, else a file under $MI355GP_ID_DIR or /tmp).  device: HIP device
+        of this rank (default LOCAL_RANK; under MI355GP_TRANSPORT=ipc, where ranks SHARE devices, LOCAL_RANK modulo the number
+        of visible devices)."""
         rank = int(os.environ.get("RANK", "0"))
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        local = int(os.environ.get("LOCAL_RANK", str(rank)))
+        local = int(os.environ.get("LOCAL_RANK", str(rank))) if device is None else int(device)
+        if device is None and os.environ.get("MI355GP_TRANSPORT") == "ipc":
+            local %= max(1, _lib.device_count())
         if Pr is None or Pc is None:
             Pr, Pc = grid_shape(world)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -11,7 +11,7 @@ cd "$(dirname "$0")/.."
 N=${1:-8}
 MODE=${2:-small}
 export MI355GP_BENCH_BACKEND=gloo MI355GP_TRANSPORT=ipc HSA_ENABLE_IPC_MODE_LEGACY=0 MI355GP_GRID_CHECK_SEQ=1
-export MI355GP_IPC_TIMEOUT_S=${MI355GP_IPC_TIMEOUT_S:-300}
+export MI355GP_IPC_TIMEOUT_S=${MI355GP_IPC_TIMEOUT_S:-120}
 PORT=$((29600 + RANDOM % 300))
 mkdir -p gpurun_out
 if [ "$MODE" = full ]; then

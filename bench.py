@@ -441,7 +441,7 @@ def main():
     ap.add_argument("--nb", type=int, default=512, help="tile edge of the block-cyclic layout")
     ap.add_argument("--sparse", action="store_true", help="BASELINE configs[4]: SparseGPRegression (VarDTC) N=200000 "
                     "rows per GPU, M=2048, D=16; rows sharded across GPUs with one RCCL all-reduce per pass")
-    ap.add_argument("--m", type=int, default=2048, help="inducing points (--sparse)")
+    ap.add_argument("--m", "--inducing", dest="m", type=int, default=2048, help="inducing points (--sparse)")
     args = ap.parse_args()
     if args.grid:
         return main_grid(args)
@@ -801,6 +801,8 @@ def main_grid(args):
         last["r"] = r
 
     dt = timed_region(comm, step, args.steps, args.warmup)
+    transport = "loopback" if g.is_loopback else ("hipIpc (ranks = processes sharing a GPU)" if os.environ.get("MI355GP_TRANSPORT") == "ipc"
+                                                  else "RCCL")
     if comm.rank == 0:
         r = last["r"]
         its = args.steps / dt                                 # one problem, all GPUs
@@ -812,7 +814,7 @@ def main_grid(args):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s %s exact GP, one parameters_changed on a %dx%d block-cyclic grid (nb=%d, %s "
                                    "transport), N=%d D=%d Dy=1" % (args.kind, "ARD" if ARD else "iso", Pr, Pc, args.nb,
-                                                                  "loopback" if g.is_loopback else "RCCL", N, D),
+                                                                  transport, N, D),
                        "N": N, "D": D, "kernel": args.kind, "ARD": ARD, "parallelism": "grid %dx%d" % (Pr, Pc)},
             "iteration_tflops": flops / (dt / args.steps) / 1e12,
             "iteration_frac_of_fp64_peak": flops / (dt / args.steps) / 1e12 / (PEAK_FP64_TFLOPS * comm.world),
@@ -828,7 +830,7 @@ def main_grid(args):
             keep = ("ms_per_step", "value", "n_gpus", "scaling", "iteration_tflops", "iteration_frac_of_fp64_peak",
                     "stage_ms", "comm_bytes_per_step", "lml", "parity_vs_golden", "steps", "warmup")
             sub = {k: out[k] for k in keep if k in out}
-            sub.update(grid="%dx%d" % (Pr, Pc), nb=args.nb, transport="loopback" if g.is_loopback else "RCCL", N=N)
+            sub.update(grid="%dx%d" % (Pr, Pc), nb=args.nb, transport=transport, N=N)
             with open(leg, "w") as f:
                 json.dump(sub, f)
         print(json.dumps(out), flush=True)

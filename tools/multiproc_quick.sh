@@ -8,7 +8,7 @@ PORT=$((29300 + RANDOM % 200))
 case "$N" in 2) SHAPE=1x2 ;; 4) SHAPE=2x2 ;; 8) SHAPE=2x4 ;; *) SHAPE=1x$N ;; esac
 echo "== --sparse, rows sharded over $N ranks"
 timeout -k 5 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port "$PORT" \
-    bench.py --sparse --gpus "$N" --size 20000 --m 512 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -c 2500
+    bench.py --sparse --gpus "$N" --size 20000 --inducing 512 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -c 2500
 echo
 echo "== --grid $SHAPE"
 timeout -k 5 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((PORT + 31)) \

@@ -21,9 +21,23 @@ else
 fi
 echo "== default bench line with $N ranks on one GPU ($MODE legs)"
 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port "$PORT" \
-    bench.py $ARGS | tee gpurun_out/dryrun_bench_${N}.json | tail -c 3000
+    bench.py $ARGS > gpurun_out/dryrun_bench_${N}.json 2> gpurun_out/dryrun_bench_${N}.err
+echo "rc $?"; grep -v "Gloo\|socket.cpp\|amdgpu.ids\|OMP_NUM\|\*\*\*\*" gpurun_out/dryrun_bench_${N}.err | head -40 | cut -c1-400
+grep "^{" gpurun_out/dryrun_bench_${N}.json | tail -1 | python -c "
+import json, sys
+try:
+    d = json.loads(sys.stdin.read())
+    print({k: d.get(k) for k in ('value', 'n_gpus', 'ms_per_step', 'scaling')})
+    for leg in ('c2', 'grid', 'c5', 'c4_single'):
+        r = d.get(leg) or {}
+        print(' ', leg, {k: r.get(k) for k in ('ms_per_step', 'n_gpus', 'transport', 'error', 'stderr_tail', 'parity_vs_golden') if r.get(k) is not None})
+except Exception as e:
+    print('no JSON line:', e)
+"
 echo
 echo "== --grid mode with $N ranks: one problem on the block-cyclic grid"
 case "$N" in 2) SHAPE=1x2 ;; 4) SHAPE=2x2 ;; 8) SHAPE=2x4 ;; *) SHAPE=1x$N ;; esac
 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((PORT + 50)) \
-    bench.py --grid "$SHAPE" --gpus "$N" --size 8192 --dims 8 --kind rbf --iso --steps 2 --warmup 1 | tee gpurun_out/dryrun_grid_${N}.json | tail -c 1500
+    bench.py --grid "$SHAPE" --gpus "$N" --size 8192 --dims 8 --kind rbf --iso --steps 2 --warmup 1 > gpurun_out/dryrun_grid_${N}.json 2> gpurun_out/dryrun_grid_${N}.err
+echo "rc $?"; grep -v "Gloo\|socket.cpp\|amdgpu.ids\|OMP_NUM\|\*\*\*\*" gpurun_out/dryrun_grid_${N}.err | head -20 | cut -c1-400
+grep "^{" gpurun_out/dryrun_grid_${N}.json | tail -1 | cut -c1-900

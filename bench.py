@@ -307,14 +307,31 @@ def golden_check(kind, ARD, N, D, seed, lml, alpha, grad):
     return None
 
 
+def child_env(port_offset, **extra):
+    """Environment of a child leg that keeps this rank's RANK / WORLD_SIZE / LOCAL_RANK (the children of all ranks form their own
+    process group): MASTER_PORT moved by port_offset and EVERY TORCHELASTIC_* variable removed.  torch.distributed.run exports
+    TORCHELASTIC_USE_AGENT_STORE=True to its workers, which makes env:// rendezvous expect the launcher's agent to host the store
+    at MASTER_PORT: a child that inherits it only ever CONNECTS to the moved port, where nobody listens, and the leg hangs to its
+    time-out (found by the 8-process dry run of round 4; tests/test_bench_dist.py covers it over gloo)."""
+    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset))
+    nonce = "%s+%d" % (os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("MASTER_PORT", "job")), port_offset)
+    for k in list(env):
+        if k.startswith("TORCHELASTIC_"):
+            env.pop(k)
+    env["MI355GP_JOB_NONCE"] = nonce                        # what gpy_amd.grid's file exchange keys on when torch is not used
+    env.update(extra)
+    return env
+
+
 def run_child(argv, timeout, env=None, single=True):
     """`python bench.py <argv>` in a child process; returns the parsed JSON line (or {"error": ...}).  single: the child is a
     one-process run of its own (rank variables of the parent launch are removed)."""
     import subprocess
     env = dict(os.environ if env is None else env)
     if single:
-        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
-            env.pop(k, None)
+        for k in list(env):
+            if k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK") or k.startswith("TORCHELASTIC_"):
+                env.pop(k, None)
     t0 = time.perf_counter()
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, capture_output=True, text=True,
@@ -358,8 +375,7 @@ def c4_single_leg(comm, args):
 def sparse_leg(comm, args, timeout=300.0):
     """BASELINE configs[4] over ALL ranks of this launch (rows sharded, one all-reduce per pass) -- every rank spawns its own
     child with its rank variables, like the grid leg."""
-    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 29))
-    env.pop("TORCHELASTIC_RUN_ID", None)
+    env = child_env(29)
     argv = ["--sparse", "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
     if args.dry_run_sizes:
         argv = ["--sparse", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--n", "20000", "--m", "512"]
@@ -383,9 +399,7 @@ def grid_leg(comm, args, timeout=180.0):
     Pr, Pc = G.grid_shape(comm.world) if comm.world > 1 else (2, 4)
     out_path = os.path.join(ROOT, "gpurun_out", "grid_leg_%s_%d.json" % (os.environ.get("MASTER_PORT", "0"), os.getpid()))
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
-    env = dict(os.environ, MI355GP_GRID_LEG_OUT=out_path if comm.rank == 0 else "",
-               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
-    env.pop("TORCHELASTIC_RUN_ID", None)
+    env = child_env(17, MI355GP_GRID_LEG_OUT=out_path if comm.rank == 0 else "")
     cmd = [sys.executable, os.path.abspath(__file__), "--grid", "%dx%d" % (Pr, Pc), "--n", str(args.grid_n), "--d", "8",
            "--kind", "rbf", "--iso", "--steps", "3", "--warmup", "1", "--nb", str(args.nb), "--grid-child"]
     rec = {"workload": "RBF iso exact GP N=%d D=8, one parameters_changed on a %dx%d block-cyclic grid (%s)" % (

@@ -55,3 +55,38 @@ def test_single_process_comm_is_a_no_op():
         for k, v in env_backup.items():
             if v is not None:
                 os.environ[k] = v
+
+
+LEG_PARENT = textwrap.dedent("""
+    import json, os, subprocess, sys
+    sys.path.insert(0, %r)
+    import bench
+    comm = bench.Comm(backend="gloo")
+    # what grid_leg / sparse_leg do: every rank spawns ITS child with its own rank variables; the children form their own group
+    child = "import sys; sys.path.insert(0, %r); import bench; c = bench.Comm(backend='gloo'); c.barrier(); " \\
+            "print('CHILD', c.rank, c.world, c.max_over_ranks(c.rank)); c.close()"
+    try:
+        r = subprocess.run([sys.executable, "-c", child], env=bench.child_env(17), capture_output=True, text=True, timeout=60)
+        out = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "rc %%d %%s" %% (r.returncode, r.stderr[-200:])
+    except subprocess.TimeoutExpired:
+        out = "TIMEOUT"
+    with open(os.path.join(%r, "leg%%d.txt" %% comm.rank), "w") as f:
+        f.write(out)
+    comm.barrier()
+    comm.close()
+""")
+
+
+def test_child_legs_of_a_torchrun_launch_can_rendezvous(tmp_path):
+    """The `grid` and `c5` records of the default line come from CHILD processes that every rank spawns with its own rank variables
+    and a moved MASTER_PORT.  Under `torch.distributed.run` the workers' environment carries TORCHELASTIC_USE_AGENT_STORE=True: a
+    child inheriting it never starts the store of its own group and hangs to the leg's time-out -- `bench.child_env` strips it.
+    (Found by round 4's 8-process dry run; on an 8-GPU node both legs would have timed out.)"""
+    script = tmp_path / "parent.py"
+    script.write_text(LEG_PARENT % (ROOT, ROOT, str(tmp_path)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29741", str(script)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    outs = [open(tmp_path / ("leg%d.txt" % i)).read() for i in range(2)]
+    assert outs[0].startswith("CHILD 0 2 1.0") and outs[1].startswith("CHILD 1 2 1.0"), outs

@@ -102,6 +102,8 @@ struct FactorWs {
     // persist_skip: calls of potrf_device that stay on the launch-per-step schedule (set after a called-off / aborted persistent
     // launch: PS_SKIP_AFTER_CLEAN, or INT_MAX after a dirty abort); persist_aborts counts them (MI355GP_OPT_PERSIST_ABORTS)
     int persist_skip = 0, persist_aborts = 0, persist_used = 0;
+    hipEvent_t ev_persist_pre = nullptr;   // optional (not owned): recorded on the launching stream once the progress words are zeroed
+    int persist_grid_last = 0;             // workgroups of the last persistent launch
     int persist_tune = 0;            // MI355GP_PERSIST_TUNE: schedule bits of the folded launch (1: near owners take W tiles only after
                                      // their X tiles, 2: two-stage worker GEMM instead of the 4-stage ring)
     int persist_test = 0;            // MI355GP_OPT_PERSIST_TEST: fault injection for the NEXT persistent launch (1 clean, 2 dirty)
@@ -166,6 +168,8 @@ int potrf_persist_sync_ints();
 bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg = nullptr, double* X = nullptr,
                           double* W = nullptr, long long* dbg2 = nullptr);
 bool pdinv_persist_eligible(long npad, FactorWs* ws, int want_w);
+// on `st`: wait (<= 2 ms) until the persistent launch announced by ws->ev_persist_pre has all its workgroups resident
+void launch_wait_persist_resident(hipStream_t st, const FactorWs* ws);
 // A -> L in place, X = L^-1, W = X^T X (W may be NULL): the folded persistent launch when eligible (returns true; ws->persist_used
 // = 2), else false and NOTHING was enqueued: the caller takes potrf_device / trtri_device / lauum_device
 bool pdinv_device(hipStream_t st, double* A, double* X, double* W, long npad, FactorWs* ws);

@@ -1119,6 +1119,8 @@ bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, lo
     const int inv_mode = X ? (W ? 2 : 1) : 0;
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
     (void)hipMemsetAsync(ws->persist_sync, 0, sizeof(int) * PS_SYNC_INTS, st);
+    if (ws->ev_persist_pre) (void)hipEventRecord(ws->ev_persist_pre, st);   // "the progress words of THIS launch are zeroed"
+    ws->persist_grid_last = (int)grid;
     const double flops = (double)npad * npad * npad / 3.0 * (1 + inv_mode);
     ws->prof.begin(st, PF_PERSIST, flops);
     hipLaunchKernelGGL(k_potrf_persist, dim3((unsigned)grid), dim3(64 * PS_CHAIN_WAVES), PS_LDS_BYTES, st, A, npad, nt, ws->dinv, ws->logsum,
@@ -1127,4 +1129,21 @@ bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, lo
     const bool ok = hipGetLastError() == hipSuccess;
     ws->prof.end(st);
     return ok;
+}
+
+// One thread that returns once the persistent launch whose progress words follow ws->ev_persist_pre has ALL its workgroups
+// resident (arrival word complete), was called off, or 2 ms have passed.  Put on ANOTHER stream in front of wide kernels that
+// are meant to run underneath the persistent launch (sparse.hip: pass 1 underneath Kmm's factorisation), it keeps them from
+// taking the CUs' LDS before the 147 KB workgroups are in place.
+__global__ void k_wait_persist_resident(const int* __restrict__ sync, int n) {
+    const long long t0 = wall_clock64();
+    for (;;) {
+        const int v = ld_flag(sync + PS_ARRIVE);
+        if ((v & PS_ARRIVE_ABORT) || (v & ~PS_ARRIVE_ABORT) >= n) return;
+        if (wall_clock64() - t0 > 2 * PS_ARRIVE_TICKS) return;
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+void launch_wait_persist_resident(hipStream_t st, const FactorWs* ws) {
+    hipLaunchKernelGGL(k_wait_persist_resident, dim3(1), dim3(1), 0, st, ws->persist_sync, ws->persist_grid_last);
 }

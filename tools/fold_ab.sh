@@ -18,16 +18,14 @@ except Exception as e:
 PY
   done
 done
-for CFG in "2 1" "2 0" "1 1" "2 1"; do
-  set -- $CFG
-  P=$1; K=$2
-  MI355GP_PERSIST=$P MI355GP_KBUILD_STRIP=$K timeout 300 python bench.py --sparse --steps 12 --warmup 3 --no-cpu-baseline > "$OUT/sparse_p${P}_k${K}.json" 2> "$OUT/sparse_p${P}_k${K}.err"
-  python - "$OUT/sparse_p${P}_k${K}.json" $P $K <<'PY'
+for P in 2 1; do
+  MI355GP_PERSIST=$P timeout 300 python bench.py --sparse --steps 12 --warmup 3 --no-cpu-baseline > "$OUT/sparse_p${P}.json" 2> "$OUT/sparse_p${P}.err"
+  python - "$OUT/sparse_p${P}.json" $P <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print("sparse persist=%s kbuild_strip=%s  %.3f ms/step  stage %s  parity %s" % (sys.argv[2], sys.argv[3], d["ms_per_step"], d["stage_ms"], d.get("parity_checked")))
+    print("sparse persist=%s  %.3f ms/step  stage %s" % (sys.argv[2], d["ms_per_step"], d["stage_ms"]))
 except Exception as e:
-    print("sparse persist=%s strip=%s FAILED %r" % (sys.argv[2], sys.argv[3], e))
+    print("sparse persist=%s FAILED %r" % (sys.argv[2], e))
 PY
 done

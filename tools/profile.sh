@@ -2,14 +2,14 @@
 # Run on the GPU box (gpurun): rocprofv3 kernel stats + the PMC passes (separate runs, kernel-trace only) of the SHIPPED
 # schedule for BASELINE configs[2] (C3, the default bench.py workload), configs[1] (C2) and configs[4] (C5, --sparse).
 # Outputs under gpurun_out/prof_$TAG; summarise with tools/summarize_profile.py and commit profiles/$TAG_*.
-TAG=${1:-r3}
+TAG=${1:-r4}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 PMC_SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 run() {   # run <subdir> <rocprof args...> -- <cmd...>
     local sub=$1; shift
-    timeout 300 rocprofv3 --output-format csv --kernel-trace "$@" > $OUT/$sub.log 2>&1 || echo "$sub: rc $?"
+    timeout -k 5 150 rocprofv3 --output-format csv --kernel-trace "$@" > $OUT/$sub.log 2>&1 || echo "$sub: rc $?"
 }
 C3="python $PWD/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs --no-parity-gate --abi-only"
 C3ONE="python $PWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-legs --no-parity-gate --abi-only"

@@ -141,3 +141,34 @@ def test_id_file_is_validated_by_job_nonce_not_by_age(tmp_path, monkeypatch):
     monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "2")
     monkeypatch.delenv("MI355GP_JOB_NONCE", raising=False)
     assert G.job_nonce() == "abc#2"
+
+
+def test_expected_collectives_equals_a_brute_force_enumeration_of_one_evaluation():
+    """`grid.expected_collectives` (closed form per rank, asserted against the real collective logs on the GPU) against an
+    enumeration of every broadcast `crit(k)` of csrc/grid.hip enqueues -- (communicator kind, communicator index, doubles) -- with
+    the membership rule of `grid_bcast` (a rank takes part iff it belongs to that process row / column; empty broadcasts are
+    skipped by everybody)."""
+    from gpy_amd import grid as G
+    for N, nb, Pr, Pc in ((4096, 512, 2, 4), (1536, 256, 2, 2), (1300, 256, 1, 2), (3000, 128, 3, 2), (700, 128, 1, 1)):
+        T = -(-N // nb)
+        tile = nb * nb
+        calls = []                                   # (kind, index, doubles)
+        for k in range(T):
+            opr, opc = k % Pr, k % Pc
+            calls.append(("col", opc, tile))                                     # D down its process column
+            calls.append(("row", opr, tile))                                     # D along its process row
+            for pr in range(Pr):                                                 # row panel along every process row
+                below = sum(1 for i in range(k + 1, T) if i % Pr == pr)
+                calls.append(("row", pr, below * tile))
+            for j in range(k + 1, T):                                            # column-panel tiles
+                calls.append(("col", j % Pc, tile))
+            for pc in range(Pc):                                                 # X row panel down every process column
+                upto = sum(1 for j in range(k + 1) if j % Pc == pc)
+                calls.append(("col", pc, upto * tile))
+            for i in range(k + 1):                                               # transposed X tiles
+                calls.append(("row", i % Pr, tile))
+        for rank in range(Pr * Pc):
+            pr, pc = rank // Pc, rank % Pc
+            row = sum(1 for kind, idx, cnt in calls if kind == "row" and idx == pr and cnt > 0)
+            col = sum(1 for kind, idx, cnt in calls if kind == "col" and idx == pc and cnt > 0)
+            assert G.expected_collectives(N, nb, Pr, Pc, rank) == {"world": 5, "row": row, "col": col}, (N, nb, Pr, Pc, rank)

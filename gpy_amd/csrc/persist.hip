@@ -491,7 +491,7 @@ __device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double*
 // ---- a worker workgroup -----------------------------------------------------------------------------------------------
 __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
                                  int* __restrict__ sync, int kcap, double* __restrict__ hs, long long* __restrict__ dbg,
-                                 int tune, double* sm) {
+                                 double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
     __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished
     __shared__ int s_wait[PS_MAXT];                            // 1: all columns applied, waiting for L_kk (general tiles)
@@ -558,16 +558,9 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
         if (pj1 > pj0 || (handover && subdiag)) {              // ---- columns [pj0, pj1): C -= L(i, cols) L(k, cols)^T
             d4 acc[4][4];
             gt_load_buf<4>(Ct, ld, acc);
-            if (pj1 > pj0) {
-                // tune bit 3: the 4-stage ring pipeline (a worker is alone on its CU: the two-stage pipeline exposes the DMA
-                // latency of every slab); same slab order, same bits
-                if (tune & 8)
-                    gemm_tile_128_ring<true, true, true, 4>(A + (long)pi * NB * ld + (long)pj0 * NB, ld,
-                                                            A + (long)pk * NB * ld + (long)pj0 * NB, ld, (pj1 - pj0) * NB, acc, sm);
-                else
-                    gemm_tile_128<true, true, 4, true>(A + (long)pi * NB * ld + (long)pj0 * NB, ld,
-                                                       A + (long)pk * NB * ld + (long)pj0 * NB, ld, (pj1 - pj0) * NB, acc, sm);
-            }
+            if (pj1 > pj0)
+                gemm_tile_128<true, true, 4, true>(A + (long)pi * NB * ld + (long)pj0 * NB, ld,
+                                                   A + (long)pk * NB * ld + (long)pj0 * NB, ld, (pj1 - pj0) * NB, acc, sm);
             if (handover || subdiag) {                         // through the LDS image: coalesced write-through
                 // A sub-diagonal tile is written through on EVERY pass: its last version goes to the hand-off buffer and
                 // its place in A is later overwritten by the chain (the final L(j+1, j)) -- a dirty line of an earlier pass
@@ -1013,7 +1006,7 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
         if (threadIdx.x == 0 && dbg2) dbg2[1 + nt] = wall_clock64();
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
     } else if (inv_mode == 0) {
-        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, tune, sm);
+        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, sm);
     } else {
         worker_workgroup_inv(A, X, Wm, ld, nt, dinv_all, sync, kcap, hs, inv_mode >= 2 ? 1 : 0, tune, dbg2, sm);
     }

@@ -48,7 +48,8 @@
 #define PS_SUB (16 + PS_MAXNT)             // [nt] tile (i, i-1) holds columns 0 .. i-2, published for the chain
 #define PS_DIA (16 + 2 * PS_MAXNT)         // [nt] tile (i, i)   holds columns 0 .. i-2, published for the chain
 #define PS_XCOL (16 + 3 * PS_MAXNT)         // [nt] xcol[k]: X(k .. k+xcol[k]-1, k) final (the inverse, column k, from the diagonal down)
-#define PS_SYNC_INTS (16 + 4 * PS_MAXNT)
+#define PS_PRE (16 + 4 * PS_MAXNT)          // [nt] tile (i, i-1) holds columns 0 .. i-3 in place (its owner is done with it)
+#define PS_SYNC_INTS (16 + 5 * PS_MAXNT)
 #define PS_RING 4                          // LDS stages of the folded launch's worker GEMM (4 x 34,816 B of the 147,456)
 #define PS_MAXTASK 64                      // tasks (P / X / W tiles) one worker of the folded launch can own
 
@@ -428,20 +429,28 @@ __device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double*
                 break;
             }
             // Block j is being factored by waves 0..3: keep its sixteen barriers company.  Meanwhile poll the hand-over word
-            // of tile (j+1, j) (looked at one barrier after its load was issued: the poll never delays a barrier).
-            int fs = 0;
-            for (int b = 0; b < 16; ++b) {
-                if (fs < 1) fs = ld_flag(sync + PS_SUB + j + 1);
+            // of tile (j+1, j) (looked at one barrier after its load was issued: the poll never delays a barrier) and, the
+            // moment it is set, issue the loads of this wave's FIRST strip from the hand-off buffer (sixteen 1-KB-contiguous
+            // 16-byte loads): they land underneath the rest of the factorisation (bare s_barriers do not wait for them); the
+            // second strip's land underneath the first strip's solve.
+            int fs = 0, b = 0;
+            for (; b < 16 && fs < 1; ++b) {
+                fs = ld_flag(sync + PS_SUB + j + 1);
                 raw_barrier();
             }
-            if (fs < 1 && !wave_wait(sync + PS_SUB + j + 1, sync, lane)) {     // the owner was late
-                if (lane == 0) s_fail = 1;
+            if (fs >= 1) chain_load_strip(hsj, g, lane, P0);                   // the first strip early (128 registers)
+            for (; b < 16; ++b) raw_barrier();
+            if (fs < 1) {
+                if (!wave_wait(sync + PS_SUB + j + 1, sync, lane)) {           // the owner was late
+                    if (lane == 0) s_fail = 1;
+                } else {
+                    chain_load_strip(hsj, g, lane, P0);
+                    loaded = true;
+                }
             } else {
-                // two strips from the hand-off buffer: thirty-two 1-KB-contiguous 16-byte loads per wave
-                chain_load_strip(hsj, g, lane, P0);
-                chain_load_strip(hsj, g + 4, lane, P1);
                 loaded = true;
             }
+            if (loaded) chain_load_strip(hsj, g + 4, lane, P1);                // lands underneath the first strip's solve
             if (dbg && t == 256) dbg[8 * j + 2] = wall_clock64();
             // ---- L(j+1, j) = A(j+1, j) L_jj^-T, strips g and g + 4, one after the other
             if (loaded) {
@@ -468,20 +477,40 @@ __device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double*
             // ---- L(j+1, j) to global from the image: 16 B per lane, 1 KB rows per wave instruction, write-through;
             //      then row j+1's progress word -- all underneath the update
             {
-                // wave 4 + g stores rows g, g + 4, ..., g + 124: lane -> columns 2 lane, 2 lane + 1
+                // wave 4 + g stores rows g, g + 4, ..., g + 124: lane -> columns 2 lane, 2 lane + 1.  Two strips (eight rows)
+                // per round: eight LDS reads in flight, then their eight stores.  The loop stays ROLLED over the strips and the
+                // lane's image address is re-derived in every step: fully unrolled the compiler keeps 32 loop-invariant LDS
+                // addresses, spills them, and reloads one per row with s_waitcnt vmcnt(0) -- which also waits for the previous
+                // row's write-through store: 13 us per tile instead of ~2, and row j+1's progress word is what the owners of
+                // tile (j+2, j+1) wait for.
                 const __amdgpu_buffer_rsrc_t rs = rsrc_at(A + r1 * ld + c0);
                 const int jb = lane >> 3, kk = 2 * (lane & 7), q = kk >> 2, m = kk & 3;
-                const double* Tl = sm + jb * TSZ + q + 4 * m;                  // per-lane part of the image address
+                int toff = jb * TSZ + q + 4 * m + g * TS;                      // per-lane part of the image address
+                asm volatile("" : "+v"(toff));
+                const double* Tg = sm + toff;
+                const int rowb = (int)ld * 8;
+#pragma unroll 1
+                for (int a = 0; a < 8; a += 2) {
+                    d2 v[8];
 #pragma unroll
-                for (int it = 0; it < 32; ++it) {
-                    const int row = it * 4 + g;
-                    const double* T = Tl + ((row >> 4) * 8) * TSZ + (row & 15) * TS;
-                    const d2 v = {T[0], T[4]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, lane * 16, row * (int)ld * 8, 16);
+                    for (int u = 0; u < 8; ++u) {
+                        const double* T = Tg + ((a + (u >> 2)) * 8) * TSZ + 4 * (u & 3) * TS;
+                        v[u] = d2{T[0], T[4]};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int row = 16 * (a + (u >> 2)) + 4 * (u & 3) + g;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v[u]), rs, lane * 16, row * rowb, 16);
+                    }
                 }
             }
+            if (dbg && t == 256) dbg[8 * nt + 4 * (3 * (j + 1) + 1) + 3] = wall_clock64();   // stores issued
             drain_stores();
-            if (lane == 0 && atomicAdd(&s_arr, 1) == 4 * (j + 1) - 1) st_flag(sync + PS_CNT + j + 1, j + 1);
+            if (dbg && t == 256) dbg[8 * nt + 4 * (3 * (j + 1) + 2) + 3] = wall_clock64();   // stores drained
+            if (lane == 0 && atomicAdd(&s_arr, 1) == 4 * (j + 1) - 1) {
+                st_flag(sync + PS_CNT + j + 1, j + 1);
+                if (dbg) dbg[8 * nt + 4 * (3 * (j + 1)) + 3] = wall_clock64();     // near slot (j+1, 0, 3): row j+1 published
+            }
             lds_barrier();                                     // (Z)
             lds_barrier();                                     // (W)
         }
@@ -489,11 +518,20 @@ __device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double*
 }
 
 // ---- a worker workgroup -----------------------------------------------------------------------------------------------
+//
+// The hand-over of sub-diagonal tile (i, i-1) is the LAST link of the owners' path from dcnt = i-1 to the chain's step i-1
+// (solve of tile (i, i-2), then its column applied to tile (i, i-1)).  With one owner per tile the two links are separated
+// by a flag and the second owner's polling (~11 us of the path's 53).  `split` (the default): the owner of tile (i, i-1)
+// applies columns 0 .. i-3 only and says so (PS_PRE); the owner of tile (i, i-2) goes on, right after its solve, with that
+// ONE column on tile (i, i-1) and hands the tile to the chain itself.  Same passes on the same data in the same order, the
+// accumulator carried through memory in fp64 between them as before: the same bits.
 __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
                                  int* __restrict__ sync, int kcap, double* __restrict__ hs, long long* __restrict__ dbg,
-                                 double* sm) {
+                                 int split, double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
-    __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished
+    __shared__ int s_pre[PS_MAXNT];                            // PS_PRE snapshot
+    __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished;
+                                                               // -2: tile (i, i-2) final, last column of tile (i, i-1) pending
     __shared__ int s_wait[PS_MAXT];                            // 1: all columns applied, waiting for L_kk (general tiles)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (w >= 4) return;              // the launch has eight waves per workgroup for the chain's sake; a worker uses four
@@ -513,17 +551,23 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
         if (t < nt) s_cnt[t] = ld_flag(sync + PS_CNT + t);
         if (t == 64) s_cnt[nt] = ld_flag(sync + PS_DCNT);
         if (t == 65) s_cnt[nt + 1] = ld_flag(sync + PS_ABORT);
+        if (split && t >= 128 && t < 128 + nt) s_pre[t - 128] = ld_flag(sync + PS_PRE + t - 128);
         if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
         if (s_cnt[nt + 1] != 0) return;
         // ---- pick the first owned tile (ascending row: the chain needs low rows first) that has something to do
-        int pick = -1, pi = 0, pk = 0, pj0 = 0, pj1 = 0, ptrsm = 0;
+        int pick = -1, pi = 0, pk = 0, pj0 = 0, pj1 = 0, ptrsm = 0, pfin = 0;
         for (int s = 0; s < nmine; ++s) {
             const int p = s_prog[s];
-            if (p < 0) continue;
+            if (p == -1) continue;
             int i, k;
             own.tile(me, s, i, k);
-            const int limit = (i == k) ? i - 1 : k;            // diagonal tiles stop one column short (the chain's)
+            if (p == -2) {                                     // column i-2 of tile (i, i-1): L(i, i-2) is this worker's own
+                if (s_cnt[i - 1] >= i - 1 && s_pre[i]) { pick = s; pi = i; pk = i - 1; pj0 = i - 2; pj1 = i - 1; pfin = 1; break; }
+                continue;
+            }
+            // diagonal tiles stop one column short (the chain's); split: sub-diagonal tiles two (the owner of tile (i, i-2)'s)
+            const int limit = (i == k) ? i - 1 : ((split && i == k + 1 && i >= 2) ? k - 1 : k);
             if (s_wait[s]) {
                 if (s_cnt[nt] >= k + 1) { pick = s; pi = i; pk = k; pj0 = pj1 = limit; ptrsm = 1; break; }
                 continue;
@@ -547,14 +591,15 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
             continue;
         }
         idle0 = 0;
-        const int limit = (pi == pk) ? pi - 1 : pk;
+        const bool subdiag = (pi == pk + 1);
+        const int limit = (pi == pk) ? pi - 1 : ((split && subdiag && pi >= 2 && !pfin) ? pk - 1 : pk);
         const bool general = pi >= pk + 2;
         double* Ct = A + (long)pi * NB * ld + (long)pk * NB;
         // diagnostics: the LAST task of a near tile: [picked, compute done, published]
         long long* dn = (dbg && pi - pk <= 2 && (pj1 == limit)) ? dbg + 8 * nt + 4 * (3 * pi + (pi - pk)) : nullptr;
         if (dn && t == 0) dn[0] = wall_clock64();
-        const bool handover = (pj1 == limit && !general);      // the tile's last write before the chain takes it
-        const bool subdiag = (pi == pk + 1);
+        const bool pre = (pj1 == limit && split && subdiag && pi >= 2 && !pfin);   // all but the last column: leave it in place
+        const bool handover = (pj1 == limit && !general && !pre);                  // the tile's last write before the chain takes it
         if (pj1 > pj0 || (handover && subdiag)) {              // ---- columns [pj0, pj1): C -= L(i, cols) L(k, cols)^T
             d4 acc[4][4];
             gt_load_buf<4>(Ct, ld, acc);
@@ -584,6 +629,14 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
                 s_prog[pick] = -1;
             }
             --left;
+        } else if (pre) {                                      // ---- the rest is the owner of tile (i, i-2)'s
+            drain_stores();
+            __syncthreads();
+            if (t == 0) {
+                st_flag(sync + PS_PRE + pi, 1);
+                s_prog[pick] = -1;
+            }
+            --left;
         } else if (pj1 == limit && !ptrsm) {                   // ---- general tile complete, L_kk not there yet
             drain_stores();
             __syncthreads();
@@ -603,12 +656,13 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
             stage_store_coherent<256>(sm, Ct, ld, t);
             drain_stores();
             __syncthreads();
+            const bool more = split && pi == pk + 2;           // goes on with the last column of tile (i, i-1)
             if (t == 0) {
                 st_flag(sync + PS_CNT + pi, pk + 1);
                 if (dn) dn[2] = wall_clock64();
-                s_prog[pick] = -1;
+                s_prog[pick] = more ? -2 : -1;
             }
-            --left;
+            if (!more) --left;
         } else {
             __syncthreads();
             if (t == 0) s_prog[pick] = pj1;
@@ -1006,7 +1060,7 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
         if (threadIdx.x == 0 && dbg2) dbg2[1 + nt] = wall_clock64();
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
     } else if (inv_mode == 0) {
-        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, sm);
+        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, sm);
     } else {
         worker_workgroup_inv(A, X, Wm, ld, nt, dinv_all, sync, kcap, hs, inv_mode >= 2 ? 1 : 0, tune, dbg2, sm);
     }

@@ -38,9 +38,12 @@ def main():
                 print("   step j=%d, times relative to the end of factor(j): dcnt %+.1f | tile (j+2,j) picked %+.1f solved %+.1f "
                       "published %+.1f | chain cnt[j+1]: update starts %+.1f | tile (j+2,j+1) picked %+.1f computed %+.1f published "
                       "%+.1f | tile (j+2,j+2) picked %+.1f computed %+.1f published %+.1f | factor(j+1) starts %+.1f ends %+.1f, "
-                      "solver has P at %+.1f" % ((j, st[j, 4] - T) + tuple(nr[j + 2, 2] - T) + (st[j, 3] - T,) +
-                                                 tuple(nr[j + 2, 1] - T) + tuple(nr[j + 2, 0] - T) +
+                      "solver has P at %+.1f" % ((j, st[j, 4] - T) + tuple(nr[j + 2, 2, :3] - T) + (st[j, 3] - T,) +
+                                                 tuple(nr[j + 2, 1, :3] - T) + tuple(nr[j + 2, 0, :3] - T) +
                                                  (st[j + 1, 0] - T, st[j + 1, 1] - T, st[j + 1, 2] - T)))
+                print("   chain publishes row j+1 at %+.1f (mean over steps: %.1f us after its update starts)" % (
+                    nr[j + 1, 0, 3] - T, np.mean([nr[q + 1, 0, 3] - st[q, 3] for q in range(1, nt - 2)])))
+                print("   wave 4: stores of L(j+1,j) issued %+.1f, drained %+.1f" % (nr[j + 1, 1, 3] - T, nr[j + 1, 2, 3] - T))
                 if len(sys.argv) > 3:
                     for j in range(nt - 1):
                         print("   j=%2d %s" % (j, " ".join("%7.1f" % v for v in (st[j] - st[j, 0]))))

@@ -35,7 +35,11 @@
 
 #define PS_MAXNT 64                        // tiles per dimension the sync block is laid out for
 #define PS_MAXT 48                         // tiles one worker can own
-#define PS_LDS_BYTES (64 * TSZ * 8)        // 147,456 B: the chain's Y image (64 tiles); one workgroup per CU
+#define PS_STAGE_CHUNKS 14                 // 1-KB chunks (of 16) of a strip of tile (j+1, j) staged in LDS while block j is factored
+#define PS_STAGE_DOUBLES (PS_STAGE_CHUNKS * 128)
+// the chain's Y image (64 tiles, 147,456 B) or, while a block is factored, L_jj (36 tiles) + its inverted diagonal tiles (8)
+// + four staged strips: 158,720 B; one workgroup per CU
+#define PS_LDS_BYTES ((44 * TSZ + 4 * PS_STAGE_DOUBLES) * 8)
 #define PS_TIMEOUT_TICKS 50000000LL        // 0.5 s of the 100 MHz wall clock: no wait of a sane run comes near it
 #define PS_ARRIVE_TICKS 100000LL           // 1 ms: every workgroup of the launch must be resident by then (see ps_arrive)
 #define PS_ARRIVE_ABORT (1 << 30)          // bit of the arrival word: the launch was called off before anything was written
@@ -52,6 +56,21 @@
 #define PS_SYNC_INTS (16 + 5 * PS_MAXNT)
 #define PS_RING 4                          // LDS stages of the folded launch's worker GEMM (4 x 34,816 B of the 147,456)
 #define PS_MAXTASK 64                      // tasks (P / X / W tiles) one worker of the folded launch can own
+
+// a pointer / int that is the same in every lane, moved to scalar registers (arguments of a non-inlined device function
+// arrive in vector registers: without this every buffer access built from them becomes a waterfall loop)
+template <typename T>
+__device__ __forceinline__ T* uni(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long uni(long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)v >> 32));
+    return (long)(((unsigned long)hi << 32) | lo);
+}
 
 __device__ __forceinline__ int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_flag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -236,14 +255,17 @@ __device__ __forceinline__ void stage_store_chain_order(const double* sm, double
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The chain workgroup has EIGHT waves with two roles:
-//   factor waves 0..3 : diag128_factor exactly as k_diag128 runs it; then, underneath the solve, they write L_jj through,
-//                       publish dcnt and fetch the 36 accumulator tiles of block (j+1, j+1); then the update: wave 0 / 1 own
-//                       the lower triangle of tile rows 0..3 / 4..7 (ten 16 x 16 tiles), waves 2 / 3 the rectangle rows 4..7
-//                       x columns 0..1 / 2..3 (eight tiles) -- every LDS fragment feeds two or more MFMAs;
-//   solver waves 4..7 : idle while block j is factored, so they fetch tile (j+1, j) THEN (strips g and g+4 for wave 4+g,
-//                       sc1 loads in flight underneath the factorisation), keep the factor's sixteen barriers company with
-//                       bare s_barriers, run the solve the moment L_jj is there, write the Y image and -- underneath the
-//                       update -- store L(j+1, j) through and publish row j+1.
+//   factor waves 0..3 : diag128_factor exactly as k_diag128 runs it; then wave w fetches strip w + 4 of tile (j+1, j) (the
+//                       loads land underneath the write-through of L_jj and the publication of dcnt), solves it next to the
+//                       solver waves, fetches its share of the 36 accumulator tiles of block (j+1, j+1); then the update:
+//                       wave 0 / 1 own the lower triangle of tile rows 0..3 / 4..7 (ten 16 x 16 tiles), waves 2 / 3 the
+//                       rectangle rows 4..7 x columns 0..1 / 2..3 (eight tiles) -- every LDS fragment feeds two or more MFMAs;
+//   solver waves 4..7 : idle while block j is factored, so wave 4 + g fetches strip g of tile (j+1, j) THEN (sc1 loads in
+//                       flight underneath the factorisation, issued the moment the tile's hand-over word is set), keeps the
+//                       factor's sixteen barriers company with bare s_barriers, solves the strip the moment L_jj is there,
+//                       and -- underneath the update -- stores L(j+1, j) through from the Y image and publishes row j+1.
+//   One strip per wave: the solve of the 128 x 128 tile is eight independent 16-row strips, 5 us of dependent MFMA chains
+//   each; two strips per solver wave cost 10 us and a spill of the first strip's 128 result registers.
 #define PS_CHAIN_WAVES 8
 
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -272,6 +294,26 @@ __device__ __forceinline__ void chain_load_strip(const double* __restrict__ hs, 
         P[c >> 1][2 * (c & 1)] = v[0];
         P[c >> 1][2 * (c & 1) + 1] = v[1];
     }
+}
+
+// chunks [C0, C1) of a strip into their registers
+template <int C0, int C1>
+__device__ __forceinline__ void chain_load_strip_part(const double* __restrict__ hs, int a, int lane, d4 (&P)[8]) {
+    const __amdgpu_buffer_rsrc_t rs = rsrc_at(hs + a * 2048);
+#pragma unroll
+    for (int c = C0; c < C1; ++c) {
+        const d2 v = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, c * 1024, 16));
+        P[c >> 1][2 * (c & 1)] = v[0];
+        P[c >> 1][2 * (c & 1) + 1] = v[1];
+    }
+}
+// chunks [0, PS_STAGE_CHUNKS) of a strip straight into LDS (chunk c: 1 KB at dst + 128 c doubles, lane l's 16 bytes at 2 l);
+// four strips = 52 KB behind the 44 tile images of the factor phase
+__device__ __forceinline__ void chain_stage_strip(const double* __restrict__ hs, int a, int lane, double* dst) {
+    const __amdgpu_buffer_rsrc_t rs = rsrc_at(hs + a * 2048);
+#pragma unroll
+    for (int c = 0; c < PS_STAGE_CHUNKS; ++c)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst + c * 128, 16, lane * 16, c * 1024, 0, 16);
 }
 
 // L_jj from the LDS image to global, write-through (diag128_store with scalar addressing), sum(log diag) -> logsum[0]
@@ -362,6 +404,14 @@ __device__ __forceinline__ void chain_put_w(double* Tt, int fi, int fk, const d4
         default: FN<3>(__VA_ARGS__); break;          \
     }
 
+#define CHAIN_DISPATCH_G(FN, ...)                    \
+    switch (g) {                                     \
+        case 0: FN<0>(__VA_ARGS__); break;           \
+        case 1: FN<1>(__VA_ARGS__); break;           \
+        case 2: FN<2>(__VA_ARGS__); break;           \
+        default: FN<3>(__VA_ARGS__); break;          \
+    }
+
 // one wave blocks until word p is set; false on abort / timeout (wave-uniform answer)
 __device__ __forceinline__ bool wave_wait(int* p, int* sync, int lane) {
     int ok = 1;
@@ -369,152 +419,208 @@ __device__ __forceinline__ bool wave_wait(int* p, int* sync, int lane) {
     return __builtin_amdgcn_readfirstlane(ok) != 0;
 }
 
-__device__ void chain_workgroup(double* __restrict__ A, long ld, int nt, double* __restrict__ dinv_all,
-                                double* __restrict__ logsum, int* __restrict__ info, int* __restrict__ sync,
-                                const double* __restrict__ hs, long long* __restrict__ dbg, double* sm) {
-    __shared__ int s_fail, s_arr, s_arr0;
+// The two roles are separate NON-INLINED functions: inlined into the kernel next to the workers' code the compiler hoists the
+// loop-invariant per-lane addresses of every role out of every loop, keeps them live across the whole kernel and then spills
+// each freshly loaded strip chunk (with an s_waitcnt per pair of loads: the loads serialise) -- one register allocation per role
+// keeps the strips in registers.  Arguments of a non-inlined function arrive in vector registers: uni() moves them back.
+static __shared__ int s_fail, s_arr, s_arr0;
+#define CHAIN_ARGS                                                                                                        \
+    double *A_, long ld_, int nt_, double *dinv_all_, double *logsum_, int *info_, int *sync_, const double *hs_, long long *dbg_
+
+__device__ __attribute__((noinline)) void chain_factor_waves(CHAIN_ARGS) {
+    double* __restrict__ A = uni(A_);
+    const long ld = uni(ld_);
+    const int nt = uni(nt_);
+    double* __restrict__ dinv_all = uni(dinv_all_);
+    double* __restrict__ logsum = uni(logsum_);
+    int* __restrict__ info = uni(info_);
+    int* __restrict__ sync = uni(sync_);
+    const double* __restrict__ hs = uni(hs_);
+    long long* __restrict__ dbg = uni(dbg_);
+    extern __shared__ __attribute__((aligned(16))) double sm[];
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), fi = lane & 15, fk = lane >> 4;
     double* Tt = sm;
     double* Dinv8 = sm + NTILE * TSZ;
-    if (t == 0) { s_fail = 0; s_arr = 0; s_arr0 = 0; }
-    if (w < 4) {
-        // ================================================= factor waves ==================================================
-        diag128_load<false>(A, ld, Tt);                        // block (0,0): written by the previous kernel
-        __syncthreads();
-        for (int j = 0; j < nt; ++j) {
-            const long c0 = (long)j * NB, r1 = c0 + NB;        // r1: first row / column of block j+1
-            const bool last = (j + 1 == nt);
-            if (dbg && t == 0) dbg[8 * j + 0] = wall_clock64();
-            diag128_factor<true, TSZ>(Tt, Dinv8, c0, dinv_all + (long)j * 8 * 256, info);      // 16 barriers, ends with one
-            if (dbg && t == 0) dbg[8 * j + 1] = wall_clock64();
-            // L_jj write-through, dcnt (the owners of row j+2 start from it), then this wave's accumulators: all of it
-            // underneath the solve of the other four waves
-            chain_store_diag(A + c0 * ld + c0, ld, Tt, logsum + j, t, lane, w);
-            drain_stores();
-            if (lane == 0 && atomicAdd(&s_arr0, 1) == 4 * (j + 1) - 1) {
-                st_flag(sync + PS_DCNT, j + 1);
-                if (dbg) dbg[8 * j + 4] = wall_clock64();
-            }
-            if (last) break;
-            d4 acc[10];
-            if (!wave_wait(sync + PS_DIA + j + 1, sync, lane)) {
+    double* stage = sm + (NTILE + 8) * TSZ;                    // behind L_jj and its inverted diagonal tiles
+    (void)A; (void)ld; (void)dinv_all; (void)logsum; (void)info; (void)hs; (void)dbg; (void)fi; (void)fk; (void)stage; (void)Dinv8;
+    // ================================================= factor waves ==================================================
+    diag128_load<false>(A, ld, Tt);                        // block (0,0): written by the previous kernel
+    __syncthreads();
+    for (int j = 0; j < nt; ++j) {
+        const long c0 = (long)j * NB, r1 = c0 + NB;        // r1: first row / column of block j+1
+        const bool last = (j + 1 == nt);
+        if (dbg && t == 0) dbg[8 * j + 0] = wall_clock64();
+        diag128_factor<true, TSZ>(Tt, Dinv8, c0, dinv_all + (long)j * 8 * 256, info);      // 16 barriers, ends with one
+        if (dbg && t == 0) dbg[8 * j + 1] = wall_clock64();
+        // L_jj write-through, dcnt (the owners of row j+2 start from it), then this wave's share of the 36 accumulator tiles
+        // of block (j+1, j+1): all of it underneath the solve of the other four waves
+        chain_store_diag(A + c0 * ld + c0, ld, Tt, logsum + j, t, lane, w);
+        drain_stores();
+        if (lane == 0 && atomicAdd(&s_arr0, 1) == 4 * (j + 1) - 1) {
+            st_flag(sync + PS_DCNT, j + 1);
+            if (dbg) dbg[8 * j + 4] = wall_clock64();
+        }
+        if (last) break;
+        d4 acc[10];
+        if (!wave_wait(sync + PS_DIA + j + 1, sync, lane)) {
+            if (lane == 0) s_fail = 1;
+        } else {
+            CHAIN_DISPATCH(chain_load_acc_w, A + r1 * ld + r1, ld, fi, fk, acc);
+        }
+        lds_barrier();                                     // (X) every wave is done reading Tt / Dinv8
+        if (s_fail) return;
+        lds_barrier();                                     // (Y) the Y image is written
+        if (dbg && t == 0) dbg[8 * j + 3] = wall_clock64();
+        // ---- block (j+1, j+1) -= Y Y^T on its 36 lower 16 x 16 tiles (columns 0 .. j-1 were applied by its owner)
+        CHAIN_DISPATCH(chain_update_w, sm, fi, fk, acc);
+        if (dbg && t == 0) dbg[8 * j + 7] = wall_clock64();
+        lds_barrier();                                     // (Z) Yim is dead: its space becomes Tt again
+        CHAIN_DISPATCH(chain_put_w, Tt, fi, fk, acc);
+        lds_barrier();                                     // (W)
+        if (dbg && t == 0) dbg[8 * j + 5] = wall_clock64();
+    }
+}
+
+__device__ __attribute__((noinline)) void chain_solver_waves(CHAIN_ARGS) {
+    double* __restrict__ A = uni(A_);
+    const long ld = uni(ld_);
+    const int nt = uni(nt_);
+    double* __restrict__ dinv_all = uni(dinv_all_);
+    double* __restrict__ logsum = uni(logsum_);
+    int* __restrict__ info = uni(info_);
+    int* __restrict__ sync = uni(sync_);
+    const double* __restrict__ hs = uni(hs_);
+    long long* __restrict__ dbg = uni(dbg_);
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), fi = lane & 15, fk = lane >> 4;
+    double* Tt = sm;
+    double* Dinv8 = sm + NTILE * TSZ;
+    double* stage = sm + (NTILE + 8) * TSZ;                    // behind L_jj and its inverted diagonal tiles
+    (void)A; (void)ld; (void)dinv_all; (void)logsum; (void)info; (void)hs; (void)dbg; (void)fi; (void)fk; (void)stage; (void)Dinv8;
+    // ================================================= solver waves ==================================================
+    const int g = w - 4;
+    __syncthreads();                                       // pairs with the barrier after diag128_load
+    for (int j = 0; j < nt; ++j) {
+        const long c0 = (long)j * NB, r1 = c0 + NB;
+        const bool last = (j + 1 == nt);
+        d4 P0[8], P1[8], Y0[8], Y1[8];
+        bool loaded = false, staged = false;
+        const double* hsj = hs + (long)(j + 1) * (NB * NB);                // hand-off buffer of row j+1
+        if (last) {
+            for (int b = 0; b < 16; ++b) raw_barrier();
+            break;
+        }
+        // Block j is being factored by waves 0..3: keep its sixteen barriers company.  Meanwhile poll the hand-over word
+        // of tile (j+1, j) (looked at one barrier after its load was issued: the poll never delays a barrier) and, the
+        // moment it is set, fetch this wave's two strips from the hand-off buffer underneath the rest of the factorisation
+        // (bare s_barriers do not wait for loads): strip g into registers (sixteen 1-KB-contiguous 16-byte loads), strip
+        // g + 4 -- for which there are no registers -- by LDS-DMA into the space behind the factor's tile images (14 of its
+        // 16 chunks: that is what fits) and its last two chunks (the last column block the solve gets to) into registers.
+        int fs = 0, b = 0;
+        for (; b < 16 && fs < 1; ++b) {
+            fs = ld_flag(sync + PS_SUB + j + 1);
+            raw_barrier();
+        }
+        if (fs >= 1) {
+            chain_load_strip(hsj, g, lane, P0);
+            chain_stage_strip(hsj, g + 4, lane, stage + g * PS_STAGE_DOUBLES);
+            chain_load_strip_part<PS_STAGE_CHUNKS, 16>(hsj, g + 4, lane, P1);
+            staged = true;
+        }
+        for (; b < 16; ++b) raw_barrier();
+        if (fs < 1) {
+            if (!wave_wait(sync + PS_SUB + j + 1, sync, lane)) {           // the owner was late
                 if (lane == 0) s_fail = 1;
             } else {
-                CHAIN_DISPATCH(chain_load_acc_w, A + r1 * ld + r1, ld, fi, fk, acc);
-            }
-            lds_barrier();                                     // (X) every wave is done reading Tt / Dinv8
-            if (s_fail) return;
-            lds_barrier();                                     // (Y) the Y image is written
-            if (dbg && t == 0) dbg[8 * j + 3] = wall_clock64();
-            // ---- block (j+1, j+1) -= Y Y^T on its 36 lower 16 x 16 tiles (columns 0 .. j-1 were applied by its owner)
-            CHAIN_DISPATCH(chain_update_w, sm, fi, fk, acc);
-            if (dbg && t == 0) dbg[8 * j + 7] = wall_clock64();
-            lds_barrier();                                     // (Z) Yim is dead: its space becomes Tt again
-            CHAIN_DISPATCH(chain_put_w, Tt, fi, fk, acc);
-            lds_barrier();                                     // (W)
-            if (dbg && t == 0) dbg[8 * j + 5] = wall_clock64();
-        }
-    } else {
-        // ================================================= solver waves ==================================================
-        const int g = w - 4;
-        __syncthreads();                                       // pairs with the barrier after diag128_load
-        for (int j = 0; j < nt; ++j) {
-            const long c0 = (long)j * NB, r1 = c0 + NB;
-            const bool last = (j + 1 == nt);
-            d4 P0[8], P1[8], Y0[8], Y1[8];
-            bool loaded = false;
-            const double* hsj = hs + (long)(j + 1) * (NB * NB);                // hand-off buffer of row j+1
-            if (last) {
-                for (int b = 0; b < 16; ++b) raw_barrier();
-                break;
-            }
-            // Block j is being factored by waves 0..3: keep its sixteen barriers company.  Meanwhile poll the hand-over word
-            // of tile (j+1, j) (looked at one barrier after its load was issued: the poll never delays a barrier) and, the
-            // moment it is set, issue the loads of this wave's FIRST strip from the hand-off buffer (sixteen 1-KB-contiguous
-            // 16-byte loads): they land underneath the rest of the factorisation (bare s_barriers do not wait for them); the
-            // second strip's land underneath the first strip's solve.
-            int fs = 0, b = 0;
-            for (; b < 16 && fs < 1; ++b) {
-                fs = ld_flag(sync + PS_SUB + j + 1);
-                raw_barrier();
-            }
-            if (fs >= 1) chain_load_strip(hsj, g, lane, P0);                   // the first strip early (128 registers)
-            for (; b < 16; ++b) raw_barrier();
-            if (fs < 1) {
-                if (!wave_wait(sync + PS_SUB + j + 1, sync, lane)) {           // the owner was late
-                    if (lane == 0) s_fail = 1;
-                } else {
-                    chain_load_strip(hsj, g, lane, P0);
-                    loaded = true;
-                }
-            } else {
+                chain_load_strip(hsj, g, lane, P0);
                 loaded = true;
             }
-            if (loaded) chain_load_strip(hsj, g + 4, lane, P1);                // lands underneath the first strip's solve
-            if (dbg && t == 256) dbg[8 * j + 2] = wall_clock64();
-            // ---- L(j+1, j) = A(j+1, j) L_jj^-T, strips g and g + 4, one after the other
-            if (loaded) {
-                trsm_strip_core(P0, Y0, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
-                                [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
-                __builtin_amdgcn_sched_barrier(0);             // do not interleave the two strips: 128 live registers more
-                trsm_strip_core(P1, Y1, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
-                                [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
-            }
-            if (dbg && t == 256) dbg[8 * j + 6] = wall_clock64();
-            lds_barrier();                                     // (X)
-            if (s_fail) return;
-#pragma unroll
-            for (int jb = 0; jb < 8; ++jb) {
-                double* Ta = sm + (g * 8 + jb) * TSZ + fi * TS + 4 * fk;       // column fk + 4r -> position r + 4 fk
-                double* Tb = sm + ((g + 4) * 8 + jb) * TSZ + fi * TS + 4 * fk;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    Ta[r] = Y0[jb][r];
-                    Tb[r] = Y1[jb][r];
-                }
-            }
-            lds_barrier();                                     // (Y)
-            // ---- L(j+1, j) to global from the image: 16 B per lane, 1 KB rows per wave instruction, write-through;
-            //      then row j+1's progress word -- all underneath the update
-            {
-                // wave 4 + g stores rows g, g + 4, ..., g + 124: lane -> columns 2 lane, 2 lane + 1.  Two strips (eight rows)
-                // per round: eight LDS reads in flight, then their eight stores.  The loop stays ROLLED over the strips and the
-                // lane's image address is re-derived in every step: fully unrolled the compiler keeps 32 loop-invariant LDS
-                // addresses, spills them, and reloads one per row with s_waitcnt vmcnt(0) -- which also waits for the previous
-                // row's write-through store: 13 us per tile instead of ~2, and row j+1's progress word is what the owners of
-                // tile (j+2, j+1) wait for.
-                const __amdgpu_buffer_rsrc_t rs = rsrc_at(A + r1 * ld + c0);
-                const int jb = lane >> 3, kk = 2 * (lane & 7), q = kk >> 2, m = kk & 3;
-                int toff = jb * TSZ + q + 4 * m + g * TS;                      // per-lane part of the image address
-                asm volatile("" : "+v"(toff));
-                const double* Tg = sm + toff;
-                const int rowb = (int)ld * 8;
-#pragma unroll 1
-                for (int a = 0; a < 8; a += 2) {
-                    d2 v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const double* T = Tg + ((a + (u >> 2)) * 8) * TSZ + 4 * (u & 3) * TS;
-                        v[u] = d2{T[0], T[4]};
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int row = 16 * (a + (u >> 2)) + 4 * (u & 3) + g;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v[u]), rs, lane * 16, row * rowb, 16);
-                    }
-                }
-            }
-            if (dbg && t == 256) dbg[8 * nt + 4 * (3 * (j + 1) + 1) + 3] = wall_clock64();   // stores issued
-            drain_stores();
-            if (dbg && t == 256) dbg[8 * nt + 4 * (3 * (j + 1) + 2) + 3] = wall_clock64();   // stores drained
-            if (lane == 0 && atomicAdd(&s_arr, 1) == 4 * (j + 1) - 1) {
-                st_flag(sync + PS_CNT + j + 1, j + 1);
-                if (dbg) dbg[8 * nt + 4 * (3 * (j + 1)) + 3] = wall_clock64();     // near slot (j+1, 0, 3): row j+1 published
-            }
-            lds_barrier();                                     // (Z)
-            lds_barrier();                                     // (W)
+        } else {
+            loaded = true;
         }
+        if (dbg && t == 256) dbg[8 * j + 2] = wall_clock64();
+        // ---- L(j+1, j) = A(j+1, j) L_jj^-T, strips g and g + 4, one after the other
+        if (loaded) {
+            trsm_strip_core(P0, Y0, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
+                            [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
+            __builtin_amdgcn_sched_barrier(0);             // do not interleave the two strips: 128 live registers more
+            if (staged) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the DMAs (issued a factorisation ago) have landed
+                const double* sp = stage + g * PS_STAGE_DOUBLES + 2 * lane;
+#pragma unroll
+                for (int c = 0; c < PS_STAGE_CHUNKS; ++c) {
+                    const d2 v = *reinterpret_cast<const d2*>(sp + c * 128);
+                    P1[c >> 1][2 * (c & 1)] = v[0];
+                    P1[c >> 1][2 * (c & 1) + 1] = v[1];
+                }
+            } else {
+                chain_load_strip(hsj, g + 4, lane, P1);
+            }
+            trsm_strip_core(P1, Y1, [Tt](int jb, int k) { return Tt + tix(jb, k) * TSZ; },
+                            [Dinv8](int jb) { return Dinv8 + jb * TSZ; }, lane);
+        }
+        if (dbg && t == 256) dbg[8 * j + 6] = wall_clock64();
+        lds_barrier();                                     // (X)
+        if (s_fail) return;
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            double* Ta = sm + (g * 8 + jb) * TSZ + fi * TS + 4 * fk;       // column fk + 4r -> position r + 4 fk
+            double* Tb = sm + ((g + 4) * 8 + jb) * TSZ + fi * TS + 4 * fk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Ta[r] = Y0[jb][r];
+                Tb[r] = Y1[jb][r];
+            }
+        }
+        lds_barrier();                                     // (Y)
+        // ---- L(j+1, j) to global from the image: 16 B per lane, 1 KB rows per wave instruction, write-through;
+        //      then row j+1's progress word -- all underneath the update
+        {
+            // wave 4 + g stores rows g, g + 4, ..., g + 124: lane -> columns 2 lane, 2 lane + 1.  Two strips (eight rows)
+            // per round: eight LDS reads in flight, then their eight stores.  The loop stays ROLLED over the strips and the
+            // lane's image address is re-derived in every step: fully unrolled the compiler keeps 32 loop-invariant LDS
+            // addresses, spills them, and reloads one per row with s_waitcnt vmcnt(0) -- which also waits for the previous
+            // row's write-through store: 13 us per tile instead of ~2, and row j+1's progress word is what the owners of
+            // tile (j+2, j+1) wait for.
+            const __amdgpu_buffer_rsrc_t rs = rsrc_at(A + r1 * ld + c0);
+            const int jb = lane >> 3, kk = 2 * (lane & 7), q = kk >> 2, m = kk & 3;
+            int toff = jb * TSZ + q + 4 * m + g * TS;                      // per-lane part of the image address
+            asm volatile("" : "+v"(toff));
+            const double* Tg = sm + toff;
+            const int rowb = (int)ld * 8;
+#pragma unroll 1
+            for (int a = 0; a < 8; a += 2) {
+                d2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double* T = Tg + ((a + (u >> 2)) * 8) * TSZ + 4 * (u & 3) * TS;
+                    v[u] = d2{T[0], T[4]};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = 16 * (a + (u >> 2)) + 4 * (u & 3) + g;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v[u]), rs, lane * 16, row * rowb, 16);
+                }
+            }
+        }
+        if (dbg && t == 256) dbg[8 * nt + 4 * (3 * (j + 1) + 1) + 3] = wall_clock64();   // stores issued
+        drain_stores();
+        if (dbg && t == 256) dbg[8 * nt + 4 * (3 * (j + 1) + 2) + 3] = wall_clock64();   // stores drained
+        if (lane == 0 && atomicAdd(&s_arr, 1) == 4 * (j + 1) - 1) {
+            st_flag(sync + PS_CNT + j + 1, j + 1);
+            if (dbg) dbg[8 * nt + 4 * (3 * (j + 1)) + 3] = wall_clock64();     // near slot (j+1, 0, 3): row j+1 published
+        }
+        lds_barrier();                                     // (Z)
+        lds_barrier();                                     // (W)
     }
+}
+
+__device__ __forceinline__ void chain_workgroup(double* A, long ld, int nt, double* dinv_all, double* logsum, int* info, int* sync,
+                                                const double* hs, long long* dbg) {
+    const int t = threadIdx.x;
+    if (t == 0) { s_fail = 0; s_arr = 0; s_arr0 = 0; }
+    if (t < 256) chain_factor_waves(A, ld, nt, dinv_all, logsum, info, sync, hs, dbg);
+    else chain_solver_waves(A, ld, nt, dinv_all, logsum, info, sync, hs, dbg);
 }
 
 // ---- a worker workgroup -----------------------------------------------------------------------------------------------
@@ -1056,7 +1162,7 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
         return;
     }
     if (blockIdx.x == 0) {
-        chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, hs, dbg, sm);
+        chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, hs, dbg);
         if (threadIdx.x == 0 && dbg2) dbg2[1 + nt] = wall_clock64();
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
     } else if (inv_mode == 0) {

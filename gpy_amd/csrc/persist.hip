@@ -33,6 +33,7 @@
 #include "gemm_tile.h"
 #include "internal.h"
 
+#define PS_NEARD 2                         // block diagonals below the main one whose tiles get dedicated owners (Ownership)
 #define PS_MAXNT 64                        // tiles per dimension the sync block is laid out for
 #define PS_MAXT 48                         // tiles one worker can own
 #define PS_STAGE_CHUNKS 14                 // 1-KB chunks (of 16) of a strip of tile (j+1, j) staged in LDS while block j is factored
@@ -71,6 +72,9 @@ __device__ __forceinline__ long uni(long v) {
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)v >> 32));
     return (long)(((unsigned long)hi << 32) | lo);
 }
+
+// tune bits 6 / 7 (diagnostics): near ownership of D = 3 / 4 block diagonals instead of PS_NEARD
+__host__ __device__ __forceinline__ int ps_neard(int tune) { return (tune & 64) ? 3 : ((tune & 128) ? 4 : PS_NEARD); }
 
 __device__ __forceinline__ int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_flag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -136,17 +140,23 @@ __device__ __forceinline__ bool ps_arrive(int* sync, int* info, int extra) {
     return s_go != 0;
 }
 
-// Static tile ownership.  NEAR tiles (i - k <= 2: the diagonal, the sub-diagonal and the one below it) feed the chain within
-// one step of becoming computable, so they get dedicated owners that own nothing else (H workers, about one tile each): an
-// owner busy with a deep update of a far tile would stall the chain by that update's length.  FAR tiles go round-robin
+// Static tile ownership.  NEAR tiles (i - k <= D: the diagonal and the D block diagonals below it) feed the chain within a
+// step or two of becoming computable, so they get dedicated owners that own nothing else (H workers, about one tile each):
+// an owner busy with a deep update of a far tile would stall the chain by that update's length.  FAR tiles go round-robin
 // over the remaining workers.  Both enumerations ascend by row, the order in which the chain needs the tiles.
-//   near: e = 0 is (0,0) (the chain's own); e >= 1: i = e / 3 + 1, k = i - 2 + e % 3          (3 nt - 3 tiles)
-//   far : f = r (r + 1) / 2 + k, i = r + 3                                                     ((nt-3)(nt-2)/2 tiles)
+//   near: rows i < D whole (e = i (i + 1) / 2 + k), then D + 1 tiles per row: i = D + q / (D + 1), k = i - D + q % (D + 1)
+//   far : f = r (r + 1) / 2 + k, i = r + D + 1                                          ((nt-D-1)(nt-D)/2 tiles)
+// D = 2 (PS_NEARD) is the measured optimum: with D = 3 or 4 (tune bits 6 / 7) the far tiles share fewer workers and the
+// first steps of a large matrix, which are bound by the trailing update's throughput rather than by the chain, get slower
+// (N = 4096: 1.80 ms -> 1.93 / 1.89 ms; N <= 2048: +-1 %).
+__host__ __device__ __forceinline__ int near_tiles_in_rows(int rows, int D) {       // near tiles in rows 0 .. rows-1
+    return rows <= D ? rows * (rows + 1) / 2 : D * (D + 1) / 2 + (rows - D) * (D + 1);
+}
 struct Ownership {
-    int H, nnear, nfar, nw;
-    __device__ Ownership(int nt, int nworkers) : nw(nworkers) {
-        nnear = 3 * nt - 3;
-        nfar = nt >= 3 ? (nt - 3) * (nt - 2) / 2 : 0;
+    int H, nnear, nfar, nw, D;
+    __device__ Ownership(int nt, int nworkers, int neard) : nw(nworkers), D(neard) {
+        nnear = near_tiles_in_rows(nt, D);
+        nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
         H = nw / 2 > 0 ? nw / 2 : 1;
         if (H > nnear) H = nnear;
         if (nfar == 0) H = nw < nnear ? nw : nnear;
@@ -156,19 +166,23 @@ struct Ownership {
         const int m = me - H, W = nw - H;
         return m < nfar ? (nfar - m + W - 1) / W : 0;
     }
+    __device__ static void tri(int f, int& r, int& k) {
+        r = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > f) --r;
+        while ((r + 1) * (r + 2) / 2 <= f) ++r;
+        k = f - r * (r + 1) / 2;
+    }
     __device__ void tile(int me, int s, int& i, int& k) const {
         if (me < H) {
-            const int e = me + s * H;
-            if (e == 0) { i = 0; k = 0; return; }
-            i = e / 3 + 1;
-            k = i - 2 + e % 3;
+            const int e = me + s * H, T0 = D * (D + 1) / 2;
+            if (e < T0) { tri(e, i, k); return; }
+            const int q = e - T0;
+            i = D + q / (D + 1);
+            k = i - D + q % (D + 1);
         } else {
-            const int f = (me - H) + s * (nw - H);
-            int r = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
-            while (r * (r + 1) / 2 > f) --r;
-            while ((r + 1) * (r + 2) / 2 <= f) ++r;
-            i = r + 3;
-            k = f - r * (r + 1) / 2;
+            int r;
+            tri((me - H) + s * (nw - H), r, k);
+            i = r + D + 1;
         }
     }
 };
@@ -633,7 +647,7 @@ __device__ __forceinline__ void chain_workgroup(double* A, long ld, int nt, doub
 // accumulator carried through memory in fp64 between them as before: the same bits.
 __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
                                  int* __restrict__ sync, int kcap, double* __restrict__ hs, long long* __restrict__ dbg,
-                                 int split, double* sm) {
+                                 int split, int neard, double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
     __shared__ int s_pre[PS_MAXNT];                            // PS_PRE snapshot
     __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished;
@@ -642,7 +656,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (w >= 4) return;              // the launch has eight waves per workgroup for the chain's sake; a worker uses four
     const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
-    const Ownership own(nt, nw);
+    const Ownership own(nt, nw, neard);
     const int nmine = own.count(me);
     if (nmine == 0) return;
     for (int s = t; s < PS_MAXT; s += 256) {
@@ -845,8 +859,8 @@ __device__ __forceinline__ void inv128_col_coh(const double* __restrict__ Lb, do
     } while (0)
 
 // who owns X tile (i,k) (a near owner e < H; row i only among the owners whose own near tile lies in a row <= i) / W tile (k,l)
-__device__ __forceinline__ int own_x(int i, int k, int H) {
-    int span = 3 * i + 1;
+__device__ __forceinline__ int own_x(int i, int k, int H, int D) {
+    int span = near_tiles_in_rows(i + 1, D);
     if (span > H) span = H;
     return (i * (i + 1) / 2 + k) % span;
 }
@@ -866,7 +880,8 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (w >= 4) return;              // the launch has eight waves per workgroup for the chain's sake; a worker uses four
     const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
-    const Ownership own(nt, nw);
+    const int neard = ps_neard(tune);
+    const Ownership own(nt, nw, neard);
     // ---- this worker's task list: P tiles (ownership of the factorisation), then X tiles by row, then W tiles ---------------
     if (w == 0) {
         int n = 0;
@@ -892,7 +907,7 @@ __device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict_
                     while (i * (i + 1) / 2 > u) --i;
                     while ((i + 1) * (i + 2) / 2 <= u) ++i;
                     k = u - i * (i + 1) / 2;
-                    mine = (pass == 0) ? (own_x(i, k, own.H) == me) : (own_w(i, k, nw) == me);
+                    mine = (pass == 0) ? (own_x(i, k, own.H, own.D) == me) : (own_w(i, k, nw) == me);
                 }
                 const unsigned long long m = __ballot(mine);
                 if (mine) {
@@ -1166,7 +1181,7 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
         if (threadIdx.x == 0 && dbg2) dbg2[1 + nt] = wall_clock64();
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
     } else if (inv_mode == 0) {
-        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, sm);
+        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, ps_neard(tune), sm);
     } else {
         worker_workgroup_inv(A, X, Wm, ld, nt, dinv_all, sync, kcap, hs, inv_mode >= 2 ? 1 : 0, tune, dbg2, sm);
     }
@@ -1220,8 +1235,8 @@ static int persist_max_grid(int cus) {
 }
 
 // host mirror of the folded launch's ownership: the longest task list any worker gets (P tiles + X tiles + W tiles)
-static int inv_max_tasks(int nt, int nw, int want_w) {
-    int nnear = 3 * nt - 3, nfar = nt >= 3 ? (nt - 3) * (nt - 2) / 2 : 0;
+static int inv_max_tasks(int nt, int nw, int want_w, int D) {
+    int nnear = near_tiles_in_rows(nt, D), nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
     int H = nw / 2 > 0 ? nw / 2 : 1;
     if (H > nnear) H = nnear;
     if (nfar == 0) H = nw < nnear ? nw : nnear;
@@ -1235,7 +1250,7 @@ static int inv_max_tasks(int nt, int nw, int want_w) {
     }
     for (int i = 0; i < nt; ++i)
         for (int k = 0; k <= i; ++k) {
-            int span = 3 * i + 1;
+            int span = near_tiles_in_rows(i + 1, D);
             if (span > H) span = H;
             cnt[(size_t)((i * (i + 1) / 2 + k) % span)] += 1;
             if (want_w) cnt[(size_t)((i * (i + 1) / 2 + k) % nw)] += 1;
@@ -1261,7 +1276,7 @@ bool pdinv_persist_eligible(long npad, FactorWs* ws, int want_w) {
     if (ws->persist < 2 || !potrf_persist_eligible(npad, ws)) return false;
     const long grid = persist_grid_for(npad, ws);
     if (grid < 2) return false;
-    return inv_max_tasks((int)(npad / NB), (int)grid - 1, want_w) <= PS_MAXTASK;
+    return inv_max_tasks((int)(npad / NB), (int)grid - 1, want_w, ps_neard(ws->persist_tune)) <= PS_MAXTASK;
 }
 
 bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg, double* X, double* W,

@@ -335,9 +335,18 @@ __device__ __forceinline__ void chain_store_diag(double* __restrict__ Ab, long l
                                                  int t, int lane, int w) {
     const __amdgpu_buffer_rsrc_t rs = rsrc_at(Ab);
     const int er = t >> 4, ec = t & 15, voff = (er * (int)ld + ec) * 8;
+    // twelve LDS reads in flight, then their twelve stores (one read per store serialises 36 LDS round trips while the
+    // solver waves hammer the LDS)
 #pragma unroll
-    for (int u = 0; u < NTILE; ++u)
-        bst_sc1(rs, voff, (tile_I(u) * 16 * (int)ld + tile_J(u) * 16) * 8, Tt[u * TSZ + er * TS + ec]);
+    for (int u0 = 0; u0 < NTILE; u0 += 12) {
+        double v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v[u] = Tt[(u0 + u) * TSZ + er * TS + ec];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 12; ++u)
+            bst_sc1(rs, voff, (tile_I(u0 + u) * 16 * (int)ld + tile_J(u0 + u) * 16) * 8, v[u]);
+    }
     if (w == 0) {
         const int i0 = lane, i1 = lane + 64;
         double sl = log(Tt[tix(i0 >> 4, i0 >> 4) * TSZ + (i0 & 15) * TS + (i0 & 15)]) +

@@ -103,12 +103,32 @@ __device__ __forceinline__ void stage_x(const double* __restrict__ Xt, long ldx,
     }
 }
 
+// The COLUMN-side slab is stored permuted with rows of KTJ doubles: element ii = 4 tx + b of dimension q sits at
+// q KTJ + 40 (b >> 1) + 2 tx + (b & 1).  A thread's four values are then two 16-byte reads whose 16 lanes of a ds_read_b128
+// lane group cover 256 contiguous bytes: conflict-free.  In the natural layout (4 tx + b) the two reads of a lane are 32 bytes
+// apart and lanes tx, tx + 8 of a group land on the same banks (2-way on every read of the slab: the 28 % of LDS cycles that
+// SQ_LDS_BANK_CONFLICT showed for k_grad / k_kbuild).  The offset of the second half (40, not 32) keeps the 64-bit stores of
+// the staging pass conflict-free as well (ds_write_b64: groups of 16 consecutive lanes, banks modulo 32 dwords).
+#define KTJ 72
+__device__ __forceinline__ int xj_pos(int ii) { return 40 * ((ii >> 1) & 1) + 2 * (ii >> 2) + (ii & 1); }
+__device__ __forceinline__ void stage_xj(const double* __restrict__ Xt, long ldx, long i0, int q0, int qc, double* s, int t) {
+    for (int idx = t; idx < qc * KT; idx += 256) {
+        const int q = idx >> 6, ii = idx & 63;
+        s[q * KTJ + xj_pos(ii)] = Xt[(long)(q0 + q) * ldx + i0 + ii];
+    }
+}
+__device__ __forceinline__ d4 ld_xj(const double* sj, int q, int tx) {
+    const d2 lo = *reinterpret_cast<const d2*>(sj + q * KTJ + 2 * tx);
+    const d2 hi = *reinterpret_cast<const d2*>(sj + q * KTJ + 40 + 2 * tx);
+    return d4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // r2[a][b] += sum_q (xi[q][ty*4+a] - xj[q][tx*4+b])^2
 __device__ __forceinline__ void accum_r2(const double* si, const double* sj, int qc, int ty, int tx,
                                          double (&r2)[4][4]) {
     for (int q = 0; q < qc; ++q) {
         const d4 xi = *reinterpret_cast<const d4*>(si + q * KT + ty * 4);
-        const d4 xj = *reinterpret_cast<const d4*>(sj + q * KT + tx * 4);
+        const d4 xj = ld_xj(sj, q, tx);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -131,7 +151,7 @@ __global__ __launch_bounds__(256) void k_kbuild(KernParams kp, const double* __r
                                                 const double* mul) {
     // mul (may alias out): element-wise multiplier with out's layout -- product kernels (GPy/kern/src/prod.py:58-65)
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
-    __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
+    __shared__ __attribute__((aligned(16))) double sj[KDC * KTJ];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const long ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
     if (SYM && lower_only && tj > ti) return;
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(256) void k_kbuild(KernParams kp, const double* __r
             const int qc = (kp.D - q0 < KDC) ? (kp.D - q0) : KDC;
             __syncthreads();
             stage_x(Xt1, ld1, i0, q0, qc, si, t);
-            stage_x(Xt2, ld2, j0, q0, qc, sj, t);
+            stage_xj(Xt2, ld2, j0, q0, qc, sj, t);
             __syncthreads();
             accum_r2(si, sj, qc, ty, tx, r2);
         }
@@ -201,7 +221,7 @@ __global__ __launch_bounds__(256) void k_kbuild_cols(KernParams kp, const double
                                                      long ldo, const double* __restrict__ V, int Dy, int ntc, int ntr,
                                                      int tiles_per_split, double* __restrict__ colpart, long mcols) {
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
-    __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
+    __shared__ __attribute__((aligned(16))) double sj[KDC * KTJ];
     __shared__ double sv[KT * KBC_DY];
     __shared__ double red[256];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
@@ -213,7 +233,7 @@ __global__ __launch_bounds__(256) void k_kbuild_cols(KernParams kp, const double
     for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int d = 0; d < KBC_DY; ++d) csum[b][d] = 0.0;
-    stage_x(Xt2, ld2, j0, 0, D, sj, t);
+    stage_xj(Xt2, ld2, j0, 0, D, sj, t);
     const bool fullcols = j0 + KT <= m;
     const int ti_end = ((split + 1) * tiles_per_split < ntr) ? (split + 1) * tiles_per_split : ntr;
     for (int ti = split * tiles_per_split; ti < ti_end; ++ti) {
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
                                               const double* __restrict__ Mul = nullptr, long ldm = 0,
                                               RankTerm rk = RankTerm{nullptr, nullptr, 0, 0.0, 1.0, nullptr}) {
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
-    __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
+    __shared__ __attribute__((aligned(16))) double sj[KDC * KTJ];
     __shared__ double red[256];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     double a_var = 0.0, a_iso = 0.0;
@@ -358,7 +378,7 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
             const int qc = (kp.D - q0 < KDC) ? (kp.D - q0) : KDC;
             __syncthreads();
             stage_x(Xt1, ld1, i0, q0, qc, si, t);
-            stage_x(Xt2, ld2, j0, q0, qc, sj, t);
+            stage_xj(Xt2, ld2, j0, q0, qc, sj, t);
             __syncthreads();
             accum_r2(si, sj, qc, ty, tx, r2);
             last_q0 = q0;
@@ -413,14 +433,14 @@ __global__ __launch_bounds__(256) void k_grad(KernParams kp, const double* __res
             if (last_q0 != q_off) {   // D > 32: bring the dims of this launch back into LDS
                 __syncthreads();
                 stage_x(Xt1, ld1, i0, q_off, qcnt, si, t);
-                stage_x(Xt2, ld2, j0, q_off, qcnt, sj, t);
+                stage_xj(Xt2, ld2, j0, q_off, qcnt, sj, t);
                 __syncthreads();
             }
 #pragma unroll
             for (int q = 0; q < KDC; ++q) {
                 if (q < qcnt) {
                     const d4 xi = *reinterpret_cast<const d4*>(si + q * KT + ty * 4);
-                    const d4 xj = *reinterpret_cast<const d4*>(sj + q * KT + tx * 4);
+                    const d4 xj = ld_xj(sj, q, tx);
                     double s = 0.0;
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
@@ -506,7 +526,7 @@ __global__ __launch_bounds__(256) void k_grad_cols(KernParams kp, const double* 
                                                    double* __restrict__ colpart, long mcols, int nv) {
     constexpr int NVMAX = 17;
     __shared__ __attribute__((aligned(16))) double si[KDC * KT];
-    __shared__ __attribute__((aligned(16))) double sj[KDC * KT];
+    __shared__ __attribute__((aligned(16))) double sj[KDC * KTJ];
     __shared__ double red[256];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const int tj = blockIdx.x % ntc, split = blockIdx.x / ntc;
@@ -531,7 +551,7 @@ __global__ __launch_bounds__(256) void k_grad_cols(KernParams kp, const double* 
             for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
         __syncthreads();
         stage_x(Xt1, ld1, i0, 0, D, si, t);
-        stage_x(Xt2, ld2, j0, 0, D, sj, t);
+        stage_xj(Xt2, ld2, j0, 0, D, sj, t);
         __syncthreads();
         accum_r2(si, sj, D, ty, tx, r2);
         double gT[4][4];
@@ -562,7 +582,7 @@ __global__ __launch_bounds__(256) void k_grad_cols(KernParams kp, const double* 
             if (q < D) {
                 const d4 xi = *reinterpret_cast<const d4*>(si + q * KT + ty * 4);
                 if (ARD) {
-                    const d4 xj = *reinterpret_cast<const d4*>(sj + q * KT + tx * 4);
+                    const d4 xj = ld_xj(sj, q, tx);
                     double sacc = 0.0;
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
@@ -649,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void k_grad_cols_mfma(KernParams kp, const 
                                                            double* __restrict__ colpart, long mcols, int nv) {
     constexpr int DM = 16;                               // D <= 16
     __shared__ __attribute__((aligned(16))) double si[DM * KT];
-    __shared__ __attribute__((aligned(16))) double sj[DM * KT];
+    __shared__ __attribute__((aligned(16))) double sj[DM * KTJ];
     __shared__ __attribute__((aligned(16))) double sit[KT * 18];   // x~ slab row-major [i][c], stride 18: the B operand
     __shared__ __attribute__((aligned(16))) double sh[KT * GC_HS];
     __shared__ double red[256];
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void k_grad_cols_mfma(KernParams kp, const 
             si[q * KT + ii] = v;
             sit[ii * 18 + q] = v;
         }
-        stage_x(Xt2, ld2, j0, 0, D, sj, t);
+        stage_xj(Xt2, ld2, j0, 0, D, sj, t);
         __syncthreads();
         accum_r2(si, sj, D, ty, tx, r2);
         double gT[4][4];
@@ -712,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void k_grad_cols_mfma(KernParams kp, const 
             for (int q = 0; q < DM; ++q) {
                 if (q < D) {
                     const d4 xi = *reinterpret_cast<const d4*>(si + q * KT + ty * 4);
-                    const d4 xj = *reinterpret_cast<const d4*>(sj + q * KT + tx * 4);
+                    const d4 xj = ld_xj(sj, q, tx);
                     double sacc = 0.0;
 #pragma unroll
                     for (int a = 0; a < 4; ++a)

@@ -17,24 +17,29 @@ C2="python $PWD/bench.py --n 4096 --d 8 --kind rbf --iso --steps 20 --warmup 3 -
 C2ONE="python $PWD/bench.py --n 4096 --d 8 --kind rbf --iso --steps 2 --warmup 3 --no-cpu-baseline --no-legs --no-parity-gate --abi-only"
 C5="python $PWD/bench.py --sparse --steps 3 --warmup 1 --no-cpu-baseline"
 C5ONE="python $PWD/bench.py --sparse --steps 1 --warmup 1 --no-cpu-baseline"
+# PROFILE_SET=mini: the three kernel-stats runs and the SQ counter pass of the headline only
 # PROFILE_SET=lite: the three kernel-stats runs, the PMC passes of the headline (C3) and of the sparse path (C5) only
 LITE=${PROFILE_SET:-full}
 run stats --stats -d $OUT/stats -o run -- $C3
 run pmc_a --pmc $PMC_SQ -d $OUT/pmc_a -o run -- $C3ONE
+if [ "$LITE" != mini ]; then
 run pmc_b --pmc FETCH_SIZE -d $OUT/pmc_b -o run -- $C3ONE
 run pmc_c --pmc WRITE_SIZE -d $OUT/pmc_c -o run -- $C3ONE
+fi
 run c2_stats --stats -d $OUT/c2_stats -o run -- $C2
-if [ "$LITE" != lite ]; then
+if [ "$LITE" != lite ] && [ "$LITE" != mini ]; then
 run c2_pmc_a --pmc $PMC_SQ -d $OUT/c2_pmc_a -o run -- $C2ONE
 run c2_pmc_b --pmc FETCH_SIZE -d $OUT/c2_pmc_b -o run -- $C2ONE
 run c2_pmc_c --pmc WRITE_SIZE -d $OUT/c2_pmc_c -o run -- $C2ONE
 fi
 run sparse_stats --stats -d $OUT/sparse_stats -o run -- $C5
-if [ "$LITE" != lite ]; then
+if [ "$LITE" != lite ] && [ "$LITE" != mini ]; then
 run sparse_pmc_a --pmc $PMC_SQ -d $OUT/sparse_pmc_a -o run -- $C5ONE
 fi
+if [ "$LITE" != mini ]; then
 run sparse_pmc_b --pmc FETCH_SIZE -d $OUT/sparse_pmc_b -o run -- $C5ONE
 run sparse_pmc_c --pmc WRITE_SIZE -d $OUT/sparse_pmc_c -o run -- $C5ONE
+fi
 # the kernel traces are large: keep the stats tables and the counter tables only
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 find $OUT -name "*.csv" | head -60

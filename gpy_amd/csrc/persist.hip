@@ -11,7 +11,8 @@
 //   * every other workgroup (WORKERS, one per CU) owns a fixed set of 128 x 128 tiles and applies to each the columns of L
 //     that are final, K = 128 per column, several columns per pass when they are available (same LDS-DMA MFMA tile
 //     pipeline as k_update_nt), solves the finished tile against L_kk and publishes it.  Tiles (j+1,j) and (j+1,j+1) are
-//     handed to the chain one column short; the hand-off has the whole potf2 of block j (~25 us) as slack.
+//     handed to the chain one column short, ~5 us before the potf2 of block j ends: the chain's idle waves fetch tile
+//     (j+1,j) underneath that potf2 (one strip per wave into registers, one by LDS-DMA into LDS).
 // Ownership is static and every workgroup is resident (one per CU, grid <= number of CUs), so there is no work queue and
 // no possibility of deadlock: the dependence graph is the acyclic tile DAG of the right-looking Cholesky.
 //

@@ -105,7 +105,8 @@ struct FactorWs {
     hipEvent_t ev_persist_pre = nullptr;   // optional (not owned): recorded on the launching stream once the progress words are zeroed
     int persist_grid_last = 0;             // workgroups of the last persistent launch
     int persist_tune = 0;            // MI355GP_PERSIST_TUNE: schedule bits of the folded launch (1: near owners take W tiles only after
-                                     // their X tiles, 2: two-stage worker GEMM instead of the 4-stage ring)
+                                     // their X tiles, 2: two-stage worker GEMM instead of the 4-stage ring) and A/B bits of the
+                                     // factorisation-only launch (4: no split hand-over, 64 / 128: near ownership of 3 / 4 diagonals)
     int persist_test = 0;            // MI355GP_OPT_PERSIST_TEST: fault injection for the NEXT persistent launch (1 clean, 2 dirty)
     int* persist_sync = nullptr;     // progress words of the persistent launch (zeroed before every launch)
     double* persist_hs = nullptr;    // [min(nblk, 64)][128 x 128]: sub-diagonal tile of every row, handed to the chain in ITS load order

@@ -155,9 +155,30 @@ ncclResult_t ipcGetUniqueId(ncclUniqueId* id) {
     return ncclSuccess;
 }
 
+// everything a World holds: mapped / opened staging buffers, the control block, the object itself
+static void world_release(World* w) {
+    for (int r = 0; r < w->world; ++r) {
+        if (!w->stage[r]) continue;
+        if (w->host) munmap(w->stage[r], IPC_STAGE_BYTES);
+        else if (r == w->rank) (void)hipFree(w->stage[r]);
+        else (void)hipIpcCloseMemHandle(w->stage[r]);
+    }
+    if (w->ctl) munmap(w->ctl, sizeof(Ctl));
+    delete w;
+}
+
 ncclResult_t ipcCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int rank) {
     if (nranks < 1 || nranks > IPC_MAXR || rank < 0 || rank >= nranks) return ncclInvalidArgument;
     World* w = new World();
+    auto fail = [&](ncclResult_t rc) {                     // a failed initialisation leaves nothing mapped, opened or allocated
+        if (w->host && w->stage[rank]) {
+            char nm[128];
+            snprintf(nm, sizeof(nm), "%s_r%d", w->name, rank);
+            shm_unlink(nm);
+        }
+        world_release(w);
+        return rc;
+    };
     memcpy(w->name, id.internal, sizeof(w->name) - 1);
     w->world = nranks;
     w->rank = rank;
@@ -168,33 +189,30 @@ ncclResult_t ipcCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int r
         if (t && atof(t) > 0.0) w->timeout_s = atof(t);
     }
     w->ctl = (Ctl*)map_shm(w->name, sizeof(Ctl), false);
-    if (!w->ctl) {
-        delete w;
-        return ncclSystemError;
-    }
+    if (!w->ctl) return fail(ncclSystemError);
     w->ctl->world.store(nranks);
     // my staging buffer, published through the control block
     char sname[128];
     if (w->host) {
         snprintf(sname, sizeof(sname), "%s_r%d", w->name, rank);
         w->stage[rank] = (double*)map_shm(sname, IPC_STAGE_BYTES, true);
-        if (!w->stage[rank]) return ncclSystemError;
+        if (!w->stage[rank]) return fail(ncclSystemError);
     } else {
-        if (hipMalloc(&w->stage[rank], IPC_STAGE_BYTES) != hipSuccess) return ncclUnhandledCudaError;
-        if (hipIpcGetMemHandle(&w->ctl->rank[rank].handle, w->stage[rank]) != hipSuccess) return ncclUnhandledCudaError;
+        if (hipMalloc(&w->stage[rank], IPC_STAGE_BYTES) != hipSuccess) return fail(ncclUnhandledCudaError);
+        if (hipIpcGetMemHandle(&w->ctl->rank[rank].handle, w->stage[rank]) != hipSuccess) return fail(ncclUnhandledCudaError);
     }
     w->ctl->rank[rank].ready.store(1, std::memory_order_release);
     for (int r = 0; r < nranks; ++r) {
         if (r == rank) continue;
-        if (!wait_for(w, [&]() { return w->ctl->rank[r].ready.load(std::memory_order_acquire) != 0; })) return ncclSystemError;
+        if (!wait_for(w, [&]() { return w->ctl->rank[r].ready.load(std::memory_order_acquire) != 0; })) return fail(ncclSystemError);
         if (w->host) {
             snprintf(sname, sizeof(sname), "%s_r%d", w->name, r);
             w->stage[r] = (double*)map_shm(sname, IPC_STAGE_BYTES, false);
-            if (!w->stage[r]) return ncclSystemError;
+            if (!w->stage[r]) return fail(ncclSystemError);
         } else {
             void* p = nullptr;
             if (hipIpcOpenMemHandle(&p, w->ctl->rank[r].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess)
-                return ncclUnhandledCudaError;
+                return fail(ncclUnhandledCudaError);
             w->stage[r] = (double*)p;
         }
     }
@@ -205,7 +223,10 @@ ncclResult_t ipcCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int r
     c->me = rank;
     for (int r = 0; r < nranks; ++r) c->global[r] = r;
     w->refs = 1;
-    if (!barrier(c)) return ncclSystemError;               // everyone has mapped everything: the names can go
+    if (!barrier(c)) {                                     // everyone has mapped everything: the names can go
+        delete c;
+        return fail(ncclSystemError);
+    }
     if (rank == 0) shm_unlink(w->name);
     if (w->host) {
         snprintf(sname, sizeof(sname), "%s_r%d", w->name, rank);
@@ -247,16 +268,7 @@ ncclResult_t ipcCommDestroy(ncclComm_t comm) {
     if (!c) return ncclSuccess;
     World* w = c->w;
     delete c;
-    if (--w->refs == 0) {
-        for (int r = 0; r < w->world; ++r) {
-            if (!w->stage[r]) continue;
-            if (w->host) munmap(w->stage[r], IPC_STAGE_BYTES);
-            else if (r == w->rank) (void)hipFree(w->stage[r]);
-            else (void)hipIpcCloseMemHandle(w->stage[r]);
-        }
-        munmap(w->ctl, sizeof(Ctl));
-        delete w;
-    }
+    if (--w->refs == 0) world_release(w);
     return ncclSuccess;
 }
 
@@ -301,7 +313,10 @@ ncclResult_t ipcAllReduce(const void* send, void* recv, size_t count, ncclDataTy
     for (int r = 0; r < c->n; ++r) src[(size_t)r] = w->stage[c->global[r]];
     if (!w->host) {
         if (hipMalloc((void**)&dsrc, sizeof(double*) * c->n) != hipSuccess) return ncclUnhandledCudaError;
-        if (hipMemcpy((void*)dsrc, src.data(), sizeof(double*) * c->n, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+        if (hipMemcpy((void*)dsrc, src.data(), sizeof(double*) * c->n, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree((void*)dsrc);
+            return ncclUnhandledCudaError;
+        }
     }
     ncclResult_t rc = ncclSuccess;
     for (size_t off = 0; off < count && rc == ncclSuccess; off += cap) {

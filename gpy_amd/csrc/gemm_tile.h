@@ -229,7 +229,7 @@ __device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, l
 
 
 // The same tile pipeline on a RING of NST LDS stages (NST * 34,816 B), for a workgroup that has a CU to ITSELF (the workers of
-// the persistent launch of persist.hip: one 147 KB workgroup per CU, one wave per SIMD).  With two workgroups per CU the
+// the persistent launch of persist.hip: one 155 KB workgroup per CU, one wave per SIMD).  With two workgroups per CU the
 // one-slab look-ahead of gemm_tile_128_v3 is enough: while one workgroup waits for its DMA the other one computes.  Alone on the
 // CU, every slab exposes what is left of the global -> LDS latency after one slab of MFMAs (1.7 us): operands last written by
 // another XCD come from HBM, ~2 us away, and the pipe ran at a third of its rate.  Here the DMA of slab kt + NST - 1 is issued

@@ -56,7 +56,7 @@
 #define PS_XCOL (16 + 3 * PS_MAXNT)         // [nt] xcol[k]: X(k .. k+xcol[k]-1, k) final (the inverse, column k, from the diagonal down)
 #define PS_PRE (16 + 4 * PS_MAXNT)          // [nt] tile (i, i-1) holds columns 0 .. i-3 in place (its owner is done with it)
 #define PS_SYNC_INTS (16 + 5 * PS_MAXNT)
-#define PS_RING 4                          // LDS stages of the folded launch's worker GEMM (4 x 34,816 B of the 147,456)
+#define PS_RING 4                          // LDS stages of the folded launch's worker GEMM (4 x 34,816 B of the 158,720)
 #define PS_MAXTASK 64                      // tasks (P / X / W tiles) one worker of the folded launch can own
 
 // a pointer / int that is the same in every lane, moved to scalar registers (arguments of a non-inlined device function
@@ -1217,7 +1217,7 @@ bool potrf_persist_aborted(int info, FactorWs* ws, bool* clean) {
 int potrf_persist_sync_ints() { return PS_SYNC_INTS; }
 
 // Workgroups the launch may have: one per CU, and never more than the occupancy query says can be resident at once (the
-// kernel asks for 147 KB of LDS: one workgroup per CU).  What ELSE holds CUs at launch time is only known to the GPU:
+// kernel asks for 155 KB of LDS: one workgroup per CU).  What ELSE holds CUs at launch time is only known to the GPU:
 // ps_arrive() settles that.  The large-LDS opt-in is a per-device function attribute.
 static int persist_max_grid(int cus) {
     static int cached[16] = {0};
@@ -1312,7 +1312,7 @@ bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, lo
 // One thread that returns once the persistent launch whose progress words follow ws->ev_persist_pre has ALL its workgroups
 // resident (arrival word complete), was called off, or 2 ms have passed.  Put on ANOTHER stream in front of wide kernels that
 // are meant to run underneath the persistent launch (sparse.hip: pass 1 underneath Kmm's factorisation), it keeps them from
-// taking the CUs' LDS before the 147 KB workgroups are in place.
+// taking the CUs' LDS before the 155 KB workgroups are in place.
 __global__ void k_wait_persist_resident(const int* __restrict__ sync, int n) {
     const long long t0 = wall_clock64();
     for (;;) {

@@ -773,7 +773,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     if (!overlap_kmm) {
         if (int rc = factor_check(sk, s->Lm, s->Xm, s->Tm, nullptr, mp, &s->ws, &s->h_info[0], rebuild_kmm)) return rc;
     } else if (s->ws.persist_used) {
-        // pass 1 must not take the CUs' LDS before the 147 KB workgroups of the persistent launch are in place
+        // pass 1 must not take the CUs' LDS before the 155 KB workgroups of the persistent launch are in place
         HIP_CHECK(hipStreamWaitEvent(st, s->ev_z, 0));
         launch_wait_persist_resident(st, &s->ws);
     }

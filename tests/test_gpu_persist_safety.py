@@ -190,7 +190,7 @@ c.close()
 
 def test_two_processes_sharing_one_gpu_at_n4096():
     """Two PROCESSES on the one GPU, each 50 evaluations at N = 4096 on the default (persistent) schedule.  Their persistent
-    launches cannot be co-resident (147 KB of LDS per workgroup, one per CU): whichever comes second waits at the gate, and if
+    launches cannot be co-resident (155 KB of LDS per workgroup, one per CU): whichever comes second waits at the gate, and if
     the two interleave both are called off and redo on launches.  No error, no -6, and every evaluation of both processes has
     the bits a process that has the GPU to itself produces (on the persistent schedule or on its fall-back)."""
     import json

@@ -163,10 +163,8 @@ def cpu_baseline(kind, ARD, D, n_small, n_full, full=False, fit=True):
     if direct:
         dt = _oracle_seconds(kind, ARD, D, n_full)
         rec.update(value=1.0 / dt, measured_seconds=dt, sample_N=n_full,
-                   sample="one full iteration of the NumPy/SciPy oracle (GPy's CPU algorithm, paramz-style K/r caching) "
-                          "timed directly at N=%d D=%d: %.1f s on %d BLAS threads of %d host cores, while the GPU legs of the "
-                          "other configurations run (they leave the host cores idle)" % (
-                              n_full, D, dt, threads, os.cpu_count() or 1))
+                   sample="1 full iteration of the oracle (port of GPy's CPU path) timed directly at N=%d D=%d: %.1f s, "
+                          "%d BLAS threads of %d host cores" % (n_full, D, dt, threads, os.cpu_count() or 1))
     if (fit or not direct) and 2 * n_small < n_full:
         n1, n2 = n_small, 2 * n_small
         t1, t2 = _oracle_seconds(kind, ARD, D, n1), _oracle_seconds(kind, ARD, D, n2)
@@ -183,9 +181,9 @@ def cpu_baseline(kind, ARD, D, n_small, n_full, full=False, fit=True):
             rec["fit_cross_check"] = fitrec
         else:
             rec.update(value=1.0 / est, estimated_seconds=est, fit=fitrec,
-                       sample="one full iteration of the NumPy/SciPy oracle at N=%d (%.2f s) and N=%d (%.2f s), D=%d, on %d "
-                              "BLAS threads of %d host cores; t = a N^2 + b N^3 fitted through both and evaluated at N=%d "
-                              "(%.0f s)" % (n1, t1, n2, t2, D, threads, os.cpu_count() or 1, n_full, est))
+                       sample="oracle (port) at N=%d (%.2f s) and N=%d (%.2f s), D=%d, %d BLAS threads of %d host cores; "
+                              "t = a N^2 + b N^3 through both, evaluated at N=%d (%.0f s)" % (
+                                  n1, t1, n2, t2, D, threads, os.cpu_count() or 1, n_full, est))
     committed = committed_cpu_record(kind, ARD, D, n_full)
     if committed:
         rec["committed_full_size"] = committed
@@ -226,16 +224,23 @@ def profiled_traffic(kernel_prefix, with_source=False):
     import glob
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))
                    if "sparse" not in f and "_c2_" not in f)
-    if not files:
-        return (None, None) if with_source else None
-    try:
-        ks = json.load(open(files[-1]))["kernels"]
-        for name, v in ks.items():
-            if name.startswith(kernel_prefix):
-                return (v["hbm_bytes_per_launch"], os.path.basename(files[-1])) if with_source else v["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return (None, None) if with_source else None
+    hit = _latest_traffic(files, kernel_prefix)
+    if with_source:
+        return hit if hit else (None, None)
+    return hit[0] if hit else None
+
+
+def _latest_traffic(files, kernel_prefix):
+    """(bytes per launch, file name) from the newest summary that HAS the kernel (a summary whose counter pass failed holds an
+    empty table and must not shadow an older good one), or None."""
+    for f in reversed(files):
+        try:
+            for name, v in json.load(open(f)).get("kernels", {}).items():
+                if name.startswith(kernel_prefix) and v.get("hbm_bytes_per_launch"):
+                    return v["hbm_bytes_per_launch"], os.path.basename(f)
+        except Exception:
+            pass
+    return None
 
 
 def profiled_c2_traffic(kernel_prefix):
@@ -243,26 +248,15 @@ def profiled_c2_traffic(kernel_prefix):
     (bytes, file) or (None, None)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c2_traffic.json")))
-    try:
-        for name, v in json.load(open(files[-1]))["kernels"].items():
-            if name.startswith(kernel_prefix):
-                return v["hbm_bytes_per_launch"], os.path.basename(files[-1])
-    except Exception:
-        pass
-    return None, None
+    return _latest_traffic(files, kernel_prefix) or (None, None)
 
 
 def profiled_sparse_traffic(kernel_prefix):
     """HBM-side bytes per launch of a sparse-path kernel from the committed PMC summary (profiles/*sparse_traffic.json)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*sparse_traffic.json")))
-    try:
-        for name, v in json.load(open(files[-1]))["kernels"].items():
-            if name.startswith(kernel_prefix):
-                return v["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+    hit = _latest_traffic(files, kernel_prefix)
+    return hit[0] if hit else None
 
 
 def parity_gate(kind, ARD, D, device):
@@ -426,6 +420,54 @@ def grid_leg(comm, args, timeout=180.0):
     return rec
 
 
+# ---- the printed line -------------------------------------------------------------------------------------------------------
+# The driver keeps an 8 KB tail of stdout: the line is kept under 6 KB so that every leg is in it.  Prose (what a sample was,
+# what a kernel does, committed full-size records) lives in DESIGN.md section 5 and profiles/; the untrimmed record of a run goes
+# to gpurun_out/bench_full.json.
+LINE_DROP = ("note", "what", "committed_full_size", "fit", "fit_cross_check", "cholesky_standalone", "host_cores", "baseline_wall_s",
+             "abi_steps", "drop_in_ms_per_step", "algorithmic_flops_per_step", "k_update_nt64", "against", "fixture",
+             "cholesky_frac_of_fp64_peak", "iteration_tflops", "rows_per_s", "gemm_tflops", "higher_is_better", "vs_baseline")
+LEG_DROP = ("config", "families", "host_path", "roofline_k_lauum", "unit", "steps", "warmup", "value", "dtype", "data", "scaling",
+            "n_gpus", "parity_checked", "workload", "sample", "sample_N", "comm_bytes_per_step", "leg_wall_s")
+
+
+def _slim(o, drop, sig=5):
+    if isinstance(o, dict):
+        return {k: _slim(v, drop, sig) for k, v in o.items() if k not in drop}
+    if isinstance(o, (list, tuple)):
+        return [_slim(v, drop, sig) for v in o]
+    if isinstance(o, float):
+        return float("%.*g" % (sig, o))
+    return o
+
+
+def compact_line(out):
+    """The one JSON line of the run: the headline record trimmed of prose, the legs trimmed to their numbers, and -- last, so that
+    it survives any tail cut -- `legs_ms`, every leg's ms per step."""
+    full_path = os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(full_path), exist_ok=True)
+        with open(full_path, "w") as f:
+            json.dump(out, f)
+    except OSError:
+        pass
+    line = {}
+    legs = ("c2", "grid", "c5", "c4_single")
+    for k, v in out.items():
+        if k in legs:
+            continue
+        line[k] = _slim(v, LINE_DROP) if k not in ("higher_is_better", "vs_baseline") else v
+    line["higher_is_better"], line["vs_baseline"] = out.get("higher_is_better", True), out.get("vs_baseline")
+    if isinstance(line.get("families"), dict):               # name -> [summed launch ms, launches, TFLOP/s]
+        line["families"] = {k: [round(v["ms"], 3), v["launches"], round(v["tflops"], 2)] for k, v in out["families"].items()}
+    for leg in legs:
+        if isinstance(out.get(leg), dict):
+            line[leg] = _slim(out[leg], LINE_DROP + LEG_DROP)
+    line["legs_ms"] = {leg: (round(out[leg]["ms_per_step"], 4) if isinstance(out.get(leg), dict) and "ms_per_step" in out[leg]
+                             else (out.get(leg) or {}).get("error", None) and "error") for leg in legs if leg in out}
+    return json.dumps(line, separators=(",", ":"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -529,14 +571,12 @@ def main():
                      tflops=t["flops"] / ((t["ms"] + ov_ms) * 1e-3) / 1e12 if t["ms"] + ov_ms > 0 else 0.0,
                      note="ms = exposed_ms (after potrf, main stream) + overlapped_ms (side stream underneath potrf)")
         upd_ms, upd_flops, upd_n = pf["update_nt"]
-        roof_kernel = ("k_update_nt<4, true> (fp64 MFMA trailing update of the blocked Cholesky, 128 x 128 tiles; in the pipeline "
-                       "it shares the CUs with the chain kernels and the overlapped inverse)")
+        roof_kernel = "k_update_nt<4, true>"       # fp64 MFMA trailing update of the blocked Cholesky, 128 x 128 tiles, in situ
         if upd_n == 0 and pf.get("potrf_persist", (0, 0, 0))[2] > 0:
             # small N: the whole factorisation is ONE persistent dataflow launch (persist.hip) -- it IS the dominant kernel;
             # algorithmic flops N^3/3, bound by the fp64 MFMA pipe in principle, by its one-CU chain in practice
             upd_ms, upd_flops, upd_n = pf["potrf_persist"]
-            roof_kernel = ("k_potrf_persist (the whole Cholesky as one persistent dataflow launch: chain workgroup + static tile "
-                           "owners; N^3/3 algorithmic flops)")
+            roof_kernel = "k_potrf_persist"
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
         traffic = traffic_source = None
         if (N, D, args.kind) == (16384, 32, "matern52"):
@@ -548,15 +588,16 @@ def main():
             "metric": "exact-GP log_lik+grad iters/sec", "value": its, "unit": "iters/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s %s exact GP, one GPRegression parameters_changed (K build + Cholesky + alpha + LML + "
-                                   "Ky^-1 + all gradients), N=%d D=%d Dy=1 per GPU" % (args.kind, "ARD" if ARD else "iso", N, D),
+            "config": {"workload": "BASELINE configs[2]: %s %s exact GP, one GPRegression.parameters_changed, N=%d D=%d Dy=1 per GPU" % (
+                           args.kind, "ARD" if ARD else "iso", N, D),
                        "N": N, "D": D, "kernel": args.kind, "ARD": ARD, "parallelism": "replicas x%d" % n_gpus,
-                       "path": "C-ABI only" if args.abi_only else "drop-in classes (gpy_amd.GPRegression: param_array "
-                               "write -> parameters_changed -> log_likelihood + gradient)"},
+                       "path": "C-ABI" if args.abi_only else "drop-in classes"},
             # "cholesky_gflops" (the metric's Cholesky GF/s, filled in below) is the factorisation timed ALONE on a resident
             # matrix; the pipeline's potrf stage also hosts the overlapped inverse kernels and is only reported as stage_ms
-            "iteration_tflops": float(N) ** 3 / (st["total"] * 1e-3) / 1e12,
-            "iteration_frac_of_fp64_peak": float(N) ** 3 / (st["total"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+            # N^3 flops over the WALL CLOCK of a timed step; the device-side stage sum of one evaluation under its own name
+            "iteration_tflops": float(N) ** 3 / (dt / args.steps) / 1e12,
+            "iteration_frac_of_fp64_peak": float(N) ** 3 / (dt / args.steps) / 1e12 / PEAK_FP64_TFLOPS,
+            "stage_sum_frac_of_fp64_peak": float(N) ** 3 / (st["total"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
             "stage_ms": {k: round(float(v), 4) for k, v in st.items()},
             "roofline": {"bound": "mfma", "kernel": roof_kernel,
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
@@ -653,7 +694,7 @@ def main():
                         out[leg]["cpu_baseline"] = cpu.get(leg)
         if args.dry_run_sizes:
             out["dry_run_sizes"] = True
-        print(json.dumps(out), flush=True)
+        print(compact_line(out), flush=True)
     comm.close()
 
 
@@ -683,9 +724,9 @@ def sparse_cpu_baseline(D, M, n_full, n_small=4000):
     est = a + b * n_full
     rec = {"unit": "iters/s", "cores": int(threads), "kind": "port", "host_cores": os.cpu_count() or 1, "value": 1.0 / est,
            "estimated_seconds": est, "fit": {"a": a, "b_per_row": b, "n": [n1, n2], "seconds": [t1, t2]},
-           "sample": "one SparseGP.parameters_changed of the NumPy/SciPy sparse oracle (GPy's VarDTC algorithm) at N=%d (%.2f s) "
-                     "and N=%d (%.2f s), M=%d D=%d, on %d BLAS threads of %d host cores; t = a + b N fitted through both and "
-                     "evaluated at N=%d (%.0f s)" % (n1, t1, n2, t2, M, D, threads, os.cpu_count() or 1, n_full, est)}
+           "sample": "sparse oracle (port of GPy's VarDTC) at N=%d (%.2f s) and N=%d (%.2f s), M=%d D=%d, %d BLAS threads of %d "
+                     "host cores; t = a + b N through both, evaluated at N=%d (%.0f s)" % (
+                         n1, t1, n2, t2, M, D, threads, os.cpu_count() or 1, n_full, est)}
     try:
         g = np.load(os.path.join(ROOT, "tests", "golden", "baseline_c5_sparse_rbf_n200000_m2048_d16.npz"), allow_pickle=False)
         if (int(g["N"]), int(g["M"]), int(g["D"])) == (n_full, M, D):
@@ -765,8 +806,7 @@ def main_sparse(args):
                "gemm_frac_of_fp64_peak": flops / (dt / args.steps) / 1e12 / (PEAK_FP64_TFLOPS * world),
                "stage_ms": {k: round(float(v), 3) for k, v in r["stage_ms"].items()}, "lml": r["lml"],
                # dominant kernel of the path: T = Kfu dL_dpsi2 (var_dtc.py:231), 2 N M^2 flops on this rank's rows
-               "roofline": {"bound": "mfma", "kernel": "k_gemm_full<true, false, 4> (fp64 MFMA tile GEMM T = Kfu dL_dpsi2 of pass 2, "
-                                                       "128 x 128 tiles, K = M)",
+               "roofline": {"bound": "mfma", "kernel": "k_gemm_full<true, false, 4>",     # T = Kfu dL_dpsi2 of pass 2, K = M
                             "achieved": gm_fl / (gm_ms * 1e-3) / 1e12 if gm_ms > 0 else 0.0, "peak": PEAK_FP64_TFLOPS,
                             "unit": "TFLOP/s", "frac": (gm_fl / (gm_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS) if gm_ms > 0 else 0.0,
                             "traffic": profiled_sparse_traffic("k_gemm_full<true, false"),

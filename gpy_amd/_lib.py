@@ -12,7 +12,7 @@ import numpy as np
 from numpy.ctypeslib import ndpointer
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355gp.so")
+LIB_PATH = os.environ.get("MI355GP_LIB") or os.path.join(_HERE, "libmi355gp.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 KIND_IDS = {"rbf": 0, "matern52": 1, "matern32": 2, "exponential": 3, "white": 4, "bias": 5}

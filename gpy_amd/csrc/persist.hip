@@ -266,8 +266,7 @@ __device__ __forceinline__ void stage_store_chain_order(const double* sm, double
 // Yim tile (a, jb) = rows 16a .. 16a+15, columns 16jb .. 16jb+15 of Y = L(j+1, j), element (row, col 4q + m) stored at
 // row * TS + q + 4m (the k-index transposed 4 x 4): the fragment read of MFMA m, lane (fi, fk), is row fi, position fk + 4m --
 // the bank-conflict-free pattern of chain_dev.h.
-// barrier for LDS traffic only: outstanding GLOBAL stores / loads keep flying (a __syncthreads() would drain them)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (lds_barrier(), chain_dev.h: a barrier for LDS traffic only -- outstanding GLOBAL stores / loads keep flying)
 
 // The chain workgroup has EIGHT waves with two roles:
 //   factor waves 0..3 : diag128_factor exactly as k_diag128 runs it; then wave w fetches strip w + 4 of tile (j+1, j) (the

@@ -20,8 +20,9 @@ enforced by the tracker below: a DPP read of a VGPR written by a VALU instructio
 transcendental (v_rsq_f64) needs 1 wait state before a non-transcendental VALU reads it.
 
 Upper triangle: rows i < c of a[c] are never read by another lane and come out as garbage (the caller never stores
-them); a non-positive or NaN pivot poisons every later pivot with NaN, so the NUMBER of bad pivots gives the index of the
-first one.
+them).  No pivot test inside the chain: a pivot that is not positive (or NaN) turns into NaN -- rsq of a negative number is
+NaN, rsq(0) * 0 is NaN -- and poisons every later one, so the caller reads the index of the first bad pivot off the
+diagonal of the result (the first L[j][j] that is not > 0).
 
     python tools/gen_potf2.py > gpy_amd/csrc/potf2_asm.h
 """
@@ -87,9 +88,7 @@ def main():
     g.pad = args.pad
     A = ["%%%d" % c for c in range(16)]           # operands 0..15: a[c]
     X = ["%%%d" % (16 + k) for k in range(4)]     # operands 16..19: xs[k]
-    CNT = "%20"                                   # number of bad pivots (SGPR, output)
-    VI = "%21"                                    # row index i = lane & 15 (input)
-    # temporaries, two sets (column parity): piv, y, t, e, u, rd, nl, nlx
+    # temporaries, two sets (column parity): piv, y, t, e, u, rd, nl
     def T(p, k):
         return BASE + 16 * p + 2 * k
     PIV, Y, TT, E, U, RD, NL, NLX = range(8)
@@ -113,15 +112,12 @@ def main():
     g.salu("s_mov_b32 s%d, 0x3fd80000" % (SB + 1))            # 0.375
     g.salu("s_mov_b32 s%d, 0x00010001" % (SB + 2))
     g.salu("s_mov_b32 s%d, 0x00010001" % (SB + 3))
-    g.salu("s_mov_b32 %s, 0" % CNT)
     g.nop(2)                                                   # whatever VALU wrote a[] just before the block
 
     def head(j):
         """pivot chain of column j as a list of thunks (one instruction each), in dependence order"""
         p = j & 1
         piv, y, t, e, u, rd, nl = (vp(T(p, k)) for k in (PIV, Y, TT, E, U, RD, NL))
-        nlx_lo, nlx_hi = T(p, NLX), T(p, NLX) + 1
-        nl_lo, nl_hi = T(p, NL), T(p, NL) + 1
         aj = A[j]
         dpp = "row_newbcast:%d row_mask:0xf bank_mask:0xf" % j
         ops = []
@@ -138,36 +134,34 @@ def main():
         ops.append(lambda: g.valu("v_fma_f64 %s, %s, %s, %s" % (rd, u, t, y), writes=[rd], reads=[u, t, y]))
         ops.append(lambda: g.valu("v_mul_f64 %s, -%s, %s" % (nl, aj, rd), writes=[nl], reads=[aj, rd]))
         ops.append(lambda: g.valu("v_mul_f64 %s, %s, %s" % (aj, aj, rd), writes=[aj], reads=[aj, rd]))
-        # off the chain: bad-pivot count, the masked multiplier of the inverse's rows
-        tail = []
-        tail.append(lambda: g.valu("v_cmp_nlt_f64_e32 vcc, 0, %s" % piv, reads=[piv]))
-        tail.append(lambda: g.salu("s_cmp_lg_u64 vcc, 0"))
-        tail.append(lambda: g.salu("s_addc_u32 %s, %s, 0" % (CNT, CNT)))
-        tail.append(lambda: g.valu("v_cmp_lt_u32_e32 vcc, %d, %s" % (j, VI), reads=[VI]))
-        tail.append(lambda: g.valu("v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (nlx_lo, nl_lo), writes=[vp(T(p, NLX))], reads=[nl]))
-        tail.append(lambda: g.valu("v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (nlx_hi, nl_hi), writes=[vp(T(p, NLX))], reads=[nl]))
-        return ops, tail
-
-    def work(j):
-        """everything of column j that is not on the chain to column j + 1: rank-1 updates of columns j + 2 .., the
-        inverse's rows; needs nl / nlx / rd of column j"""
-        p = j & 1
-        rd, nl, nlx = vp(T(p, RD)), vp(T(p, NL)), vp(T(p, NLX))
-        aj = A[j]
-        ops = []
+        # off the chain, ONE schedulable unit (nothing else may run under a narrowed exec): the multiplier is zeroed on rows
+        # <= j (they are final in the inverse and "don't care" in the factor), row j of the inverse is scaled by rd
         nk = (j >> 2) + 1
-        # row j of the inverse is scaled by rd (exec = the four lanes of row j), then eliminated from the rows below
-        # (ONE schedulable unit: nothing else may run under the narrowed exec)
-        def scale_row():
+        m16 = (1 << (j + 1)) - 1
+        def masked():
+            g.salu("s_mov_b32 s%d, 0x%08x" % (SB + 4, m16 | (m16 << 16)))
+            g.salu("s_mov_b32 s%d, 0x%08x" % (SB + 5, m16 | (m16 << 16)))
+            g.salu("s_mov_b64 exec, s[%d:%d]" % (SB + 4, SB + 5))
+            g.valu("v_mov_b64_e32 %s, 0" % nl, writes=[nl])
             g.salu("s_lshl_b64 exec, %s, %d" % (ROW0, j))
             for k in range(nk):
                 g.valu("v_mul_f64 %s, %s, %s" % (X[k], X[k], rd), writes=[X[k]], reads=[X[k], rd])
             g.salu("s_mov_b64 exec, -1")
-        ops.append(scale_row)
+        tail = [masked]
+        return ops, tail
+
+    def work(j):
+        """everything of column j that is not on the chain to column j + 1: rank-1 updates of columns j + 2 .., the
+        inverse's rows; needs nl of column j"""
+        p = j & 1
+        nl = vp(T(p, NL))
+        aj = A[j]
+        ops = []
+        nk = (j >> 2) + 1
         for c in range(j + 2, 16):
             ops.append(lambda c=c: fmac_bcast(A[c], aj, nl, c))
         for k in range(nk):
-            ops.append(lambda k=k: fmac_bcast(X[k], X[k], nlx, j))
+            ops.append(lambda k=k: fmac_bcast(X[k], X[k], nl, j))
         return ops
 
     # column 0's chain has nothing to hide behind
@@ -203,27 +197,25 @@ def main():
                 op()
     g.nop(4)                                                   # the results feed MFMAs / LDS stores of compiler code
 
-    clob = ["\"v%d\"" % r for r in range(BASE, BASE + (40 if args.plain_fmac else 32))] + ["\"s%d\"" % r for r in range(SB, SB + 4)] + ["\"vcc\"", "\"scc\""]
+    clob = ["\"v%d\"" % r for r in range(BASE, BASE + (40 if args.plain_fmac else 32))] + ["\"s%d\"" % r for r in range(SB, SB + 6)] + ["\"vcc\"", "\"scc\""]
     out = []
     out.append("// potf2_asm.h -- GENERATED by tools/gen_potf2.py; do not edit.  %d VALU instructions." % g.nvalu)
     out.append("// 16x16 Cholesky + inverse of the factor in the registers of one wave (see the generator for the layout and the")
     out.append("// hazard rules).  a[c]: row i = lane & 15 of column c, mirrored in the four lane groups; on return the lower triangle")
     out.append("// holds L (rows i < c of a[c] are garbage), xs[k] = column 4k + (lane >> 4) of row i of L^-1.")
-    out.append("// Returns 0 or the 1-based index of the first pivot that is not positive (NaN included).")
+    out.append("// A pivot that is not positive leaves NaN on the diagonal from that column on (the caller tests L[j][j] > 0).")
     out.append("#pragma once")
-    out.append("__device__ __forceinline__ int %s(double (&a)[16], double (&xs)[4], int lane) {" % args.name)
+    out.append("__device__ __forceinline__ void %s(double (&a)[16], double (&xs)[4], int lane) {" % args.name)
     out.append("    const int vi = lane & 15, vg = lane >> 4;")
-    out.append("    int bad;")
     out.append("#pragma unroll")
     out.append("    for (int k = 0; k < 4; ++k) xs[k] = (4 * k + vg == vi) ? 1.0 : 0.0;")
     out.append("    asm volatile(")
     for ln in g.lines:
         out.append("        \"%s\\n\\t\"" % ln)
     ops_out = ", ".join("\"+v\"(a[%d])" % c for c in range(16)) + ", " + ", ".join("\"+v\"(xs[%d])" % k for k in range(4))
-    out.append("        : %s, \"=&s\"(bad)" % ops_out)
-    out.append("        : \"v\"(vi)")
+    out.append("        : %s" % ops_out)
+    out.append("        :")
     out.append("        : %s);" % ", ".join(clob))
-    out.append("    return bad ? 17 - bad : 0;")
     out.append("}")
     sys.stdout.write("\n".join(out) + "\n")
     sys.stderr.write("potf2: %d VALU, %d wait states, %d lines\n" % (g.nvalu, g.idx, len(g.lines)))

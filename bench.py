@@ -25,8 +25,8 @@ line carries one sub-record per other GPU configuration of BASELINE.json, each m
                                  its dominant MFMA GEMM + cpu_baseline from the sparse oracle)
     "c4_single"      configs[3]'s problem (RBF N=32768 D=8) on the dedicated SINGLE-GPU path (rank 0's GPU): the N = 1 anchor
                                  of the strong-scaling series, parity against the N=32768 golden
-Every `cpu_baseline` of the line is measured by one background thread of rank 0 while those child legs run (the host cores are
-idle then): the headline configuration DIRECTLY at N=16384, configs[1] directly at N=4096, the sparse oracle at two sizes.
+Every `cpu_baseline` of the line is measured on rank 0 AFTER the GPU legs have ended, one after the other (nothing else of the
+run on the host): the headline configuration DIRECTLY at N=16384, configs[1] directly at N=4096, the sparse oracle at two sizes.
 """
 import argparse
 import json
@@ -190,31 +190,16 @@ def cpu_baseline(kind, ARD, D, n_small, n_full, full=False, fit=True):
     return rec
 
 
-class CpuBaselines(object):
-    """All CPU baselines of the default run, measured by ONE background thread of the parent process while the GPU legs
-    (child processes, host cores idle) run: the headline configuration timed directly at its full N, configs[1] directly at
-    N = 4096, and the sparse oracle at two bounded sizes.  Sequential, so that they do not compete with each other."""
-
-    def __init__(self, jobs):
-        import threading
-        self.results, self.errors = {}, {}
-        self._t = threading.Thread(target=self._run, args=(jobs,), daemon=True)
-        self._t.start()
-
-    def _run(self, jobs):
-        for name, fn in jobs:
-            t0 = time.perf_counter()
-            try:
-                self.results[name] = fn()
-                self.results[name]["baseline_wall_s"] = round(time.perf_counter() - t0, 1)
-            except Exception as e:                        # noqa: BLE001 -- a failed baseline must not take the line down
-                self.errors[name] = repr(e)[-300:]
-
-    def get(self, name, timeout=900.0):
-        self._t.join(timeout)
-        if name in self.results:
-            return self.results[name]
-        return {"error": self.errors.get(name, "not finished within %.0f s" % timeout)}
+def timed_baseline(fn):
+    """One CPU baseline, measured with NOTHING else of this run on the host (after the GPU legs have ended: a baseline timed
+    underneath the legs' host loops competes with them for cores and perturbs the latency-bound small legs)."""
+    t0 = time.perf_counter()
+    try:
+        rec = fn()
+        rec["baseline_wall_s"] = round(time.perf_counter() - t0, 1)
+        return rec
+    except Exception as e:                                # noqa: BLE001 -- a failed baseline must not take the line down
+        return {"error": repr(e)[-300:]}
 
 
 def profiled_traffic(kernel_prefix, with_source=False):
@@ -656,15 +641,6 @@ def main():
                     out["parity"]["timed_config_vs_reference"] = g
     ctx.close()
     del m
-    cpu = None
-    if comm.rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        # every CPU baseline of the line in ONE background thread, while the GPU legs below run in child processes
-        jobs = [("headline", lambda: cpu_baseline(args.kind, ARD, D, min(args.cpu_sample_n, N // 2), N,
-                                                  full=not args.cpu_fit_only))]
-        if not args.no_legs:
-            jobs.append(("c2", lambda: cpu_baseline("rbf", False, 8, 2048, 4096, full=True, fit=False)))
-            jobs.append(("c5", lambda: sparse_cpu_baseline(16, args.m, 200000)))
-        cpu = CpuBaselines(jobs)
     if not args.no_legs:
         comm.barrier()
         if comm.rank == 0:
@@ -686,12 +662,15 @@ def main():
             out["c4_single"] = c4_single_leg(comm, args)      # configs[3]'s problem on the dedicated single-GPU path (rank 0's GPU)
         comm.barrier()
     if comm.rank == 0:
-        if cpu is not None:
-            out["cpu_baseline"] = cpu.get("headline")
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            # the CPU baselines, one after the other, after every GPU leg has ended (nothing else of this run uses the host)
+            out["cpu_baseline"] = timed_baseline(lambda: cpu_baseline(args.kind, ARD, D, min(args.cpu_sample_n, N // 2), N,
+                                                                       full=not args.cpu_fit_only, fit=False))
             if not args.no_legs:
-                for leg in ("c2", "c5"):
-                    if isinstance(out.get(leg), dict) and "error" not in out[leg]:
-                        out[leg]["cpu_baseline"] = cpu.get(leg)
+                if isinstance(out.get("c2"), dict) and "error" not in out["c2"]:
+                    out["c2"]["cpu_baseline"] = timed_baseline(lambda: cpu_baseline("rbf", False, 8, 2048, 4096, full=True, fit=False))
+                if isinstance(out.get("c5"), dict) and "error" not in out["c5"]:
+                    out["c5"]["cpu_baseline"] = timed_baseline(lambda: sparse_cpu_baseline(16, args.m, 200000))
         if args.dry_run_sizes:
             out["dry_run_sizes"] = True
         print(compact_line(out), flush=True)

@@ -65,6 +65,7 @@ def build(force=False):
     """Compile every HIP translation unit for gfx950 and link libmi355gp.so in-tree (make -C gpy_amd/csrc)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(_HERE, "..", "include", "mi355gp.h"))
+    srcs.append(os.path.join(_HERE, "..", "include", "mi355gp_debug.h"))
     if not force and os.path.exists(LIB_PATH):
         t = os.path.getmtime(LIB_PATH)
         if all(os.path.getmtime(s) <= t for s in srcs if os.path.exists(s)):
@@ -154,8 +155,6 @@ def lib():
     L.mi355gp_dbg_gemm_clock.argtypes = [_c_dp, _c_dp]
     L.mi355gp_dbg_mask_probe.argtypes = [ci, ci, ci, _dp]
     L.mi355gp_dbg_persist.argtypes = [ci, i64, ci, ci, _dp]
-    L.mi355gp_dbg_fold.argtypes = [ci, i64, ci, ci, _dp]
-    L.mi355gp_dbg_fold.restype = ci
     L.mi355gp_dbg_ipc_selftest.argtypes = [ctypes.c_char_p, ci, ci, ci, ci, i64, _dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
                  "update_gradients_full", "exact_inference", "inference_given_K", "fetch", "predict", "potrf",
@@ -188,7 +187,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share", "mi355gp_pdinv_full", "mi355gp_dbg_graph_factor",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe", "mi355gp_get_option",
             "mi355gp_sparse_get_profile", "mi355gp_dbg_persist", "mi355gp_dbg_grid_multi", "mi355gp_dbg_update_nt", "mi355gp_dbg_update_rect",
-            "mi355gp_dbg_ipc_selftest", "mi355gp_grid_coll_log", "mi355gp_dbg_fold")
+            "mi355gp_dbg_ipc_selftest", "mi355gp_grid_coll_log")
 
 
 # mi355gp_set_option / mi355gp_get_option ids (include/mi355gp.h, MI355GP_OPT_*)
@@ -631,16 +630,6 @@ def dbg_persist(N, reps=3, kcap=0, device=0):
     near = out[8 + 8 * nt:].reshape(nt, 3, 4)              # [..., 3] of entry (j+1, 0): the chain published row j+1
     return dict(ms_steps=out[0], ms_persist=out[1], mismatches=int(out[2]), info=int(out[3]), abort=int(out[4]), nt=nt,
                 steps=(st - st[0, 0]) / 100.0, near=(near - st[0, 0]) / 100.0)
-
-
-def dbg_fold(N, reps=2, tune=0, device=0):
-    """The FOLDED persistent launch (option persist = 2: factorisation + L^-1 + X^T X as one tile dataflow) next to the
-    launch-per-step schedule on a resident SPD matrix: dict(ms_steps, ms_fold, dX, dW (relative max differences of L^-1 and of the
-    lower triangle of A^-1), info, nt, stamps (the launch's raw timeline, see mi355gp.h / tools/fold_probe.py))."""
-    require_device(device)
-    out = np.zeros(8 + 2048)
-    check(lib().mi355gp_dbg_fold(device, int(N), int(reps), int(tune), out), "mi355gp_dbg_fold")
-    return dict(ms_steps=out[0], ms_fold=out[1], dX=out[2], dW=out[3], info=int(out[4]), nt=int(out[5]), stamps=out[8:])
 
 
 def dbg_mask_probe(pct=75, order=0, device=0):

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/mi355gp.h"
+#include "../../include/mi355gp_debug.h"
 #include "internal.h"
 
 int run_peaks(int device, double* out4);
@@ -290,14 +291,6 @@ static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_gra
     // The factorisation region: potrf -> trtri -> (alpha solve on the side stream) || lauum.  `timing`: record the stage events.
     auto region = [&](bool timing) -> int {
         if (timing) HIP_CHECK(hipEventRecord(c->ev[1], st));
-        // small N: ONE persistent dataflow launch for the factorisation, the inverse and X^T X (persist.hip, "folded launch")
-        if (pdinv_device(st, c->A, c->B, c->C, np, &c->ws)) {
-            if (timing) HIP_CHECK(hipEventRecord(c->ev[2], st));
-            HIP_CHECK(hipEventRecord(c->ev[3], st));
-            if (timing) HIP_CHECK(hipEventRecord(c->ev[4], st));
-            launch_tri_matvec(st, c->B, np, n, c->dR, c->Dy, c->dTmp, c->dAlpha, c->dTrmvPart);
-            return 0;
-        }
         potrf_device(st, c->A, np, &c->ws);
         if (timing) HIP_CHECK(hipEventRecord(c->ev[2], st));
         trtri_device(st, c->A, c->B, c->C, np, &c->ws);
@@ -877,12 +870,10 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
     for (int attempt = 0; attempt < 2; ++attempt) {
         launch_pad_from_dense(0, tmp, N, A, np, nullptr, 0, 0.0);
         HIP_CHECK(hipEventRecord(e0, 0));
-        if (!(invert && pdinv_device(0, A, B, C, np, &ws))) {     // small N: the folded persistent launch does all three
-            potrf_device(0, A, np, &ws);
-            if (invert) {
-                trtri_device(0, A, B, C, np, &ws);
-                lauum_device(0, B, C, np, &ws);
-            }
+        potrf_device(0, A, np, &ws);
+        if (invert) {
+            trtri_device(0, A, B, C, np, &ws);
+            lauum_device(0, B, C, np, &ws);
         }
         HIP_CHECK(hipEventRecord(e1, 0));
         HIP_CHECK(hipMemcpy(&info, ws.info, sizeof(int), hipMemcpyDeviceToHost));
@@ -1283,7 +1274,7 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
     const KernParams kp{MI355GP_RBF, 0, D, 1.0};
     launch_scale_inputs(st, dX, N, D, dIl, 0, dXt, np);
     double acc[3] = {0.0, 0.0, 0.0};
-    int info = 0;
+    int info = 0, first_info = 0, redone = 0;
     for (int r = -1; r < reps; ++r) {                          // r = -1: warm-up
         launch_kbuild_sym(st, kp, dXt, np, N, np, A, dNoise, 1, 1e-8, 1, 1);
         HIP_CHECK(hipEventRecord(e[0], st));
@@ -1295,6 +1286,18 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
         HIP_CHECK(hipEventRecord(e[3], st));
         HIP_CHECK(hipStreamSynchronize(st));
         HIP_CHECK(hipMemcpy(&info, ws.info, sizeof(int), hipMemcpyDeviceToHost));
+        bool clean = false;
+        if (potrf_persist_aborted(info, &ws, &clean)) {         // a called-off / aborted persistent launch factored nothing: the
+            if (++redone > reps + 2) {                          // repetition does not count, the context is on launches now
+                mi355gp_set_error("mi355gp_bench_factor: the persistent launch kept being called off");
+                for (auto& ev : e) (void)hipEventDestroy(ev);
+                factor_ws_free(&ws);
+                return -6;
+            }
+            --r;
+            continue;
+        }
+        if (info > 0 && first_info == 0) first_info = info;
         if (r < 0) continue;
         for (int i = 0; i < 3; ++i) {
             float ms;
@@ -1302,6 +1305,7 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
             acc[i] += ms;
         }
     }
+    info = first_info;
     *ms_potrf = acc[0] / reps;
     *ms_trtri = acc[1] / reps;
     *ms_lauum = acc[2] / reps;
@@ -1408,120 +1412,6 @@ int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out) 
     return 0;
 }
 
-
-// out2[0] = max |a - b|, out2[1] = max |a| over the lower triangle (n x n inside ld): non-negative doubles order like their bits
-__global__ void k_maxdiff_lower(const double* __restrict__ a, const double* __restrict__ b, long n, long ld,
-                                unsigned long long* __restrict__ out2) {
-    double d = 0.0, m = 0.0;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += (long)gridDim.x * blockDim.x) {
-        const long i = idx / n, j = idx - i * n;
-        if (j > i) continue;
-        const double x = a[i * ld + j], y = b[i * ld + j];
-        d = fmax(d, fabs(x - y));
-        m = fmax(m, fabs(x));
-    }
-    atomicMax(out2, (unsigned long long)__double_as_longlong(d));
-    atomicMax(out2 + 1, (unsigned long long)__double_as_longlong(m));
-}
-
-// Diagnostic of the FOLDED persistent launch (persist.hip: potrf + X = L^-1 + W = X^T X as one tile dataflow) on a resident SPD
-// matrix against the launch-per-step schedule: out[0] ms per repetition launch-per-step (potrf + trtri + lauum), out[1] ms folded,
-// out[2] / out[3] max |dX| / max |X| and max |dW| / max |W| over the lower triangles, out[4] info of the folded run, out[5] nt,
-// out[6] workgroups; out[8 ...] the launch's timeline (PS_DBG2 layout, 100 MHz ticks): [0] start, [1 + i] X(i,0) final,
-// [1 + nt] chain end, then per worker ticks spent in P / X / W tasks and the end of its last task.  tune: FactorWs::persist_tune.
-int mi355gp_dbg_fold(int device, int64_t N, int reps, int tune, double* out) {
-    ARG_CHECK(N >= 2 * NB && reps >= 1 && out, "mi355gp_dbg_fold: N >= 256, reps >= 1");
-    HIP_CHECK(hipSetDevice(device));
-    const long np = round_up(N, NB);
-    const int nt = (int)(np / NB), D = 4, NDBG = 2048;
-    std::vector<double> X((size_t)N * D);
-    unsigned long long state = 0x9E3779B97F4A7C15ull;
-    for (double& v : X) {
-        state = state * 6364136223846793005ull + 1442695040888963407ull;
-        v = ((double)(state >> 11) / 9007199254740992.0 - 0.5) * 4.0;
-    }
-    DevBuf dX, dXt, dIl, dNoise, A1, B1, C1, A2, B2, C2, dStamp, dMax;
-    HIP_CHECK(dX.alloc(N * D));
-    HIP_CHECK(dXt.alloc(D * np));
-    HIP_CHECK(dIl.alloc(D));
-    HIP_CHECK(dNoise.alloc(1));
-    for (DevBuf* b : {&A1, &B1, &C1, &A2, &B2, &C2}) HIP_CHECK(b->alloc(np * np));
-    HIP_CHECK(dStamp.alloc(NDBG));
-    HIP_CHECK(dMax.alloc(4));
-    const double il[4] = {0.7, 0.7, 0.7, 0.7}, noise = 0.1;
-    HIP_CHECK(hipMemcpy(dX, X.data(), sizeof(double) * N * D, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(dIl, il, sizeof(il), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(dNoise, &noise, sizeof(double), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemset(dMax, 0, sizeof(double) * 4));
-    hipStream_t st;
-    if (factor_engine(device, &st, nullptr, nullptr) != 0) return -2;
-    EngineShared gate(device);
-    FactorWs ws;
-    if (factor_ws_alloc(&ws, np) != 0) return -3;
-    ws.tri_overlap = 0;
-    ws.persist_max_nt = 64;
-    ws.persist_tune = tune;
-    hipEvent_t e[2];
-    for (auto& ev : e) HIP_CHECK(hipEventCreate(&ev));
-    const KernParams kp{MI355GP_RBF, 0, D, 1.0};
-    launch_scale_inputs(st, dX, N, D, dIl, 0, dXt, np);
-    for (int i = 0; i < 8 + NDBG; ++i) out[i] = 0.0;
-    int rc = 0;
-    for (int mode = 0; mode < 2 && rc == 0; ++mode) {           // 0: launch per step, 1: folded
-        double *A = mode ? (double*)A2 : (double*)A1, *B = mode ? (double*)B2 : (double*)B1, *C = mode ? (double*)C2 : (double*)C1;
-        ws.persist = mode ? 2 : 0;
-        ws.scratchX = nullptr;
-        ws.scratchT = nullptr;
-        if (mode == 1 && !pdinv_persist_eligible(np, &ws, 1)) {
-            mi355gp_set_error("mi355gp_dbg_fold: N = %ld is not eligible for the folded launch", (long)N);
-            rc = -1;
-            break;
-        }
-        double acc = 0.0;
-        for (int r = -1; r < reps; ++r) {                       // r = -1: warm-up
-            launch_kbuild_sym(st, kp, dXt, np, N, np, A, dNoise, 1, 1e-8, 1, 1);
-            HIP_CHECK(hipMemsetAsync(dStamp, 0, sizeof(double) * NDBG, st));
-            HIP_CHECK(hipEventRecord(e[0], st));
-            if (mode == 1) {
-                launch_potrf_persist(st, A, np, &ws, nullptr, B, C, reinterpret_cast<long long*>((double*)dStamp));
-            } else {
-                potrf_device(st, A, np, &ws);
-                trtri_device(st, A, B, C, np, &ws);
-                lauum_device(st, B, C, np, &ws);
-            }
-            HIP_CHECK(hipEventRecord(e[1], st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            if (r < 0) continue;
-            float ms;
-            HIP_CHECK(hipEventElapsedTime(&ms, e[0], e[1]));
-            acc += ms;
-        }
-        out[mode] = acc / reps;
-        if (mode == 1) {
-            int info = 0;
-            HIP_CHECK(hipMemcpy(&info, ws.info, sizeof(int), hipMemcpyDeviceToHost));
-            out[4] = info;
-        }
-    }
-    if (rc == 0) {
-        unsigned long long* mx = reinterpret_cast<unsigned long long*>((double*)dMax);
-        hipLaunchKernelGGL(k_maxdiff_lower, dim3(1024), dim3(256), 0, st, (const double*)B1, (const double*)B2, (long)N, np, mx);
-        hipLaunchKernelGGL(k_maxdiff_lower, dim3(1024), dim3(256), 0, st, (const double*)C1, (const double*)C2, (long)N, np, mx + 2);
-        double h[4];
-        HIP_CHECK(hipStreamSynchronize(st));
-        HIP_CHECK(hipMemcpy(h, dMax, sizeof(h), hipMemcpyDeviceToHost));
-        out[2] = h[1] > 0.0 ? h[0] / h[1] : h[0];
-        out[3] = h[3] > 0.0 ? h[2] / h[3] : h[2];
-        out[5] = nt;
-        std::vector<long long> stamps((size_t)NDBG);
-        HIP_CHECK(hipMemcpy(stamps.data(), dStamp, sizeof(long long) * NDBG, hipMemcpyDeviceToHost));
-        for (int i = 0; i < NDBG; ++i) out[8 + i] = (double)stamps[(size_t)i];
-    }
-    for (auto& ev : e) (void)hipEventDestroy(ev);
-    factor_ws_free(&ws);
-    HIP_CHECK(hipGetLastError());
-    return rc;
-}
 
 // Diagnostic: the same build + factorisation sequence as mi355gp_bench_factor, once launched kernel by kernel and once
 // replayed from a hipGraph captured from the same streams (main + look-ahead panel stream; sizes below the overlapped-inverse

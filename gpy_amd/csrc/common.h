@@ -11,8 +11,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define FACTOR_NBO_SMALL_N 0      // npad up to which the outer panels are FACTOR_NBO_SMALL wide (0: never)
 #define FACTOR_NBO_SMALL 256
 #define FACTOR_DEFAULT_TRI_OVERLAP 1    // 1: inverse of the leading block overlapped with the second half of potrf
-#define FACTOR_DEFAULT_PERSIST 1        // 1: small factorisations run as ONE persistent dataflow launch (persist.hip); 2 (opt-in,
-                                        // measured SLOWER: DESIGN 3c): the inverse and X^T X folded into the same launch
+#define FACTOR_DEFAULT_PERSIST 1        // 1: small factorisations run as ONE persistent dataflow launch (persist.hip)
 #define FACTOR_PERSIST_MAX_NT 36        // ... up to this many 128-tiles per dimension (N <= 4608): measured A/B on one box, whole
                                         // evaluation N=2048 -3.2 %, N=4096 -4.4 % (potrf stage -16 %), N=5120 +4 % (the far-tile
                                         // owners saturate and starve the near tiles); MI355GP_PERSIST_MAX_NT overrides

@@ -398,18 +398,6 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     (void)hipStreamWaitEvent(st, ws->ev_panel[P], 0);
 }
 
-bool pdinv_device(hipStream_t st, double* A, double* X, double* W, long npad, FactorWs* ws) {
-    ws->persist_used = 0;
-    if (!pdinv_persist_eligible(npad, ws, W != nullptr)) return false;
-    ws->ovl_h = 0;
-    if (!launch_potrf_persist(st, A, npad, ws, nullptr, X, W)) {
-        ws->persist = 0;
-        return false;
-    }
-    ws->persist_used = 2;
-    return true;
-}
-
 // X = L^-1: diagonal 128-blocks on single CUs (all blocks concurrently), then log2(nt) batched levels.  If the preceding
 // potrf_device already put the leading ovl_h tiles and the top-level T21 on st_tri (same X / T buffers), only the
 // trailing block and the top-level X21 = -X22 T21 are left.

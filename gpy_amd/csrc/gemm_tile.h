@@ -228,96 +228,6 @@ __device__ __forceinline__ void gemm_tile_128_v3(const double* __restrict__ A, l
 }
 
 
-// The same tile pipeline on a RING of NST LDS stages (NST * 34,816 B), for a workgroup that has a CU to ITSELF (the workers of
-// the persistent launch of persist.hip: one 155 KB workgroup per CU, one wave per SIMD).  With two workgroups per CU the
-// one-slab look-ahead of gemm_tile_128_v3 is enough: while one workgroup waits for its DMA the other one computes.  Alone on the
-// CU, every slab exposes what is left of the global -> LDS latency after one slab of MFMAs (1.7 us): operands last written by
-// another XCD come from HBM, ~2 us away, and the pipe ran at a third of its rate.  Here the DMA of slab kt + NST - 1 is issued
-// when slab kt starts (right after the barrier that retires stage (kt - 1) % NST), the wait before slab kt is a COUNTED
-// s_waitcnt (the DMAs of the younger slabs stay in flight) and the barrier is a bare s_barrier (__syncthreads() would drain
-// vmcnt).  Same slab order, same k -> MFMA-slice assignment: the bits of gemm_tile_128_v3.
-template <int N>
-__device__ __forceinline__ void gt_wait_vm_barrier() {
-    if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (N == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <bool AK, bool BK, bool NEGA, int NST>
-__device__ __forceinline__ void gemm_tile_128_ring(const double* __restrict__ A, long lda, const double* __restrict__ B,
-                                                   long ldb, int K, d4 (&acc)[4][4], double* smem) {
-    static_assert(NST >= 2 && NST <= 4, "2..4 stages");
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
-    const int nk = K / 16;
-    const int arow = wr * 64 + (lane & 15), bcol = wc * 64 + (lane & 15), kq = lane >> 4;
-    auto rsrc = [](const double* p) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000);
-    };
-    int va[4], vb[4];
-    gt3_src_offsets<AK>(lda, lane, w, va);
-    gt3_src_offsets<BK>(ldb, lane, w, vb);
-    const long sa = AK ? 16 : 16 * lda, sb = BK ? 16 : 16 * ldb;
-    int fa0[4], fb0[4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int r = arow + mi * 16, c = bcol + mi * 16;
-        fa0[mi] = AK ? r * 16 : r;
-        fb0[mi] = BK ? c * 16 : c;
-    }
-    const int ha = gt3_h(arow), hb = gt3_h(bcol);
-    // every wave has to be done with the LDS (an earlier use of smem by the caller) before the first DMA lands
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < nk) {
-            double* st = smem + s * 2 * GT3_OP;
-            gt3_issue<AK>(rsrc(A + s * sa), va, 0, st, w);
-            gt3_issue<BK>(rsrc(B + s * sb), vb, 0, st + GT3_OP, w);
-        }
-    int stage = 0;                                           // stage of slab kt
-    for (int kt = 0; kt < nk; ++kt) {
-        // slab kt has landed when at most the DMAs of the slabs issued after it are outstanding: 8 per slab and wave
-        const int younger = (nk - 1 - kt < NST - 2) ? nk - 1 - kt : NST - 2;
-        if (younger <= 0) gt_wait_vm_barrier<0>();
-        else if (younger == 1) gt_wait_vm_barrier<8>();
-        else gt_wait_vm_barrier<16>();
-        // the barrier also retired stage (kt - 1) % NST: refill it with slab kt + NST - 1
-        if (kt + NST - 1 < nk) {
-            const int ps = (stage == 0) ? NST - 1 : stage - 1;
-            double* nxt = smem + ps * 2 * GT3_OP;
-            gt3_issue<AK>(rsrc(A + (kt + NST - 1) * sa), va, 0, nxt, w);
-            gt3_issue<BK>(rsrc(B + (kt + NST - 1) * sb), vb, 0, nxt + GT3_OP, w);
-        }
-        const double* a_s = smem + stage * 2 * GT3_OP;
-        const double* b_s = a_s + GT3_OP;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {                        // slices 2e, 2e+1
-            d2 af[4], bf[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                if (AK) af[mi] = *reinterpret_cast<const d2*>(a_s + fa0[mi] + 2 * ((2 * kq + e) ^ ha));
-                else af[mi] = (d2){a_s[(4 * kq + 2 * e) * GT3_SMN + fa0[mi]], a_s[(4 * kq + 2 * e + 1) * GT3_SMN + fa0[mi]]};
-            }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                if (BK) bf[ni] = *reinterpret_cast<const d2*>(b_s + fb0[ni] + 2 * ((2 * kq + e) ^ hb));
-                else bf[ni] = (d2){b_s[(4 * kq + 2 * e) * GT3_SMN + fb0[ni]], b_s[(4 * kq + 2 * e + 1) * GT3_SMN + fb0[ni]]};
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc[mi][ni] = mfma_f64(NEGA ? -af[mi][s] : af[mi][s], bf[ni][s], acc[mi][ni]);
-        }
-        stage = (stage + 1 == NST) ? 0 : stage + 1;
-    }
-    // the caller may reuse smem right away: every wave has consumed the last slab
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // The same pipeline with the K dimension running over a LIST of operand panels (grid.hip: the aggregated updates of the
 // block-cyclic mode apply panels k0 .. k1-1 of `slabs` 16-wide slabs each in ONE pass over C).  Atab[k] / Btab[k] are the
 // panels' base pointers (workgroup-uniform: scalar loads), aoff / boff this tile's offset inside every panel.  The two

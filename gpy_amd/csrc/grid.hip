@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/mi355gp.h"
+#include "../../include/mi355gp_debug.h"
 #include "gemm_tile.h"
 #include "internal.h"
 
@@ -466,7 +467,8 @@ struct GridRank {
     // the logs of all members after every evaluation (mi355gp_grid_coll_log reads them).
     uint64_t coll_hash[3] = {0, 0, 0};
     long coll_count[3] = {0, 0, 0};
-    double* seqbuf = nullptr;        // 2 * world doubles: the exchange buffer of the check
+    double* seqbuf = nullptr;        // 3 * max(world, Pr, Pc) doubles: the exchange buffer of the sequence check
+    int seqbuf_members = 0;          // members it was sized for
     FactorWs ws;
     hipStream_t st = nullptr;        // bulk updates and everything outside the factorisation loop
     hipStream_t sc = nullptr;        // the critical path of a step: diagonal tile, panel solves, all panel broadcasts
@@ -672,9 +674,14 @@ static int grid_check_sequences(mi355gp_grid* g) {
         return 0;
     }
     GridRank& r = g->ranks[0];
-    if (!r.seqbuf) HIP_CHECK(hipMalloc(&r.seqbuf, sizeof(double) * 3 * 64));
     const ncclComm_t comms[3] = {g->comm_world, g->comm_row, g->comm_col};
     const int sizes[3] = {g->world, g->Pc, g->Pr}, me[3] = {r.rank, r.pc, r.pr};
+    if (r.seqbuf_members < g->world) {                      // world >= Pr, Pc: one buffer serves the three communicators
+        if (r.seqbuf) (void)hipFree(r.seqbuf);
+        r.seqbuf = nullptr;
+        HIP_CHECK(hipMalloc(&r.seqbuf, sizeof(double) * 3 * (size_t)g->world));
+        r.seqbuf_members = g->world;
+    }
     const uint64_t hash[3] = {r.coll_hash[0], r.coll_hash[1], r.coll_hash[2]};       // before the check's own collectives
     const long cnt[3] = {r.coll_count[0], r.coll_count[1], r.coll_count[2]};
     for (int c = 0; c < 3; ++c) {
@@ -976,8 +983,11 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
     //   st                : bulk(g) [after crit of the group's last step]
     //   sw (low priority) : the W updates [after crit of the last step they read]; st joins it after the loop
     // bulk(g) touches columns / rows >= the start of group g+2 only, the critical path of group g+1 stays inside group
-    // g+1's columns / rows: they run concurrently.  Every panel has its own buffer for the whole evaluation (no reuse
-    // hazards).  Every rank enqueues the same sequence of collectives on sc, so their order is consistent across the grid.
+    // g+1's columns / rows: they run concurrently.  The X panels keep one buffer per step for the whole evaluation (the
+    // deferred W = X^T X reads them late); the L panels live in a RING of 2 G full-height slots (alloc_panel_stores): slot
+    // reuse is safe because sc waits for ev_p1[gi-1] -- i.e. for bulk(g-1) on st -- before part1(g), so every reader of group
+    // g's panels has been enqueued behind the event that group g+2's crit (the next writer of those slots) waits for.
+    // Every rank enqueues the same sequence of collectives on sc, so their order is consistent across the grid.
     const bool la = g->lookahead != 0;
     hipStream_t scs = la ? g->sc : g->st;
     const long G = g->G < 1 ? 1 : g->G, GW = g->GW;

@@ -104,9 +104,8 @@ struct FactorWs {
     int persist_skip = 0, persist_aborts = 0, persist_used = 0;
     hipEvent_t ev_persist_pre = nullptr;   // optional (not owned): recorded on the launching stream once the progress words are zeroed
     int persist_grid_last = 0;             // workgroups of the last persistent launch
-    int persist_tune = 0;            // MI355GP_PERSIST_TUNE: schedule bits of the folded launch (1: near owners take W tiles only after
-                                     // their X tiles, 2: two-stage worker GEMM instead of the 4-stage ring) and A/B bits of the
-                                     // factorisation-only launch (4: no split hand-over, 64 / 128: near ownership of 3 / 4 diagonals)
+    int persist_tune = 0;            // MI355GP_PERSIST_TUNE: A/B bits of the persistent launch (4: no split hand-over, 64 / 128: near
+                                     // ownership of 3 / 4 block diagonals)
     int persist_test = 0;            // MI355GP_OPT_PERSIST_TEST: fault injection for the NEXT persistent launch (1 clean, 2 dirty)
     int* persist_sync = nullptr;     // progress words of the persistent launch (zeroed before every launch)
     double* persist_hs = nullptr;    // [min(nblk, 64)][128 x 128]: sub-diagonal tile of every row, handed to the chain in ITS load order
@@ -164,16 +163,9 @@ bool potrf_persist_aborted(int info, FactorWs* ws, bool* clean);
 int potrf_persist_sync_ints();
 // dbg (optional, 8 * nt wall-clock stamps): per chain step [factor start, factor end, sub tile seen, solve end, diag tile seen, update end]
 // false: the launch could not be made (no large-LDS opt-in on this device, launch error): nothing was enqueued that writes A
-// X != NULL: the FOLDED launch -- the same dataflow goes on to X = L^-1 (by rows, into X) and, with W != NULL, to the lower tiles
-// of W = X^T X (dtrtri + dlauum of dpotri, GPy/util/linalg.py:127-145) inside the one launch
-bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg = nullptr, double* X = nullptr,
-                          double* W = nullptr, long long* dbg2 = nullptr);
-bool pdinv_persist_eligible(long npad, FactorWs* ws, int want_w);
+bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg = nullptr);
 // on `st`: wait (<= 2 ms) until the persistent launch announced by ws->ev_persist_pre has all its workgroups resident
 void launch_wait_persist_resident(hipStream_t st, const FactorWs* ws);
-// A -> L in place, X = L^-1, W = X^T X (W may be NULL): the folded persistent launch when eligible (returns true; ws->persist_used
-// = 2), else false and NOTHING was enqueued: the caller takes potrf_device / trtri_device / lauum_device
-bool pdinv_device(hipStream_t st, double* A, double* X, double* W, long npad, FactorWs* ws);
 
 // ---- kern.hip : covariance assembly, reductions, solves, fetch helpers ----------------------------
 struct KernParams {

@@ -53,11 +53,8 @@
 #define PS_CNT 16                          // [nt] cnt[i]: L(i, 0 .. cnt[i]-1) final
 #define PS_SUB (16 + PS_MAXNT)             // [nt] tile (i, i-1) holds columns 0 .. i-2, published for the chain
 #define PS_DIA (16 + 2 * PS_MAXNT)         // [nt] tile (i, i)   holds columns 0 .. i-2, published for the chain
-#define PS_XCOL (16 + 3 * PS_MAXNT)         // [nt] xcol[k]: X(k .. k+xcol[k]-1, k) final (the inverse, column k, from the diagonal down)
 #define PS_PRE (16 + 4 * PS_MAXNT)          // [nt] tile (i, i-1) holds columns 0 .. i-3 in place (its owner is done with it)
 #define PS_SYNC_INTS (16 + 5 * PS_MAXNT)
-#define PS_RING 4                          // LDS stages of the folded launch's worker GEMM (4 x 34,816 B of the 158,720)
-#define PS_MAXTASK 64                      // tasks (P / X / W tiles) one worker of the folded launch can own
 
 // a pointer / int that is the same in every lane, moved to scalar registers (arguments of a non-inlined device function
 // arrive in vector registers: without this every buffer access built from them becomes a waterfall loop)
@@ -801,381 +798,10 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
 }
 
 
-// ---- the folded launch: potrf + X = L^-1 + W = X^T X as ONE tile dataflow -------------------------------
-// While the chain walks the diagonal (~57 us per 128 columns on one CU) most of the machine idles: the owners of the near
-// tiles are done with row i once the chain has taken it, and after the last step only the inverse (dtrtri) and X^T X (dlauum:
-// GPy/util/linalg.py:127-145,193-214) are left -- 2 N^3 / 3 flops that the launch-per-step schedule runs as ~11 dependent
-// launches AFTER the factorisation.  Here the same workers go on, inside the same launch, with two more families of tile tasks:
-//   X(i,k) (i >= k), the inverse by ROWS:  X(i,i) = L_ii^-1 (from the inverted 16 x 16 diagonal tiles, the arithmetic of
-//           k_inv128);  X(i,k) = -X(i,i) * S,  S = sum_{j=k}^{i-1} L(i,j) X(j,k): term j is available once L(i,j) is final
-//           (cnt[i] > j) and X(j,k) is (xcol[k] > j-k); S accumulates in place (plain stores: only the owner reads it), the
-//           finished tile is written through and published by xcol[k] = i-k+1.  Row i of X trails row i of L by one K = 128
-//           term + one 128^3 triangular product;
-//   W(k,l) (k >= l), the lauum by tiles:  W(k,l) = sum_{i>=k} X(i,k)^T X(i,l): term i is available once both X tiles are.
-// X tiles belong to the NEAR owners (free from step ~e/3 on), row i only to owners whose own tile is in a row <= i; W tiles go
-// round-robin over all workers and are served after everything else a worker owns (a far owner gets to them when its share of
-// the factorisation is done, in deep-K passes).  Each worker walks its own list in the global order "P tiles, X tiles by row, W
-// tiles", which is a topological order of the task DAG: static ownership cannot deadlock.  Terms are applied in ascending
-// order with the accumulator carried in fp64 through memory between passes: the result does not depend on how the terms fell
-// into passes (run-to-run bit reproducible); it is NOT the summation order of k_trtri_stage / k_lauum (tolerance, not bits,
-// between the folded and the launch-per-step schedule; L itself has the same bits).
-#define TK_P 0
-#define TK_XD 1
-#define TK_X 2
-#define TK_W 3
-
-// X(i,i) = L_ii^-1: tile-column JB of the 128 x 128 block by one wave (inv128_col of small.hip with write-through stores)
-template <int JB>
-__device__ __forceinline__ void inv128_col_coh(const double* __restrict__ Lb, double* __restrict__ Xb, long ld,
-                                               const double* __restrict__ dv, int lane) {
-    const int fi = lane & 15, fk = lane >> 4;
-    d4 Xt[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Xt[JB][r] = ldg<true>(dv + JB * 256 + (fk + 4 * r) * 16 + fi);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) stg<true>(Xb + (long)(JB * 16 + fk + 4 * r) * ld + JB * 16 + fi, Xt[JB][r]);
-#pragma unroll
-    for (int ib = 0; ib < JB; ++ib)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stg<true>(Xb + (long)(ib * 16 + fk + 4 * r) * ld + JB * 16 + fi, 0.0);
-#pragma unroll
-    for (int ib = JB + 1; ib < 8; ++ib) {
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = JB; k < ib; ++k)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double a = ldg<true>(Lb + (long)(ib * 16 + fi) * ld + k * 16 + fk + 4 * s);
-                acc = mfma_f64(a, Xt[k][s], acc);
-            }
-        d4 y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double a = -ldg<true>(dv + ib * 256 + fi * 16 + fk + 4 * s);
-            y = mfma_f64(a, acc[s], y);
-        }
-        Xt[ib] = y;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stg<true>(Xb + (long)(ib * 16 + fk + 4 * r) * ld + JB * 16 + fi, y[r]);
-    }
-}
-
-// the worker's tile GEMM: the 4-stage ring (a workgroup alone on its CU) or, tune bit 1, the two-stage pipeline (A/B diagnostics)
-#define WGEMM(AK, BK, NEGA, ...)                                                    \
-    do {                                                                            \
-        if (tune & 2) gemm_tile_128_v3<AK, BK, NEGA>(__VA_ARGS__);                   \
-        else gemm_tile_128_ring<AK, BK, NEGA, PS_RING>(__VA_ARGS__);                 \
-    } while (0)
-
-// who owns X tile (i,k) (a near owner e < H; row i only among the owners whose own near tile lies in a row <= i) / W tile (k,l)
-__device__ __forceinline__ int own_x(int i, int k, int H, int D) {
-    int span = near_tiles_in_rows(i + 1, D);
-    if (span > H) span = H;
-    return (i * (i + 1) / 2 + k) % span;
-}
-#define PS_DBG2_DOUBLES 2048               // diagnostics of the folded launch: [0] start, [1 + i] X(i,0) final, [1 + nt] chain end,
-                                           // [2 + nt + 4 me ..] worker me: ticks in P / X / W tasks, end of its last task
-__device__ __forceinline__ int own_w(int k, int l, int nw) { return (k * (k + 1) / 2 + l) % nw; }
-
-__device__ void worker_workgroup_inv(double* __restrict__ A, double* __restrict__ X, double* __restrict__ Wm, long ld, int nt,
-                                     const double* __restrict__ dinv_all, int* __restrict__ sync, int kcap,
-                                     double* __restrict__ hs, int want_w, int tune, long long* __restrict__ dbg2, double* sm) {
-    __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress of L, [nt] dcnt, [nt+1] abort
-    __shared__ int s_x[PS_MAXNT];                              // xcol snapshot
-    __shared__ int s_prog[PS_MAXTASK];                         // terms applied per task; -1: task finished
-    __shared__ int s_wait[PS_MAXTASK];                         // P tiles: all columns applied, waiting for L_kk
-    __shared__ short s_kind[PS_MAXTASK], s_ti[PS_MAXTASK], s_tk[PS_MAXTASK];
-    __shared__ int s_ntask;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    if (w >= 4) return;              // the launch has eight waves per workgroup for the chain's sake; a worker uses four
-    const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
-    const int neard = ps_neard(tune);
-    const Ownership own(nt, nw, neard);
-    // ---- this worker's task list: P tiles (ownership of the factorisation), then X tiles by row, then W tiles ---------------
-    if (w == 0) {
-        int n = 0;
-        const int np = own.count(me);
-        for (int s = lane; s < np; s += 64) {
-            int i, k;
-            own.tile(me, s, i, k);
-            s_kind[s] = TK_P;
-            s_ti[s] = (short)i;
-            s_tk[s] = (short)k;
-        }
-        n = np;
-        const int ntl = nt * (nt + 1) / 2;
-        for (int pass = 0; pass < 2; ++pass) {                 // 0: X tiles (near owners only), 1: W tiles
-            if (pass == 0 && me >= own.H) continue;
-            if (pass == 1 && !want_w) continue;
-            for (int base = 0; base < ntl; base += 64) {
-                const int u = base + lane;
-                int i = 0, k = 0;
-                bool mine = false;
-                if (u < ntl) {
-                    i = (int)((sqrtf(8.0f * (float)u + 1.0f) - 1.0f) * 0.5f);
-                    while (i * (i + 1) / 2 > u) --i;
-                    while ((i + 1) * (i + 2) / 2 <= u) ++i;
-                    k = u - i * (i + 1) / 2;
-                    mine = (pass == 0) ? (own_x(i, k, own.H, own.D) == me) : (own_w(i, k, nw) == me);
-                }
-                const unsigned long long m = __ballot(mine);
-                if (mine) {
-                    const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < PS_MAXTASK) {
-                        s_kind[pos] = (pass == 1) ? TK_W : (i == k ? TK_XD : TK_X);
-                        s_ti[pos] = (short)i;
-                        s_tk[pos] = (short)k;
-                    }
-                }
-                n += __popcll(m);
-            }
-        }
-        if (lane == 0) s_ntask = n < PS_MAXTASK ? n : PS_MAXTASK;      // the host only launches grids whose lists fit
-    }
-    __syncthreads();
-    const int ntask = s_ntask;
-    for (int s = t; s < PS_MAXTASK; s += 256) {
-        s_prog[s] = (s < ntask && !(s_kind[s] == TK_P && s_ti[s] == 0 && s_tk[s] == 0)) ? 0 : -1;   // tile (0,0): the chain's
-        s_wait[s] = 0;
-    }
-    __syncthreads();
-    int left = 0, xleft = 0, pleft = 0;
-    for (int s = 0; s < ntask; ++s) {
-        left += (s_prog[s] >= 0) ? 1 : 0;
-        xleft += (s_prog[s] >= 0 && (s_kind[s] == TK_X || s_kind[s] == TK_XD)) ? 1 : 0;
-        pleft += (s_prog[s] >= 0 && s_kind[s] == TK_P) ? 1 : 0;
-    }
-    // A near owner's tile of the factorisation feeds the chain: nothing else may occupy this workgroup while it is pending
-    // (a 100 us pass over an inverse tile in front of it stretched the chain's step from 57 to 104 us).  Terms of X / W tiles
-    // trickle in one per finished row: a pass is only worth its C round trip (~15 us) when it applies a BATCH of terms, or
-    // when the tile is on the frontier (row i of L about to be final / every term of a W tile available).
-    const bool near_owner = me < own.H;
-    const int xbatch = (tune & 4) ? 1 : 8, wbatch = (tune & 4) ? 1 : 8;
-    long long idle0 = 0, tk0 = 0, busy[3] = {0, 0, 0};
-    if (dbg2 && me == 0 && t == 0) dbg2[0] = wall_clock64();
-    while (left > 0) {
-        // ---- snapshot of the progress words (sc1 loads), then one agent acquire for this CU's L1
-        if (t < nt) s_cnt[t] = ld_flag(sync + PS_CNT + t);
-        if (t >= 64 && t < 64 + nt) s_x[t - 64] = ld_flag(sync + PS_XCOL + t - 64);
-        if (t == 128) s_cnt[nt] = ld_flag(sync + PS_DCNT);
-        if (t == 129) s_cnt[nt + 1] = ld_flag(sync + PS_ABORT);
-        if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __syncthreads();
-        if (s_cnt[nt + 1] != 0) return;
-        const int dcnt = s_cnt[nt];
-        int rowP = 1 << 20;                                    // row of this owner's next tile of the factorisation
-        if (near_owner && pleft > 0)
-            for (int s = 0; s < ntask; ++s)
-                if (s_kind[s] == TK_P && s_prog[s] >= 0 && s_ti[s] < rowP) rowP = s_ti[s];
-        // ---- the first task of the list that has something to do
-        int pick = -1, kind = 0, pi = 0, pk = 0, pj0 = 0, pj1 = 0, ptrsm = 0, pfin = 0;
-        for (int s = 0; s < ntask && pick < 0; ++s) {
-            const int p = s_prog[s];
-            if (p < 0) continue;
-            const int kd = s_kind[s], i = s_ti[s], k = s_tk[s];
-            if (kd == TK_P) {
-                const int limit = (i == k) ? i - 1 : k;        // diagonal tiles stop one column short (the chain's)
-                if (s_wait[s]) {
-                    if (dcnt >= k + 1) { pick = s; pj0 = pj1 = limit; ptrsm = 1; }
-                } else {
-                    int jmax = s_cnt[i] < s_cnt[k] ? s_cnt[i] : s_cnt[k];
-                    if (jmax > limit) jmax = limit;
-                    if (jmax > p || p == limit) {
-                        pick = s; pj0 = p;
-                        pj1 = (jmax > p + kcap) ? p + kcap : (jmax > p ? jmax : p);
-                        ptrsm = (pj1 == limit && i >= k + 2 && dcnt >= k + 1) ? 1 : 0;
-                    }
-                }
-            } else if (near_owner && rowP <= dcnt + 3) {
-                continue;                                      // the chain will want this owner's tile within a few steps: stay free
-            } else if (kd == TK_XD) {
-                if (dcnt >= i + 1) pick = s;
-            } else if (kd == TK_X) {                           // terms j = k + p ...: need L(i,j) and X(j,k)
-                int jmax = s_cnt[i] < k + s_x[k] ? s_cnt[i] : k + s_x[k];
-                if (jmax > i) jmax = i;
-                const int navail = jmax - (k + p), rem = (i - k) - p;
-                if (rem >= 2) {                                // terms before the last one: in batches, or all that are left
-                    const int nf = navail < rem - 1 ? navail : rem - 1;
-                    if (nf >= 1 && (nf >= xbatch || nf == rem - 1)) {
-                        pick = s; pj0 = k + p;
-                        pj1 = pj0 + (nf > 16 ? 16 : nf);
-                    }
-                } else if (navail >= 1 && s_x[i] >= 1) {       // the last term (j = i - 1) and the product with X(i,i), in one visit
-                    pick = s; pj0 = k + p; pj1 = i; pfin = 1;
-                }
-            } else if (dcnt >= nt && !((tune & 1) && xleft > 0)) {   // TK_W, once the chain is through: (i,k) = (row, column) tile
-                int rmax = i + s_x[i] < k + s_x[k] ? i + s_x[i] : k + s_x[k];
-                if (rmax > nt) rmax = nt;
-                const int navail = rmax - (i + p);
-                if (navail > 0 && (navail >= wbatch || rmax == nt)) {
-                    pick = s; pj0 = i + p;
-                    pj1 = (rmax > pj0 + 16) ? pj0 + 16 : rmax;
-                }
-            }
-            if (pick >= 0) { kind = kd; pi = i; pk = k; }
-        }
-        if (pick < 0) {                                        // nothing ready: back off, give up after the timeout
-            if (t == 0) {
-                if (idle0 == 0) idle0 = wall_clock64();
-                else if (wall_clock64() - idle0 > PS_TIMEOUT_TICKS) st_flag(sync + PS_ABORT, 1);
-                if (me >= own.H) __builtin_amdgcn_s_sleep(8);    // owners of near tiles are on the chain's critical path
-            }
-            __syncthreads();
-            continue;
-        }
-        idle0 = 0;
-        if (dbg2 && t == 0) tk0 = wall_clock64();
-        if (kind == TK_P) {
-            // ===== a tile of the factorisation: exactly worker_workgroup's step =====
-            const int limit = (pi == pk) ? pi - 1 : pk;
-            const bool general = pi >= pk + 2;
-            double* Ct = A + (long)pi * NB * ld + (long)pk * NB;
-            const bool handover = (pj1 == limit && !general);
-            const bool subdiag = (pi == pk + 1);
-            if (pj1 > pj0 || (handover && subdiag)) {
-                d4 acc[4][4];
-                gt_load_buf<4>(Ct, ld, acc);
-                if (pj1 > pj0)
-                    WGEMM(true, true, true, A + (long)pi * NB * ld + (long)pj0 * NB, ld,
-                                                       A + (long)pk * NB * ld + (long)pj0 * NB, ld, (pj1 - pj0) * NB, acc, sm);
-                if (handover || subdiag) {
-                    __syncthreads();
-                    stage_put_acc(sm, acc);
-                    __syncthreads();
-                    if (handover && subdiag) stage_store_chain_order<256>(sm, hs + (long)pi * (NB * NB), t);
-                    else stage_store_coherent<256>(sm, Ct, ld, t);
-                } else {
-                    gt_store<0, 4>(Ct, ld, acc);
-                }
-            }
-            if (handover) {
-                drain_stores();
-                __syncthreads();
-                if (t == 0) {
-                    st_flag(sync + ((pi == pk) ? PS_DIA : PS_SUB) + pi, 1);
-                    s_prog[pick] = -1;
-                }
-                --left;
-                --pleft;
-            } else if (pj1 == limit && !ptrsm) {
-                drain_stores();
-                __syncthreads();
-                if (t == 0) { s_prog[pick] = pj1; s_wait[pick] = 1; }
-            } else if (ptrsm) {
-                drain_stores();
-                __syncthreads();
-                trsm_stage_L(A, ld, (long)pk * NB, dinv_all + (long)pk * 8 * 256, sm);
-                __syncthreads();
-                {
-                    d4 Y0[8], Y1[8];
-                    trsm_strip2_regs(A, ld, (long)pk * NB, (long)pi * NB + 16 * w, sm, lane, Y0, Y1);
-                    __syncthreads();
-                    stage_put_strips(sm, w, Y0, Y1, lane);
-                }
-                __syncthreads();
-                stage_store_coherent<256>(sm, Ct, ld, t);
-                drain_stores();
-                __syncthreads();
-                if (t == 0) {
-                    st_flag(sync + PS_CNT + pi, pk + 1);
-                    s_prog[pick] = -1;
-                }
-                --left;
-                --pleft;
-            } else {
-                __syncthreads();
-                if (t == 0) s_prog[pick] = pj1;
-            }
-        } else if (kind == TK_XD) {
-            // ===== X(i,i) = L_ii^-1, two tile columns per wave, written through =====
-            const double* Lb = A + (long)pi * NB * ld + (long)pi * NB;
-            double* Xb = X + (long)pi * NB * ld + (long)pi * NB;
-            const double* dv = dinv_all + (long)pi * 8 * 256;
-            switch (w) {
-                case 0: inv128_col_coh<0>(Lb, Xb, ld, dv, lane); inv128_col_coh<7>(Lb, Xb, ld, dv, lane); break;
-                case 1: inv128_col_coh<1>(Lb, Xb, ld, dv, lane); inv128_col_coh<6>(Lb, Xb, ld, dv, lane); break;
-                case 2: inv128_col_coh<2>(Lb, Xb, ld, dv, lane); inv128_col_coh<5>(Lb, Xb, ld, dv, lane); break;
-                default: inv128_col_coh<3>(Lb, Xb, ld, dv, lane); inv128_col_coh<4>(Lb, Xb, ld, dv, lane); break;
-            }
-            drain_stores();
-            __syncthreads();
-            if (t == 0) {
-                st_flag(sync + PS_XCOL + pi, 1);
-                s_prog[pick] = -1;
-                if (dbg2 && pi == 0) dbg2[1] = wall_clock64();
-            }
-            --left;
-            --xleft;
-        } else if (kind == TK_X) {
-            // ===== S(i,k) += sum_{j in [pj0, pj1)} L(i,j) X(j,k), in place in X(i,k) (owner-private until final); with the last
-            //       term (pfin) the tile is finished in the same visit: X(i,k) = -X(i,i) S, written through, column k published =====
-            double* St = X + (long)pi * NB * ld + (long)pk * NB;
-            {
-                d4 acc[4][4];
-                if (pj0 == pk) gt_zero<4>(acc);
-                else gt_load_buf<4>(St, ld, acc);
-                WGEMM(true, false, false, A + (long)pi * NB * ld + (long)pj0 * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
-                      (pj1 - pj0) * NB, acc, sm);
-                gt_store<0, 4>(St, ld, acc);
-            }
-            drain_stores();
-            __syncthreads();
-            if (!pfin) {
-                if (t == 0) s_prog[pick] = pj1 - pk;
-            } else {
-                if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // S was read through this CU's L1 earlier in the visit
-                __syncthreads();
-                d4 acc[4][4];
-                gt_zero<4>(acc);
-                WGEMM(true, false, true, X + (long)pi * NB * ld + (long)pi * NB, ld, St, ld, NB, acc, sm);
-                __syncthreads();                               // the GEMM's LDS stages are free, every read of S has landed
-                stage_put_acc(sm, acc);
-                __syncthreads();
-                stage_store_coherent<256>(sm, St, ld, t);
-                drain_stores();
-                __syncthreads();
-                if (t == 0) {
-                    st_flag(sync + PS_XCOL + pk, pi - pk + 1);
-                    s_prog[pick] = -1;
-                    if (dbg2 && pk == 0) dbg2[1 + pi] = wall_clock64();
-                }
-                --left;
-                --xleft;
-            }
-        } else {
-            // ===== W(i,k) += sum_{r in [pj0, pj1)} X(r,i)^T X(r,k)  (W tile row i, column k; read by nobody in this launch) =====
-            double* Wt = Wm + (long)pi * NB * ld + (long)pk * NB;
-            d4 acc[4][4];
-            if (pj0 == pi) gt_zero<4>(acc);
-            else gt_load_buf<4>(Wt, ld, acc);
-            WGEMM(false, false, false, X + (long)pj0 * NB * ld + (long)pi * NB, ld, X + (long)pj0 * NB * ld + (long)pk * NB, ld,
-                                           (pj1 - pj0) * NB, acc, sm);
-            gt_store<0, 4>(Wt, ld, acc);
-            drain_stores();
-            __syncthreads();
-            const bool done = (pj1 == nt);
-            if (t == 0) s_prog[pick] = done ? -1 : pj1 - pi;
-            if (done) --left;
-        }
-        if (dbg2 && t == 0) busy[kind == TK_P ? 0 : (kind == TK_W ? 2 : 1)] += wall_clock64() - tk0;
-        __syncthreads();
-    }
-    if (dbg2 && t == 0 && 2 + nt + 4 * me + 3 < PS_DBG2_DOUBLES) {
-        long long* o = dbg2 + 2 + nt + 4 * me;
-        o[0] = busy[0];
-        o[1] = busy[1];
-        o[2] = busy[2];
-        o[3] = wall_clock64();
-    }
-}
-
 __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A, long ld, int nt,
                                                           double* __restrict__ dinv_all, double* __restrict__ logsum,
                                                           int* __restrict__ info, int* __restrict__ sync, int kcap,
-                                                          double* __restrict__ hs, long long* __restrict__ dbg, int test,
-                                                          double* __restrict__ X, double* __restrict__ Wm, int inv_mode, int tune,
-                                                          long long* __restrict__ dbg2) {
-    // inv_mode 0: the factorisation alone; 1: + X = L^-1 into X; 2: + W = X^T X (lower tiles) into Wm
+                                                          double* __restrict__ hs, long long* __restrict__ dbg, int test, int tune) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if (!ps_arrive(sync, info, test == 1 ? 1 : 0)) return;    // not all workgroups resident: called off, A untouched
     if (test == 2 && blockIdx.x == 0) {                       // fault injection: the chain gives up, the workers time out on it
@@ -1187,12 +813,9 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
     }
     if (blockIdx.x == 0) {
         chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, hs, dbg);
-        if (threadIdx.x == 0 && dbg2) dbg2[1 + nt] = wall_clock64();
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
-    } else if (inv_mode == 0) {
-        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, ps_neard(tune), sm);
     } else {
-        worker_workgroup_inv(A, X, Wm, ld, nt, dinv_all, sync, kcap, hs, inv_mode >= 2 ? 1 : 0, tune, dbg2, sm);
+        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, ps_neard(tune), sm);
     }
 }
 
@@ -1243,32 +866,6 @@ static int persist_max_grid(int cus) {
     return cached[dev] < cus ? cached[dev] : cus;
 }
 
-// host mirror of the folded launch's ownership: the longest task list any worker gets (P tiles + X tiles + W tiles)
-static int inv_max_tasks(int nt, int nw, int want_w, int D) {
-    int nnear = near_tiles_in_rows(nt, D), nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
-    int H = nw / 2 > 0 ? nw / 2 : 1;
-    if (H > nnear) H = nnear;
-    if (nfar == 0) H = nw < nnear ? nw : nnear;
-    std::vector<int> cnt((size_t)nw, 0);
-    for (int me = 0; me < nw; ++me) {
-        if (me < H) cnt[(size_t)me] = (nnear - me + H - 1) / H;
-        else {
-            const int m = me - H, W = nw - H;
-            cnt[(size_t)me] = m < nfar ? (nfar - m + W - 1) / W : 0;
-        }
-    }
-    for (int i = 0; i < nt; ++i)
-        for (int k = 0; k <= i; ++k) {
-            int span = near_tiles_in_rows(i + 1, D);
-            if (span > H) span = H;
-            cnt[(size_t)((i * (i + 1) / 2 + k) % span)] += 1;
-            if (want_w) cnt[(size_t)((i * (i + 1) / 2 + k) % nw)] += 1;
-        }
-    int mx = 0;
-    for (int c : cnt) mx = c > mx ? c : mx;
-    return mx;
-}
-
 // workgroups of the launch for this matrix; 0: the device cannot host the kernel (no large-LDS opt-in / occupancy query failed)
 static long persist_grid_for(long npad, FactorWs* ws) {
     const int nt = (int)(npad / NB);
@@ -1279,29 +876,18 @@ static long persist_grid_for(long npad, FactorWs* ws) {
     return grid;
 }
 
-// The folded launch (potrf + X = L^-1 [+ W = X^T X]) is possible for this matrix: the persistent schedule is, the option asks
-// for it (persist >= 2) and every worker's task list fits.
-bool pdinv_persist_eligible(long npad, FactorWs* ws, int want_w) {
-    if (ws->persist < 2 || !potrf_persist_eligible(npad, ws)) return false;
-    const long grid = persist_grid_for(npad, ws);
-    if (grid < 2) return false;
-    return inv_max_tasks((int)(npad / NB), (int)grid - 1, want_w, ps_neard(ws->persist_tune)) <= PS_MAXTASK;
-}
-
-bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg, double* X, double* W,
-                          long long* dbg2) {
+bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg) {
     const int nt = (int)(npad / NB);
     const long grid = persist_grid_for(npad, ws);
     if (grid < 2) return false;
-    const int inv_mode = X ? (W ? 2 : 1) : 0;
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
     (void)hipMemsetAsync(ws->persist_sync, 0, sizeof(int) * PS_SYNC_INTS, st);
     if (ws->ev_persist_pre) (void)hipEventRecord(ws->ev_persist_pre, st);   // "the progress words of THIS launch are zeroed"
     ws->persist_grid_last = (int)grid;
-    const double flops = (double)npad * npad * npad / 3.0 * (1 + inv_mode);
+    const double flops = (double)npad * npad * npad / 3.0;
     ws->prof.begin(st, PF_PERSIST, flops);
     hipLaunchKernelGGL(k_potrf_persist, dim3((unsigned)grid), dim3(64 * PS_CHAIN_WAVES), PS_LDS_BYTES, st, A, npad, nt, ws->dinv, ws->logsum,
-                       ws->info, ws->persist_sync, ws->persist_kcap, ws->persist_hs, dbg, ws->persist_test, X, W, inv_mode, ws->persist_tune, dbg2);
+                       ws->info, ws->persist_sync, ws->persist_kcap, ws->persist_hs, dbg, ws->persist_test, ws->persist_tune);
     ws->persist_test = 0;
     const bool ok = hipGetLastError() == hipSuccess;
     ws->prof.end(st);

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/mi355gp.h"
+#include "../../include/mi355gp_debug.h"
 #include "internal.h"
 
 #define GP_STRIDE 34
@@ -650,11 +651,9 @@ static int factor_launch(hipStream_t st, double* A, double* X, double* T, double
     // A -> L (in place), X = L^-1 (T: scratch of the launch-per-step inverse), W = X^T X if W != NULL.  X is used as a FULL
     // matrix by the GEMMs of the M x M phase: its strictly upper tiles are zeroed here (no schedule writes them).
     HIP_CHECK(hipMemsetAsync(X, 0, sizeof(double) * mp * mp, st));
-    if (!pdinv_device(st, A, X, W, mp, ws)) {
-        potrf_device(st, A, mp, ws);
-        trtri_device(st, A, X, T, mp, ws);
-        if (W) lauum_device(st, X, W, mp, ws);
-    }
+    potrf_device(st, A, mp, ws);
+    trtri_device(st, A, X, T, mp, ws);
+    if (W) lauum_device(st, X, W, mp, ws);
     return 0;
 }
 // the host side of the same: reads info[0] (one stream sync when the persistent schedule was taken) and redoes the factorisation

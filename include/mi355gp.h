@@ -211,10 +211,6 @@ enum { MI355GP_PF_UPDATE = 0 /* k_update_nt<4,true>: trailing update of potrf on
  * flops of those launches, launch count.  Arrays of MI355GP_PF_NUM. */
 int mi355gp_get_profile(mi355gp_ctx* ctx, double* ms, double* flops, int* launches);
 
-/* Device-only benchmark of the factorisation on a synthetic SPD matrix already resident in HBM:
- * returns average milliseconds of potrf / trtri / lauum over `reps` runs. */
-int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, double* ms_trtri, double* ms_lauum);
-
 /* ---- optional multi-GPU mode: 2D block-cyclic factorisation on a Pr x Pc process grid ---------------------------
  * (north_star config 4; no GPy counterpart -- GPy's only parallel code is the mpi4py sparse GP,
  *  inference/latent_function_inference/var_dtc_parallel.py).  One process per GPU; rank = pr*Pc + pc.
@@ -254,18 +250,6 @@ int mi355gp_grid_get_option(mi355gp_grid* g, int option, int* value);
  * process: the caller's own): out9 = [collectives on the world / row / column communicator, then per communicator an FNV-1a hash
  * over (operation, root, doubles) as (high 32 bits, low 32 bits)]. */
 int mi355gp_grid_coll_log(mi355gp_grid* g, int rank, double* out9);
-/* Self-test of the multi-PROCESS transport (csrc/ipc_comm.hip; MI355GP_TRANSPORT=ipc binds it in place of RCCL for ranks that
- * are processes sharing one GPU): communicator set-up as in mi355gp_grid_create, then broadcasts / all-reduces of `count` doubles
- * on the world, row and column communicators.  With MI355GP_IPC_HOST=1 every buffer is host memory (no HIP call): the protocol
- * is testable without a GPU.  out4 = [mismatching doubles, checksum, rank inside the row communicator, inside the column one].
- * id128: from mi355gp_grid_unique_id under MI355GP_TRANSPORT=ipc. */
-int mi355gp_dbg_ipc_selftest(const void* id128, int rank, int world, int Pr, int Pc, int64_t count, double* out4);
-/* diagnostics: the deep-K X^T X pass of the grid mode against the single-GPU lauum kernel */
-int mi355gp_dbg_grid_multi(int device, int T, int nb, int reps, double* out_ms4);
-/* diagnostics: the trailing-update kernel alone, lower triangle of nt x nt tiles, panel depths ks[0..nk) */
-int mi355gp_dbg_update_nt(int device, int nt, const int* ks, int nk, int reps, double* out_ms);
-int mi355gp_dbg_update_rect(int device, int ntr, int ntc, const int* ks, int nk, int reps, double* out_ms);
-
 /* ---- sparse GP (VarDTC) path: BASELINE config 5 -----------------------------------------------------------------
  * One SparseGP.parameters_changed (core/sparse_gp.py:76-119) for certain inputs and a homoscedastic Gaussian likelihood:
  * VarDTC.inference (inference/latent_function_inference/var_dtc.py:66-215, helpers :217-276) + the kernel and
@@ -322,45 +306,6 @@ int mi355gp_sparse_fetch(mi355gp_sparse* s, int which, double* out);
  * stream, recorded on every call): out6 = [T = Kfu dL_dpsi2 GEMM: summed ms, algorithmic flops (2 rows M^2), launches,
  * split-K Gram psi2: summed ms, algorithmic flops (rows M^2, lower half), launches]. */
 int mi355gp_sparse_get_profile(mi355gp_sparse* s, double* out6);
-
-/* ---- diagnostics (used by tests/ and tools/) --------------------------------------------------------- */
-/* raw lane dump of one v_mfma_f64_16x16x4_f64: a[64], b[64] -> d[64*4] */
-int mi355gp_dbg_mfma(int device, const double* a, const double* b, double* d);
-/* C (M x N) = alpha*op(A) op(B) + beta*C with the tiled MFMA kernel; M,N,K multiples of 128.
- * transa/transb: 0 = operand stored k-contiguous (A: M x K row-major, B: N x K row-major), 1 = stored K x M / K x N. */
-int mi355gp_dbg_gemm(int device, int a_mcontig, int b_ncontig, int64_t M, int64_t N, int64_t K,
-                     const double* A, const double* B, double* C, double alpha, double beta, int reps, double* ms);
-/* microbenchmarks, out8: [0] fp64 MFMA TFLOP/s (8 workgroups/CU), [1] fp64 VALU FMA TFLOP/s, [2] HBM copy GB/s,
- * [3] HBM fill GB/s, [4] shader cycles per v_mfma_f64_16x16x4 at one wave/SIMD, [5] effective shader MHz under the
- * full MFMA load, [6] MFMA TFLOP/s at one wave/SIMD, [7] shader cycles per MFMA per SIMD under the full load */
-int mi355gp_dbg_peaks(int device, double* out8);
-/* effective shader clock (MHz) and shader cycles of workgroup 0 of the last mi355gp_dbg_gemm launch */
-int mi355gp_dbg_gemm_clock(double* mhz, double* cycles);
-/* diagnostics: where do workgroups land?  out[2b] = HW_REG_HW_ID, out[2b+1] = HW_REG_XCC_ID of workgroup b of a launch of nwg
- * spinning workgroups, machine-wide (mask_bit < 0) or on a stream whose CU mask has the single bit mask_bit
- * (tools/cu_map.py: logical CU b is CU (b/8)/4 of shader engine (b/8)%4 of XCD b%8; an XCD WITHOUT a mask bit is unrestricted) */
-int mi355gp_dbg_cu_map(int device, int nwg, int mask_bit, unsigned* out);
-/* Diagnostic: do fp64 MFMA and fp64 VALU FMA share one issue pipe?  out4 = ms of the same launch shape with all workgroups
- * on the MFMA stream / all on the FMA stream / alternating, and the MFMA TF/s of the first. */
-int mi355gp_dbg_pipe_share(int device, double* out4);
-/* Diagnostic: build + potrf + trtri + lauum of a synthetic N x N problem launched kernel by kernel vs replayed from a hipGraph
- * captured from the same streams.  out3 = ms launched, ms replayed, graph nodes. */
-int mi355gp_dbg_graph_factor(int device, int64_t N, int reps, double* out3);
-/* Diagnostic: the persistent dataflow Cholesky (persist.hip) against the launch-per-step schedule on the same resident SPD
- * matrix.  out[0] ms per factorisation launch-per-step, [1] persistent, [2] doubles of the lower triangle of L that differ
- * bitwise between the two, [3] info, [4] abort word; out[8 + 8 j + q]: wall-clock stamps (100 MHz ticks) of chain step j
- * (q = 0 factor start, 1 factor end, 2 sub-diagonal tile seen, 3 solve end, 4 diagonal tile seen, 5 update end).
- * then for tile row i and d = i - k in 0..2 (the near tiles): out[8 + 8 nt + 4 (3 i + d) + q], q = 0 last task picked, 1 computed,
- * 2 published.  kcap: columns a worker applies per pass (0 = default).  out: 8 + 20 ceil(N / 128) doubles. */
-int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out);
-/* the FOLDED persistent launch (factorisation + inverse + X^T X as one tile dataflow) against the launch-per-step schedule on a
- * resident SPD matrix: out[0] / out[1] ms per repetition (steps / folded), out[2] / out[3] relative max differences of L^-1 and
- * of (lower) A^-1, out[4] info, out[5] tiles per dimension; out[8 .. 8 + 2048) the launch's timeline in 100 MHz ticks (start,
- * X(i,0) final per row, chain end, per worker the ticks spent in factorisation / inverse / X^T X tasks and its end).
- * tune: bit 0 near owners take X^T X tiles only after their inverse tiles, bit 1 two-stage worker GEMM. */
-int mi355gp_dbg_fold(int device, int64_t N, int reps, int tune, double* out);
-/* diagnostics: is a CU-masked stream really confined?  out3 = ms of a 4096^3 GEMM on [plain, masked, masked] streams */
-int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,5 @@
-"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/mi355gp.h declares.
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/mi355gp.h (the drop-in boundary) and
+include/mi355gp_debug.h (diagnostics for tests / tools) declare.
 No compute calls here (no GPU in this container); device entry points must fail loudly instead of falling back."""
 import os
 import re
@@ -10,8 +11,8 @@ from conftest import ROOT
 from gpy_amd import _lib
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "mi355gp.h")).read()
+def _declared_symbols(header="mi355gp.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mi355gp_[a-z_0-9A-Z]+)\s*\(", text)))
 
@@ -20,8 +21,10 @@ def test_library_builds_and_exports_every_declared_symbol():
     path = _lib.build()
     assert os.path.exists(path)
     lib = _lib.lib()
-    declared = _declared_symbols()
-    assert len(declared) >= 20
+    product, debug = _declared_symbols(), _declared_symbols("mi355gp_debug.h")
+    assert len(product) >= 20
+    assert not [s for s in product if s.startswith("mi355gp_dbg_")], "diagnostics belong in mi355gp_debug.h"
+    declared = product + debug
     for sym in declared:
         assert hasattr(lib, sym), "libmi355gp.so does not export %s" % sym
     assert set(_lib.EXPORTED) <= set(declared)

@@ -61,15 +61,6 @@ def test_persistent_dataflow_cholesky_is_bit_identical_to_the_launch_per_step_sc
     assert r["ms_persist"] < 2.0 * r["ms_steps"] + 0.05
 
 
-@pytest.mark.parametrize("N", [256, 640, 1024, 2500])
-def test_folded_persistent_launch_matches_the_launch_per_step_inverse(N):
-    """Option persist = 2 (opt-in): the same dataflow launch goes on to X = L^-1 by rows and W = X^T X by tiles.
-    Against trtri + lauum of the launch-per-step schedule on the same matrix: agreement to rounding (another summation
-    order), no call-off, no abort."""
-    r = L.dbg_fold(N, reps=1)
-    assert r["info"] == 0 and r["dX"] <= 1e-13 and r["dW"] <= 1e-13, r
-
-
 @pytest.mark.parametrize("N", [6400, 7300, 8192])
 def test_paired_far_updates_are_bit_identical_to_one_panel_per_pass(N):
     """Option "agg2": from N = 6144 the look-ahead schedule applies two adjacent panels to the far columns in ONE pass over C
@@ -97,9 +88,8 @@ def test_paired_far_updates_are_bit_identical_to_one_panel_per_pass(N):
 
 def test_persistent_cholesky_option_reports_non_pd_and_can_be_switched_off_per_context():
     """The product path takes the persistent launch below N = 4608 (`FACTOR_PERSIST_MAX_NT`): option "persist" = 1 (default)
-    runs the factorisation as one launch, 0 returns a context to the launch-per-step schedule, 2 (opt-in, measured slower)
-    folds the inverse and X^T X into the launch as well.  1 and 0 give the same bits; 2 agrees to rounding (another summation
-    order of L^-1 / Ky^-1) and is bit-reproducible from run to run; all report the same LAPACK-style info on a non-PD matrix."""
+    runs the factorisation as one launch, 0 returns a context to the launch-per-step schedule.  Both give the same bits and
+    report the same LAPACK-style info on a non-PD matrix."""
     X, Y = O.synthetic(1500, 3, seed=5)
     var, ls, noise = O.default_theta(3, False)
     th = L.theta_vec(var, ls, False, 3)
@@ -107,21 +97,13 @@ def test_persistent_cholesky_option_reports_non_pd_and_can_be_switched_off_per_c
     try:
         c.set_data(X, Y)
         assert c.get_option("persist") == 1
-        c.set_option("persist", 2)
-        info, rf = c.exact_inference("rbf", False, th, noise)
-        assert info == 0 and c.get_option("persist_aborts") == 0        # the folded launch ran to completion (no silent redo)
-        info, rf2 = c.exact_inference("rbf", False, th, noise)
-        assert (rf2["lml"], rf2["dtheta"].tobytes(), rf2["alpha"].tobytes()) == (rf["lml"], rf["dtheta"].tobytes(), rf["alpha"].tobytes())
         outs = []
         for p in (1, 0, 1):
             c.set_option("persist", p)
             info, r = c.exact_inference("rbf", False, th, noise)
             assert info == 0
             outs.append((r["lml"], r["dtheta"].tobytes(), r["alpha"].tobytes()))
-        assert outs[0] == outs[1] == outs[2]
-        assert abs(rf["lml"] - r["lml"]) <= 1e-12 * abs(r["lml"])
-        assert np.abs(rf["alpha"] - r["alpha"]).max() <= 1e-11 * np.abs(r["alpha"]).max()
-        assert np.abs(rf["dtheta"] - r["dtheta"]).max() <= 1e-10 * np.abs(r["dtheta"]).max()
+        assert outs[0] == outs[1] == outs[2] and c.get_option("persist_aborts") == 0
         # duplicated inputs, no noise, negative jitter: the Gram matrix is not positive definite -> same info either way
         Xd = np.vstack([X[:700], X[:700], X[:100]])
         c.set_data(Xd, Y)

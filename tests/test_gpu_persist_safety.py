@@ -27,8 +27,8 @@ def _key(r):
 
 
 def _close(r, r0):
-    """the folded persistent launch (default) and the launch-per-step schedule it falls back to sum L^-1 / Ky^-1 in different
-    orders: equal to rounding, not to the bit"""
+    """equal to rounding (the persistent launch and the launch-per-step schedule it falls back to give the same bits; the
+    looser check keeps the safety tests independent of that)"""
     return (abs(r["lml"] - r0["lml"]) <= 1e-12 * abs(r0["lml"]) and
             np.abs(r["alpha"] - r0["alpha"]).max() <= 1e-11 * np.abs(r0["alpha"]).max() and
             np.abs(r["dtheta"] - r0["dtheta"]).max() <= 1e-10 * np.abs(r0["dtheta"]).max())

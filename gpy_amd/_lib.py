@@ -120,6 +120,8 @@ def lib():
     L.mi355gp_set_option.argtypes = [vp, ci, ci]
     L.mi355gp_get_option.argtypes = [vp, ci, ctypes.POINTER(ci)]
     L.mi355gp_sparse_get_profile.argtypes = [vp, _dp]
+    L.mi355gp_dbg_comm_selftest.argtypes = [ci, ctypes.c_char_p, ci, ci, ci, ci, i64, ci, _dp]
+    L.mi355gp_dbg_comm_selftest.restype = ci
     L.mi355gp_bench_factor.argtypes = [ci, i64, ci, _c_dp, _c_dp, _c_dp]
     L.mi355gp_bench_factor.restype = ci
     L.mi355gp_get_profile.argtypes = [vp, _dp, _dp, ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]

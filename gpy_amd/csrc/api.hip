@@ -313,7 +313,7 @@ static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_gra
     // stage timing was asked for and launch bracketing is off; the first evaluation of a context runs plain (one-time
     // function attributes), the second captures, every later one replays.
     const bool structural = c->graph_enabled && !c->ws.prof.on && c->ws.lookahead == 1 && c->ws.persist_skip == 0 &&
-                            (!c->ws.tri_overlap || (int)(np / NB) < c->ws.tri_min_nt);
+                            (!c->ws.tri_overlap || (int)(np / NB) < c->ws.tri_min_nt) && persist_early_h(np, &c->ws) == 0;
     if (c->fgraph && !structural) drop_graph(c);
     const bool graphable = structural && !stage_ms;          // a call that wants the stage timings runs plain, the graph stays
     if (!graphable) {

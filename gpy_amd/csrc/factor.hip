@@ -146,6 +146,15 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     }
     const char* envp1 = getenv("MI355GP_PART1_ON_PANEL");
     if (envp1 && *envp1) ws->part1_on_panel = atoi(envp1) ? 1 : 0;
+    const char* envptri = getenv("MI355GP_PERSIST_TRI");
+    if (envptri && *envptri) ws->persist_tri = atoi(envptri) ? 1 : 0;
+    const char* envptn = getenv("MI355GP_PERSIST_TRI_MIN_NT");
+    if (envptn && *envptn) ws->persist_tri_min_nt = atoi(envptn);
+    const char* envuq = getenv("MI355GP_DBG_UPD_QUEUE");
+    if (envuq && *envuq && atoi(envuq)) {
+        ws->upd_queue_probe = 1;
+        HIP_CHECK(hipMalloc(&ws->upd_tasks, sizeof(UpdTask) * 64 + 64));
+    }
     const char* envag = getenv("MI355GP_AGG2");
     if (envag && *envag) ws->agg2 = atoi(envag) ? 1 : 0;
     const char* envnbo = getenv("MI355GP_NBO");
@@ -205,6 +214,8 @@ void factor_ws_free(FactorWs* ws) {
     ws->ev_tri_lead = nullptr;
     if (ws->tri_counter) (void)hipFree(ws->tri_counter);
     ws->tri_counter = nullptr;
+    if (ws->upd_tasks) (void)hipFree(ws->upd_tasks);
+    ws->upd_tasks = nullptr;
     if (ws->persist_sync) (void)hipFree(ws->persist_sync);
     ws->persist_sync = nullptr;
     if (ws->persist_hs) (void)hipFree(ws->persist_hs);
@@ -270,17 +281,74 @@ static void potrf_serial(hipStream_t st, double* A, long npad, FactorWs* ws) {
     }
 }
 
+// The part of X = L^-1 that only needs the leading h tile columns of L, on the side stream `sq` while the factorisation goes on:
+// the inverse of the leading h x h tiles, then pair 0 of level log2(h), T21 = L21 X11 (rows h .. 2h of the finished columns; the
+// tile list is shared with the machine-wide instance that trtri_device launches after potrf).  trtri_device picks up from
+// ws->ovl_h.  gated: the factorisation is the PERSISTENT launch -- there is no stream event inside it, so each of the two steps
+// is preceded by a one-thread kernel that waits on the launch's progress words (persist.hip).
+static void early_inverse(hipStream_t sq, double* A, long npad, int h, FactorWs* ws, bool gated) {
+    const int ntl = (int)(npad / NB);
+    (void)hipMemsetAsync(ws->tri_counter, 0, sizeof(int) * 4, sq);
+    if (gated) launch_wait_persist_rows(sq, ws, 0, h, 0);       // rows 0 .. h-1 of L and their inverted diagonal tiles are final
+    ws->prof.begin(sq, PF_TRTRI_EARLY, 0.0);                    // elapsed on the side stream; the flops are billed to PF_TRTRI
+    launch_inv128(sq, A, ws->scratchX, npad, h, ws->dinv);
+    int level = 0;
+    for (; (1 << level) < h; ++level) launch_trtri_level(sq, A, ws->scratchX, ws->scratchT, npad, h, level);
+    (void)hipEventRecord(ws->ev_tri_lead, sq);
+    const int nt_pair = ntl < 2 * h ? ntl : 2 * h;
+    if (gated) launch_wait_persist_rows(sq, ws, h, nt_pair, h); // columns 0 .. h-1 of rows h .. 2h-1 are final
+    launch_trtri_stage1_steal(sq, A, ws->scratchX, ws->scratchT, npad, nt_pair, level, ws->tri_counter,
+                              ws->tri_wgs > 0 ? ws->tri_wgs : 512 * ws->tri_cur_pct / 100);
+    ws->prof.end(sq);
+    (void)hipEventRecord(ws->ev_tri, sq);
+    ws->early_pending = 1;
+}
+
+// Leading tiles whose inverse (+ T21) goes on the side stream underneath the PERSISTENT launch: the largest power of two <= nt/2,
+// 0 = not this time.  (The hipGraph replay of the factorisation region is not used then -- api.hip asks here: measured at
+// N = 4096, replay + early inverse 3.73 ms per evaluation, replay alone 3.35, plain launches + early inverse 3.05.)
+int persist_early_h(long npad, const FactorWs* ws) {
+    const int ntl = (int)(npad / NB);
+    if (!potrf_persist_eligible(npad, ws) || !ws->tri_overlap || !ws->persist_tri || !ws->st_tri || !ws->scratchX || !ws->scratchT ||
+        ntl < ws->persist_tri_min_nt)
+        return 0;
+    int h = 1;
+    while (4 * h <= ntl) h *= 2;
+    return h;
+}
+
 // Two-level right-looking Cholesky with one panel of look-ahead (default).  Outer panels of NBO = 512 columns keep
 // the big trailing update at K = 512 (64 flop per byte of C traffic).  The update of outer step p is split into the
 // next panel's 512 columns (part 1) and the rest (part 2); panel p+1 is factored on a second, high-priority stream
 // while part 2 of step p still runs, so the latency-bound diag/trsm chain hides behind MFMA-bound work.  All
 // trailing updates stay in order on `st`: their launch durations are not inflated by overlapping each other.
 void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
+    if (ws->early_pending) {                                    // early-inverse work of a factorisation whose inverse was never taken
+        (void)hipStreamWaitEvent(st, ws->ev_tri, 0);            // (a called-off persistent launch that is being redone): it writes
+        ws->early_pending = 0;                                  // the scratch buffers this run is about to use
+    }
     ws->ovl_h = 0;
     ws->persist_used = 0;
     if (potrf_persist_eligible(npad, ws)) {                     // small factorisation: one persistent dataflow launch
-        if (launch_potrf_persist(st, A, npad, ws)) {
+        // Its near-tile owners leave as the chain passes their rows (three CUs per step), so the part of the inverse that
+        // needs only the leading half of L starts on the side stream as soon as that half is final: the leading h x h
+        // inverse and T21 = L21 X11 on the CUs the launch has given back, keyed on its progress words.
+        const int h = persist_early_h(npad, ws);
+        hipEvent_t pre_saved = ws->ev_persist_pre;
+        if (h > 0 && !ws->ev_persist_pre) ws->ev_persist_pre = ws->ev_fork;
+        const bool ok = launch_potrf_persist(st, A, npad, ws);
+        hipEvent_t pre = ws->ev_persist_pre;
+        ws->ev_persist_pre = pre_saved;
+        if (ok) {
             ws->persist_used = 1;
+            if (h > 0) {
+                hipStream_t sq = ws->st_tri;
+                ws->tri_cur_pct = ws->tri_cu_pct;
+                (void)hipStreamWaitEvent(sq, pre, 0);           // the progress words of THIS launch are zeroed
+                launch_wait_persist_resident(sq, ws, 50);       // nothing wide may reach the CUs before the launch is in place
+                early_inverse(sq, A, npad, h, ws, true);
+                ws->ovl_h = h;
+            }
             return;
         }
         ws->persist = 0;                                        // the launch cannot be made on this device: never try again
@@ -329,34 +397,39 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     }
     ws->ovl_h = 0;
     ws->excl_first_ok = (ovl_h == 0 && ntl < ws->tri_min_nt) ? 1 : 0;   // small factorisations only (measured: N >= 8192 loses)
+    const bool uq = ws->upd_queue_probe && ws->upd_tasks && ws->part1_on_panel && ntl >= ws->tri_min_nt && !ws->agg2 && P <= 64;
+    if (uq) {
+        // bounding experiment (wrong results by construction): all part-2 updates as ONE resident launch with every dependence
+        // ignored, on the main stream from the start; the panel stream runs chain + part 1 as always, minus its waits for part 2
+        std::vector<UpdTask> tasks;
+        for (long p = 0; p + 2 < P; ++p) {
+            const long c0 = pcol(p + 2), ntr = (npad - c0) / NB;
+            tasks.push_back(UpdTask{c0 * npad + c0, c0 * npad + pcol(p), ntr * (ntr + 1) / 2, (int)(pcol(p + 1) - pcol(p)), (int)ntr});
+        }
+        int* counter = reinterpret_cast<int*>(ws->upd_tasks + 64);
+        (void)hipMemcpyAsync(ws->upd_tasks, tasks.data(), sizeof(UpdTask) * tasks.size(), hipMemcpyHostToDevice, su);
+        (void)hipMemsetAsync(counter, 0, sizeof(int), su);
+        ws->prof.begin(su, PF_UPDATE, 0.0);
+        launch_update_nt_queue(su, A, npad, ws->upd_tasks, (int)tasks.size(), counter, 512);
+        ws->prof.end(su);
+    }
     for (long p = 0; p + 1 < P; ++p) {
         const long K0 = pcol(p), W = pcol(p + 1) - K0;
         (void)hipEventRecord(ws->ev_panel[p], sp);
         if (ovl_h > 0 && pcol(p + 1) == (long)ovl_h * NB) {       // columns < 128 h are final: start on their inverse
             hipStream_t sq = ws->st_tri_cur ? ws->st_tri_cur : ws->st_tri;
             (void)hipStreamWaitEvent(sq, ws->ev_panel[p], 0);
-            (void)hipMemsetAsync(ws->tri_counter, 0, sizeof(int) * 4, sq);
-            ws->prof.begin(sq, PF_TRTRI_EARLY, 0.0);            // elapsed on the side stream; the flops are billed to PF_TRTRI
-            launch_inv128(sq, A, ws->scratchX, npad, ovl_h, ws->dinv);
-            int level = 0;
-            for (; (1 << level) < ovl_h; ++level) launch_trtri_level(sq, A, ws->scratchX, ws->scratchT, npad, ovl_h, level);
-            (void)hipEventRecord(ws->ev_tri_lead, sq);
-            // pair 0 of level log2(h): T21 = L21 X11 (rows h .. 2h of the finished columns), tile list shared with the
-            // machine-wide instance that trtri_device launches after potrf
-            const int nt_pair = ntl < 2 * ovl_h ? ntl : 2 * ovl_h;
-            launch_trtri_stage1_steal(sq, A, ws->scratchX, ws->scratchT, npad, nt_pair, level, ws->tri_counter,
-                                      ws->tri_wgs > 0 ? ws->tri_wgs : 512 * ws->tri_cur_pct / 100);
-            ws->prof.end(sq);
-            (void)hipEventRecord(ws->ev_tri, sq);
+            early_inverse(sq, A, npad, ovl_h, ws, false);
             ws->ovl_h = ovl_h;
         }
         if (ws->part1_on_panel && ntl >= ws->tri_min_nt) {   // measured: N=16384 potrf 35.5 -> 33.3 ms (evaluation -0.9 %), N=4096 +1.4..3.5 %
             // part 1 (the next panel's columns) on the panel stream itself: chain(p) -> part 1 -> chain(p+1) then runs in one
             // stream's order, no cross-stream hand-off on the critical path of a chain-bound factorisation.  Its tiles were
             // last written by part 2 of step p-1 (main stream): that event is long signalled when the chain is the bottleneck.
-            if (p > 0) (void)hipStreamWaitEvent(sp, ws->ev_cols[p], 0);
+            if (p > 0 && !uq) (void)hipStreamWaitEvent(sp, ws->ev_cols[p], 0);
             update_cols(sp, A, npad, K0, W, pcol(p + 1), pcol(p + 2), ws);
             factor_panel(sp, A, npad, pcol(p + 1), pcol(p + 2) - pcol(p + 1), ws);
+            if (uq) continue;
             (void)hipStreamWaitEvent(su, ws->ev_panel[p], 0);
             if (!ws->agg2) {
                 update_cols(su, A, npad, K0, W, pcol(p + 2), npad, ws);      // part 2: everything to the right
@@ -406,6 +479,7 @@ void trtri_device(hipStream_t st, const double* L, double* X, double* T, long np
     ws->prof.begin(st, PF_TRTRI, (double)npad * npad * npad / 3.0);
     const int h = ws->ovl_h;
     ws->ovl_h = 0;
+    ws->early_pending = 0;                                      // every branch below joins the side stream (ev_tri) if h > 0
     if (h > 0 && X == ws->scratchX && T == ws->scratchT && h < nt) {
         int lev = 0;
         while ((1 << lev) < h) ++lev;

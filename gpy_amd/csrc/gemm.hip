@@ -111,6 +111,43 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
                        ntc, row0t, col0t, tri, nblocks);
 }
 
+// ---- bounding experiment for a persistent trailing updater (tools/upd_queue_probe.py) ------------------------------
+// ONE launch of 2 x CUs resident workgroups that drains the tile lists of ALL "part 2" updates of a factorisation from a single
+// atomic queue, as if every dependence were already satisfied: the same tile code as k_update_nt<4, true> on the same operands, so
+// the instruction stream and the memory traffic are those of the real updates, but no launch boundary, no ramp-up / drain per
+// launch and no wait for the panel chain.  The RESULT IS WRONG BY CONSTRUCTION (tiles are updated before their panels are final):
+// it measures what the launch boundaries cost in situ, i.e. an upper bound on what a dataflow updater with ready flags could gain.
+__global__ LB(4) void k_update_nt_queue(double* __restrict__ A, long ld, const UpdTask* __restrict__ tasks, int ntasks,
+                                        int* __restrict__ counter) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ long s_tile;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_tile = (long)atomicAdd(counter, 1);
+        __syncthreads();
+        long bid = s_tile;
+        int q = 0;
+        while (q < ntasks && bid >= tasks[q].ntiles) bid -= tasks[q++].ntiles;
+        if (q >= ntasks) return;
+        const UpdTask tk = tasks[q];
+        int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+        while ((long)ti * (ti + 1) / 2 > bid) --ti;
+        while ((long)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+        const int tj = (int)(bid - (long)ti * (ti + 1) / 2);
+        d4 acc[4][GTCfg<4>::NI];
+        double* Ct = A + tk.c_off + (long)ti * NB * ld + (long)tj * NB;
+        const double* P = A + tk.p_off;
+        gt_load_buf<4>(Ct, ld, acc);
+        gemm_tile_128<true, true, 4, true>(P + (long)ti * NB * ld, ld, P + (long)tj * NB * ld, ld, tk.K, acc, smem);
+        gt_store<0, 4>(Ct, ld, acc);
+    }
+}
+
+void launch_update_nt_queue(hipStream_t st, double* A, long ld, const UpdTask* tasks_dev, int ntasks, int* counter, int wgs) {
+    LDS_OPT_IN(k_update_nt_queue);
+    hipLaunchKernelGGL(k_update_nt_queue, dim3((unsigned)wgs), dim3(256), GT_LDS_BYTES, st, A, ld, tasks_dev, ntasks, counter);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Batched bottom-up triangular inverse (the dtrtri half of LAPACK dpotri, GPy/util/linalg.py:127-145).
 // Level s merges diagonal blocks of nbt = 2^s tiles pairwise:

@@ -588,6 +588,114 @@ static int grid_group_end(mi355gp_grid* g) {
     if (!g->loopback) NCCL_CHECK(g_rccl.GroupEnd());
     return 0;
 }
+// ---- self-test of the bound transport (RCCL, or the hipIpc stand-in under MI355GP_TRANSPORT=ipc) --------------------------------
+// Exactly the communicator set-up and the call patterns of the per-rank grid code, without the numerics: world communicator,
+// row / column communicators by CommSplit (colour = own grid row / column, key = the other coordinate), then
+//   (1) a world broadcast, (2) inside ONE group: `rounds` tile broadcasts on the row communicator with rotating roots (the
+//   pattern of crit(k) step (i)), (3) the same on the column communicator (steps (d) / (f)), (4) a world all-reduce in place,
+//   (5) a row-communicator all-reduce -- all on one non-default stream, every payload checked element by element.
+// out4 = [mismatching doubles, checksum, rank inside the row communicator, rank inside the column communicator].
+// This is the first thing to run on a node with more than one GPU (tools/rccl_first_light.sh): it separates "RCCL does not do
+// what grid.hip assumes" (split numbering, several roots in one group, out-of-place broadcast on the root) from everything else.
+extern "C" int mi355gp_dbg_comm_selftest(int device, const void* id128, int rank, int world, int Pr, int Pc, int64_t count,
+                                         int rounds, double* out4) {
+    if (!id128 || !out4 || world != Pr * Pc || count <= 0 || rounds < 1 || rank < 0 || rank >= world) {
+        mi355gp_set_error("mi355gp_dbg_comm_selftest: invalid argument");
+        return -1;
+    }
+    if (!g_rccl.load()) return -2;
+    HIP_CHECK(hipSetDevice(device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t cw = nullptr, crow = nullptr, ccol = nullptr;
+    NCCL_CHECK(g_rccl.CommInitRank(&cw, world, id, rank));
+    const int pr = rank / Pc, pc = rank % Pc;
+    NCCL_CHECK(g_rccl.CommSplit(cw, pr, pc, &crow, nullptr));
+    NCCL_CHECK(g_rccl.CommSplit(cw, pc, pr, &ccol, nullptr));
+    hipStream_t st;
+    HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const size_t n = (size_t)count, total = n * (size_t)(rounds + 1);
+    double *dsend = nullptr, *drecv = nullptr;
+    HIP_CHECK(hipMalloc(&dsend, sizeof(double) * total));
+    HIP_CHECK(hipMalloc(&drecv, sizeof(double) * total));
+    std::vector<double> hs(total), hr(total);
+    double bad = 0.0, sum = 0.0;
+    auto val = [](double tag, size_t i) { return tag + 1e-3 * (double)(i % 1000); };
+    auto fill = [&](int slot, double tag) {
+        for (size_t i = 0; i < n; ++i) hs[(size_t)slot * n + i] = val(tag, i);
+    };
+    auto upload = [&]() -> int {
+        HIP_CHECK(hipMemcpyAsync(dsend, hs.data(), sizeof(double) * total, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemsetAsync(drecv, 0, sizeof(double) * total, st));
+        return 0;
+    };
+    auto download = [&]() -> int {
+        HIP_CHECK(hipMemcpyAsync(hr.data(), drecv, sizeof(double) * total, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        return 0;
+    };
+    auto expect = [&](int slot, double tag) {
+        for (size_t i = 0; i < n; ++i) {
+            const double got = hr[(size_t)slot * n + i];
+            if (got != val(tag, i)) bad += 1.0;
+            sum += got;
+        }
+    };
+    // (1) world broadcast from the last rank, out of place everywhere (the root included, as grid_bcast does it)
+    fill(0, 100.0 + rank);
+    if (int rc = upload()) return rc;
+    NCCL_CHECK(g_rccl.Broadcast(dsend, drecv, n, ncclFloat64, world - 1, cw, st));
+    if (int rc = download()) return rc;
+    expect(0, 100.0 + (world - 1));
+    // (2) / (3): one GROUP of `rounds` broadcasts with rotating roots on the row, then on the column communicator
+    for (int which = 0; which < 2; ++which) {
+        const int size = which == 0 ? Pc : Pr, me = which == 0 ? pc : pr, line = which == 0 ? pr : pc;
+        const ncclComm_t comm = which == 0 ? crow : ccol;
+        for (int q = 0; q < rounds; ++q) fill(q, 1000.0 * (which + 1) + 10.0 * line + me + 0.25 * q);
+        if (int rc = upload()) return rc;
+        NCCL_CHECK(g_rccl.GroupStart());
+        for (int q = 0; q < rounds; ++q)
+            NCCL_CHECK(g_rccl.Broadcast(dsend + (size_t)q * n, drecv + (size_t)q * n, n, ncclFloat64, q % size, comm, st));
+        NCCL_CHECK(g_rccl.GroupEnd());
+        if (int rc = download()) return rc;
+        for (int q = 0; q < rounds; ++q) expect(q, 1000.0 * (which + 1) + 10.0 * line + (q % size) + 0.25 * q);
+    }
+    // (4) world all-reduce in place: sum over ranks of (rank + pattern)
+    fill(0, (double)rank);
+    if (int rc = upload()) return rc;
+    NCCL_CHECK(g_rccl.AllReduce(dsend, dsend, n, ncclFloat64, ncclSum, cw, st));
+    HIP_CHECK(hipMemcpyAsync(hr.data(), dsend, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; ++i) {
+        double want = 0.0;
+        for (int r = 0; r < world; ++r) want += val((double)r, i);          // rank order = the order the loopback transport sums in
+        if (fabs(hr[i] - want) > 1e-9 * fabs(want) + 1e-12) bad += 1.0;
+        sum += hr[i];
+    }
+    // (5) row all-reduce out of place
+    fill(0, 10.0 * rank);
+    if (int rc = upload()) return rc;
+    NCCL_CHECK(g_rccl.AllReduce(dsend, drecv, n, ncclFloat64, ncclSum, crow, st));
+    if (int rc = download()) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        double want = 0.0;
+        for (int c = 0; c < Pc; ++c) want += val(10.0 * (pr * Pc + c), i);
+        if (fabs(hr[i] - want) > 1e-9 * fabs(want) + 1e-12) bad += 1.0;
+        sum += hr[i];
+    }
+    out4[0] = bad;
+    out4[1] = sum;
+    out4[2] = (double)pc;                                          // key of the row split = grid column: must be the rank inside crow
+    out4[3] = (double)pr;
+    (void)hipFree(dsend);
+    (void)hipFree(drecv);
+    (void)hipStreamDestroy(st);
+    NCCL_CHECK(g_rccl.CommDestroy(crow));
+    NCCL_CHECK(g_rccl.CommDestroy(ccol));
+    NCCL_CHECK(g_rccl.CommDestroy(cw));
+    return 0;
+}
+
 // sum `count` doubles at `pick(rank)` over all ranks, result everywhere
 static int grid_allreduce(mi355gp_grid* g, size_t count, const std::function<double*(GridRank&)>& pick) {
     for (GridRank& r : g->ranks) coll_log(r, 0, 2, 0, count);

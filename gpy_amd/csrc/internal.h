@@ -8,6 +8,10 @@
 // ---- gemm.hip : tiled fp64 MFMA GEMM family (all dimensions multiples of 128) -------------------
 // C[ti,tj] -= A[ti,:] * B[tj,:]^T over a (ntr x ntc)-tile region; tiles with (col0t+tj) > (row0t+ti) skipped.
 bool update_nt_uses_64(int ntr, int ntc, int row0t, int col0t);   // which kernel (and profile family) a launch of this shape takes
+// one "part 2" update of the blocked Cholesky as a task of the bounding experiment k_update_nt_queue: the lower triangle of
+// ntr x ntr tiles at A + c_off, panel P at A + p_off (K columns), ntiles = ntr (ntr + 1) / 2
+struct UpdTask { long c_off, p_off, ntiles; int K, ntr; };
+void launch_update_nt_queue(hipStream_t st, double* A, long ld, const UpdTask* tasks_dev, int ntasks, int* counter, int wgs);
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
                       int K, int ntr, int ntc, int row0t, int col0t);
 // one bottom-up level of the batched triangular inverse: X21 = -X22 * (L21 * X11) for every block pair
@@ -71,6 +75,12 @@ struct FactorWs {
     std::vector<hipEvent_t> ev_cols;         // [p]: every update of panel p's columns has been issued (-> its factorisation)
     hipEvent_t ev_fork = nullptr;
     int agg2 = 0;               // MI355GP_AGG2: part 2 of the look-ahead schedule in pairs of panels (K = 2 nbo far updates; N >= 6144); measured: no gain
+    int early_pending = 0;      // early-inverse kernels are in flight on the side stream and nobody has joined them yet (ev_tri)
+    int persist_tri = 1;        // MI355GP_PERSIST_TRI: leading-block inverse + T21 on the side stream UNDERNEATH the persistent launch
+    int persist_tri_min_nt = 16;    // ... for factorisations of at least this many tiles (MI355GP_PERSIST_TRI_MIN_NT)
+    int upd_queue_probe = 0;    // MI355GP_DBG_UPD_QUEUE=1 (diagnostic, WRONG RESULTS): every part-2 update of the look-ahead schedule from ONE
+                                // resident launch with all dependences ignored -- the bounding experiment of DESIGN.md 6f
+    UpdTask* upd_tasks = nullptr;   // device copy of the task list (64 entries) + the queue counter behind it
     int part1_on_panel = 1;     // MI355GP_PART1_ON_PANEL: part 1 of a step on the panel stream (no cross-stream hop before the next chain)
     int lookahead = 1;          // 1: panel p+1 factored on st_panel while the big update of step p runs; 0: serial reference schedule
     // outer panel width of the two-level right-looking Cholesky: NBO (512) keeps the big trailing update at 64 flop per
@@ -165,7 +175,11 @@ int potrf_persist_sync_ints();
 // false: the launch could not be made (no large-LDS opt-in on this device, launch error): nothing was enqueued that writes A
 bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg = nullptr);
 // on `st`: wait (<= 2 ms) until the persistent launch announced by ws->ev_persist_pre has all its workgroups resident
-void launch_wait_persist_resident(hipStream_t st, const FactorWs* ws);
+void launch_wait_persist_resident(hipStream_t st, const FactorWs* ws, int timeout_ms = 2);
+int persist_early_h(long npad, const FactorWs* ws);
+// on `st`: one thread that returns once rows r0 .. r1-1 of L are final in their first `cols` tile columns (cols = 0: the whole
+// row up to and including the diagonal block and its inverted diagonal tiles), the launch was called off / aborted, or 20 ms passed
+void launch_wait_persist_rows(hipStream_t st, const FactorWs* ws, int r0, int r1, int cols);
 
 // ---- kern.hip : covariance assembly, reductions, solves, fetch helpers ----------------------------
 struct KernParams {

@@ -872,6 +872,10 @@ static long persist_grid_for(long npad, FactorWs* ws) {
     const long ntl = (long)nt * (nt + 1) / 2;
     long grid = persist_max_grid(ws->persist_cus);             // one workgroup per CU: all resident
     if (grid < 16) return 0;
+    // One CU stays out of the launch: a workgroup asks for ALL of a CU's registers (8 waves x 256), so a single wave of anything
+    // else that reaches a CU first -- the one-thread gate kernels of the early inverse on the side stream, a neighbour's memset
+    // kernel -- would keep one workgroup from ever becoming resident and the whole launch would be called off at its gate.
+    if (grid > 32) grid -= 1;
     if (grid > ntl + 1) grid = ntl + 1;
     return grid;
 }
@@ -895,18 +899,37 @@ bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, lo
 }
 
 // One thread that returns once the persistent launch whose progress words follow ws->ev_persist_pre has ALL its workgroups
-// resident (arrival word complete), was called off, or 2 ms have passed.  Put on ANOTHER stream in front of wide kernels that
+// resident (arrival word complete), was called off, or timeout_ms have passed.  Put on ANOTHER stream in front of wide kernels that
 // are meant to run underneath the persistent launch (sparse.hip: pass 1 underneath Kmm's factorisation), it keeps them from
 // taking the CUs' LDS before the 155 KB workgroups are in place.
-__global__ void k_wait_persist_resident(const int* __restrict__ sync, int n) {
+__global__ void k_wait_persist_resident(const int* __restrict__ sync, int n, int timeout_ms) {
     const long long t0 = wall_clock64();
     for (;;) {
         const int v = ld_flag(sync + PS_ARRIVE);
         if ((v & PS_ARRIVE_ABORT) || (v & ~PS_ARRIVE_ABORT) >= n) return;
-        if (wall_clock64() - t0 > 2 * PS_ARRIVE_TICKS) return;
+        if (wall_clock64() - t0 > timeout_ms * PS_ARRIVE_TICKS) return;
         __builtin_amdgcn_s_sleep(4);
     }
 }
-void launch_wait_persist_resident(hipStream_t st, const FactorWs* ws) {
-    hipLaunchKernelGGL(k_wait_persist_resident, dim3(1), dim3(1), 0, st, ws->persist_sync, ws->persist_grid_last);
+// One thread that returns once the rows r0 .. r1-1 of L are final as far as a consumer on another stream needs them: cols > 0:
+// their first `cols` tile columns (cnt[i] >= cols); cols = 0: whole rows including the diagonal block, i.e. cnt[i] >= i and
+// dcnt >= r1 (L_ii and its inverted 16 x 16 tiles).  Everything the launch publishes is written through before its progress word
+// is, and the consumer kernels start behind this kernel's end (a kernel boundary: their caches are invalidated), so they read
+// the final values.  Gives up when the launch was called off / aborted (the host redoes the evaluation anyway) or after 20 ms.
+__global__ void k_wait_persist_rows(const int* __restrict__ sync, int r0, int r1, int cols) {
+    const long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = cols > 0 || ld_flag(sync + PS_DCNT) >= r1;
+        for (int i = r0; ok && i < r1; ++i) ok = ld_flag(sync + PS_CNT + i) >= (cols > 0 ? cols : i);
+        if (ok) return;
+        if ((ld_flag(sync + PS_ARRIVE) & PS_ARRIVE_ABORT) || ld_flag(sync + PS_ABORT) != 0) return;
+        if (wall_clock64() - t0 > 20 * PS_ARRIVE_TICKS) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+void launch_wait_persist_rows(hipStream_t st, const FactorWs* ws, int r0, int r1, int cols) {
+    hipLaunchKernelGGL(k_wait_persist_rows, dim3(1), dim3(1), 0, st, ws->persist_sync, r0, r1, cols);
+}
+void launch_wait_persist_resident(hipStream_t st, const FactorWs* ws, int timeout_ms) {
+    hipLaunchKernelGGL(k_wait_persist_resident, dim3(1), dim3(1), 0, st, ws->persist_sync, ws->persist_grid_last, timeout_ms);
 }

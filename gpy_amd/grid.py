@@ -191,6 +191,28 @@ def exchange_id_file(id_bytes, rank, path, timeout=120.0, world=None, nonce=None
     raise _lib.MI355GPError("timed out waiting for the RCCL id at %s" % path)
 
 
+def comm_selftest(Pr, Pc, count=1 << 16, rounds=6, device=None, id_dir=None):
+    """This rank's part of `mi355gp_dbg_comm_selftest` (the transport's CommInitRank / CommSplit / grouped multi-root
+    broadcasts / all-reduces with checked payloads; RANK / WORLD_SIZE / LOCAL_RANK from the launcher, the id through the file
+    channel).  Returns (mismatches, checksum, rank inside the row communicator, rank inside the column communicator)."""
+    import numpy as np
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == Pr * Pc
+    local = int(os.environ.get("LOCAL_RANK", str(rank))) if device is None else int(device)
+    if device is None and os.environ.get("MI355GP_TRANSPORT") == "ipc":
+        local %= max(1, _lib.device_count())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    idb = unique_id() if rank == 0 else b"\0" * ID_BYTES
+    if world > 1:
+        d = id_dir or os.environ.get("MI355GP_ID_DIR") or "/tmp"
+        idb = exchange_id_file(idb, rank, os.path.join(d, "mi355gp_selftest_id_%dx%d" % (Pr, Pc)), world=world)
+    out = np.zeros(4)
+    check(_lib.lib().mi355gp_dbg_comm_selftest(local, idb, rank, world, Pr, Pc, int(count), int(rounds), out),
+          "mi355gp_dbg_comm_selftest")
+    return int(out[0]), float(out[1]), int(out[2]), int(out[3])
+
+
 def unique_id():
     buf = ctypes.create_string_buffer(ID_BYTES)
     check(_lib.lib().mi355gp_grid_unique_id(buf), "mi355gp_grid_unique_id")

@@ -18,6 +18,13 @@ int mi355gp_bench_factor(int device, int64_t N, int reps, double* ms_potrf, doub
  * is testable without a GPU.  out4 = [mismatching doubles, checksum, rank inside the row communicator, inside the column one].
  * id128: from mi355gp_grid_unique_id under MI355GP_TRANSPORT=ipc. */
 int mi355gp_dbg_ipc_selftest(const void* id128, int rank, int world, int Pr, int Pc, int64_t count, double* out4);
+/* Self-test of the BOUND transport -- RCCL, or the hipIpc stand-in under MI355GP_TRANSPORT=ipc -- through the function table the
+ * grid mode calls: CommInitRank, two CommSplits (row / column), one world broadcast, `rounds` broadcasts with rotating roots
+ * inside ONE GroupStart / GroupEnd on the row and on the column communicator (the pattern of grid.hip's crit(k)), a world and a
+ * row all-reduce, on a non-default stream, every payload checked.  out4 = [mismatching doubles, checksum, grid column, grid row].
+ * The first step of tools/rccl_first_light.sh on a node with more than one GPU. */
+int mi355gp_dbg_comm_selftest(int device, const void* id128, int rank, int world, int Pr, int Pc, int64_t count, int rounds,
+                              double* out4);
 /* diagnostics: the deep-K X^T X pass of the grid mode against the single-GPU lauum kernel */
 int mi355gp_dbg_grid_multi(int device, int T, int nb, int reps, double* out_ms4);
 /* diagnostics: the trailing-update kernel alone, lower triangle of nt x nt tiles, panel depths ks[0..nk) */

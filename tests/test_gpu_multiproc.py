@@ -107,6 +107,37 @@ def test_one_process_per_rank_matches_the_single_process_loopback_bit_for_bit(Pr
         assert {k: (v[0], int(v[1])) for k, v in rec["log"].items()} == logs[r], (r, rec["log"], logs[r])
 
 
+_SELFTEST = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+from gpy_amd import grid as G
+bad, checksum, rrow, rcol = G.comm_selftest(%(Pr)d, %(Pc)d, count=%(count)d, rounds=%(rounds)d)
+rank = int(os.environ["RANK"])
+assert (rrow, rcol) == (rank %% %(Pc)d, rank // %(Pc)d), (rank, rrow, rcol)
+print("RESULT " + json.dumps(dict(bad=bad, checksum=checksum)))
+"""
+
+
+@pytest.mark.parametrize("Pr,Pc", [(1, 2), (2, 2), (2, 4)])
+def test_transport_selftest_grouped_multi_root_broadcasts(Pr, Pc, tmp_path):
+    """`mi355gp_dbg_comm_selftest` drives the BOUND transport through the function table the grid mode uses: communicator splits,
+    several broadcasts with different roots inside one group, all-reduces, payloads checked.  Here over the hipIpc stand-in, one
+    process per rank on one GPU; on a node with more GPUs `tools/rccl_first_light.sh` runs the same call over RCCL."""
+    world = Pr * Pc
+    script = tmp_path / "selftest.py"
+    script.write_text(_SELFTEST % dict(root=ROOT, Pr=Pr, Pc=Pc, count=70000, rounds=7))
+    env = dict(os.environ, WORLD_SIZE=str(world), LOCAL_RANK="0", MI355GP_TRANSPORT="ipc", MI355GP_ID_DIR=str(tmp_path),
+               MI355GP_JOB_NONCE="s%d" % os.getpid(), MI355GP_IPC_TIMEOUT_S="240", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    for r, p in enumerate(procs):
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, se[-3000:])
+        rec = json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:])
+        assert rec["bad"] == 0, (r, rec)
+
+
 def test_row_sharded_sparse_path_with_one_process_per_rank(tmp_path):
     """Three processes, rows sharded 3 ways, the two all-reduces of the reference's MPI design over the hipIpc transport: every
     rank returns the unsharded result (oracle) and all ranks the same bits."""

@@ -99,14 +99,19 @@ class Comm(object):
             self.dist.destroy_process_group()
 
 
-def timed_region(comm, step_fn, steps, warmup):
-    """W untimed steps, then exactly K steps bracketed by barrier + device sync; returns MAX-over-ranks seconds."""
+def timed_region(comm, step_fn, steps, warmup, per_step=None):
+    """W untimed steps, then exactly K steps bracketed by barrier + device sync; returns MAX-over-ranks seconds.
+    per_step (a list): this rank's host time of every timed step in ms (each step ends with a stream synchronize inside the
+    C-ABI call) -- for runs of a handful of steps, where a slow first step is visible in the mean."""
     for _ in range(warmup):
         step_fn()
     comm.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
+        t1 = time.perf_counter()
         step_fn()              # each step ends with a stream synchronize inside the C-ABI call
+        if per_step is not None:
+            per_step.append(round(1e3 * (time.perf_counter() - t1), 3))
     comm.barrier()
     dt = time.perf_counter() - t0
     return comm.max_over_ranks(dt)
@@ -329,7 +334,7 @@ def run_child(argv, timeout, env=None, single=True):
     return rec
 
 
-C2_KEEP = ("ms_per_step", "value", "unit", "steps", "warmup", "config", "stage_ms", "iteration_tflops",
+C2_KEEP = ("ms_per_step", "step_ms", "value", "unit", "steps", "warmup", "config", "stage_ms", "iteration_tflops", "stage_sum_frac_of_fp64_peak",
            "iteration_frac_of_fp64_peak", "cholesky_gflops", "cholesky_frac_of_fp64_peak", "roofline", "roofline_k_lauum",
            "families", "parity_checked", "parity", "cpu_baseline", "host_path", "lml", "leg_wall_s", "error")
 
@@ -346,7 +351,7 @@ def c4_single_leg(comm, args):
     """BASELINE configs[3]'s problem (RBF iso, N=32768, D=8) on the DEDICATED single-GPU path: the N = 1 anchor of the
     strong-scaling series north_star asks for (N in {4k, 16k, 32k} at 1/2/4/8 GPUs), next to `grid` (the same problem on the
     block-cyclic code).  26 GB resident; parity against the N=32768 golden."""
-    rec = run_child(["--n", str(args.grid_n), "--d", "8", "--kind", "rbf", "--iso", "--steps", "4", "--warmup", "1", "--no-legs",
+    rec = run_child(["--n", str(args.grid_n), "--d", "8", "--kind", "rbf", "--iso", "--steps", "4", "--warmup", "2", "--no-legs",
                      "--device", str(comm.local_rank), "--no-cpu-baseline"], timeout=420.0)
     return {k: rec[k] for k in C2_KEEP if k in rec}
 
@@ -446,8 +451,8 @@ def compact_line(out):
     if isinstance(line.get("families"), dict):               # name -> [summed launch ms, launches, TFLOP/s]
         line["families"] = {k: [round(v["ms"], 3), v["launches"], round(v["tflops"], 2)] for k, v in out["families"].items()}
     for leg in legs:
-        if isinstance(out.get(leg), dict):
-            line[leg] = _slim(out[leg], LINE_DROP + LEG_DROP)
+        if isinstance(out.get(leg), dict):                    # LEG_DROP at the top level of a leg only (its cpu_baseline keeps `value`)
+            line[leg] = _slim({k: v for k, v in out[leg].items() if k not in LEG_DROP}, LINE_DROP + ("sample", "sample_N", "unit"))
     line["legs_ms"] = {leg: (round(out[leg]["ms_per_step"], 4) if isinstance(out.get(leg), dict) and "ms_per_step" in out[leg]
                              else (out.get(leg) or {}).get("error", None) and "error") for leg in legs if leg in out}
     return json.dumps(line, separators=(",", ":"))
@@ -524,7 +529,8 @@ def main():
         assert info == 0
         last["r"] = r
 
-    dt = timed_region(comm, step_abi if args.abi_only else step_model, args.steps, args.warmup)
+    per_step = [] if args.steps <= 8 else None
+    dt = timed_region(comm, step_abi if args.abi_only else step_model, args.steps, args.warmup, per_step)
     n_gpus = comm.world
     its = n_gpus * args.steps / dt
     out = None
@@ -603,6 +609,8 @@ def main():
             "families": families,
             "lml": lml,
         }
+        if per_step:
+            out["step_ms"] = per_step
         if not args.abi_only:
             # host overhead of the drop-in classes: the same evaluation through the bare C-ABI, same context, same data
             k2 = max(3, min(args.steps, 10))

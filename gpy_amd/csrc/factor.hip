@@ -110,6 +110,23 @@ int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t
                 e.tri_half = nullptr;
             }
         }
+        // Hardware queues are allocated on a stream's FIRST submission, not when it is created: a process whose first small
+        // evaluation uses main + tri (persistent launch + early inverse) and only later panel would hand the queues to the
+        // command processor's pipes in another order than one that starts with a large evaluation (main, panel, tri) -- measured
+        // as +0.5 ms per evaluation at N = 16384 behind a parity-gate run at N = 2048.  One tiny submission per stream, in
+        // creation order, pins the order for the life of the process.
+        {
+            void* touch = nullptr;
+            if (hipMalloc(&touch, 256) == hipSuccess) {
+                hipStream_t order[4] = {e.main, e.panel, e.tri, e.tri_half};
+                for (hipStream_t s : order)
+                    if (s) {
+                        (void)hipMemsetAsync(touch, 0, 256, s);
+                        (void)hipStreamSynchronize(s);
+                    }
+                (void)hipFree(touch);
+            }
+        }
         e.ready = true;
     }
     if (main) *main = e.main;

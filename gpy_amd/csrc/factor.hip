@@ -163,6 +163,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     }
     const char* envp1 = getenv("MI355GP_PART1_ON_PANEL");
     if (envp1 && *envp1) ws->part1_on_panel = atoi(envp1) ? 1 : 0;
+    const char* envls = getenv("MI355GP_LAUUM_SPLIT");
+    if (envls && *envls) ws->lauum_split = atoi(envls) ? 1 : 0;
     const char* envptri = getenv("MI355GP_PERSIST_TRI");
     if (envptri && *envptri) ws->persist_tri = atoi(envptri) ? 1 : 0;
     const char* envptn = getenv("MI355GP_PERSIST_TRI_MIN_NT");
@@ -233,6 +235,11 @@ void factor_ws_free(FactorWs* ws) {
     ws->tri_counter = nullptr;
     if (ws->upd_tasks) (void)hipFree(ws->upd_tasks);
     ws->upd_tasks = nullptr;
+    if (ws->lauum_plan_dev) (void)hipFree(ws->lauum_plan_dev);
+    ws->lauum_plan_dev = nullptr;
+    if (ws->lauum_part) (void)hipFree(ws->lauum_part);
+    ws->lauum_part = nullptr;
+    ws->lauum_plan_nt = 0;
     if (ws->persist_sync) (void)hipFree(ws->persist_sync);
     ws->persist_sync = nullptr;
     if (ws->persist_hs) (void)hipFree(ws->persist_hs);
@@ -326,8 +333,10 @@ static void early_inverse(hipStream_t sq, double* A, long npad, int h, FactorWs*
 // N = 4096, replay + early inverse 3.73 ms per evaluation, replay alone 3.35, plain launches + early inverse 3.05.)
 int persist_early_h(long npad, const FactorWs* ws) {
     const int ntl = (int)(npad / NB);
+    // (not in a workspace's FIRST evaluation: with the one-time set-up of a dozen kernels in between, the side stream's launches
+    //  reached the GPU spread out enough that the persistent launch was called off at its gate once per context)
     if (!potrf_persist_eligible(npad, ws) || !ws->tri_overlap || !ws->persist_tri || !ws->st_tri || !ws->scratchX || !ws->scratchT ||
-        ntl < ws->persist_tri_min_nt)
+        ntl < ws->persist_tri_min_nt || ws->evals_done < 1)
         return 0;
     int h = 1;
     while (4 * h <= ntl) h *= 2;
@@ -496,6 +505,7 @@ void trtri_device(hipStream_t st, const double* L, double* X, double* T, long np
     ws->prof.begin(st, PF_TRTRI, (double)npad * npad * npad / 3.0);
     const int h = ws->ovl_h;
     ws->ovl_h = 0;
+    ws->evals_done += 1;
     ws->early_pending = 0;                                      // every branch below joins the side stream (ev_tri) if h > 0
     if (h > 0 && X == ws->scratchX && T == ws->scratchT && h < nt) {
         int lev = 0;
@@ -526,7 +536,40 @@ void trtri_device(hipStream_t st, const double* L, double* X, double* T, long np
 }
 
 void lauum_device(hipStream_t st, const double* X, double* W, long npad, FactorWs* ws) {
+    const int nt = (int)(npad / NB);
     ws->prof.begin(st, PF_LAUUM, (double)npad * npad * npad / 3.0);
-    launch_lauum(st, X, W, npad, (int)(npad / NB));
+    // small matrix, long k ranges: the split work list (gemm.hip); the plan is made once per size and lives on the device
+    bool split = ws->lauum_split && lauum_uses_64(nt) && (long)nt * NB > 1024;
+    if (split && ws->lauum_plan_nt != nt) {
+        std::vector<LauumItem> items;
+        std::vector<LauumSum> sums;
+        int nparts = 0;
+        lauum_split_plan(nt, items, sums, &nparts);
+        if (ws->lauum_plan_dev) (void)hipFree(ws->lauum_plan_dev);
+        if (ws->lauum_part) (void)hipFree(ws->lauum_part);
+        ws->lauum_plan_dev = nullptr;
+        ws->lauum_part = nullptr;
+        ws->lauum_plan_nt = 0;
+        const size_t bi = sizeof(LauumItem) * items.size(), bs = sizeof(LauumSum) * sums.size();
+        if (hipMalloc(&ws->lauum_plan_dev, bi + bs + 16) == hipSuccess &&
+            hipMalloc(&ws->lauum_part, sizeof(double) * (size_t)lauum_split_tile(nt) * lauum_split_tile(nt) * (size_t)(nparts + 1)) ==
+                hipSuccess) {
+            // (pageable copies: done before they return; the plan is made once per size)
+            (void)hipMemcpy(ws->lauum_plan_dev, items.data(), bi, hipMemcpyHostToDevice);
+            if (bs) (void)hipMemcpy((char*)ws->lauum_plan_dev + bi, sums.data(), bs, hipMemcpyHostToDevice);
+            ws->lauum_plan_nt = nt;
+            ws->lauum_nitems = (int)items.size();
+            ws->lauum_nsums = (int)sums.size();
+        } else {
+            (void)hipGetLastError();
+            split = false;
+        }
+    }
+    if (split && ws->lauum_plan_nt == nt)
+        launch_lauum_split(st, X, W, npad, nt, (const LauumItem*)ws->lauum_plan_dev, ws->lauum_nitems,
+                           (const LauumSum*)((const char*)ws->lauum_plan_dev + sizeof(LauumItem) * ws->lauum_nitems), ws->lauum_nsums,
+                           ws->lauum_part);
+    else
+        launch_lauum(st, X, W, npad, nt);
     ws->prof.end(st);
 }

@@ -14,7 +14,9 @@
         }                                                                                               \
     } while (0)
 
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
@@ -318,10 +320,107 @@ __global__ __launch_bounds__(256) void k_lauum64(const double* __restrict__ X, d
     gt64_store<0>(W + r0 * ld + c0, ld, acc);
 }
 
+// The same on a work list with the long k ranges CUT (small matrices: nt <= 32).  W(k,l) sums over the tile rows i >= k, so the
+// tiles of the first block columns carry K ~ N while most carry a fraction of it: one quadrant of tile (0,0) at N = 4096 is 3.4e7
+// flops, 0.44 ms at the quarter of a CU it gets while four workgroups share the CU -- alone more than the whole product needs at
+// the machine's rate (0.29 ms).  Every quadrant's k range is cut into chunks of at most LAUUM_KC rows; a quadrant with ONE chunk
+// stores W directly, the others store partial products that k_lauum64_reduce adds up in chunk order (fixed order: run-to-run
+// bit-reproducible; no atomics).  Items are issued longest first.
+#define LAUUM_KC 1024
+#define LAUUM_T128_MIN_NT 24
+__global__ __launch_bounds__(256) void k_lauum64_items(const double* __restrict__ X, double* __restrict__ W, long ld,
+                                                       const LauumItem* __restrict__ items, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LauumItem it = items[blockIdx.x];
+    d4 acc[2][2];
+    gt64_zero(acc);
+    const long r0 = (long)it.ti * NB + (it.q >> 1) * 64, c0 = (long)it.tj * NB + (it.q & 1) * 64;
+    gemm_tile_64_v3<false, false>(X + (long)it.k0 * ld + r0, ld, X + (long)it.k0 * ld + c0, ld, it.klen, acc, smem);
+    if (it.part < 0) gt64_store<0>(W + r0 * ld + c0, ld, acc);
+    else gt64_store<0>(part + (long)it.part * 4096, 64, acc);
+}
+
+// From N ~ 3000 on the chunks are long enough for the 128 x 128 tile (half the operand traffic per flop of the 64 x 64 one): the
+// same list with whole tiles as items (q = -1), partials of 128 x 128.
+__global__ LB(4) void k_lauum128_items(const double* __restrict__ X, double* __restrict__ W, long ld,
+                                       const LauumItem* __restrict__ items, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LauumItem it = items[blockIdx.x];
+    d4 acc[4][GTCfg<4>::NI];
+    gt_zero<4>(acc);
+    const long r0 = (long)it.ti * NB, c0 = (long)it.tj * NB;
+    gemm_tile_128<false, false, 4>(X + (long)it.k0 * ld + r0, ld, X + (long)it.k0 * ld + c0, ld, it.klen, acc, smem);
+    if (it.part < 0) gt_store<0, 4>(W + r0 * ld + c0, ld, acc);
+    else gt_store<0, 4>(part + (long)it.part * (NB * NB), NB, acc);
+}
+
+__global__ __launch_bounds__(256) void k_lauum128_reduce(double* __restrict__ W, long ld, const LauumSum* __restrict__ sums,
+                                                         const double* __restrict__ part) {
+    const LauumSum sm = sums[blockIdx.x];
+    const long r0 = (long)sm.ti * NB, c0 = (long)sm.tj * NB;
+    for (int e = threadIdx.x; e < NB * NB / 2; e += 256) {
+        const int i = e >> 6, j = 2 * (e & 63);
+        d2 s = *reinterpret_cast<const d2*>(part + (long)sm.first * (NB * NB) + i * NB + j);
+        for (int c = 1; c < sm.n; ++c) s += *reinterpret_cast<const d2*>(part + (long)(sm.first + c) * (NB * NB) + i * NB + j);
+        *reinterpret_cast<d2*>(W + (r0 + i) * ld + c0 + j) = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lauum64_reduce(double* __restrict__ W, long ld, const LauumSum* __restrict__ sums,
+                                                        const double* __restrict__ part) {
+    const LauumSum sm = sums[blockIdx.x];
+    const long r0 = (long)sm.ti * NB + (sm.q >> 1) * 64, c0 = (long)sm.tj * NB + (sm.q & 1) * 64;
+    for (int e = threadIdx.x; e < 2048; e += 256) {           // two doubles per element index
+        const int i = e >> 5, j = 2 * (e & 31);
+        d2 s = *reinterpret_cast<const d2*>(part + (long)sm.first * 4096 + i * 64 + j);
+        for (int c = 1; c < sm.n; ++c) s += *reinterpret_cast<const d2*>(part + (long)(sm.first + c) * 4096 + i * 64 + j);
+        *reinterpret_cast<d2*>(W + (r0 + i) * ld + c0 + j) = s;
+    }
+}
+
+// work list of the split lauum for nt x nt tiles (host side, cached by the caller): items longest first
+int lauum_split_tile(int nt) { return nt >= LAUUM_T128_MIN_NT ? 128 : 64; }
+
+void lauum_split_plan(int nt, std::vector<LauumItem>& items, std::vector<LauumSum>& sums, int* nparts) {
+    items.clear();
+    sums.clear();
+    int np = 0;
+    const int nq = lauum_split_tile(nt) == 128 ? 1 : 4;       // whole tiles (q = -1 in spirit: q is ignored) or quadrants
+    for (int ti = 0; ti < nt; ++ti)
+        for (int tj = 0; tj <= ti; ++tj)
+            for (int q = 0; q < nq; ++q) {
+                const int k0 = ti * NB, K = (nt - ti) * NB, nch = (K + LAUUM_KC - 1) / LAUUM_KC;
+                if (nch > 1) sums.push_back(LauumSum{ti, tj, q, np, nch});
+                for (int c = 0; c < nch; ++c) {
+                    const int len = (c + 1 < nch) ? LAUUM_KC : K - c * LAUUM_KC;
+                    items.push_back(LauumItem{ti, tj, q, k0 + c * LAUUM_KC, len, nch > 1 ? np++ : -1});
+                }
+            }
+    std::stable_sort(items.begin(), items.end(), [](const LauumItem& a, const LauumItem& b) { return a.klen > b.klen; });
+    *nparts = np;
+}
+
+void launch_lauum_split(hipStream_t st, const double* X, double* W, long ld, int nt, const LauumItem* items_dev, int nitems,
+                        const LauumSum* sums_dev, int nsums, double* part) {
+    if (lauum_split_tile(nt) == 128) {
+        LDS_OPT_IN(k_lauum128_items);
+        hipLaunchKernelGGL(k_lauum128_items, dim3((unsigned)nitems), dim3(256), GT_LDS_BYTES, st, X, W, ld, items_dev, part);
+        if (nsums > 0) hipLaunchKernelGGL(k_lauum128_reduce, dim3((unsigned)nsums), dim3(256), 0, st, W, ld, sums_dev, part);
+        return;
+    }
+    hipLaunchKernelGGL(k_lauum64_items, dim3((unsigned)nitems), dim3(256), GT64_LDS_BYTES, st, X, W, ld, items_dev, part);
+    if (nsums > 0) hipLaunchKernelGGL(k_lauum64_reduce, dim3((unsigned)nsums), dim3(256), 0, st, W, ld, sums_dev, part);
+}
+
 template <int NW>
 static void launch_lauum_t(hipStream_t st, long nblocks, const double* X, double* W, long ld, int nt) {
     LDS_OPT_IN((k_lauum<NW>));
     hipLaunchKernelGGL((k_lauum<NW>), dim3((unsigned)nblocks), dim3(NW * 64), GT_LDS_BYTES, st, X, W, ld, nt);
+}
+
+bool lauum_uses_64(int nt) {
+    static const int lauum64_max = env_int("MI355GP_LAUUM64_MAX", GEMM_DEFAULT_LAUUM64_MAX);
+    return (long)nt * (nt + 1) / 2 <= lauum64_max;
 }
 
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt) {

@@ -19,6 +19,14 @@ void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, l
                         int stages = 3);
 // W (lower tiles) = X^T X for lower-triangular X
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt);
+// X^T X of a SMALL matrix with the long k ranges cut into chunks (gemm.hip, "k_lauum64_items"): one quadrant chunk per item
+struct LauumItem { int ti, tj, q, k0, klen, part; };       // part: index of the 64 x 64 partial it stores, -1: stores W itself
+struct LauumSum { int ti, tj, q, first, n; };              // W quadrant = sum of partials first .. first + n - 1
+void lauum_split_plan(int nt, std::vector<LauumItem>& items, std::vector<LauumSum>& sums, int* nparts);
+int lauum_split_tile(int nt);                               // edge of the items' output tile: 64 (quadrants) or 128
+void launch_lauum_split(hipStream_t st, const double* X, double* W, long ld, int nt, const LauumItem* items_dev, int nitems,
+                        const LauumSum* sums_dev, int nsums, double* part);
+bool lauum_uses_64(int nt);
 void launch_trmm_lower(hipStream_t st, const double* X, long ldx, const double* B, long ldb, double* Out, long ldo,
                        int ntr, int ntc);
 // Out = X^T B (X lower triangular npad x npad, B npad x mpad)
@@ -75,7 +83,12 @@ struct FactorWs {
     std::vector<hipEvent_t> ev_cols;         // [p]: every update of panel p's columns has been issued (-> its factorisation)
     hipEvent_t ev_fork = nullptr;
     int agg2 = 0;               // MI355GP_AGG2: part 2 of the look-ahead schedule in pairs of panels (K = 2 nbo far updates; N >= 6144); measured: no gain
+    int evals_done = 0;         // inverses taken through this workspace (the early inverse under the persistent launch starts with the second)
     int early_pending = 0;      // early-inverse kernels are in flight on the side stream and nobody has joined them yet (ev_tri)
+    // split lauum of a small matrix (lauum_device): the plan of the last nt it was made for, on the device
+    int lauum_split = 1, lauum_plan_nt = 0, lauum_nitems = 0, lauum_nsums = 0;     // MI355GP_LAUUM_SPLIT=0 switches it off
+    void* lauum_plan_dev = nullptr;  // [items | sums | partials]
+    double* lauum_part = nullptr;
     int persist_tri = 1;        // MI355GP_PERSIST_TRI: leading-block inverse + T21 on the side stream UNDERNEATH the persistent launch
     int persist_tri_min_nt = 16;    // ... for factorisations of at least this many tiles (MI355GP_PERSIST_TRI_MIN_NT)
     int upd_queue_probe = 0;    // MI355GP_DBG_UPD_QUEUE=1 (diagnostic, WRONG RESULTS): every part-2 update of the look-ahead schedule from ONE

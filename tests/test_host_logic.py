@@ -304,3 +304,51 @@ def test_device_state_uploads_again_after_an_unsampled_in_place_edit():
     st.invalidate()
     st.ensure_data(Xf, Yf)
     assert st.ctx.log[-1][0] == "data"
+
+
+def test_generated_potf2_header_is_what_the_generator_emits():
+    import os
+    """gpy_amd/csrc/potf2_asm.h is GENERATED (tools/gen_potf2.py: the hand-scheduled 16 x 16 Cholesky + inverse of the chain
+    kernels, with the DPP / transcendental wait states inserted by the generator's hazard tracker): the committed header must be
+    the generator's current output, and no DPP read may follow the VALU write of its source by fewer than two wait states."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_potf2.py")], capture_output=True, text=True, check=True).stdout
+    assert out == open(os.path.join(root, "gpy_amd", "csrc", "potf2_asm.h")).read()
+    lines = [ln.strip().strip('"').replace("\\n\\t", "") for ln in out.splitlines() if ln.strip().startswith('"')]
+    last_write = {}
+    slot = 0
+    for ln in lines:
+        m = re.match(r"(\S+)\s+(.*)", ln)
+        op, args = m.group(1), m.group(2)
+        if op == "s_nop":
+            slot += int(args) + 1
+            continue
+        regs = re.findall(r"%\d+|v\[\d+:\d+\]", args)
+        if "row_newbcast" in ln:
+            src = regs[1]                                      # operand read through the DPP
+            assert slot - last_write.get(src, -10) >= 3, ln
+        if op.startswith("v_") and regs:
+            last_write[regs[0]] = slot
+        slot += 1
+
+
+def test_bench_line_stays_under_the_drivers_tail():
+    import os
+    """bench.compact_line: the one JSON line keeps every leg and stays under 6 KB (the driver keeps an 8 KB tail of stdout)."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    full = json.load(open(os.path.join(root, "profiles", "r4b_bench.json")))
+    line = bench.compact_line(full)
+    rec = json.loads(line)
+    assert len(line) < 6144
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "c2", "grid", "c5", "c4_single", "legs_ms"):
+        assert k in rec, k
+    assert list(rec)[-1] == "legs_ms" and set(rec["legs_ms"]) == {"c2", "grid", "c5", "c4_single"}
+    assert rec["cpu_baseline"]["value"] > 0 and rec["c2"]["cpu_baseline"]["value"] > 0

@@ -475,6 +475,13 @@ struct GridRank {
     hipStream_t sw = nullptr;        // W = X^T X updates
 };
 
+// loopback transport: destinations of one broadcast / the broadcasts of one group (kernel arguments of k_bcast_copy / k_bcast_batch)
+#define BCAST_MAX_DST 8
+#define BCAST_BATCH 24
+struct BcastDst { double* p[BCAST_MAX_DST]; };
+struct BcastItem { const double* src; double* dst[BCAST_MAX_DST]; int nd; };
+struct BcastBatch { BcastItem it[BCAST_BATCH]; };
+
 struct mi355gp_grid {
     int device = 0, world = 1, Pr = 1, Pc = 1, my_rank = 0;
     long nb = 512;
@@ -498,6 +505,11 @@ struct mi355gp_grid {
     // degenerate to the single-GPU path"): deep-K trtri / lauum tiles instead of three K = nb read-modify-write updates per
     // step (N=32768: 527 vs 623 ms).  MI355GP_GRID_FORCE_GENERIC=1 keeps the generic one-pass code (tests).
     mi355gp_ctx* single = nullptr;
+    // loopback transport: the broadcasts of an open group, launched together at its end
+    bool batching = false;
+    size_t batch_count = 0;
+    hipStream_t batch_stream = nullptr;
+    std::vector<BcastItem> batch;
 };
 
 // process defaults of the schedule options: environment, else built-in
@@ -548,8 +560,6 @@ static void free_rank(GridRank& r) {
 // receive pointer may differ from its send pointer: out-of-place on the root, like ncclBroadcast).
 enum { GROUP_ROW = 0, GROUP_COL = 1 };
 // loopback transport: a broadcast is a device copy from the root's buffer into every other member's
-#define BCAST_MAX_DST 8
-struct BcastDst { double* p[BCAST_MAX_DST]; };
 __global__ __launch_bounds__(256) void k_bcast_copy(const double* __restrict__ src, BcastDst dst, int nd, long count) {
     const long n2 = count >> 1;                               // tiles and panels are 16-byte aligned and even-sized
     const d2* s2 = reinterpret_cast<const d2*>(src);
@@ -560,6 +570,30 @@ __global__ __launch_bounds__(256) void k_bcast_copy(const double* __restrict__ s
     if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0)
         for (int q = 0; q < nd; ++q) dst.p[q][count - 1] = src[count - 1];
 }
+// a GROUP of loopback broadcasts (grid_group_start .. grid_group_end: the per-tile broadcasts of crit(k), up to k + 1 of them
+// with different roots) as ONE launch per 24 of them instead of one per broadcast: blockIdx.y picks the broadcast
+__global__ __launch_bounds__(256) void k_bcast_batch(BcastBatch b, long count) {
+    const BcastItem& it = b.it[blockIdx.y];
+    const long n2 = count >> 1;
+    const d2* s2 = reinterpret_cast<const d2*>(it.src);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+        const d2 v = s2[i];
+        for (int q = 0; q < it.nd; ++q) reinterpret_cast<d2*>(it.dst[q])[i] = v;
+    }
+    if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        for (int q = 0; q < it.nd; ++q) it.dst[q][count - 1] = it.src[count - 1];
+}
+// nt tiles of nb x nb, contiguous at src, into the row block dst (row stride ldd): tile t at columns t * nb ..  (one launch
+// instead of one 2-D copy per tile: 7,000 of them per evaluation at N = 32768 on a 2 x 4 grid)
+__global__ __launch_bounds__(256) void k_tiles_to_rowblock(double* __restrict__ dst, long ldd, const double* __restrict__ src, int nb) {
+    const double* s = src + (long)blockIdx.y * nb * nb;
+    double* d = dst + (long)blockIdx.y * nb;
+    const int half = nb >> 1;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)nb * half; e += (long)gridDim.x * blockDim.x) {
+        const long i = e / half, j = 2 * (e - i * half);
+        *reinterpret_cast<d2*>(d + i * ldd + j) = *reinterpret_cast<const d2*>(s + i * nb + j);
+    }
+}
 static void launch_bcast_copy(hipStream_t st, const double* src, const BcastDst& dst, int nd, size_t count) {
     long blocks = (long)((count / 2 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -568,6 +602,23 @@ static void launch_bcast_copy(hipStream_t st, const double* src, const BcastDst&
 }
 typedef std::function<double*(GridRank&, bool)> BufFn;
 
+// loopback transport: launch the broadcasts collected since grid_group_start
+static int grid_flush_bcasts(mi355gp_grid* g) {
+    const size_t n = g->batch.size();
+    for (size_t i0 = 0; i0 < n; i0 += BCAST_BATCH) {
+        BcastBatch b;
+        const int m = (int)((n - i0 < BCAST_BATCH) ? n - i0 : BCAST_BATCH);
+        for (int q = 0; q < m; ++q) b.it[q] = g->batch[i0 + (size_t)q];
+        long blocks = (long)((g->batch_count / 2 + 255) / 256);
+        if (blocks > 256) blocks = 256;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_bcast_batch, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, g->batch_stream, b, (long)g->batch_count);
+    }
+    g->batch.clear();
+    g->batch_count = 0;
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
 static int grid_bcast(mi355gp_grid* g, int group, int index, int root_coord, size_t count, const BufFn& buf) {
     if (count == 0) return 0;
     hipStream_t lst = g->lookahead ? g->sc : g->st;            // every panel broadcast travels on the communication stream
@@ -579,21 +630,35 @@ static int grid_bcast(mi355gp_grid* g, int group, int index, int root_coord, siz
             if (in && coord == root_coord) root = &r;
         }
         const double* src = buf(*root, true);
-        BcastDst dsts;                                        // every member's copy in ONE launch (one blit per member cost the
-        int nd = 0;                                           // loopback run ~13,000 copy launches per evaluation at N = 32768)
+        if (g->batching && (g->batch_count != count || g->batch_stream != lst)) {
+            if (int rc = grid_flush_bcasts(g)) return rc;      // (a group of equal-sized tiles in practice: one flush at its end)
+        }
+        BcastItem item;                                       // every member's copy in ONE launch (one blit per member cost the
+        item.src = src;                                       // loopback run ~13,000 copy launches per evaluation at N = 32768)
+        item.nd = 0;
+        auto emit = [&]() {
+            if (item.nd == 0) return;
+            if (g->batching) {
+                g->batch_count = count;
+                g->batch_stream = lst;
+                g->batch.push_back(item);
+            } else {
+                BcastDst dsts;
+                for (int q = 0; q < item.nd; ++q) dsts.p[q] = item.dst[q];
+                launch_bcast_copy(lst, src, dsts, item.nd, count);
+            }
+            item.nd = 0;
+        };
         for (GridRank& r : g->ranks) {
             const bool in = (group == GROUP_ROW) ? (r.pr == index) : (r.pc == index);
             if (!in) continue;
             coll_log(r, group == GROUP_ROW ? 1 : 2, 1, root_coord, count);
             double* dst = buf(r, false);
             if (dst == src) continue;
-            if (nd == BCAST_MAX_DST) {
-                launch_bcast_copy(lst, src, dsts, nd, count);
-                nd = 0;
-            }
-            dsts.p[nd++] = dst;
+            if (item.nd == BCAST_MAX_DST) emit();
+            item.dst[item.nd++] = dst;
         }
-        if (nd > 0) launch_bcast_copy(lst, src, dsts, nd, count);
+        emit();
         return 0;
     }
     GridRank& r = g->ranks[0];
@@ -609,11 +674,16 @@ static int grid_bcast(mi355gp_grid* g, int group, int index, int root_coord, siz
 }
 static int grid_group_start(mi355gp_grid* g) {
     if (!g->loopback) NCCL_CHECK(g_rccl.GroupStart());
+    else g->batching = true;
     return 0;
 }
 static int grid_group_end(mi355gp_grid* g) {
-    if (!g->loopback) NCCL_CHECK(g_rccl.GroupEnd());
-    return 0;
+    if (!g->loopback) {
+        NCCL_CHECK(g_rccl.GroupEnd());
+        return 0;
+    }
+    g->batching = false;
+    return grid_flush_bcasts(g);
 }
 // ---- self-test of the bound transport (RCCL, or the hipIpc stand-in under MI355GP_TRANSPORT=ipc) --------------------------------
 // Exactly the communicator set-up and the call patterns of the per-rank grid code, without the numerics: world communicator,
@@ -1195,10 +1265,9 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
             if (r.pc == opc) HIP_CHECK(hipMemcpyAsync(r.hXR[k] + (long)lcB * tile, r.Dv, sizeof(double) * tile,
                                                       hipMemcpyDeviceToDevice, s));
             const int lc0 = cnt_le(k, r.pc, Pc);
-            for (int lj = 0; lj < lc0; ++lj)                           // final X row block back into the local matrix
-                HIP_CHECK(hipMemcpy2DAsync(r.X + lkr * nb * r.LC + (long)lj * nb, sizeof(double) * r.LC,
-                                           r.hXR[k] + (long)lj * tile, sizeof(double) * nb, sizeof(double) * nb, nb,
-                                           hipMemcpyDeviceToDevice, s));
+            if (lc0 > 0)                                                // final X row block back into the local matrix
+                hipLaunchKernelGGL(k_tiles_to_rowblock, dim3(64, (unsigned)lc0), dim3(256), 0, s, r.X + lkr * nb * r.LC, (long)r.LC,
+                                   (const double*)r.hXR[k], (int)nb);
         }
         // (h) X row panel down every process column
         for (int pc = 0; pc < Pc; ++pc) {

@@ -2,11 +2,14 @@
 # Same-box A/B of the headline configuration (C3: Matern-5/2 ARD N=16384 D=32, drop-in classes, the driver's --steps 20 --warmup 5):
 # the final trees of rounds 3 and 4 (git archive into .ab/r3, .ab/r4, built there) against the working tree, alternating, three
 # times each.  VERDICT r4 weak 3 / next 4(f): did round 4 lose ~1 ms outside the stage timers?
+#   tools/c3_ab.sh [abi]     abi: the bare C-ABI without the parity gate (--abi-only --no-parity-gate) instead of the driver's command
+# Build the old trees first (here, not on the GPU box):  for t in r3:<commit> r4:<commit>; do git archive ... | tar -x -C .ab/r3; make -C .ab/r3/gpy_amd/csrc; done
 export TMPDIR=/tmp
+EXTRA=""; [ "${1:-}" = abi ] && EXTRA="--abi-only --no-parity-gate"
 for rep in 1 2 3; do
 for t in r3 r4 HEAD; do
     d=.ab/$t; [ $t = HEAD ] && d=.
-    ( cd $d && timeout 200 python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline 2>/dev/null ) | python -c "
+    ( cd $d && timeout 200 python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline $EXTRA 2>/dev/null ) | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$t run $rep: ms_per_step %.3f  stage total %.3f  potrf %.2f trtri %.2f lauum %.2f grad %.2f  host_path %s' % (d['ms_per_step'], d['stage_ms']['total'], d['stage_ms']['potrf'], d['stage_ms']['trtri'], d['stage_ms']['lauum'], d['stage_ms']['grad'], {k: round(v, 3) for k, v in (d.get('host_path') or {}).items() if isinstance(v, float)}))"

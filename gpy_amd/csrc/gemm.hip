@@ -156,20 +156,51 @@ void launch_update_nt_queue(hipStream_t st, double* A, long ld, const UpdTask* t
 //   [X11 0; X21 X22] with X21 = -X22 * L21 * X11.
 // stage 1: T21 = L21 * X11   (X11 lower triangular -> k from tj to the end of the left block)
 // stage 2: X21 = -X22 * T21  (X22 lower triangular -> k from the start of the right block to ti)
+// Tiles of one level: pair p joins the diagonal blocks [2 p nbt, (2p+1) nbt) and [(2p+1) nbt, (2p+2) nbt); its X21 has nbt x nbt
+// tiles -- except the LAST pair of a matrix whose tile count is not a multiple of 2 nbt, whose right block has only
+// rows_last = nt - right0 rows (possibly none).  Only LIVE tiles are enumerated: a grid padded to nbt x nbt per pair hands most
+// of its workgroups an early exit (N = 4608, top level: 7 of 8), and since workgroups go to the XCDs round-robin by index the
+// live ones then land unevenly (the dead-workgroup effect of section 6 of DESIGN.md: trtri 1.82 -> 0.9 ms at N = 4608).
+__host__ __device__ __forceinline__ int trtri_rows_last(int nt, int nbt) {
+    const int pairs = (nt + 2 * nbt - 1) / (2 * nbt), right0 = (2 * (pairs - 1) + 1) * nbt;
+    const int rows = nt - right0;
+    return rows < 0 ? 0 : (rows > nbt ? nbt : rows);
+}
+__host__ __device__ __forceinline__ long trtri_level_tiles(int nt, int nbt) {
+    const int pairs = (nt + 2 * nbt - 1) / (2 * nbt);
+    return (long)(pairs - 1) * nbt * nbt + (long)nbt * trtri_rows_last(nt, nbt);
+}
+template <int STAGE>
+__device__ __forceinline__ void trtri_map(int bid, int nt, int nbt, int& p, int& ri, int& cj) {
+    const int per = nbt * nbt, pairs = (nt + 2 * nbt - 1) / (2 * nbt), full = (pairs - 1) * per;
+    if (bid < full) {
+        p = bid / per;
+        const int rem = bid - p * per;
+        if (STAGE == 1) {          // heavy tiles (small cj) first
+            cj = rem / nbt;
+            ri = rem - cj * nbt;
+        } else {                   // heavy tiles (large ri) first
+            ri = nbt - 1 - rem / nbt;
+            cj = rem % nbt;
+        }
+    } else {
+        p = pairs - 1;
+        const int rem = bid - full, rows = trtri_rows_last(nt, nbt);
+        if (STAGE == 1) {
+            cj = rem / rows;
+            ri = rem - cj * rows;
+        } else {
+            ri = rows - 1 - rem / nbt;
+            cj = rem % nbt;
+        }
+    }
+}
+
 template <int STAGE, int NW>
 __device__ __forceinline__ void trtri_stage_tile(int bid, const double* __restrict__ L, double* __restrict__ X,
                                                  double* __restrict__ T, long ld, int nt, int nbt, double* smem) {
-    const int per = nbt * nbt;
-    const int p = bid / per;
-    const int rem = bid - p * per;
-    int ri, cj;
-    if (STAGE == 1) {          // heavy tiles (small cj) first
-        cj = rem / nbt;
-        ri = rem - cj * nbt;
-    } else {                   // heavy tiles (large ri) first
-        ri = nbt - 1 - rem / nbt;
-        cj = rem % nbt;
-    }
+    int p, ri, cj;
+    trtri_map<STAGE>(bid, nt, nbt, p, ri, cj);
     const int left0 = 2 * p * nbt, right0 = left0 + nbt;
     const int ti = right0 + ri, tj = left0 + cj;
     if (ti >= nt) return;
@@ -194,17 +225,8 @@ __global__ __launch_bounds__(256) void k_trtri_stage64(const double* __restrict_
                                                        double* __restrict__ T, long ld, int nt, int nbt) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int bid = blockIdx.x >> 2, qi = (blockIdx.x >> 1) & 1, qj = blockIdx.x & 1;
-    const int per = nbt * nbt;
-    const int p = bid / per;
-    const int rem = bid - p * per;
-    int ri, cj;
-    if (STAGE == 1) {
-        cj = rem / nbt;
-        ri = rem - cj * nbt;
-    } else {
-        ri = nbt - 1 - rem / nbt;
-        cj = rem % nbt;
-    }
+    int p, ri, cj;
+    trtri_map<STAGE>(bid, nt, nbt, p, ri, cj);
     const int left0 = 2 * p * nbt, right0 = left0 + nbt;
     const int ti = right0 + ri, tj = left0 + cj;
     if (ti >= nt) return;
@@ -251,8 +273,8 @@ void launch_trtri_stage1_steal(hipStream_t st, const double* L, double* X, doubl
                                int* counter, int grid) {
     const int nbt = 1 << level;
     if (nbt >= nt) return;
-    const int pairs = (nt + 2 * nbt - 1) / (2 * nbt);
-    const int nblocks = pairs * nbt * nbt;
+    const int nblocks = (int)trtri_level_tiles(nt, nbt);
+    if (nblocks <= 0) return;
     LDS_OPT_IN(k_trtri_stage1_steal);
     if (grid > nblocks) grid = nblocks;
     hipLaunchKernelGGL(k_trtri_stage1_steal, dim3((unsigned)grid), dim3(256), GT_LDS_BYTES, st, L, X, T, ld, nt, nbt,
@@ -274,8 +296,8 @@ static void launch_trtri_level_t(hipStream_t st, long nblocks, const double* L, 
 void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, long ld, int nt, int level, int stages) {
     const int nbt = 1 << level;
     if (nbt >= nt) return;
-    const int pairs = (nt + 2 * nbt - 1) / (2 * nbt);
-    const long nblocks = (long)pairs * nbt * nbt;
+    const long nblocks = trtri_level_tiles(nt, nbt);
+    if (nblocks <= 0) return;
     static const int tri64_max = env_int("MI355GP_TRI64_MAX", GEMM_DEFAULT_TRI64_MAX);
     if (nblocks <= tri64_max) {
         if (stages & 1)

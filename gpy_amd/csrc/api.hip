@@ -313,7 +313,8 @@ static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_gra
     // stage timing was asked for and launch bracketing is off; the first evaluation of a context runs plain (one-time
     // function attributes), the second captures, every later one replays.
     const bool structural = c->graph_enabled && !c->ws.prof.on && c->ws.lookahead == 1 && c->ws.persist_skip == 0 &&
-                            (!c->ws.tri_overlap || (int)(np / NB) < c->ws.tri_min_nt) && persist_early_h(np, &c->ws) == 0;
+                            (!c->ws.tri_overlap || (int)(np / NB) < c->ws.tri_min_nt) && persist_early_h(np, &c->ws) == 0 &&
+                            c->ws.sched_state != 1;           // (the calibration's evaluation on launches is timed: plain launches)
     if (c->fgraph && !structural) drop_graph(c);
     const bool graphable = structural && !stage_ms;          // a call that wants the stage timings runs plain, the graph stays
     if (!graphable) {
@@ -426,6 +427,23 @@ static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_gra
     }
     c->have_factor = true;
     c->studentt = studentt_nu > 0.0;
+    // schedule of a small factorisation by measurement (FactorWs::persist_auto): potrf .. lauum of this evaluation, device time
+    if (c->ws.persist_auto && c->ws.sched_state < 2 && !graphable && attempt == 0 && (int)(np / NB) >= c->ws.persist_tri_min_nt) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[4]) == hipSuccess) {
+            if (c->ws.sched_state == 0 && c->ws.persist_used && c->ws.evals_done >= 3) {     // persistent launch + early inverse, warm
+                c->ws.sched_ms_persist = ms;
+                c->ws.sched_state = 1;
+                c->ws.sched_force_steps = 1;
+            } else if (c->ws.sched_state == 1 && !c->ws.persist_used) {
+                c->ws.sched_ms_steps = ms;
+                c->ws.sched_state = 2;
+                c->ws.persist_auto_off = (ms < 0.97f * c->ws.sched_ms_persist) ? 1 : 0;
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     const double datafit = scal[0], alpha2 = scal[1], trw = scal[2], logdet = scal[3];
     const double Dy = (double)c->Dy;
     for (int i = 0; i < MI355GP_NUM_OUT; ++i) out_scalars[i] = 0.0;
@@ -1211,6 +1229,11 @@ int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
             case MI355GP_OPT_GRAPH: c->graph_enabled = env("MI355GP_GRAPH", 1) ? 1 : 0; break;
             default: break;
         }
+    }
+    if (option == MI355GP_OPT_PERSIST) {  // an explicit choice ends the calibration by measurement, -1 re-opens it
+        c->ws.persist_auto_off = 0;
+        c->ws.sched_force_steps = 0;
+        c->ws.sched_state = (value < 0) ? 0 : 2;
     }
     apply_options(c);
     drop_graph(c);                        // a captured factorisation region carries the old schedule

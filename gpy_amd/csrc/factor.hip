@@ -163,6 +163,10 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     }
     const char* envp1 = getenv("MI355GP_PART1_ON_PANEL");
     if (envp1 && *envp1) ws->part1_on_panel = atoi(envp1) ? 1 : 0;
+    ws->sched_state = ws->sched_force_steps = ws->persist_auto_off = 0;
+    ws->evals_done = ws->early_pending = 0;
+    const char* envpa = getenv("MI355GP_PERSIST_AUTO");
+    if (envpa && *envpa) ws->persist_auto = atoi(envpa) ? 1 : 0;
     const char* envls = getenv("MI355GP_LAUUM_SPLIT");
     if (envls && *envls) ws->lauum_split = atoi(envls) ? 1 : 0;
     const char* envptri = getenv("MI355GP_PERSIST_TRI");
@@ -381,6 +385,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     } else if (ws->persist_skip > 0 && ws->persist_skip != 0x7fffffff) {
         --ws->persist_skip;                                     // a called-off launch is retried after a number of evaluations
     }
+    ws->sched_force_steps = 0;                                  // (the calibration's one evaluation on launches is this one)
     if (ws->lookahead != 1) {
         potrf_serial(st, A, npad, ws);
         return;

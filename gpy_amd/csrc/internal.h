@@ -83,6 +83,13 @@ struct FactorWs {
     std::vector<hipEvent_t> ev_cols;         // [p]: every update of panel p's columns has been issued (-> its factorisation)
     hipEvent_t ev_fork = nullptr;
     int agg2 = 0;               // MI355GP_AGG2: part 2 of the look-ahead schedule in pairs of panels (K = 2 nbo far updates; N >= 6144); measured: no gain
+    // Which schedule a small factorisation takes is decided BY MEASUREMENT per workspace (MI355GP_PERSIST_AUTO=0: always the
+    // persistent launch): on most boxes the persistent launch + early inverse wins at N = 4096 (2.85 against 3.3 ms per evaluation),
+    // on some the very same binary runs the persistent launch at half speed (3.2-3.6 ms against 1.75 for the factorisation alone,
+    // the launch-per-step schedule only 10 % slower than elsewhere).  The third evaluation of a workspace is timed on the
+    // persistent schedule, the fourth on launches; the faster one stays (both give the same bits).
+    int persist_auto = 1, sched_state = 0, sched_force_steps = 0, persist_auto_off = 0;
+    float sched_ms_persist = 0.f, sched_ms_steps = 0.f;
     int evals_done = 0;         // inverses taken through this workspace (the early inverse under the persistent launch starts with the second)
     int early_pending = 0;      // early-inverse kernels are in flight on the side stream and nobody has joined them yet (ev_tri)
     // split lauum of a small matrix (lauum_device): the plan of the last nt it was made for, on the device
@@ -128,7 +135,7 @@ struct FactorWs {
     hipEvent_t ev_persist_pre = nullptr;   // optional (not owned): recorded on the launching stream once the progress words are zeroed
     int persist_grid_last = 0;             // workgroups of the last persistent launch
     int persist_tune = 0;            // MI355GP_PERSIST_TUNE: A/B bits of the persistent launch (4: no split hand-over, 64 / 128: near
-                                     // ownership of 3 / 4 block diagonals)
+                                     // ownership of 3 / 4 block diagonals; bits 8..15: share of near owners = workers / that number)
     int persist_test = 0;            // MI355GP_OPT_PERSIST_TEST: fault injection for the NEXT persistent launch (1 clean, 2 dirty)
     int* persist_sync = nullptr;     // progress words of the persistent launch (zeroed before every launch)
     double* persist_hs = nullptr;    // [min(nblk, 64)][128 x 128]: sub-diagonal tile of every row, handed to the chain in ITS load order

@@ -71,6 +71,14 @@ __device__ __forceinline__ long uni(long v) {
     return (long)(((unsigned long)hi << 32) | lo);
 }
 
+// Share of the workers that own NEAR tiles: nworkers / ps_hdiv(nt) of them, at most one per near tile.  A near owner is busy for
+// one step per tile it owns and idle otherwise; from nt ~ 21 on the launch fills the machine and its first steps are bound by the
+// FAR workers' throughput, so fewer near owners (two or three near tiles each, rows 14-20 steps apart) and more far workers win:
+// same box, N = 4096: 1.781 (half) -> 1.626 (a quarter) -> 1.602 ms (a sixth); N = 4608: 2.310 -> 1.945 -> 1.892; N = 3072:
+// 1.207 -> 1.184 -> 1.256; N = 2048 (137 workgroups, chain-bound): 0.697 -> 0.727 -> 0.738.  MI355GP_PERSIST_TUNE bits 8..15
+// override the divisor (diagnostics).
+__host__ __device__ __forceinline__ int ps_hdiv(int nt) { return nt <= 20 ? 2 : (nt <= 27 ? 4 : 6); }
+
 // tune bits 6 / 7 (diagnostics): near ownership of D = 3 / 4 block diagonals instead of PS_NEARD
 __host__ __device__ __forceinline__ int ps_neard(int tune) { return (tune & 64) ? 3 : ((tune & 128) ? 4 : PS_NEARD); }
 
@@ -152,10 +160,10 @@ __host__ __device__ __forceinline__ int near_tiles_in_rows(int rows, int D) {   
 }
 struct Ownership {
     int H, nnear, nfar, nw, D;
-    __device__ Ownership(int nt, int nworkers, int neard) : nw(nworkers), D(neard) {
+    __device__ Ownership(int nt, int nworkers, int neard, int hdiv = 2) : nw(nworkers), D(neard) {
         nnear = near_tiles_in_rows(nt, D);
         nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
-        H = nw / 2 > 0 ? nw / 2 : 1;
+        H = nw / hdiv > 0 ? nw / hdiv : 1;
         if (H > nnear) H = nnear;
         if (nfar == 0) H = nw < nnear ? nw : nnear;
     }
@@ -653,7 +661,7 @@ __device__ __forceinline__ void chain_workgroup(double* A, long ld, int nt, doub
 // accumulator carried through memory in fp64 between them as before: the same bits.
 __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
                                  int* __restrict__ sync, int kcap, double* __restrict__ hs, long long* __restrict__ dbg,
-                                 int split, int neard, double* sm) {
+                                 int split, int neard, int hdiv, double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
     __shared__ int s_pre[PS_MAXNT];                            // PS_PRE snapshot
     __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished;
@@ -662,7 +670,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (w >= 4) return;              // the launch has eight waves per workgroup for the chain's sake; a worker uses four
     const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
-    const Ownership own(nt, nw, neard);
+    const Ownership own(nt, nw, neard, hdiv);
     const int nmine = own.count(me);
     if (nmine == 0) return;
     for (int s = t; s < PS_MAXT; s += 256) {
@@ -815,7 +823,8 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
         chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, hs, dbg);
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
     } else {
-        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, ps_neard(tune), sm);
+        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, ps_neard(tune),
+                         ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt), sm);
     }
 }
 
@@ -823,6 +832,7 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
 bool potrf_persist_eligible(long npad, const FactorWs* ws) {
     const long nt = npad / NB;
     if (!ws->persist || ws->persist_skip > 0 || !ws->persist_sync || !ws->persist_hs || ws->lookahead != 1) return false;
+    if ((ws->persist_auto_off || ws->sched_force_steps) && ws->persist_test == 0) return false;   // decided / being timed on launches
     if (nt < 2 || nt > PS_MAXNT || nt > ws->persist_max_nt) return false;
     // tiles per worker: near 3 nt / (cus / 2) <= 2, far (nt-3)(nt-2)/2 / (cus / 2)
     return ws->persist_cus >= 16 && (nt - 3) * (nt - 2) / 2 / (ws->persist_cus / 2 - 1) + 2 <= PS_MAXT;

@@ -314,10 +314,10 @@ static void potrf_serial(hipStream_t st, double* A, long npad, FactorWs* ws) {
 // tile list is shared with the machine-wide instance that trtri_device launches after potrf).  trtri_device picks up from
 // ws->ovl_h.  gated: the factorisation is the PERSISTENT launch -- there is no stream event inside it, so each of the two steps
 // is preceded by a one-thread kernel that waits on the launch's progress words (persist.hip).
-static void early_inverse(hipStream_t sq, double* A, long npad, int h, FactorWs* ws, bool gated) {
+static void early_inverse(hipStream_t sq, double* A, long npad, int h, FactorWs* ws, bool gated, int gate_gives_up = 0) {
     const int ntl = (int)(npad / NB);
     (void)hipMemsetAsync(ws->tri_counter, 0, sizeof(int) * 4, sq);
-    if (gated) launch_wait_persist_rows(sq, ws, 0, h, 0);       // rows 0 .. h-1 of L and their inverted diagonal tiles are final
+    if (gated) launch_wait_persist_rows(sq, ws, 0, h, 0, gate_gives_up);   // rows 0 .. h-1 of L, inverted diagonal tiles: final
     ws->prof.begin(sq, PF_TRTRI_EARLY, 0.0);                    // elapsed on the side stream; the flops are billed to PF_TRTRI
     launch_inv128(sq, A, ws->scratchX, npad, h, ws->dinv);
     int level = 0;
@@ -364,6 +364,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
         // needs only the leading half of L starts on the side stream as soon as that half is final: the leading h x h
         // inverse and T21 = L21 X11 on the CUs the launch has given back, keyed on its progress words.
         const int h = persist_early_h(npad, ws);
+        const int gate_gives_up = (ws->persist_test == 3) ? 1 : 0;       // fault injection: the first gate times out at once
         hipEvent_t pre_saved = ws->ev_persist_pre;
         if (h > 0 && !ws->ev_persist_pre) ws->ev_persist_pre = ws->ev_fork;
         const bool ok = launch_potrf_persist(st, A, npad, ws);
@@ -376,7 +377,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
                 ws->tri_cur_pct = ws->tri_cu_pct;
                 (void)hipStreamWaitEvent(sq, pre, 0);           // the progress words of THIS launch are zeroed
                 launch_wait_persist_resident(sq, ws, 50);       // nothing wide may reach the CUs before the launch is in place
-                early_inverse(sq, A, npad, h, ws, true);
+                early_inverse(sq, A, npad, h, ws, true, gate_gives_up);
                 ws->ovl_h = h;
             }
             return;

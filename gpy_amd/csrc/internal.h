@@ -199,7 +199,7 @@ void launch_wait_persist_resident(hipStream_t st, const FactorWs* ws, int timeou
 int persist_early_h(long npad, const FactorWs* ws);
 // on `st`: one thread that returns once rows r0 .. r1-1 of L are final in their first `cols` tile columns (cols = 0: the whole
 // row up to and including the diagonal block and its inverted diagonal tiles), the launch was called off / aborted, or 20 ms passed
-void launch_wait_persist_rows(hipStream_t st, const FactorWs* ws, int r0, int r1, int cols);
+void launch_wait_persist_rows(hipStream_t st, const FactorWs* ws, int r0, int r1, int cols, int give_up = 0);
 
 // ---- kern.hip : covariance assembly, reductions, solves, fetch helpers ----------------------------
 struct KernParams {

@@ -925,20 +925,31 @@ __global__ void k_wait_persist_resident(const int* __restrict__ sync, int n, int
 // their first `cols` tile columns (cnt[i] >= cols); cols = 0: whole rows including the diagonal block, i.e. cnt[i] >= i and
 // dcnt >= r1 (L_ii and its inverted 16 x 16 tiles).  Everything the launch publishes is written through before its progress word
 // is, and the consumer kernels start behind this kernel's end (a kernel boundary: their caches are invalidated), so they read
-// the final values.  Gives up when the launch was called off / aborted (the host redoes the evaluation anyway) or after 20 ms.
-__global__ void k_wait_persist_rows(const int* __restrict__ sync, int r0, int r1, int cols) {
+// the final values.  Gives up when the launch was called off / aborted (the host redoes the evaluation anyway) or after 20 ms --
+// and then marks the evaluation as aborted itself, because what follows it reads unfinished rows.
+__global__ void k_wait_persist_rows(const int* __restrict__ sync, int* __restrict__ info, int r0, int r1, int cols, int give_up) {
     const long long t0 = wall_clock64();
     for (;;) {
+        if (give_up) {                                         // fault injection (MI355GP_OPT_PERSIST_TEST = 3): the gate times out at once
+            atomicMax(info, PS_ABORT_INFO);
+            return;
+        }
         bool ok = cols > 0 || ld_flag(sync + PS_DCNT) >= r1;
         for (int i = r0; ok && i < r1; ++i) ok = ld_flag(sync + PS_CNT + i) >= (cols > 0 ? cols : i);
         if (ok) return;
         if ((ld_flag(sync + PS_ARRIVE) & PS_ARRIVE_ABORT) || ld_flag(sync + PS_ABORT) != 0) return;
-        if (wall_clock64() - t0 > 20 * PS_ARRIVE_TICKS) return;
+        if (wall_clock64() - t0 > 20 * PS_ARRIVE_TICKS) {
+            // Gave up while the launch is still running (a GPU shared with something heavy): the kernels behind this gate will read
+            // rows of L that are NOT final.  Their result must never be used: report the evaluation as aborted, the host redoes
+            // it on the launch-per-step schedule (same path as a dataflow time-out inside the launch).
+            atomicMax(info, PS_ABORT_INFO);
+            return;
+        }
         __builtin_amdgcn_s_sleep(8);
     }
 }
-void launch_wait_persist_rows(hipStream_t st, const FactorWs* ws, int r0, int r1, int cols) {
-    hipLaunchKernelGGL(k_wait_persist_rows, dim3(1), dim3(1), 0, st, ws->persist_sync, r0, r1, cols);
+void launch_wait_persist_rows(hipStream_t st, const FactorWs* ws, int r0, int r1, int cols, int give_up) {
+    hipLaunchKernelGGL(k_wait_persist_rows, dim3(1), dim3(1), 0, st, ws->persist_sync, ws->info, r0, r1, cols, give_up);
 }
 void launch_wait_persist_resident(hipStream_t st, const FactorWs* ws, int timeout_ms) {
     hipLaunchKernelGGL(k_wait_persist_resident, dim3(1), dim3(1), 0, st, ws->persist_sync, ws->persist_grid_last, timeout_ms);

@@ -192,7 +192,9 @@ enum { MI355GP_OPT_PROFILE = 0, MI355GP_OPT_LOOKAHEAD = 1, MI355GP_OPT_TRI_OVERL
        MI355GP_OPT_PERSIST_SKIP = 16, MI355GP_OPT_NUM = 17 };
 /* MI355GP_OPT_PERSIST_TEST: test hook, consumed by the NEXT persistent launch of the context: 1 = the launch waits for one
    workgroup more than it has (called off at the co-residency gate, matrix untouched), 2 = the chain workgroup aborts after the
-   gate (dirty abort, matrix rebuilt); either way the evaluation is redone on the launch-per-step schedule inside the same call.
+   gate (dirty abort, matrix rebuilt), 3 = the first gate kernel of the early inverse underneath the launch gives up at once (what
+   its 20 ms limit does on a GPU shared with something heavy: the evaluation is marked aborted because the kernels behind the gate
+   read unfinished rows); either way the evaluation is redone on the launch-per-step schedule inside the same call.
    MI355GP_OPT_PERSIST_ABORTS / _SKIP: read-only (mi355gp_get_option): persistent launches of this context that did not
    complete / evaluations that still stay on the launch-per-step schedule because of the last one. */
 int mi355gp_set_option(mi355gp_ctx* ctx, int option, int value);

@@ -79,6 +79,36 @@ def test_called_off_or_aborted_persistent_launch_is_redone_inside_the_call(mode)
         c.close()
 
 
+def test_a_gate_of_the_early_inverse_that_gives_up_voids_the_evaluation():
+    """The inverse of the leading half runs on the side stream underneath the persistent launch, behind one-thread gate kernels
+    that wait on the launch's progress words.  A gate that gives up while the launch is still running (a GPU shared with
+    something heavy: 20 ms limit) lets its consumers read rows of L that are not final: it must mark the evaluation as aborted
+    so that the host redoes it on launches.  Fault injection (persist_test = 3: the gate gives up at once): the call returns
+    the undisturbed result, counts one abort, and the context stays on launches."""
+    N = 4096
+    X, Y = O.synthetic(N, 4, seed=33)
+    var, ls, noise = O.default_theta(4, False)
+    th = L.theta_vec(var, ls, False, 4)
+    c = L.Context(0)
+    try:
+        c.set_data(X, Y)
+        c.set_option("persist", 1)                            # an explicit choice: no calibration by measurement in this test
+        outs = []
+        for _ in range(3):                                    # the early inverse starts with the second evaluation
+            info, r = c.exact_inference("rbf", False, th, noise)
+            assert info == 0
+            outs.append(_key(r))
+        assert outs[0] == outs[1] == outs[2] and c.get_option("persist_aborts") == 0
+        c.set_option("persist_test", 3)
+        info, rs = c.exact_inference("rbf", False, th, noise)
+        assert info == 0 and _key(rs) == outs[0]              # redone on launches: the same bits
+        assert c.get_option("persist_aborts") == 1 and c.get_option("persist_skip") > 0
+        info, r = c.exact_inference("rbf", False, th, noise)
+        assert info == 0 and _key(r) == outs[0]
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_dense_pdinv_redoes_a_called_off_launch(mode, monkeypatch):
     n = 1411

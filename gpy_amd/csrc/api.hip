@@ -212,6 +212,7 @@ int mi355gp_set_data(mi355gp_ctx* c, const double* X, int64_t N, int D, const do
     HIP_CHECK(hipMalloc(&c->B, sizeof(double) * np * np));
     HIP_CHECK(hipMalloc(&c->C, sizeof(double) * np * np));
     if (factor_ws_alloc(&c->ws, np) != 0) return -3;
+    c->ws.can_calibrate = 1;
     {
         const int lookahead = c->ws.lookahead;
         const char* e = getenv("MI355GP_GRAPH");
@@ -439,6 +440,7 @@ static int run_pipeline(mi355gp_ctx* c, EngineShared* gate, bool with_kernel_gra
                 c->ws.sched_ms_steps = ms;
                 c->ws.sched_state = 2;
                 c->ws.persist_auto_off = (ms < 0.97f * c->ws.sched_ms_persist) ? 1 : 0;
+                if ((int)(np / NB) >= 21) persist_box_verdict(c->ws.persist_auto_off);
             }
         } else {
             (void)hipGetLastError();

@@ -89,6 +89,7 @@ struct FactorWs {
     // the launch-per-step schedule only 10 % slower than elsewhere).  The third evaluation of a workspace is timed on the
     // persistent schedule, the fourth on launches; the faster one stays (both give the same bits).
     int persist_auto = 1, sched_state = 0, sched_force_steps = 0, persist_auto_off = 0;
+    int can_calibrate = 0;      // set by the owner of a workspace that times its evaluations (the exact-inference contexts)
     float sched_ms_persist = 0.f, sched_ms_steps = 0.f;
     int evals_done = 0;         // inverses taken through this workspace (the early inverse under the persistent launch starts with the second)
     int early_pending = 0;      // early-inverse kernels are in flight on the side stream and nobody has joined them yet (ev_tri)
@@ -186,6 +187,10 @@ void lauum_device(hipStream_t st, const double* X, double* W, long npad, FactorW
 
 // ---- persist.hip : the whole factorisation of a small matrix as one persistent dataflow launch ------------------------
 bool potrf_persist_eligible(long npad, const FactorWs* ws);
+// What the calibrated workspaces of this process found for machine-filling factorisations (nt >= 21): -1 nothing measured yet,
+// 0 the persistent launch wins on this box, 1 launches win.  Workspaces that never calibrate (the one-shot pdinv / jitchol
+// entry points, the M x M factorisations of the sparse path) follow it.
+int persist_box_verdict(int set = -2);
 // bookkeeping after the host has read info[0] of a factorisation: true if it is one of the PS_ABORT codes (then persist_skip /
 // persist_aborts are updated and the caller redoes the factorisation -- on the untouched matrix if *clean, after
 // rebuilding it otherwise)

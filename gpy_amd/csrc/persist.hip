@@ -28,6 +28,7 @@
 // Arithmetic: the chain runs diag128_factor / trsm_strip_core of chain_dev.h, the workers gemm_tile_128_v3 with C preloaded
 // and negated A fragments, and the chain's own 128^3 update issues its MFMAs in the k-order of that tile pipeline
 // (slab of 16, MFMA m of a slab covers k = 4 (lane >> 4) + m): the factor is bit-identical to factor.hip's.
+#include <atomic>
 #include <vector>
 
 #include "chain_dev.h"
@@ -829,10 +830,18 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
+int persist_box_verdict(int set) {
+    static std::atomic<int> verdict{-1};
+    if (set >= -1) verdict.store(set);
+    return verdict.load();
+}
+
 bool potrf_persist_eligible(long npad, const FactorWs* ws) {
     const long nt = npad / NB;
     if (!ws->persist || ws->persist_skip > 0 || !ws->persist_sync || !ws->persist_hs || ws->lookahead != 1) return false;
     if ((ws->persist_auto_off || ws->sched_force_steps) && ws->persist_test == 0) return false;   // decided / being timed on launches
+    if (ws->persist_auto && ws->sched_state == 0 && nt >= 21 && ws->persist_test == 0 && persist_box_verdict() == 1 && !ws->can_calibrate)
+        return false;                                          // a workspace that never calibrates itself follows the process's verdict
     if (nt < 2 || nt > PS_MAXNT || nt > ws->persist_max_nt) return false;
     // tiles per worker: near 3 nt / (cus / 2) <= 2, far (nt-3)(nt-2)/2 / (cus / 2)
     return ws->persist_cus >= 16 && (nt - 3) * (nt - 2) / 2 / (ws->persist_cus / 2 - 1) + 2 <= PS_MAXT;

@@ -115,3 +115,26 @@ def test_persistent_cholesky_option_reports_non_pd_and_can_be_switched_off_per_c
         assert infos[0] == infos[1] == infos[2] and infos[0] > 0
     finally:
         c.close()
+
+
+def test_one_shot_factorisations_follow_the_box_verdict_with_the_same_bits(tmp_path):
+    """About half of the boxes run the persistent launch at half speed; contexts find out by timing both schedules, and the
+    one-shot entry points (pdinv / jitchol: a fresh workspace per call) follow the process's verdict for machine-filling sizes.
+    Either schedule gives the same L and log-determinant bits: two fresh processes, one starting from each verdict."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import gpy_amd; from oracle import gp_oracle as O\n"
+            "X, _ = O.synthetic(3000, 3, seed=4)\n"
+            "A = O.kern_K('matern52', X, None, 1.3, np.array([0.8, 1.1, 1.9]), True) + 0.5 * np.eye(3000)\n"
+            "Ai, L, Li, ld = gpy_amd.linalg.pdinv(A)\n"
+            "np.save(sys.argv[1], L); print(repr(float(ld)))\n") % root
+    outs = []
+    for verdict in ("0", "1"):
+        f = str(tmp_path / ("L%s.npy" % verdict))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MI355GP_DBG_BOX_VERDICT=verdict),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((np.load(f), r.stdout.strip().splitlines()[-1]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]

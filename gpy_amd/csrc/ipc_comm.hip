@@ -49,6 +49,7 @@ struct CtlRank {
 struct CtlComm {
     std::atomic<unsigned> count;
     std::atomic<unsigned> gen;
+    std::atomic<int> users;                // live members bound to this slot: more than the communicator's size = two communicators share it
     int color[IPC_MAXR], key[IPC_MAXR];
 };
 struct Ctl {
@@ -239,7 +240,10 @@ ncclResult_t ipcCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int r
 // ncclCommSplit: ranks with the same colour form a communicator, ordered by key (ties: parent rank)
 ncclResult_t ipcCommSplit(ncclComm_t parent, int color, int key, ncclComm_t* out, ncclConfig_t*) {
     Comm* p = (Comm*)parent;
-    if (color < 0 || color >= 16) return ncclInvalidArgument;
+    if (color < 0 || color >= 16) {
+        mi355gp_set_error("ipc transport: split colour %d outside 0..15 (a process grid of at most 16 rows / columns)", color);
+        return ncclInvalidArgument;
+    }
     CtlComm& b = p->w->ctl->comm[p->slot];
     b.color[p->me] = color;
     b.key[p->me] = key;
@@ -257,8 +261,29 @@ ncclResult_t ipcCommSplit(ncclComm_t parent, int color, int key, ncclComm_t* out
         c->global[i] = mem[(size_t)i].second;
         if (mem[(size_t)i].second == p->w->rank) c->me = i;
     }
+    CtlComm& mine = p->w->ctl->comm[c->slot];
+    mine.users.fetch_add(1, std::memory_order_acq_rel);
+    if (!barrier(p)) {                                     // colours / keys may be overwritten by the next split
+        mine.users.fetch_sub(1, std::memory_order_acq_rel);
+        delete c;
+        return ncclSystemError;
+    }
+    const int bound = mine.users.load(std::memory_order_acquire);
+    if (!barrier(p)) {                                     // everyone has read the count before anyone takes its own back
+        mine.users.fetch_sub(1, std::memory_order_acq_rel);
+        delete c;
+        return ncclSystemError;
+    }
+    if (bound != c->n) {
+        // the slot number is a hash of (parent slot, split number, colour): a second live communicator landed on it and the two
+        // would share one barrier counter.  Every member of both sees the same count, so all of them refuse together.
+        mi355gp_set_error("ipc transport: communicator slot %d is shared by two live communicators (%d members bound, %d expected); "
+                          "destroy earlier splits first", c->slot, bound, c->n);
+        mine.users.fetch_sub(1, std::memory_order_acq_rel);
+        delete c;
+        return ncclInvalidUsage;
+    }
     p->w->refs += 1;
-    if (!barrier(p)) return ncclSystemError;               // colours / keys may be overwritten by the next split
     *out = (ncclComm_t)c;
     return ncclSuccess;
 }
@@ -267,6 +292,7 @@ ncclResult_t ipcCommDestroy(ncclComm_t comm) {
     Comm* c = (Comm*)comm;
     if (!c) return ncclSuccess;
     World* w = c->w;
+    if (c->slot != 0) w->ctl->comm[c->slot].users.fetch_sub(1, std::memory_order_acq_rel);
     delete c;
     if (--w->refs == 0) world_release(w);
     return ncclSuccess;
@@ -440,6 +466,18 @@ extern "C" int mi355gp_dbg_ipc_selftest(const void* id128, int rank, int world, 
             if (hrecv[(size_t)i] != want) bad += 1.0;
             sum += hrecv[(size_t)i];
         }
+    }
+    // (6) refusals: a colour outside 0..15, and a split whose slot number hashes onto the still-live process-row communicator
+    //     (split number 15 of the world lands where split number 0 did) -- refused by every member, nothing left bound
+    if (rc == 0) {
+        ncclComm_t t = nullptr;
+        if (ipcCommSplit(cw, 16, 0, &t, nullptr) != ncclInvalidArgument) rc = -20;
+        for (int s = 2; s < 15 && rc == 0; ++s) {
+            if (ipcCommSplit(cw, pr, pc, &t, nullptr) != ncclSuccess) rc = -21;
+            else ipcCommDestroy(t);
+        }
+        if (rc == 0 && Pc > 1 && ipcCommSplit(cw, pr, pc, &t, nullptr) != ncclInvalidUsage) rc = -22;
+        if (rc == 0 && Pc > 1 && ipcAllReduce(dsend, drecv, (size_t)count, ncclFloat64, ncclSum, crow, 0) != ncclSuccess) rc = -23;
     }
     out[0] = bad;
     out[1] = sum;

@@ -58,7 +58,9 @@ def _run(Pr, Pc, count, tmp_path):
 
 @pytest.mark.parametrize("Pr,Pc,count", [(1, 2, 5000), (2, 2, 70000), (2, 4, 2200000), (3, 1, 1000)])
 def test_ipc_transport_protocol_in_host_mode(Pr, Pc, count, tmp_path):
-    """(2, 4, 2.2e6 doubles): the 2 x 4 grid of BASELINE configs[3] with messages larger than the 16 MiB staging buffer."""
+    """(2, 4, 2.2e6 doubles): the 2 x 4 grid of BASELINE configs[3] with messages larger than the 16 MiB staging buffer.
+    rc == 0 also covers the selftest's refusals (negative codes -20..-23): a split colour outside 0..15, and a split whose
+    slot number lands on a communicator that is still alive -- refused by every member, after which the live one still works."""
     recs = _run(Pr, Pc, count, tmp_path)
     for r, rec in enumerate(recs):
         assert rec["rc"] == 0 and rec["bad"] == 0.0, (r, rec)

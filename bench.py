@@ -611,6 +611,10 @@ def main():
         }
         if per_step:
             out["step_ms"] = per_step
+        if N <= 128 * 36:
+            # which schedule of a small factorisation the context's own timing settled on (boxes differ by 2x on the persistent
+            # launch): the timed steps above ran on it
+            out["small_n_schedule"] = ("undecided", "persistent launch", "launches")[ctx.get_option("persist_sched")]
         if not args.abi_only:
             # host overhead of the drop-in classes: the same evaluation through the bare C-ABI, same context, same data
             k2 = max(3, min(args.steps, 10))

@@ -195,7 +195,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
 # mi355gp_set_option / mi355gp_get_option ids (include/mi355gp.h, MI355GP_OPT_*)
 OPTIONS = {"profile": 0, "lookahead": 1, "tri_overlap": 2, "tri_min_nt": 3, "tri_h": 4, "tri_wgs": 5, "tri_half": 6,
            "part1_on_panel": 7, "nbo": 8, "solve_overlap": 9, "diag_excl_first": 10, "graph": 11, "persist": 12, "agg2": 13,
-           "persist_test": 14, "persist_aborts": 15, "persist_skip": 16}
+           "persist_test": 14, "persist_aborts": 15, "persist_skip": 16, "persist_sched": 17}
 
 
 def last_error():

@@ -1201,7 +1201,8 @@ int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
         drop_graph(c);
         return 0;
     }
-    if (option < 0 || option >= MI355GP_OPT_NUM || option == MI355GP_OPT_PERSIST_ABORTS || option == MI355GP_OPT_PERSIST_SKIP) {
+    if (option < 0 || option >= MI355GP_OPT_NUM || option == MI355GP_OPT_PERSIST_ABORTS || option == MI355GP_OPT_PERSIST_SKIP ||
+        option == MI355GP_OPT_PERSIST_SCHED) {
         mi355gp_set_error("mi355gp_set_option: unknown or read-only option %d", option);
         return -1;
     }
@@ -1247,7 +1248,8 @@ int mi355gp_get_option(mi355gp_ctx* c, int option, int* value) {
     const FactorWs& w = c->ws;
     const int v[MI355GP_OPT_NUM] = {0, w.lookahead, w.tri_overlap, w.tri_min_nt, w.tri_h_override, w.tri_wgs, w.tri_half_ok,
                                     w.part1_on_panel, w.nbo_override, w.solve_overlap, w.diag_excl_first, c->graph_enabled,
-                                    w.persist, w.agg2, w.persist_test, w.persist_aborts, w.persist_skip};
+                                    w.persist, w.agg2, w.persist_test, w.persist_aborts, w.persist_skip,
+                                    w.sched_state == 2 ? ((w.persist_auto_off || !w.persist) ? 2 : 1) : 0};
     *value = v[option];
     return 0;
 }

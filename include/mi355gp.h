@@ -189,14 +189,17 @@ enum { MI355GP_OPT_PROFILE = 0, MI355GP_OPT_LOOKAHEAD = 1, MI355GP_OPT_TRI_OVERL
        MI355GP_OPT_TRI_H = 4, MI355GP_OPT_TRI_WGS = 5, MI355GP_OPT_TRI_HALF = 6, MI355GP_OPT_PART1_ON_PANEL = 7,
        MI355GP_OPT_NBO = 8, MI355GP_OPT_SOLVE_OVERLAP = 9, MI355GP_OPT_DIAG_EXCL_FIRST = 10, MI355GP_OPT_GRAPH = 11,
        MI355GP_OPT_PERSIST = 12, MI355GP_OPT_AGG2 = 13, MI355GP_OPT_PERSIST_TEST = 14, MI355GP_OPT_PERSIST_ABORTS = 15,
-       MI355GP_OPT_PERSIST_SKIP = 16, MI355GP_OPT_NUM = 17 };
+       MI355GP_OPT_PERSIST_SKIP = 16, MI355GP_OPT_PERSIST_SCHED = 17, MI355GP_OPT_NUM = 18 };
 /* MI355GP_OPT_PERSIST_TEST: test hook, consumed by the NEXT persistent launch of the context: 1 = the launch waits for one
    workgroup more than it has (called off at the co-residency gate, matrix untouched), 2 = the chain workgroup aborts after the
    gate (dirty abort, matrix rebuilt), 3 = the first gate kernel of the early inverse underneath the launch gives up at once (what
    its 20 ms limit does on a GPU shared with something heavy: the evaluation is marked aborted because the kernels behind the gate
    read unfinished rows); either way the evaluation is redone on the launch-per-step schedule inside the same call.
    MI355GP_OPT_PERSIST_ABORTS / _SKIP: read-only (mi355gp_get_option): persistent launches of this context that did not
-   complete / evaluations that still stay on the launch-per-step schedule because of the last one. */
+   complete / evaluations that still stay on the launch-per-step schedule because of the last one.
+   MI355GP_OPT_PERSIST_SCHED: read-only: the schedule of a small factorisation this context has settled on, by its own timing of
+   the two or by an explicit PERSIST option: 0 = not decided yet (the first evaluations),
+   1 = the persistent launch, 2 = launches (this box runs them faster, or PERSIST = 0). */
 int mi355gp_set_option(mi355gp_ctx* ctx, int option, int value);
 /* the value in effect for a schedule switch (options above MI355GP_OPT_PROFILE) */
 int mi355gp_get_option(mi355gp_ctx* ctx, int option, int* value);

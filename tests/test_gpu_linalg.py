@@ -117,6 +117,39 @@ def test_persistent_cholesky_option_reports_non_pd_and_can_be_switched_off_per_c
         c.close()
 
 
+def test_a_context_settles_on_one_schedule_by_its_own_timing_and_reports_it():
+    """`MI355GP_PERSIST_AUTO`: from nt = 16 on a context times its third evaluation (persistent launch + early
+    inverse) and its fourth (launches), keeps the faster one and says which through the read-only option "persist_sched"
+    (0 undecided, 1 persistent launch, 2 launches).  Every evaluation on the way has the same bits; an explicit "persist"
+    option ends the calibration, -1 re-opens it."""
+    X, Y = O.synthetic(2304, 4, seed=11)
+    var, ls, noise = O.default_theta(4, False)
+    th = L.theta_vec(var, ls, False, 4)
+    c = L.Context(0)
+    try:
+        c.set_data(X, Y)
+        assert c.get_option("persist_sched") == 0
+        outs = []
+        for _ in range(7):
+            info, r = c.exact_inference("rbf", False, th, noise)
+            assert info == 0
+            outs.append((r["lml"], r["dtheta"].tobytes(), r["alpha"].tobytes()))
+        assert all(o == outs[0] for o in outs)
+        assert c.get_option("persist_sched") in (1, 2) and c.get_option("persist_aborts") == 0
+        with pytest.raises(L.MI355GPError):
+            c.set_option("persist_sched", 1)
+        c.set_option("persist", 0)
+        assert c.get_option("persist_sched") == 2
+        c.set_option("persist", 1)
+        assert c.get_option("persist_sched") == 1
+        c.set_option("persist", -1)
+        assert c.get_option("persist_sched") == 0
+        info, r = c.exact_inference("rbf", False, th, noise)
+        assert info == 0 and (r["lml"], r["dtheta"].tobytes(), r["alpha"].tobytes()) == outs[0]
+    finally:
+        c.close()
+
+
 def test_one_shot_factorisations_follow_the_box_verdict_with_the_same_bits(tmp_path):
     """About half of the boxes run the persistent launch at half speed; contexts find out by timing both schedules, and the
     one-shot entry points (pdinv / jitchol: a fresh workspace per call) follow the process's verdict for machine-filling sizes.

@@ -26,6 +26,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define FACTOR_DEFAULT_DIAG_EXCL_FIRST 1   // small factorisations only (N < 6144): from N = 8192 on it measured slower
 #define GEMM_DEFAULT_TRI64_MAX 512    // levels of the triangular inverse with at most this many 128-tiles per stage run as 64 x 64 quadrants
 #define GEMM_DEFAULT_LAUUM64_MAX 528  // X^T X of at most this many lower 128-tiles (nt <= 32) runs as 64 x 64 quadrants
+#define LAUUM_SPLIT_MAX_NT 44          // X^T X runs from a work list with the long k ranges cut up to this many 128-tiles per dimension
+                                       // (measured against the single launch of whole-K tiles: N=4608 0.80 -> 0.61 ms, N=5120 0.94 -> 0.79,
+                                       //  N=6144 1.305 -> 1.295, N=7168 1.96 -> 2.00; MI355GP_LAUUM_SPLIT=n > 1 overrides the bound)
 #define GEMM_DEFAULT_UPD64_MAX 128  // trailing-update launches of at most this many 128-tiles run as 64 x 64 quadrants (0 = never)
 
 // v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) * B(4x16) + C.  Per lane (l = 0..63):

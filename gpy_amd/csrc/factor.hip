@@ -168,7 +168,7 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     const char* envpa = getenv("MI355GP_PERSIST_AUTO");
     if (envpa && *envpa) ws->persist_auto = atoi(envpa) ? 1 : 0;
     const char* envls = getenv("MI355GP_LAUUM_SPLIT");
-    if (envls && *envls) ws->lauum_split = atoi(envls) ? 1 : 0;
+    if (envls && *envls) ws->lauum_split = atoi(envls) > 0 ? atoi(envls) : 0;   // 1: on; n > 1: on up to n tiles per dimension
     const char* envptri = getenv("MI355GP_PERSIST_TRI");
     if (envptri && *envptri) ws->persist_tri = atoi(envptri) ? 1 : 0;
     const char* envptn = getenv("MI355GP_PERSIST_TRI_MIN_NT");
@@ -545,7 +545,7 @@ void lauum_device(hipStream_t st, const double* X, double* W, long npad, FactorW
     const int nt = (int)(npad / NB);
     ws->prof.begin(st, PF_LAUUM, (double)npad * npad * npad / 3.0);
     // small matrix, long k ranges: the split work list (gemm.hip); the plan is made once per size and lives on the device
-    bool split = ws->lauum_split && lauum_uses_64(nt) && (long)nt * NB > 1024;
+    bool split = ws->lauum_split && nt <= (ws->lauum_split > 1 ? ws->lauum_split : LAUUM_SPLIT_MAX_NT) && (long)nt * NB > 1024;
     if (split && ws->lauum_plan_nt != nt) {
         std::vector<LauumItem> items;
         std::vector<LauumSum> sums;

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_lauum64(const double* __restrict__ X, d
     gt64_store<0>(W + r0 * ld + c0, ld, acc);
 }
 
-// The same on a work list with the long k ranges CUT (small matrices: nt <= 32).  W(k,l) sums over the tile rows i >= k, so the
+// The same on a work list with the long k ranges CUT (small matrices: nt <= LAUUM_SPLIT_MAX_NT).  W(k,l) sums over the tile rows i >= k, so the
 // tiles of the first block columns carry K ~ N while most carry a fraction of it: one quadrant of tile (0,0) at N = 4096 is 3.4e7
 // flops, 0.44 ms at the quarter of a CU it gets while four workgroups share the CU -- alone more than the whole product needs at
 // the machine's rate (0.29 ms).  Every quadrant's k range is cut into chunks of at most LAUUM_KC rows; a quadrant with ONE chunk
@@ -350,6 +350,46 @@ __global__ __launch_bounds__(256) void k_lauum64(const double* __restrict__ X, d
 // bit-reproducible; no atomics).  Items are issued longest first.
 #define LAUUM_KC 1024
 #define LAUUM_T128_MIN_NT 24
+// 128 x 128 items: the chunk length decides how the list packs onto the machine (two workgroups per CU, 512 slots): at nt = 32 chunks
+// of 1024 rows are 1000 items = two rounds of 8 k-steps where the work is 11.7 per slot.  The length is therefore chosen PER nt by
+// running the list (longest first, next item to the first free slot -- what the dispatcher does) through a cost model calibrated on
+// the two measured points (nt = 24: 0.25 ms, nt = 32: 0.47 ms at 1024): one k-step of 128 rows 27.4 us with two workgroups on a
+// CU, 8 us per item, plus the reduction's traffic (every partial is 128 KB written and read).  MI355GP_LAUUM_KC (rows) overrides.
+// Measured against fixed lengths (tools/lauum_kc_probe.sh): the model's pick is the fastest or within 1 % of it at every size tried
+// (N=3072: 768 rows, 0.253 -> 0.236 ms; N=4096: 1536, 0.470 -> 0.455; N=4608: 2176, 0.655 at 1024 -> 0.607; N=5120: 0.848 -> 0.790).
+static int lauum_kc_rows_128(int nt) {
+    static const int forced = env_int("MI355GP_LAUUM_KC", 0);
+    if (forced >= NB) return forced / NB * NB;
+    int best = LAUUM_KC;
+    double best_us = 1e30;
+    for (int kc = 2; kc <= 32 && kc <= nt; ++kc) {             // chunk length in k-steps of 128 rows
+        std::vector<int> len;
+        long parts = 0;
+        for (int ti = 0; ti < nt; ++ti) {
+            const int K = nt - ti, nch = (K + kc - 1) / kc;
+            for (int tj = 0; tj <= ti; ++tj)
+                for (int c = 0; c < nch; ++c) len.push_back(c + 1 < nch ? kc : K - c * kc);
+            if (nch > 1) parts += (long)nch * (ti + 1);
+        }
+        std::sort(len.begin(), len.end(), [](int a, int b) { return a > b; });
+        std::vector<double> slot(512, 0.0);                    // a binary heap would do; 512 x a few thousand items is nothing
+        std::make_heap(slot.begin(), slot.end(), [](double a, double b) { return a > b; });
+        double end = 0.0;
+        for (int l : len) {
+            std::pop_heap(slot.begin(), slot.end(), [](double a, double b) { return a > b; });
+            const double t = slot.back() + 27.4 * l + 8.0;
+            slot.back() = t;
+            if (t > end) end = t;
+            std::push_heap(slot.begin(), slot.end(), [](double a, double b) { return a > b; });
+        }
+        const double us = end + (double)parts * (NB * NB * 8.0) / 3.0e6;   // the reduction reads the partials at ~3 TB/s
+        if (us < best_us - 0.5) {
+            best_us = us;
+            best = kc * NB;
+        }
+    }
+    return best;
+}
 __global__ __launch_bounds__(256) void k_lauum64_items(const double* __restrict__ X, double* __restrict__ W, long ld,
                                                        const LauumItem* __restrict__ items, double* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -408,14 +448,15 @@ void lauum_split_plan(int nt, std::vector<LauumItem>& items, std::vector<LauumSu
     sums.clear();
     int np = 0;
     const int nq = lauum_split_tile(nt) == 128 ? 1 : 4;       // whole tiles (q = -1 in spirit: q is ignored) or quadrants
+    const int kc = (nq == 1) ? lauum_kc_rows_128(nt) : LAUUM_KC;
     for (int ti = 0; ti < nt; ++ti)
         for (int tj = 0; tj <= ti; ++tj)
             for (int q = 0; q < nq; ++q) {
-                const int k0 = ti * NB, K = (nt - ti) * NB, nch = (K + LAUUM_KC - 1) / LAUUM_KC;
+                const int k0 = ti * NB, K = (nt - ti) * NB, nch = (K + kc - 1) / kc;
                 if (nch > 1) sums.push_back(LauumSum{ti, tj, q, np, nch});
                 for (int c = 0; c < nch; ++c) {
-                    const int len = (c + 1 < nch) ? LAUUM_KC : K - c * LAUUM_KC;
-                    items.push_back(LauumItem{ti, tj, q, k0 + c * LAUUM_KC, len, nch > 1 ? np++ : -1});
+                    const int len = (c + 1 < nch) ? kc : K - c * kc;
+                    items.push_back(LauumItem{ti, tj, q, k0 + c * kc, len, nch > 1 ? np++ : -1});
                 }
             }
     std::stable_sort(items.begin(), items.end(), [](const LauumItem& a, const LauumItem& b) { return a.klen > b.klen; });

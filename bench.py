@@ -336,7 +336,7 @@ def run_child(argv, timeout, env=None, single=True):
 
 C2_KEEP = ("ms_per_step", "step_ms", "value", "unit", "steps", "warmup", "config", "stage_ms", "iteration_tflops", "stage_sum_frac_of_fp64_peak",
            "iteration_frac_of_fp64_peak", "cholesky_gflops", "cholesky_frac_of_fp64_peak", "roofline", "roofline_k_lauum",
-           "families", "parity_checked", "parity", "cpu_baseline", "host_path", "lml", "leg_wall_s", "error")
+           "families", "parity_checked", "parity", "cpu_baseline", "host_path", "lml", "leg_wall_s", "error", "small_n_schedule", "persist_aborts")
 
 
 def c2_leg(comm, args):
@@ -540,13 +540,22 @@ def main():
         # overlapped-inverse threshold they replay the factorisation from a hipGraph, which carries no timing events)
         step_abi(want_stage_ms=True)
         st = last["r"]["stage_ms"]
+        aborts_timed = ctx.get_option("persist_aborts")       # persistent launches called off / aborted so far (each redone on launches)
         # roofline leg: the same step once more with hipEvent pairs around every k_update_nt / k_lauum launch (the timed
         # region above runs without them: ~2 us per bracketed launch)
-        ctx.set_option("profile", 1)
-        step_abi()
-        step_abi()
-        pf = ctx.get_profile()
-        ctx.set_option("profile", 0)
+        for attempt in range(2):
+            before = ctx.get_option("persist_aborts")
+            ctx.set_option("profile", 1)
+            step_abi()
+            step_abi()
+            pf = ctx.get_profile()
+            ctx.set_option("profile", 0)
+            if ctx.get_option("persist_aborts") == before:
+                break
+            # a persistent launch was called off at its co-residency gate inside the bracketed steps (redone on launches inside the
+            # same call): the context stays on launches for PS_SKIP_AFTER_CLEAN evaluations -- sit them out, bracket again
+            for _ in range(ctx.get_option("persist_skip") if ctx.get_option("persist_skip") < 64 else 0):
+                step_abi()
         # every bracketed kernel family of ONE evaluation: summed launch ms, launches, algorithmic flops (the chain kernels
         # k_diag128 / k_trsm128 run on the panel stream underneath the updates: their sum is not wall time)
         families = {k: {"ms": round(v[0], 4), "launches": v[2], "flops": v[1],
@@ -611,6 +620,7 @@ def main():
         }
         if per_step:
             out["step_ms"] = per_step
+        out["persist_aborts"] = {"timed_steps": aborts_timed, "profile_steps": ctx.get_option("persist_aborts") - aborts_timed}
         if N <= 128 * 36:
             # which schedule of a small factorisation the context's own timing settled on (boxes differ by 2x on the persistent
             # launch): the timed steps above ran on it

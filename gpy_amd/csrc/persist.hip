@@ -907,12 +907,14 @@ bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, lo
     const int nt = (int)(npad / NB);
     const long grid = persist_grid_for(npad, ws);
     if (grid < 2) return false;
+    // (the bracket of a profiled launch opens HERE, in front of the two memsets: a timing event between ev_persist_pre and the
+    //  launch lets the side stream's one-thread gate kernel reach a CU before the launch's workgroups do, and the launch is then
+    //  called off at its co-residency gate nearly every time -- tools/bracket_calloff_probe.py: 11 of 12 eligible launches)
+    ws->prof.begin(st, PF_PERSIST, (double)npad * npad * npad / 3.0);
     (void)hipMemsetAsync(ws->info, 0, sizeof(int) * 4, st);
     (void)hipMemsetAsync(ws->persist_sync, 0, sizeof(int) * PS_SYNC_INTS, st);
     if (ws->ev_persist_pre) (void)hipEventRecord(ws->ev_persist_pre, st);   // "the progress words of THIS launch are zeroed"
     ws->persist_grid_last = (int)grid;
-    const double flops = (double)npad * npad * npad / 3.0;
-    ws->prof.begin(st, PF_PERSIST, flops);
     hipLaunchKernelGGL(k_potrf_persist, dim3((unsigned)grid), dim3(64 * PS_CHAIN_WAVES), PS_LDS_BYTES, st, A, npad, nt, ws->dinv, ws->logsum,
                        ws->info, ws->persist_sync, ws->persist_kcap, ws->persist_hs, dbg, ws->persist_test, ws->persist_tune);
     ws->persist_test = 0;

@@ -156,6 +156,8 @@ def lib():
     L.mi355gp_dbg_graph_factor.argtypes = [ci, i64, ci, _dp]
     L.mi355gp_dbg_gemm_clock.argtypes = [_c_dp, _c_dp]
     L.mi355gp_dbg_mask_probe.argtypes = [ci, ci, ci, _dp]
+    L.mi355gp_dbg_lauum_plan.argtypes = [ci, ctypes.POINTER(ci), ci, ctypes.POINTER(ci)]
+    L.mi355gp_dbg_lauum_plan.restype = ci
     L.mi355gp_dbg_persist.argtypes = [ci, i64, ci, ci, _dp]
     L.mi355gp_dbg_ipc_selftest.argtypes = [ctypes.c_char_p, ci, ci, ci, ci, i64, _dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
@@ -189,7 +191,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share", "mi355gp_pdinv_full", "mi355gp_dbg_graph_factor",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe", "mi355gp_get_option",
             "mi355gp_sparse_get_profile", "mi355gp_dbg_persist", "mi355gp_dbg_grid_multi", "mi355gp_dbg_update_nt", "mi355gp_dbg_update_rect",
-            "mi355gp_dbg_ipc_selftest", "mi355gp_grid_coll_log")
+            "mi355gp_dbg_ipc_selftest", "mi355gp_grid_coll_log", "mi355gp_dbg_lauum_plan")
 
 
 # mi355gp_set_option / mi355gp_get_option ids (include/mi355gp.h, MI355GP_OPT_*)
@@ -701,3 +703,14 @@ def dbg_update_rect(ntr, ntc, ks, reps=5, device=0):
     out = np.zeros(len(ks))
     check(lib().mi355gp_dbg_update_rect(device, int(ntr), int(ntc), ka, len(ks), int(reps), out), "mi355gp_dbg_update_rect")
     return out
+
+
+def lauum_plan(nt):
+    """Host only: the X^T X work list for nt x nt tiles (gemm.hip): (items as an int array of rows (ti, tj, q, k0, klen, part),
+    number of partial tiles, edge of an item's output tile, longest chunk in rows)."""
+    out4 = (ctypes.c_int * 4)()
+    lib().mi355gp_dbg_lauum_plan(nt, None, 0, out4)
+    n = out4[0]
+    buf = (ctypes.c_int * (6 * max(n, 1)))()
+    check(lib().mi355gp_dbg_lauum_plan(nt, buf, n, out4), "mi355gp_dbg_lauum_plan")
+    return np.frombuffer(buf, dtype=np.int32, count=6 * n).reshape(n, 6).copy(), out4[1], out4[2], out4[3]

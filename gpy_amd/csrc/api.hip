@@ -1617,6 +1617,28 @@ int mi355gp_dbg_peaks(int device, double* out4) { return run_peaks(device, out4)
 
 int mi355gp_dbg_gemm_clock(double* mhz, double* cycles) { return gemm_last_clock(mhz, cycles); }
 
+// Host only: the X^T X work list of gemm.hip for nt x nt tiles (tests/test_host_logic.py checks that it covers every k range once).
+int mi355gp_dbg_lauum_plan(int nt, int* items_out, int max_items, int* out4) {
+    ARG_CHECK(nt >= 1 && nt <= 4096 && out4 && (items_out || max_items == 0), "mi355gp_dbg_lauum_plan: bad arguments");
+    std::vector<LauumItem> items;
+    std::vector<LauumSum> sums;
+    int nparts = 0;
+    lauum_split_plan(nt, items, sums, &nparts);
+    int longest = 0;
+    for (const LauumItem& it : items) longest = it.klen > longest ? it.klen : longest;
+    out4[0] = (int)items.size();
+    out4[1] = nparts;
+    out4[2] = lauum_split_tile(nt);
+    out4[3] = longest;
+    if ((int)items.size() > max_items) return -1;
+    for (size_t i = 0; i < items.size(); ++i) {
+        const LauumItem& it = items[i];
+        const int row[6] = {it.ti, it.tj, it.q, it.k0, it.klen, it.part};
+        for (int j = 0; j < 6; ++j) items_out[6 * i + j] = row[j];
+    }
+    return 0;
+}
+
 // Diagnostics: is a CU mask in force on a stream created with hipExtStreamCreateWithCUMask?  Times the same 4096^3 GEMM
 // on a plain stream and on a stream masked to pct % of every XCD's CUs.  order: 0 = masked stream created first,
 // 1 = plain stream first, 2 = four plain + three high-priority streams first (what a context has when it builds its

@@ -61,6 +61,10 @@ int mi355gp_dbg_graph_factor(int device, int64_t N, int reps, double* out3);
  * then for tile row i and d = i - k in 0..2 (the near tiles): out[8 + 8 nt + 4 (3 i + d) + q], q = 0 last task picked, 1 computed,
  * 2 published.  kcap: columns a worker applies per pass (0 = default).  out: 8 + 20 ceil(N / 128) doubles. */
 int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out);
+/* Host only (no GPU call): the work list of X^T X for an nt x nt tile matrix as gemm.hip plans it.
+ * items: up to max_items rows of 6 ints (ti, tj, q, k0, klen, part); out4 = number of items, number of partial tiles, edge of an
+ * item's output tile (64 or 128), longest chunk in rows.  Returns 0, or -1 if max_items is too small (out4[0] still set). */
+int mi355gp_dbg_lauum_plan(int nt, int* items, int max_items, int* out4);
 /* diagnostics: is a CU-masked stream really confined?  out3 = ms of a 4096^3 GEMM on [plain, masked, masked] streams */
 int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3);
 

@@ -352,3 +352,36 @@ def test_bench_line_stays_under_the_drivers_tail():
         assert k in rec, k
     assert list(rec)[-1] == "legs_ms" and set(rec["legs_ms"]) == {"c2", "grid", "c5", "c4_single"}
     assert rec["cpu_baseline"]["value"] > 0 and rec["c2"]["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.parametrize("nt", [9, 16, 23, 24, 25, 32, 36, 44])
+def test_lauum_work_list_covers_every_k_range_exactly_once(nt):
+    """gemm.hip `lauum_split_plan` (host code, no GPU): W(ti, tj) = sum over the tile rows k >= ti, cut into chunks.  Every output
+    tile (quadrant below nt = 24) must be covered by chunks that tile [128 ti, 128 nt) without gap or overlap, a single chunk
+    stores W itself (part = -1), several chunks store consecutive partials, items come longest first, and from nt = 24 the
+    chunk length is the packing model's pick: a multiple of 128 rows."""
+    from gpy_amd import _lib as L
+    items, nparts, edge, longest = L.lauum_plan(nt)
+    assert edge == (128 if nt >= 24 else 64) and longest % 128 == 0 and 0 < longest <= 128 * nt
+    assert list(items[:, 4]) == sorted(items[:, 4], reverse=True)
+    groups = {}
+    for ti, tj, q, k0, klen, part in items:
+        groups.setdefault((ti, tj, q if edge == 64 else 0), []).append((k0, klen, part))
+    nq = 4 if edge == 64 else 1
+    assert len(groups) == nq * nt * (nt + 1) // 2
+    parts_seen = []
+    for (ti, tj, q), chunks in groups.items():
+        assert 0 <= tj <= ti < nt
+        chunks.sort()
+        pos = 128 * ti
+        for k0, klen, part in chunks:
+            assert k0 == pos and klen > 0 and klen % 128 == 0 and klen <= longest
+            pos += klen
+        assert pos == 128 * nt
+        if len(chunks) == 1:
+            assert chunks[0][2] == -1
+        else:
+            ps = [c[2] for c in chunks]
+            assert ps == list(range(ps[0], ps[0] + len(ps))) and ps[0] >= 0      # summed in chunk order
+            parts_seen += ps
+    assert sorted(parts_seen) == list(range(nparts))

@@ -448,7 +448,10 @@ void lauum_split_plan(int nt, std::vector<LauumItem>& items, std::vector<LauumSu
     sums.clear();
     int np = 0;
     const int nq = lauum_split_tile(nt) == 128 ? 1 : 4;       // whole tiles (q = -1 in spirit: q is ignored) or quadrants
-    const int kc = (nq == 1) ? lauum_kc_rows_128(nt) : LAUUM_KC;
+    // quadrant items: 512 rows up to nt = 16, 1024 above (tools/lauum_kc64_probe.sh: N=1536 0.064 -> 0.051 ms, N=2048 0.091 -> 0.085;
+    // N=2560 / 2944 are fastest at 1024); MI355GP_LAUUM_KC64 (rows) overrides
+    static const int kc64 = env_int("MI355GP_LAUUM_KC64", 0) / NB * NB;
+    const int kc = (nq == 1) ? lauum_kc_rows_128(nt) : (kc64 >= NB ? kc64 : (nt <= 16 ? 512 : LAUUM_KC));
     for (int ti = 0; ti < nt; ++ti)
         for (int tj = 0; tj <= ti; ++tj)
             for (int q = 0; q < nq; ++q) {

@@ -45,8 +45,13 @@ WORKLOAD = dict(kind="matern52", ARD=True, N=16384, D=32, Dy=1)
 
 
 class Comm(object):
-    """Rank plumbing for the bracketing barriers and the MAX-over-ranks (torch.distributed; RCCL when CUDA
-    tensors are available, gloo otherwise).  Not on the data path."""
+    """Rank plumbing for the bracketing barriers and the MAX-over-ranks.  Not on the data path.
+
+    Default for world > 1: torch.distributed over GLOO with CPU tensors, and NO torch.cuda call anywhere in the process -- the
+    library binds RCCL itself (dlopen, csrc/grid.hip) for the grid / sparse legs, and a process that also held PyTorch's own RCCL
+    communicator and torch.cuda contexts would be a combination nothing has ever executed.  The device fence
+    of the bracket is hipDeviceSynchronize through the library (mi355gp_device_synchronize).  MI355GP_BENCH_BACKEND=nccl opts
+    into the rank plumbing over torch's NCCL (= RCCL) backend with CUDA tensors instead."""
 
     def __init__(self, backend=None):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -54,22 +59,24 @@ class Comm(object):
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
         self.dist = None
         self.device_tensor = False
+        self.backend = None
+        self._sync = None
         if self.world > 1:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if backend is None:
-                # MI355GP_BENCH_BACKEND=gloo: rank plumbing over gloo (a dry run of the multi-rank flow on a box with fewer
-                # GPUs than ranks: ranks then share devices, local_rank is taken modulo the visible device count)
-                backend = os.environ.get("MI355GP_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+                backend = os.environ.get("MI355GP_BENCH_BACKEND") or "gloo"
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device_tensor = True
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
             self.dist = dist
             self.torch = torch
-            if backend != "nccl" and os.environ.get("MI355GP_BENCH_BACKEND"):
+            self.backend = backend
+            if os.environ.get("MI355GP_TRANSPORT") == "ipc":
+                # dry run on a box with fewer GPUs than ranks (tools/multiproc_dryrun.sh): ranks share devices
                 try:
                     from gpy_amd import _lib as _L
                     self.local_rank %= max(1, _L.device_count())
@@ -77,8 +84,17 @@ class Comm(object):
                     pass
 
     def _sync_device(self):
-        if self.dist is not None and self.device_tensor:
+        if self.device_tensor:
             self.torch.cuda.synchronize()
+            return
+        if self._sync is None:
+            try:
+                from gpy_amd import _lib as _L
+                self._sync = _L.device_synchronize if _L.device_count() > self.local_rank else False
+            except Exception:
+                self._sync = False
+        if self._sync:
+            self._sync(self.local_rank)
 
     def barrier(self):
         self._sync_device()
@@ -93,6 +109,16 @@ class Comm(object):
                               device="cuda" if self.device_tensor else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather(self, values):
+        """[values of rank 0, values of rank 1, ...] (lists of floats of equal length) on every rank."""
+        vals = [float(v) for v in values]
+        if self.dist is None:
+            return [vals]
+        t = self.torch.tensor(vals, dtype=self.torch.float64, device="cuda" if self.device_tensor else "cpu")
+        outs = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return [[float(x) for x in o.cpu().tolist()] for o in outs]
 
     def close(self):
         if self.dist is not None:
@@ -192,6 +218,35 @@ def cpu_baseline(kind, ARD, D, n_small, n_full, full=False, fit=True):
     committed = committed_cpu_record(kind, ARD, D, n_full)
     if committed:
         rec["committed_full_size"] = committed
+    return rec
+
+
+REFERENCE_RATIO_FILE = "profiles/r3_cpu_baseline_reference_cached.json"
+
+
+def reference_ratio(kind, ARD, D, N):
+    """port_cached / reference_cached seconds of the committed same-host comparison (tools/cpu_reference_vs_port.py on the build
+    container, where /root/reference exists; the GPU box has no reference tree, so `cpu_baseline.kind` is "port"): how much the
+    port UNDERSTATES the reference's own time for this configuration.  None when the configuration was not compared."""
+    try:
+        for rec in json.load(open(os.path.join(ROOT, REFERENCE_RATIO_FILE))).get("records", []):
+            if (rec.get("kind"), bool(rec.get("ARD")), rec.get("D"), rec.get("N")) == (kind, bool(ARD), D, N):
+                sec = rec["seconds"]
+                return round(sec["port_cached"] / sec["reference_cached"], 3)
+    except Exception:
+        pass
+    return None
+
+
+def annotate_baseline(rec, gpu_value, kind, ARD, D, N):
+    """What the CPU baseline is and is not: `speedup` = GPU value / the PORT's value on `cores` BLAS threads
+    (reported, not credit); `reference_ratio` = the port's time / the reference's own time on one host (committed file)."""
+    if isinstance(rec, dict) and rec.get("value"):
+        rec["speedup"] = gpu_value / rec["value"]
+        r = reference_ratio(kind, ARD, D, N)
+        if r is not None:
+            rec["reference_ratio"] = r
+            rec["reference_ratio_source"] = REFERENCE_RATIO_FILE
     return rec
 
 
@@ -372,23 +427,39 @@ def sparse_leg(comm, args, timeout=300.0):
     return rec
 
 
-def grid_leg(comm, args, timeout=180.0):
-    """BASELINE configs[3] (RBF, N=32768, D=8) on the 2D block-cyclic grid over ALL ranks of this launch
-    (grid_shape(world); loopback transport when there is one process), run in CHILD processes with a timeout so that a
-    fault of the never-before-timed multi-GPU path cannot take the headline line down.  Returns the sub-record (rank 0)."""
+GRID_LEGS = {
+    # name: (N, D, kind, iso, steps, warmup, MASTER_PORT offset of the children's own process group)
+    "grid":    (None, 8, "rbf", True, 3, 1, 17),               # BASELINE configs[3]: N = --grid-n (32768)
+    "grid16k": (16384, 32, "matern52", False, 4, 1, 19),       # the headline problem (configs[2]) strong-scaled over the launch
+    "grid4k":  (4096, 8, "rbf", True, 10, 2, 23),              # configs[1] strong-scaled over the launch
+}
+
+
+def grid_leg(comm, args, name="grid", timeout=180.0):
+    """One strong-scaling leg: ONE problem on the 2D block-cyclic grid over ALL ranks of this launch (grid_shape(world);
+    loopback transport when there is one process), run in CHILD processes with a timeout so that a fault of the
+    never-before-timed multi-GPU path cannot take the headline line down.  north_star asks for N in {4k, 16k, 32k} at 1/2/4/8
+    GPUs: "grid" is BASELINE configs[3] (RBF, N=32768, D=8), "grid16k" the headline problem (configs[2]: Matern-5/2 ARD, D=32),
+    "grid4k" configs[1]; each checks its result against the golden of that configuration.  Returns the sub-record (rank 0)."""
     import subprocess
     from gpy_amd import grid as G
+    N, D, kind, iso, steps, warmup, port = GRID_LEGS[name]
+    N = args.grid_n if N is None else (N if not args.dry_run_sizes else min(N, args.grid_n))
+    if args.dry_run_sizes:
+        steps, warmup = 2, 1
     # one GPU: the 2 x 4 grid of configs[3] as LOGICAL ranks over the loopback transport -- the block-cyclic code itself
     # (tiles, panel broadcasts as device copies, look-ahead streams), not the degenerate 1 x 1 grid
     Pr, Pc = G.grid_shape(comm.world) if comm.world > 1 else (2, 4)
-    out_path = os.path.join(ROOT, "gpurun_out", "grid_leg_%s_%d.json" % (os.environ.get("MASTER_PORT", "0"), os.getpid()))
+    out_path = os.path.join(ROOT, "gpurun_out", "%s_leg_%s_%d.json" % (name, os.environ.get("MASTER_PORT", "0"), os.getpid()))
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
-    env = child_env(17, MI355GP_GRID_LEG_OUT=out_path if comm.rank == 0 else "")
-    cmd = [sys.executable, os.path.abspath(__file__), "--grid", "%dx%d" % (Pr, Pc), "--n", str(args.grid_n), "--d", "8",
-           "--kind", "rbf", "--iso", "--steps", "3", "--warmup", "1", "--nb", str(args.nb), "--grid-child"]
-    rec = {"workload": "RBF iso exact GP N=%d D=8, one parameters_changed on a %dx%d block-cyclic grid (%s)" % (
-        args.grid_n, Pr, Pc, "RCCL, one rank per GPU" if comm.world > 1 else "8 logical ranks time-sharing ONE GPU over the "
-        "loopback transport: the per-rank code path of the multi-GPU mode, no xGMI")}
+    env = child_env(port, MI355GP_GRID_LEG_OUT=out_path if comm.rank == 0 else "")
+    cmd = [sys.executable, os.path.abspath(__file__), "--grid", "%dx%d" % (Pr, Pc), "--n", str(N), "--d", str(D),
+           "--kind", kind, "--steps", str(steps), "--warmup", str(warmup), "--nb", str(args.nb), "--grid-child"]
+    if iso:
+        cmd.append("--iso")
+    rec = {"workload": "%s %s exact GP N=%d D=%d, one parameters_changed on a %dx%d block-cyclic grid (%s)" % (
+        kind, "iso" if iso else "ARD", N, D, Pr, Pc, "RCCL, one rank per GPU" if comm.world > 1 else
+        "8 logical ranks time-sharing ONE GPU over the loopback transport: the per-rank code path of the multi-GPU mode, no xGMI")}
     if comm.world == 1:
         cmd += ["--device", str(comm.local_rank)]
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -442,7 +513,7 @@ def compact_line(out):
     except OSError:
         pass
     line = {}
-    legs = ("c2", "grid", "c5", "c4_single")
+    legs = ("c2", "grid", "grid16k", "grid4k", "c5", "c4_single")
     for k, v in out.items():
         if k in legs:
             continue
@@ -657,6 +728,10 @@ def main():
         out["parity_checked"] = parity is not None
         if parity is not None:
             out["parity"] = {"gate": parity}
+            if not args.no_legs:
+                # the N=32768 legs (grid, c4_single) compare with a golden the reference itself could not produce here (its pdinv
+                # needs ~8 live N^2 temporaries; OpenBLAS dpotrf segfaults at this size in the image): a two-hop pin
+                out["parity"]["c4_golden_source"] = "lean oracle, pinned to gp_oracle (tests/test_oracle_baseline.py), which is pinned to the reference"
             if not args.abi_only:
                 g = golden_check(args.kind, ARD, N, D, 0, last["lml"], m.posterior.woodbury_vector, last["grad"])
                 if g is not None:
@@ -669,10 +744,12 @@ def main():
             out["c2"] = c2_leg(comm, args)                    # configs[1], one GPU
         comm.barrier()
     if not args.no_grid_leg:
-        comm.barrier()
-        rec = grid_leg(comm, args, timeout=240.0)
-        if out is not None:
-            out["grid"] = rec
+        # strong scaling of ONE problem over all ranks of the launch, N in {32768, 16384, 4096} (north_star)
+        for name, tmo in (("grid", 240.0), ("grid16k", 180.0), ("grid4k", 120.0)):
+            comm.barrier()
+            rec = grid_leg(comm, args, name, timeout=tmo)
+            if out is not None:
+                out[name] = rec
     if not args.no_legs:
         comm.barrier()
         rec = sparse_leg(comm, args)                          # configs[4], rows sharded over all ranks of the launch
@@ -686,11 +763,16 @@ def main():
     if comm.rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             # the CPU baselines, one after the other, after every GPU leg has ended (nothing else of this run uses the host)
-            out["cpu_baseline"] = timed_baseline(lambda: cpu_baseline(args.kind, ARD, D, min(args.cpu_sample_n, N // 2), N,
-                                                                       full=not args.cpu_fit_only, fit=False))
+            out["cpu_baseline"] = annotate_baseline(timed_baseline(lambda: cpu_baseline(
+                args.kind, ARD, D, min(args.cpu_sample_n, N // 2), N, full=not args.cpu_fit_only, fit=False)), out["value"], args.kind, ARD, D, N)
+            # vs_baseline stays null: BASELINE.md holds no published number for this metric.  The ratio to the CPU baseline is
+            # cpu_baseline.speedup -- against the PORT on cpu_baseline.cores BLAS threads; the reference's own code takes
+            # 1 / cpu_baseline.reference_ratio times as long on one host.
+            out["vs_baseline_why"] = "no published number; see cpu_baseline.speedup (vs port) and .reference_ratio"
             if not args.no_legs:
                 if isinstance(out.get("c2"), dict) and "error" not in out["c2"]:
-                    out["c2"]["cpu_baseline"] = timed_baseline(lambda: cpu_baseline("rbf", False, 8, 2048, 4096, full=True, fit=False))
+                    out["c2"]["cpu_baseline"] = annotate_baseline(timed_baseline(lambda: cpu_baseline(
+                        "rbf", False, 8, 2048, 4096, full=True, fit=False)), out["c2"].get("value", 0.0), "rbf", False, 8, 4096)
                 if isinstance(out.get("c5"), dict) and "error" not in out["c5"]:
                     out["c5"]["cpu_baseline"] = timed_baseline(lambda: sparse_cpu_baseline(16, args.m, 200000))
         if args.dry_run_sizes:
@@ -856,6 +938,8 @@ def main_grid(args):
         last["r"] = r
 
     dt = timed_region(comm, step, args.steps, args.warmup)
+    stage_keys = ("kbuild", "factor", "solve", "grad", "total")
+    per_rank = comm.gather([last["r"]["stage_ms"][k] for k in stage_keys])     # where a real node's ranks differ
     transport = "loopback" if g.is_loopback else ("hipIpc (ranks = processes sharing a GPU)" if os.environ.get("MI355GP_TRANSPORT") == "ipc"
                                                   else "RCCL")
     if comm.rank == 0:
@@ -876,6 +960,9 @@ def main_grid(args):
             "stage_ms": {k: round(float(v), 4) for k, v in r["stage_ms"].items()},
             "comm_bytes_per_step": traffic, "lml": r["lml"],
         }
+        if len(per_rank) > 1:                                 # [min, max] over the ranks of the launch, per stage
+            out["stage_ms_rank_min_max"] = {k: [round(min(p[i] for p in per_rank), 3), round(max(p[i] for p in per_rank), 3)]
+                                            for i, k in enumerate(stage_keys)}
         gc = golden_check(args.kind, ARD, N, D, 0, r["lml"], r["alpha"],
                           np.concatenate([r["dtheta"], [r["dnoise"]]]))
         if gc is not None:
@@ -883,7 +970,7 @@ def main_grid(args):
         leg = os.environ.get("MI355GP_GRID_LEG_OUT", "")
         if leg:                                               # child of the default bench: hand the sub-record back
             keep = ("ms_per_step", "value", "n_gpus", "scaling", "iteration_tflops", "iteration_frac_of_fp64_peak",
-                    "stage_ms", "comm_bytes_per_step", "lml", "parity_vs_golden", "steps", "warmup")
+                    "stage_ms", "stage_ms_rank_min_max", "comm_bytes_per_step", "lml", "parity_vs_golden", "steps", "warmup")
             sub = {k: out[k] for k in keep if k in out}
             sub.update(grid="%dx%d" % (Pr, Pc), nb=args.nb, transport=transport, N=N)
             with open(leg, "w") as f:

@@ -61,19 +61,25 @@ class MI355GPError(RuntimeError):
     pass
 
 
+DIAG_LIB_PATH = os.path.join(_HERE, "libmi355gp_diag.so")
+
+
 def build(force=False):
-    """Compile every HIP translation unit for gfx950 and link libmi355gp.so in-tree (make -C gpy_amd/csrc)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    """Compile every HIP translation unit for gfx950 and link, in-tree (make -C gpy_amd/csrc): libmi355gp.so, the product, and
+    libmi355gp_diag.so, the same sources with -DMI355GP_DIAG (schedule overrides, fault injectors and bounding experiments that
+    the product build compiles out; loaded only by the tests / tools that ask for it through MI355GP_LIB)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile"]
     srcs.append(os.path.join(_HERE, "..", "include", "mi355gp.h"))
     srcs.append(os.path.join(_HERE, "..", "include", "mi355gp_debug.h"))
-    if not force and os.path.exists(LIB_PATH):
-        t = os.path.getmtime(LIB_PATH)
+    product = os.path.join(_HERE, "libmi355gp.so")
+    if not force and os.path.exists(product) and os.path.exists(DIAG_LIB_PATH):
+        t = min(os.path.getmtime(product), os.path.getmtime(DIAG_LIB_PATH))
         if all(os.path.getmtime(s) <= t for s in srcs if os.path.exists(s)):
-            return LIB_PATH
-    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
-    if r.returncode != 0 or not os.path.exists(LIB_PATH):
+            return product
+    r = subprocess.run(["make", "-C", CSRC, "-j8", "all", "diag"], capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(product) or not os.path.exists(DIAG_LIB_PATH):
         raise MI355GPError("building libmi355gp.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
-    return LIB_PATH
+    return product
 
 
 _dp = ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -96,6 +102,7 @@ def lib():
     L.mi355gp_last_error.restype = ctypes.c_char_p
     L.mi355gp_version.restype = ctypes.c_char_p
     L.mi355gp_device_count.argtypes = [ctypes.POINTER(ci)]
+    L.mi355gp_device_synchronize.argtypes = [ci]
     L.mi355gp_create.argtypes = [ci, ctypes.POINTER(vp)]
     L.mi355gp_destroy.argtypes = [vp]
     L.mi355gp_set_data.argtypes = [vp, _dp, i64, ci, _dp, ci]
@@ -176,7 +183,7 @@ def lib():
     return L
 
 
-EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi355gp_create", "mi355gp_destroy",
+EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi355gp_device_synchronize", "mi355gp_create", "mi355gp_destroy",
             "mi355gp_set_data", "mi355gp_set_targets", "mi355gp_kern_K", "mi355gp_kern_Kdiag",
             "mi355gp_update_gradients_full", "mi355gp_exact_inference", "mi355gp_inference_given_K",
             "mi355gp_fetch", "mi355gp_predict", "mi355gp_potrf", "mi355gp_pdinv", "mi355gp_bench_factor",
@@ -215,6 +222,12 @@ def device_count():
     n = ctypes.c_int(0)
     lib().mi355gp_device_count(ctypes.byref(n))
     return n.value
+
+
+def device_synchronize(device=0):
+    """hipDeviceSynchronize through the library (no second HIP runtime user in the process)."""
+    require_device(device)
+    check(lib().mi355gp_device_synchronize(int(device)), "mi355gp_device_synchronize")
 
 
 def require_device(device=0):

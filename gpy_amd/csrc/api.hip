@@ -148,6 +148,12 @@ extern "C" {
 const char* mi355gp_last_error(void) { return g_err.c_str(); }
 const char* mi355gp_version(void) { return "mi355gp 0.1 (gfx950)"; }
 
+int mi355gp_device_synchronize(int device) {
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
 int mi355gp_device_count(int* count) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -173,7 +179,7 @@ int mi355gp_create(int device, mi355gp_ctx** out) {
     if (factor_engine(device, &c->st, nullptr, nullptr) != 0) return -2;    // the device's shared main stream (factor.hip)
     for (auto& e : c->ev) HIP_CHECK(hipEventCreate(&e));
     {
-        const char* e = getenv("MI355GP_GRAPH");
+        const char* e = PRODUCT_ENV("GRAPH");
         if (e && *e) c->graph_enabled = atoi(e) ? 1 : 0;
     }
     *out = c;
@@ -215,7 +221,7 @@ int mi355gp_set_data(mi355gp_ctx* c, const double* X, int64_t N, int D, const do
     c->ws.can_calibrate = 1;
     {
         const int lookahead = c->ws.lookahead;
-        const char* e = getenv("MI355GP_GRAPH");
+        const char* e = PRODUCT_ENV("GRAPH");
         c->graph_enabled = (e && *e) ? (atoi(e) ? 1 : 0) : 1;
         apply_options(c);
         if (c->opt[MI355GP_OPT_LOOKAHEAD] == INT_MIN) c->ws.lookahead = lookahead;
@@ -883,7 +889,7 @@ static int dense_factor(int device, const double* A_host, int64_t N, bool invert
     hipEvent_t e0 = guard.e0, e1 = guard.e1;
     HIP_CHECK(hipMemcpy(tmp, A_host, sizeof(double) * N * N, hipMemcpyHostToDevice));
     {
-        const char* et = getenv("MI355GP_DENSE_PERSIST_TEST");   // fault injection for the tests (see MI355GP_OPT_PERSIST_TEST)
+        const char* et = DIAG_ENV("DENSE_PERSIST_TEST");   // fault injection for the tests (see MI355GP_OPT_PERSIST_TEST)
         if (et && *et) ws.persist_test = atoi(et);
     }
     int info = 0;
@@ -1196,6 +1202,12 @@ int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
         return 0;
     }
     if (option == MI355GP_OPT_PERSIST_TEST) {
+#ifndef MI355GP_DIAG
+        if (value != 0) {                  // the fault injectors exist in the diagnostics build only
+            mi355gp_set_error("mi355gp_set_option: MI355GP_OPT_PERSIST_TEST is a test hook of the diagnostics build (libmi355gp_diag.so)");
+            return -1;
+        }
+#endif
         c->ws.persist_test = value;
         if (value) c->ws.persist_skip = 0;
         drop_graph(c);
@@ -1215,23 +1227,26 @@ int mi355gp_set_option(mi355gp_ctx* c, int option, int value) {
     if (value < 0) {
         // back to the process default: re-read what factor_ws_alloc reads (only the fields of this option are touched)
         FactorWs d;
-        auto env = [](const char* n, int dflt) { const char* v = getenv(n); return (v && *v) ? atoi(v) : dflt; };
+#define env(name, dflt) diag_env_int(DIAG_ENV(name), dflt)
+#define penv(name, dflt) diag_env_int(PRODUCT_ENV(name), dflt)
         switch (option) {
             case MI355GP_OPT_LOOKAHEAD: c->ws.lookahead = d.lookahead; break;
-            case MI355GP_OPT_TRI_OVERLAP: c->ws.tri_overlap = env("MI355GP_TRI_OVERLAP", d.tri_overlap) ? 1 : 0; break;
-            case MI355GP_OPT_TRI_MIN_NT: c->ws.tri_min_nt = env("MI355GP_TRI_MIN_NT", d.tri_min_nt); break;
-            case MI355GP_OPT_TRI_H: c->ws.tri_h_override = env("MI355GP_TRI_H", d.tri_h_override); break;
-            case MI355GP_OPT_TRI_WGS: c->ws.tri_wgs = env("MI355GP_TRI_WGS", d.tri_wgs); break;
-            case MI355GP_OPT_TRI_HALF: c->ws.tri_half_ok = env("MI355GP_TRI_HALF", d.tri_half_ok) ? 1 : 0; break;
-            case MI355GP_OPT_PART1_ON_PANEL: c->ws.part1_on_panel = env("MI355GP_PART1_ON_PANEL", d.part1_on_panel) ? 1 : 0; break;
-            case MI355GP_OPT_NBO: c->ws.nbo_override = env("MI355GP_NBO", d.nbo_override); break;
-            case MI355GP_OPT_SOLVE_OVERLAP: c->ws.solve_overlap = env("MI355GP_SOLVE_OVERLAP", d.solve_overlap) ? 1 : 0; break;
-            case MI355GP_OPT_DIAG_EXCL_FIRST: c->ws.diag_excl_first = env("MI355GP_DIAG_EXCL_FIRST", d.diag_excl_first) ? 1 : 0; break;
-            case MI355GP_OPT_PERSIST: c->ws.persist = env("MI355GP_PERSIST", d.persist); break;
-            case MI355GP_OPT_AGG2: c->ws.agg2 = env("MI355GP_AGG2", d.agg2) ? 1 : 0; break;
-            case MI355GP_OPT_GRAPH: c->graph_enabled = env("MI355GP_GRAPH", 1) ? 1 : 0; break;
+            case MI355GP_OPT_TRI_OVERLAP: c->ws.tri_overlap = penv("TRI_OVERLAP", d.tri_overlap) ? 1 : 0; break;
+            case MI355GP_OPT_TRI_MIN_NT: c->ws.tri_min_nt = env("TRI_MIN_NT", d.tri_min_nt); break;
+            case MI355GP_OPT_TRI_H: c->ws.tri_h_override = env("TRI_H", d.tri_h_override); break;
+            case MI355GP_OPT_TRI_WGS: c->ws.tri_wgs = env("TRI_WGS", d.tri_wgs); break;
+            case MI355GP_OPT_TRI_HALF: c->ws.tri_half_ok = env("TRI_HALF", d.tri_half_ok) ? 1 : 0; break;
+            case MI355GP_OPT_PART1_ON_PANEL: c->ws.part1_on_panel = env("PART1_ON_PANEL", d.part1_on_panel) ? 1 : 0; break;
+            case MI355GP_OPT_NBO: c->ws.nbo_override = env("NBO", d.nbo_override); break;
+            case MI355GP_OPT_SOLVE_OVERLAP: c->ws.solve_overlap = env("SOLVE_OVERLAP", d.solve_overlap) ? 1 : 0; break;
+            case MI355GP_OPT_DIAG_EXCL_FIRST: c->ws.diag_excl_first = env("DIAG_EXCL_FIRST", d.diag_excl_first) ? 1 : 0; break;
+            case MI355GP_OPT_PERSIST: c->ws.persist = penv("PERSIST", d.persist); break;
+            case MI355GP_OPT_AGG2: c->ws.agg2 = env("AGG2", d.agg2) ? 1 : 0; break;
+            case MI355GP_OPT_GRAPH: c->graph_enabled = penv("GRAPH", 1) ? 1 : 0; break;
             default: break;
         }
+#undef env
+#undef penv
     }
     if (option == MI355GP_OPT_PERSIST) {  // an explicit choice ends the calibration by measurement, -1 re-opens it
         c->ws.persist_auto_off = 0;

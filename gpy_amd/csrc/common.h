@@ -54,3 +54,21 @@ void mi355gp_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int64_t round_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
+
+// ---- environment switches ----------------------------------------------------------------------------------------------
+// The PRODUCT library (libmi355gp.so) reads nine variables, all through PRODUCT_ENV: the transport of the multi-process
+// mode (TRANSPORT, IPC_HOST, IPC_TIMEOUT_S), the collective-sequence self-check of the grid mode (GRID_CHECK_SEQ) and five
+// schedule choices that give the SAME BITS either way (GRAPH, PERSIST, PERSIST_AUTO, TRI_OVERLAP, GRID_LOOKAHEAD).
+// Everything else -- the schedule overrides of the A/B tools under tools/, the fault injectors of
+// tests/test_gpu_persist_safety.py, the bounding experiments (one of which computes WRONG numbers by construction) -- goes
+// through DIAG_ENV and exists only in the diagnostics build (make -C gpy_amd/csrc diag -> libmi355gp_diag.so, -DMI355GP_DIAG);
+// in the product build the macro is a null pointer, the names are not in the binary and the code behind them is dead.
+// tests/test_abi.py counts the names in the shipped library.
+#include <cstdlib>
+#define PRODUCT_ENV(name) getenv("MI355GP_" name)
+#ifdef MI355GP_DIAG
+#define DIAG_ENV(name) getenv("MI355GP_" name)
+#else
+#define DIAG_ENV(name) ((const char*)nullptr)
+#endif
+static inline int diag_env_int(const char* v, int dflt) { return (v && *v) ? atoi(v) : dflt; }

@@ -74,7 +74,7 @@ int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_CHECK(hipStreamCreateWithFlags(&e.main, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithPriority(&e.panel, hipStreamNonBlocking, greatest));
-        const char* envc = getenv("MI355GP_TRI_CU_PCT");
+        const char* envc = DIAG_ENV("TRI_CU_PCT");
         e.tri_pct = (envc && *envc) ? atoi(envc) : 75;
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -83,7 +83,7 @@ int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t
             // XCD-balanced mask (logical CU i sits on XCD i % 8): the same share of every XCD's CUs
             const int per = ncu / nx, keep = (per * e.tri_pct + 50) / 100;
             std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-            const char* envm = getenv("MI355GP_TRI_MASK_MODE");
+            const char* envm = DIAG_ENV("TRI_MASK_MODE");
             const int mode = (envm && *envm) ? atoi(envm) : 0;
             for (int cu = 0; cu < ncu; ++cu) {
                 const int idx = cu / nx;                       // CU index inside its XCD
@@ -148,62 +148,64 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     HIP_CHECK(hipGetDevice(&dev));
     if (factor_engine(dev, nullptr, &ws->st_panel, &ws->st_tri, &ws->st_tri_half) != 0) return -1;    // shared, never destroyed by a workspace
     {
-        const char* envo = getenv("MI355GP_TRI_OVERLAP");
+        const char* envo = PRODUCT_ENV("TRI_OVERLAP");
         if (envo && *envo) ws->tri_overlap = atoi(envo) ? 1 : 0;
-        const char* envn2 = getenv("MI355GP_TRI_MIN_NT");
+        const char* envn2 = DIAG_ENV("TRI_MIN_NT");
         if (envn2 && *envn2) ws->tri_min_nt = atoi(envn2);
-        const char* envw2 = getenv("MI355GP_TRI_WGS");
+        const char* envw2 = DIAG_ENV("TRI_WGS");
         if (envw2 && *envw2) ws->tri_wgs = atoi(envw2);
         ws->tri_cu_pct = g_engine[dev].tri_pct > 0 && g_engine[dev].tri_pct <= 100 ? g_engine[dev].tri_pct : 75;
         HIP_CHECK(hipEventCreateWithFlags(&ws->ev_tri, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ws->ev_tri_lead, hipEventDisableTiming));
         HIP_CHECK(hipMalloc(&ws->tri_counter, sizeof(int) * 4));
-        const char* envh = getenv("MI355GP_TRI_H");
+        const char* envh = DIAG_ENV("TRI_H");
         if (envh && *envh) ws->tri_h_override = atoi(envh);
     }
-    const char* envp1 = getenv("MI355GP_PART1_ON_PANEL");
+    const char* envp1 = DIAG_ENV("PART1_ON_PANEL");
     if (envp1 && *envp1) ws->part1_on_panel = atoi(envp1) ? 1 : 0;
     ws->sched_state = ws->sched_force_steps = ws->persist_auto_off = 0;
     ws->evals_done = ws->early_pending = 0;
-    const char* envpa = getenv("MI355GP_PERSIST_AUTO");
+    const char* envpa = PRODUCT_ENV("PERSIST_AUTO");
     if (envpa && *envpa) ws->persist_auto = atoi(envpa) ? 1 : 0;
-    const char* envls = getenv("MI355GP_LAUUM_SPLIT");
+    const char* envls = DIAG_ENV("LAUUM_SPLIT");
     if (envls && *envls) ws->lauum_split = atoi(envls) > 0 ? atoi(envls) : 0;   // 1: on; n > 1: on up to n tiles per dimension
-    const char* envptri = getenv("MI355GP_PERSIST_TRI");
+    const char* envptri = DIAG_ENV("PERSIST_TRI");
     if (envptri && *envptri) ws->persist_tri = atoi(envptri) ? 1 : 0;
-    const char* envptn = getenv("MI355GP_PERSIST_TRI_MIN_NT");
+    const char* envptn = DIAG_ENV("PERSIST_TRI_MIN_NT");
     if (envptn && *envptn) ws->persist_tri_min_nt = atoi(envptn);
-    const char* envuq = getenv("MI355GP_DBG_UPD_QUEUE");
+#ifdef MI355GP_DIAG
+    const char* envuq = DIAG_ENV("DBG_UPD_QUEUE");
     if (envuq && *envuq && atoi(envuq)) {
         ws->upd_queue_probe = 1;
         HIP_CHECK(hipMalloc(&ws->upd_tasks, sizeof(UpdTask) * 64 + 64));
     }
-    const char* envag = getenv("MI355GP_AGG2");
+#endif
+    const char* envag = DIAG_ENV("AGG2");
     if (envag && *envag) ws->agg2 = atoi(envag) ? 1 : 0;
-    const char* envnbo = getenv("MI355GP_NBO");
+    const char* envnbo = DIAG_ENV("NBO");
     if (envnbo && *envnbo) ws->nbo_override = atoi(envnbo);
-    const char* envso = getenv("MI355GP_SOLVE_OVERLAP");
+    const char* envso = DIAG_ENV("SOLVE_OVERLAP");
     if (envso && *envso) ws->solve_overlap = atoi(envso) ? 1 : 0;
-    const char* envth = getenv("MI355GP_TRI_HALF");
+    const char* envth = DIAG_ENV("TRI_HALF");
     if (envth && *envth) ws->tri_half_ok = atoi(envth) ? 1 : 0;
-    const char* envps = getenv("MI355GP_PERSIST");
+    const char* envps = PRODUCT_ENV("PERSIST");
     if (envps && *envps) ws->persist = atoi(envps);
-    const char* envpm = getenv("MI355GP_PERSIST_MAX_NT");
+    const char* envpm = DIAG_ENV("PERSIST_MAX_NT");
     if (envpm && *envpm) ws->persist_max_nt = atoi(envpm);
-    const char* envpt = getenv("MI355GP_PERSIST_TUNE");
+    const char* envpt = DIAG_ENV("PERSIST_TUNE");
     if (envpt && *envpt) ws->persist_tune = atoi(envpt);
-    const char* envpk = getenv("MI355GP_PERSIST_KCAP");
+    const char* envpk = DIAG_ENV("PERSIST_KCAP");
     if (envpk && *envpk) ws->persist_kcap = atoi(envpk) > 0 ? atoi(envpk) : 1;
     {
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         ws->persist_cus = prop.multiProcessorCount;
-        const char* envpc = getenv("MI355GP_PERSIST_WGS");
+        const char* envpc = DIAG_ENV("PERSIST_WGS");
         if (envpc && *envpc && atoi(envpc) >= 2 && atoi(envpc) <= ws->persist_cus) ws->persist_cus = atoi(envpc);
         HIP_CHECK(hipMalloc(&ws->persist_sync, sizeof(int) * potrf_persist_sync_ints()));
         HIP_CHECK(hipMalloc(&ws->persist_hs, sizeof(double) * (size_t)(ws->nblk < 64 ? ws->nblk : 64) * NB * NB));
     }
-    const char* envx = getenv("MI355GP_DIAG_EXCL_FIRST");
+    const char* envx = DIAG_ENV("DIAG_EXCL_FIRST");
     if (envx && *envx) ws->diag_excl_first = atoi(envx) ? 1 : 0;
     HIP_CHECK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
     const size_t nouter = (size_t)(npad + NB - 1) / NB + 2;      // enough for the narrowest outer panel (nbo = 128)
@@ -429,7 +431,12 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     }
     ws->ovl_h = 0;
     ws->excl_first_ok = (ovl_h == 0 && ntl < ws->tri_min_nt) ? 1 : 0;   // small factorisations only (measured: N >= 8192 loses)
+#ifdef MI355GP_DIAG
     const bool uq = ws->upd_queue_probe && ws->upd_tasks && ws->part1_on_panel && ntl >= ws->tri_min_nt && !ws->agg2 && P <= 64;
+#else
+    const bool uq = false;                                      // (the bounding experiment of the diagnostics build)
+#endif
+#ifdef MI355GP_DIAG
     if (uq) {
         // bounding experiment (wrong results by construction): all part-2 updates as ONE resident launch with every dependence
         // ignored, on the main stream from the start; the panel stream runs chain + part 1 as always, minus its waits for part 2
@@ -445,6 +452,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
         launch_update_nt_queue(su, A, npad, ws->upd_tasks, (int)tasks.size(), counter, 512);
         ws->prof.end(su);
     }
+#endif
     for (long p = 0; p + 1 < P; ++p) {
         const long K0 = pcol(p), W = pcol(p + 1) - K0;
         (void)hipEventRecord(ws->ev_panel[p], sp);

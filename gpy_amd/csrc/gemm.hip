@@ -17,10 +17,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
+// tuning overrides of the A/B tools: diagnostics build only (common.h "environment switches")
+#define env_int(name, dflt) diag_env_int(DIAG_ENV(name), dflt)
 #define LB(NW) __launch_bounds__((NW) * 64, (NW) / 2)
 
 // ------------------------------------------------------------------------------------------------
@@ -89,7 +87,7 @@ __global__ __launch_bounds__(256) void k_update_nt64(double* __restrict__ C, lon
 
 // does a launch of this shape take the 64 x 64 tile kernel?  (profile family of the caller)
 bool update_nt_uses_64(int ntr, int ntc, int row0t, int col0t) {
-    static const int upd64_max = env_int("MI355GP_UPD64_MAX", GEMM_DEFAULT_UPD64_MAX);
+    static const int upd64_max = env_int("UPD64_MAX", GEMM_DEFAULT_UPD64_MAX);
     const int tri = (row0t == col0t && ntr == ntc) ? 1 : 0;
     const long nblocks = tri ? (long)ntr * (ntr + 1) / 2 : (long)ntr * ntc;
     return nblocks <= upd64_max;
@@ -113,6 +111,7 @@ void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long
                        ntc, row0t, col0t, tri, nblocks);
 }
 
+#ifdef MI355GP_DIAG   // diagnostics build only: WRONG RESULTS by construction, not in the product library
 // ---- bounding experiment for a persistent trailing updater (tools/upd_queue_probe.py) ------------------------------
 // ONE launch of 2 x CUs resident workgroups that drains the tile lists of ALL "part 2" updates of a factorisation from a single
 // atomic queue, as if every dependence were already satisfied: the same tile code as k_update_nt<4, true> on the same operands, so
@@ -149,6 +148,7 @@ void launch_update_nt_queue(hipStream_t st, double* A, long ld, const UpdTask* t
     LDS_OPT_IN(k_update_nt_queue);
     hipLaunchKernelGGL(k_update_nt_queue, dim3((unsigned)wgs), dim3(256), GT_LDS_BYTES, st, A, ld, tasks_dev, ntasks, counter);
 }
+#endif   // MI355GP_DIAG
 
 // ------------------------------------------------------------------------------------------------
 // Batched bottom-up triangular inverse (the dtrtri half of LAPACK dpotri, GPy/util/linalg.py:127-145).
@@ -298,7 +298,7 @@ void launch_trtri_level(hipStream_t st, const double* L, double* X, double* T, l
     if (nbt >= nt) return;
     const long nblocks = trtri_level_tiles(nt, nbt);
     if (nblocks <= 0) return;
-    static const int tri64_max = env_int("MI355GP_TRI64_MAX", GEMM_DEFAULT_TRI64_MAX);
+    static const int tri64_max = env_int("TRI64_MAX", GEMM_DEFAULT_TRI64_MAX);
     if (nblocks <= tri64_max) {
         if (stages & 1)
             hipLaunchKernelGGL((k_trtri_stage64<1>), dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, L, X, T, ld, nt, nbt);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_lauum64(const double* __restrict__ X, d
 // Measured against fixed lengths (tools/lauum_kc_probe.sh): the model's pick is the fastest or within 1 % of it at every size tried
 // (N=3072: 768 rows, 0.253 -> 0.236 ms; N=4096: 1536, 0.470 -> 0.455; N=4608: 2176, 0.655 at 1024 -> 0.607; N=5120: 0.848 -> 0.790).
 static int lauum_kc_rows_128(int nt) {
-    static const int forced = env_int("MI355GP_LAUUM_KC", 0);
+    static const int forced = env_int("LAUUM_KC", 0);
     if (forced >= NB) return forced / NB * NB;
     int best = LAUUM_KC;
     double best_us = 1e30;
@@ -450,7 +450,7 @@ void lauum_split_plan(int nt, std::vector<LauumItem>& items, std::vector<LauumSu
     const int nq = lauum_split_tile(nt) == 128 ? 1 : 4;       // whole tiles (q = -1 in spirit: q is ignored) or quadrants
     // quadrant items: 512 rows up to nt = 16, 1024 above (tools/lauum_kc64_probe.sh: N=1536 0.064 -> 0.051 ms, N=2048 0.091 -> 0.085;
     // N=2560 / 2944 are fastest at 1024); MI355GP_LAUUM_KC64 (rows) overrides
-    static const int kc64 = env_int("MI355GP_LAUUM_KC64", 0) / NB * NB;
+    static const int kc64 = env_int("LAUUM_KC64", 0) / NB * NB;
     const int kc = (nq == 1) ? lauum_kc_rows_128(nt) : (kc64 >= NB ? kc64 : (nt <= 16 ? 512 : LAUUM_KC));
     for (int ti = 0; ti < nt; ++ti)
         for (int tj = 0; tj <= ti; ++tj)
@@ -485,13 +485,13 @@ static void launch_lauum_t(hipStream_t st, long nblocks, const double* X, double
 }
 
 bool lauum_uses_64(int nt) {
-    static const int lauum64_max = env_int("MI355GP_LAUUM64_MAX", GEMM_DEFAULT_LAUUM64_MAX);
+    static const int lauum64_max = env_int("LAUUM64_MAX", GEMM_DEFAULT_LAUUM64_MAX);
     return (long)nt * (nt + 1) / 2 <= lauum64_max;
 }
 
 void launch_lauum(hipStream_t st, const double* X, double* W, long ld, int nt) {
     const long nblocks = (long)nt * (nt + 1) / 2;
-    static const int lauum64_max = env_int("MI355GP_LAUUM64_MAX", GEMM_DEFAULT_LAUUM64_MAX);
+    static const int lauum64_max = env_int("LAUUM64_MAX", GEMM_DEFAULT_LAUUM64_MAX);
     if (nblocks <= lauum64_max) {
         hipLaunchKernelGGL(k_lauum64, dim3((unsigned)(4 * nblocks)), dim3(256), GT64_LDS_BYTES, st, X, W, ld, nt);
         return;
@@ -637,9 +637,9 @@ __global__ LB(NW) void k_gemm_full(const double* __restrict__ A, long lda,
 template <bool AK, bool BK>
 static void launch_gemm_full(hipStream_t st, unsigned nblocks, const double* A, long lda, const double* B, long ldb,
                              double* C, long ldc, int K, int ntc, double alpha, double beta) {
-    static const int dbg_ld0 = env_int("MI355GP_DBG_LD0", 0), dbg_swz = env_int("MI355GP_DBG_SWZ", 0);
+    static const int dbg_ld0 = env_int("DBG_LD0", 0), dbg_swz = env_int("DBG_SWZ", 0);
     if (dbg_ld0) lda = ldb = 0;                           // every operand row aliases row 0: cache-resident loads
-    static const int dbg_1wg = env_int("MI355GP_DBG_1WG", 0);
+    static const int dbg_1wg = env_int("DBG_1WG", 0);
     const int swz = (dbg_swz && (ntc % 8 == 0) && ((nblocks / ntc) % 8 == 0)) ? 1 : 0;
     const size_t lds = dbg_1wg ? 100 * 1024 : GT_LDS_BYTES;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_full<AK, BK, 4>),

@@ -74,7 +74,7 @@ struct Rccl {
     bool load() {
         if (h) return true;
         {
-            const char* t = getenv("MI355GP_TRANSPORT");
+            const char* t = PRODUCT_ENV("TRANSPORT");
             if (t && strcmp(t, "ipc") == 0) {                // multi-process transport over hipIpc + shared memory (ipc_comm.hip)
                 GetUniqueId = ipcGetUniqueId;
                 CommInitRank = ipcCommInitRank;
@@ -515,16 +515,16 @@ struct mi355gp_grid {
 // process defaults of the schedule options: environment, else built-in
 static void grid_default_option(mi355gp_grid* g, int o) {
     if (o == MI355GP_GRID_OPT_LOOKAHEAD) {
-        const char* e = getenv("MI355GP_GRID_LOOKAHEAD");
+        const char* e = PRODUCT_ENV("GRID_LOOKAHEAD");
         g->lookahead = (e && *e) ? (atoi(e) ? 1 : 0) : 1;
     } else if (o == MI355GP_GRID_OPT_G) {
-        const char* e = getenv("MI355GP_GRID_G");
+        const char* e = DIAG_ENV("GRID_G");
         g->G = (e && *e && atoi(e) >= 1) ? atoi(e) : 1;
     } else if (o == MI355GP_GRID_OPT_GW) {
-        const char* e = getenv("MI355GP_GRID_GW");
+        const char* e = DIAG_ENV("GRID_GW");
         g->GW = (e && *e && atoi(e) >= 0) ? atoi(e) : 4;
     } else if (o == MI355GP_GRID_OPT_CHECK_SEQ) {
-        const char* e = getenv("MI355GP_GRID_CHECK_SEQ");
+        const char* e = PRODUCT_ENV("GRID_CHECK_SEQ");
         g->check_seq = (e && *e && atoi(e)) ? 1 : 0;
     }
 }
@@ -941,7 +941,7 @@ int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb,
     g->my_rank = rank;
     g->loopback = (id128 == nullptr);
     {
-        const char* envf = getenv("MI355GP_GRID_FORCE_GENERIC");
+        const char* envf = DIAG_ENV("GRID_FORCE_GENERIC");
         if (g->loopback && world == 1 && !(envf && atoi(envf))) {
             if (int rc = mi355gp_create(device, &g->single)) return rc;
             *out = g;

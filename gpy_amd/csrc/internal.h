@@ -11,7 +11,9 @@ bool update_nt_uses_64(int ntr, int ntc, int row0t, int col0t);   // which kerne
 // one "part 2" update of the blocked Cholesky as a task of the bounding experiment k_update_nt_queue: the lower triangle of
 // ntr x ntr tiles at A + c_off, panel P at A + p_off (K columns), ntiles = ntr (ntr + 1) / 2
 struct UpdTask { long c_off, p_off, ntiles; int K, ntr; };
+#ifdef MI355GP_DIAG
 void launch_update_nt_queue(hipStream_t st, double* A, long ld, const UpdTask* tasks_dev, int ntasks, int* counter, int wgs);
+#endif
 void launch_update_nt(hipStream_t st, double* C, long ldc, const double* A, long lda, const double* B, long ldb,
                       int K, int ntr, int ntc, int row0t, int col0t);
 // one bottom-up level of the batched triangular inverse: X21 = -X22 * (L21 * X11) for every block pair
@@ -99,7 +101,7 @@ struct FactorWs {
     double* lauum_part = nullptr;
     int persist_tri = 1;        // MI355GP_PERSIST_TRI: leading-block inverse + T21 on the side stream UNDERNEATH the persistent launch
     int persist_tri_min_nt = 16;    // ... for factorisations of at least this many tiles (MI355GP_PERSIST_TRI_MIN_NT)
-    int upd_queue_probe = 0;    // MI355GP_DBG_UPD_QUEUE=1 (diagnostic, WRONG RESULTS): every part-2 update of the look-ahead schedule from ONE
+    int upd_queue_probe = 0;    // diagnostics build, MI355GP_DBG_UPD_QUEUE=1 (WRONG RESULTS): every part-2 update of the look-ahead schedule from ONE
                                 // resident launch with all dependences ignored -- the bounding experiment of DESIGN.md 6f
     UpdTask* upd_tasks = nullptr;   // device copy of the task list (64 entries) + the queue counter behind it
     int part1_on_panel = 1;     // MI355GP_PART1_ON_PANEL: part 1 of a step on the panel stream (no cross-stream hop before the next chain)

@@ -184,9 +184,9 @@ ncclResult_t ipcCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int r
     w->world = nranks;
     w->rank = rank;
     {
-        const char* e = getenv("MI355GP_IPC_HOST");
+        const char* e = PRODUCT_ENV("IPC_HOST");
         w->host = e && atoi(e) != 0;
-        const char* t = getenv("MI355GP_IPC_TIMEOUT_S");
+        const char* t = PRODUCT_ENV("IPC_TIMEOUT_S");
         if (t && atof(t) > 0.0) w->timeout_s = atof(t);
     }
     w->ctl = (Ctl*)map_shm(w->name, sizeof(Ctl), false);
@@ -389,7 +389,7 @@ const char* ipcGetErrorString(ncclResult_t r) {
 // of everything received, out[2] / out[3] = this rank's number inside its row / column communicator.
 extern "C" int mi355gp_dbg_ipc_selftest(const void* id128, int rank, int world, int Pr, int Pc, int64_t count, double* out) {
     if (!id128 || !out || world != Pr * Pc || count <= 0) return -1;
-    const char* e = getenv("MI355GP_IPC_HOST");
+    const char* e = PRODUCT_ENV("IPC_HOST");
     const bool host = e && atoi(e) != 0;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));

@@ -815,7 +815,7 @@ int launch_grad_cols(hipStream_t st, KernParams kp, const double* Xt1, long ld1,
     const int tps = (ntr + nsplit - 1) / nsplit;
     nsplit = (ntr + tps - 1) / tps;
     const int nb = ntc * nsplit;
-    static const int use_mfma = [] { const char* e = getenv("MI355GP_GRAD_COLS_MFMA"); return (e && *e) ? atoi(e) : 1; }();
+    static const int use_mfma = [] { const char* e = DIAG_ENV("GRAD_COLS_MFMA"); return (e && *e) ? atoi(e) : 1; }();
     if (use_mfma) {
         if (kp.ard)
             hipLaunchKernelGGL((k_grad_cols_mfma<true>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg, rk, ntc,

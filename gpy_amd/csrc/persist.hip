@@ -833,7 +833,7 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
 // ---- host side --------------------------------------------------------------------------------------------------------
 int persist_box_verdict(int set) {
     static std::atomic<int> verdict{[] {                       // MI355GP_DBG_BOX_VERDICT: start from a verdict (tests)
-        const char* e = getenv("MI355GP_DBG_BOX_VERDICT");
+        const char* e = DIAG_ENV("DBG_BOX_VERDICT");
         return (e && *e) ? atoi(e) : -1;
     }()};
     if (set >= -1) verdict.store(set);

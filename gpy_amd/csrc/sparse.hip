@@ -502,12 +502,12 @@ int mi355gp_sparse_create(int device, mi355gp_sparse** out) {
     s->device = device;
     if (factor_engine(device, &s->st, nullptr, nullptr) != 0) return -2;    // the device's shared main stream
     {
-        const char* e = getenv("MI355GP_SPARSE_FUSE_COLS");
+        const char* e = DIAG_ENV("SPARSE_FUSE_COLS");
         if (e && *e) s->fuse_cols = atoi(e) ? 1 : 0;
     }
     for (auto& e : s->ev) HIP_CHECK(hipEventCreate(&e));
     {
-        const char* e = getenv("MI355GP_SPARSE_KMM_OVERLAP");
+        const char* e = DIAG_ENV("SPARSE_KMM_OVERLAP");
         if (e && *e) s->kmm_overlap = atoi(e) ? 1 : 0;
         HIP_CHECK(hipStreamCreateWithFlags(&s->st_kmm, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&s->ev_z, hipEventDisableTiming));
@@ -753,7 +753,7 @@ int mi355gp_vardtc_inference_sum(mi355gp_sparse* s, int nparts, const mi355gp_pa
     s->h_info[0] = s->h_info[1] = 0;
     int inject = 0;                                            // fault injection for the tests: 1 / 2 hit Kmm's launch, 11 / 12 B's
     {
-        const char* et = getenv("MI355GP_SPARSE_PERSIST_TEST");
+        const char* et = DIAG_ENV("SPARSE_PERSIST_TEST");
         if (et && *et) inject = atoi(et);
     }
     if (inject == 1 || inject == 2) s->ws.persist_test = inject, s->ws.persist_skip = 0;

@@ -71,6 +71,10 @@ enum {
 const char* mi355gp_last_error(void);
 const char* mi355gp_version(void);
 int mi355gp_device_count(int* count);
+/* hipDeviceSynchronize on `device`: everything the library has enqueued there is complete on return.  (Every compute entry
+   point already returns after its own stream has drained; this is the device-wide fence a timing harness brackets a region
+   with -- bench.py -- without importing a second HIP runtime user into the process.) */
+int mi355gp_device_synchronize(int device);
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int mi355gp_create(int device, mi355gp_ctx** ctx);

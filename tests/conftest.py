@@ -10,6 +10,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+DIAG_LIB = os.path.join(ROOT, "gpy_amd", "libmi355gp_diag.so")
+
+
+def diag_lib(fn):
+    """Run this test in a CHILD pytest process that loads the DIAGNOSTICS build of the library (libmi355gp_diag.so,
+    -DMI355GP_DIAG): the fault injectors and schedule overrides it drives are compiled out of the product library, which is
+    what every other test -- and this process -- loads.  The child runs exactly this test node with MI355GP_LIB pointing at
+    the diagnostics build; its failure output becomes this test's."""
+    import functools
+    import subprocess
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if os.environ.get("MI355GP_TEST_DIAG_CHILD") == "1":
+            return fn(*args, **kwargs)
+        assert os.path.exists(DIAG_LIB), "diagnostics build missing: make -C gpy_amd/csrc diag (or __graft_entry__.build())"
+        node = os.environ["PYTEST_CURRENT_TEST"].rsplit(" ", 1)[0]
+        r = subprocess.run([sys.executable, "-m", "pytest", node, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"], cwd=ROOT,
+                           env=dict(os.environ, MI355GP_LIB=DIAG_LIB, MI355GP_TEST_DIAG_CHILD="1"), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, "child pytest (diagnostics library) failed:\n" + r.stdout[-6000:] + r.stderr[-3000:]
+    return wrapper
 
 
 def pytest_configure(config):

@@ -31,6 +31,33 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.mi355gp_version()
 
 
+PRODUCT_ENV = {"MI355GP_TRANSPORT", "MI355GP_IPC_HOST", "MI355GP_IPC_TIMEOUT_S", "MI355GP_GRID_CHECK_SEQ", "MI355GP_GRAPH",
+               "MI355GP_PERSIST", "MI355GP_PERSIST_AUTO", "MI355GP_TRI_OVERLAP", "MI355GP_GRID_LOOKAHEAD"}
+
+
+def _env_names(path):
+    data = open(path, "rb").read()
+    return set(m.decode() for m in re.findall(rb"MI355GP_[A-Z0-9_]+", data)) - {"MI355GP_OPT_PERSIST_TEST"}
+
+
+def test_the_product_library_reads_only_the_documented_environment_variables():
+    """the shipped library used to read 37 MI355GP_* variables, one of which (a bounding experiment)
+    produced wrong results.  Now the schedule overrides of the A/B tools, the fault injectors and the experiments are compiled
+    out of libmi355gp.so (common.h DIAG_ENV) and live in libmi355gp_diag.so only; what is left is the transport of the
+    multi-process mode, one self-check and five schedule choices that give the same bits either way."""
+    _lib.build()
+    names = _env_names(os.path.join(ROOT, "gpy_amd", "libmi355gp.so"))
+    assert names == PRODUCT_ENV, sorted(names ^ PRODUCT_ENV)
+    diag = _env_names(_lib.DIAG_LIB_PATH)
+    assert PRODUCT_ENV < diag and {"MI355GP_DBG_UPD_QUEUE", "MI355GP_DENSE_PERSIST_TEST", "MI355GP_AGG2"} <= diag
+    # the experiment that computes wrong numbers is not even linked into the product
+    sym = lambda p: open(p, "rb").read().count(b"k_update_nt_queue")
+    assert sym(os.path.join(ROOT, "gpy_amd", "libmi355gp.so")) == 0 and sym(_lib.DIAG_LIB_PATH) > 0
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    for n in PRODUCT_ENV:
+        assert n in readme, "README.md does not document %s" % n
+
+
 def test_code_object_is_gfx950_only():
     import subprocess
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH],

@@ -12,14 +12,17 @@ WORKER = textwrap.dedent("""
     import json, os, sys, time
     sys.path.insert(0, %r)
     import bench
-    comm = bench.Comm(backend="gloo")
+    comm = bench.Comm()                             # the DEFAULT rank plumbing of a multi-rank launch
     calls = []
     def step():
         calls.append(1)
         time.sleep(0.02 * (1 + comm.rank))        # rank 1 is the slow replica
     dt = bench.timed_region(comm, step, steps=5, warmup=2)
     with open(os.path.join(%r, "rank%%d.json" %% comm.rank), "w") as f:
-        json.dump({"rank": comm.rank, "world": comm.world, "dt": dt, "calls": len(calls)}, f)
+        import torch
+        json.dump({"rank": comm.rank, "world": comm.world, "dt": dt, "calls": len(calls), "backend": comm.backend,
+                   "device_tensor": comm.device_tensor, "cuda_initialized": bool(torch.cuda.is_initialized()),
+                   "gathered": comm.gather([comm.rank, 10.0 + comm.rank])}, f)
     comm.close()
 """)
 
@@ -28,6 +31,7 @@ def test_two_rank_timed_region_takes_max_over_ranks(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % (ROOT, str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    env.pop("MI355GP_BENCH_BACKEND", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
@@ -35,6 +39,10 @@ def test_two_rank_timed_region_takes_max_over_ranks(tmp_path):
     recs = [json.load(open(tmp_path / ("rank%d.json" % i))) for i in range(2)]
     assert sorted(x["rank"] for x in recs) == [0, 1]
     assert all(x["world"] == 2 and x["calls"] == 7 for x in recs)          # 2 warm-up + exactly 5 timed steps
+    # gloo with CPU tensors unless MI355GP_BENCH_BACKEND=nccl asks otherwise, and torch.cuda never touched: the library's own
+    # dlopen'ed RCCL communicator (grid / sparse legs) must not share a process with PyTorch's
+    assert all(x["backend"] == "gloo" and not x["device_tensor"] and not x["cuda_initialized"] for x in recs)
+    assert all(x["gathered"] == [[0.0, 10.0], [1.0, 11.0]] for x in recs)   # per-rank stage times reach every rank in rank order
     assert abs(recs[0]["dt"] - recs[1]["dt"]) < 1e-9                        # both ranks hold the MAX
     assert recs[0]["dt"] >= 5 * 0.04 * 0.95                                 # the slow rank's time
     # whole-job throughput of independent replicas = n_gpus * steps / max time

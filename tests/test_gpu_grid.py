@@ -4,6 +4,7 @@ Tolerances: the fp64 parity contract of the single-GPU tests."""
 import numpy as np
 import pytest
 
+from conftest import diag_lib
 from gpy_amd import _lib as L
 from gpy_amd import grid as G
 from oracle import gp_oracle as O
@@ -34,18 +35,35 @@ CASES = [
 ]
 
 
+def _generic_1x1(on):
+    """A 1 x 1 loopback grid degenerates to the single-GPU pipeline; MI355GP_GRID_FORCE_GENERIC=1 (diagnostics build only) keeps
+    the generic one-pass code of the grid mode, so that it is covered at world size 1 too."""
+    import os
+    if on:
+        os.environ["MI355GP_GRID_FORCE_GENERIC"] = "1"
+    else:
+        os.environ.pop("MI355GP_GRID_FORCE_GENERIC", None)
+
+
 @pytest.mark.parametrize("kind,ARD,N,D,Dy,Pr,Pc,nb", CASES)
 def test_loopback_grid_matches_oracle(kind, ARD, N, D, Dy, Pr, Pc, nb):
+    _loopback_case(kind, ARD, N, D, Dy, Pr, Pc, nb)
+
+
+@diag_lib
+def test_loopback_1x1_grid_on_the_generic_code_matches_oracle():
+    _generic_1x1(True)
+    try:
+        _loopback_case("rbf", False, 300, 3, 1, 1, 1, 128)
+    finally:
+        _generic_1x1(False)
+
+
+def _loopback_case(kind, ARD, N, D, Dy, Pr, Pc, nb):
     X, Y = O.synthetic(N, D, seed=N + Pr, Dy=Dy)
     var, ls, noise = O.default_theta(D, ARD)
     ref = O.parameters_changed(kind, X, Y, var, ls, ARD, noise)
-    import os
-    if Pr * Pc == 1:      # 1 x 1 loopback degenerates to the single-GPU pipeline: keep the generic one-pass code covered too
-        os.environ["MI355GP_GRID_FORCE_GENERIC"] = "1" if nb == 128 else "0"
-    try:
-        g = G.GridContext.loopback(Pr, Pc, nb)
-    finally:
-        os.environ.pop("MI355GP_GRID_FORCE_GENERIC", None)
+    g = G.GridContext.loopback(Pr, Pc, nb)
     try:
         g.set_data(X, Y)
         th = L.theta_vec(var, ls, ARD, D)
@@ -67,21 +85,29 @@ def test_loopback_grid_matches_oracle(kind, ARD, N, D, Dy, Pr, Pc, nb):
         g.close()
 
 
-@pytest.mark.parametrize("Pr,Pc,nb,N", [(2, 4, 128, 1150), (3, 2, 128, 900), (1, 1, 128, 700), (2, 2, 256, 2000)])
+@pytest.mark.parametrize("Pr,Pc,nb,N", [(2, 4, 128, 1150), (3, 2, 128, 900), (2, 2, 256, 2000)])
 def test_two_level_blocking_options(Pr, Pc, nb, N):
     """The group size G of the two-level blocked factorisation, the W = X^T X aggregation GW and the look-ahead switch
     (mi355gp_grid_set_option) change the schedule, never the result beyond rounding: every combination against the oracle,
     including groups that do not divide the number of steps and G larger than the number of steps."""
-    import os
+    _blocking_options_case(Pr, Pc, nb, N)
+
+
+@diag_lib
+def test_two_level_blocking_options_on_a_1x1_grid_with_the_generic_code():
+    _generic_1x1(True)
+    try:
+        _blocking_options_case(1, 1, 128, 700)
+    finally:
+        _generic_1x1(False)
+
+
+def _blocking_options_case(Pr, Pc, nb, N):
     kind, ARD, D = "matern52", True, 4
     X, Y = O.synthetic(N, D, seed=N + 3, Dy=2)
     var, ls, noise = O.default_theta(D, ARD)
     ref = O.parameters_changed(kind, X, Y, var, ls, ARD, noise)
-    os.environ["MI355GP_GRID_FORCE_GENERIC"] = "1"
-    try:
-        g = G.GridContext.loopback(Pr, Pc, nb)
-    finally:
-        os.environ.pop("MI355GP_GRID_FORCE_GENERIC", None)
+    g = G.GridContext.loopback(Pr, Pc, nb)
     try:
         assert g.get_option("G") == 1 and g.get_option("GW") == 4 and g.get_option("lookahead") == 1
         g.set_data(X, Y)

@@ -4,6 +4,8 @@ the oracle's restatement (itself pinned to the reference's own functions by test
 import numpy as np
 import pytest
 
+from conftest import DIAG_LIB
+
 import gpy_amd
 from gpy_amd import _lib as L
 from oracle import gp_oracle as O
@@ -166,7 +168,7 @@ def test_one_shot_factorisations_follow_the_box_verdict_with_the_same_bits(tmp_p
     outs = []
     for verdict in ("0", "1"):
         f = str(tmp_path / ("L%s.npy" % verdict))
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MI355GP_DBG_BOX_VERDICT=verdict),
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MI355GP_DBG_BOX_VERDICT=verdict, MI355GP_LIB=DIAG_LIB),   # (a switch of the diagnostics build)
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append((np.load(f), r.stdout.strip().splitlines()[-1]))

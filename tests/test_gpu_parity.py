@@ -216,14 +216,13 @@ def test_results_are_bit_reproducible_and_independent_of_lookahead(ctx):
     ctx.set_option("persist", -1)
 
 
-@pytest.mark.parametrize("env", [{"MI355GP_TRI_OVERLAP": "0"}, {"MI355GP_TRI_MIN_NT": "16", "MI355GP_TRI_H": "8"},
-                                 {"MI355GP_TRI_MIN_NT": "16", "MI355GP_TRI_H": "8", "MI355GP_TRI_HALF": "0"},
-                                 {"MI355GP_NBO": "256"}, {"MI355GP_DIAG_EXCL_FIRST": "0", "MI355GP_SOLVE_OVERLAP": "0"}])
-def test_schedule_switches_give_the_same_factorisation(env):
-    """The schedule switches that remain (read when a context allocates its factorisation workspace) change
-    how the work is launched -- the overlapped leading inverse, its side stream, the outer panel width -- not what is
-    computed: same LML / alpha / gradients as the default to rounding."""
-    import os
+@pytest.mark.parametrize("opts", [{"tri_overlap": 0}, {"tri_min_nt": 16, "tri_h": 8},
+                                  {"tri_min_nt": 16, "tri_h": 8, "tri_half": 0},
+                                  {"nbo": 256}, {"diag_excl_first": 0, "solve_overlap": 0}])
+def test_schedule_switches_give_the_same_factorisation(opts):
+    """The schedule switches that remain (per context through `mi355gp_set_option` -- the product library reads
+    none of them from the environment) change how the work is launched -- the overlapped leading inverse, its side stream,
+    the outer panel width -- not what is computed: same LML / alpha / gradients as the default to rounding."""
     X, Y = O.synthetic(2900, 5, seed=7)
     var, ls, noise = O.default_theta(5, True)
     th = L.theta_vec(var, ls, True, 5)
@@ -233,29 +232,23 @@ def test_schedule_switches_give_the_same_factorisation(env):
         _, ref = c0.exact_inference("rbf", True, th, noise)
     finally:
         c0.close()
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    c = L.Context(0)
     try:
-        c = L.Context(0)
-        try:
-            c.set_data(X, Y)
-            for _ in range(2):                                   # second call: flags carry a new generation
-                info, r = c.exact_inference("rbf", True, th, noise)
-                assert info == 0
-                assert abs(r["lml"] - ref["lml"]) <= 1e-12 * abs(ref["lml"])
-                assert np.abs(r["alpha"] - ref["alpha"]).max() <= 1e-11 * np.abs(ref["alpha"]).max()
-                assert np.abs(r["dtheta"] - ref["dtheta"]).max() <= 1e-10 * np.abs(ref["dtheta"]).max()
-            c.set_option("lookahead", 0)                         # serial schedule: must not depend on the server / flags
+        c.set_data(X, Y)
+        for k, v in opts.items():
+            c.set_option(k, v)
+            assert c.get_option(k) == v
+        for _ in range(2):                                   # second call: flags carry a new generation
             info, r = c.exact_inference("rbf", True, th, noise)
-            assert info == 0 and abs(r["lml"] - ref["lml"]) <= 1e-12 * abs(ref["lml"])
-        finally:
-            c.close()
+            assert info == 0
+            assert abs(r["lml"] - ref["lml"]) <= 1e-12 * abs(ref["lml"])
+            assert np.abs(r["alpha"] - ref["alpha"]).max() <= 1e-11 * np.abs(ref["alpha"]).max()
+            assert np.abs(r["dtheta"] - ref["dtheta"]).max() <= 1e-10 * np.abs(ref["dtheta"]).max()
+        c.set_option("lookahead", 0)                         # serial schedule: must not depend on the server / flags
+        info, r = c.exact_inference("rbf", True, th, noise)
+        assert info == 0 and abs(r["lml"] - ref["lml"]) <= 1e-12 * abs(ref["lml"])
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        c.close()
 
 
 @pytest.mark.parametrize("n", [6200])

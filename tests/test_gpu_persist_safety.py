@@ -13,6 +13,8 @@ import threading
 import numpy as np
 import pytest
 
+from conftest import diag_lib
+
 import gpy_amd
 from gpy_amd import _lib as L
 from oracle import gp_oracle as O
@@ -35,6 +37,7 @@ def _close(r, r0):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
+@diag_lib
 def test_called_off_or_aborted_persistent_launch_is_redone_inside_the_call(mode):
     """mode 1: the launch waits for a workgroup that never comes -> called off after 1 ms, matrix untouched; mode 2: the chain
     workgroup gives up after the gate -> the workers time out on it, the matrix is rebuilt.  Either way the call returns the
@@ -79,6 +82,7 @@ def test_called_off_or_aborted_persistent_launch_is_redone_inside_the_call(mode)
         c.close()
 
 
+@diag_lib
 def test_a_gate_of_the_early_inverse_that_gives_up_voids_the_evaluation():
     """The inverse of the leading half runs on the side stream underneath the persistent launch, behind one-thread gate kernels
     that wait on the launch's progress words.  A gate that gives up while the launch is still running (a GPU shared with
@@ -110,6 +114,7 @@ def test_a_gate_of_the_early_inverse_that_gives_up_voids_the_evaluation():
 
 
 @pytest.mark.parametrize("mode", [1, 2])
+@diag_lib
 def test_dense_pdinv_redoes_a_called_off_launch(mode, monkeypatch):
     n = 1411
     X, _ = O.synthetic(n, 3, seed=9)
@@ -125,6 +130,7 @@ def test_dense_pdinv_redoes_a_called_off_launch(mode, monkeypatch):
 
 
 @pytest.mark.parametrize("inject", [1, 2, 11, 12])
+@diag_lib
 def test_vardtc_redoes_either_m_by_m_factorisation_in_place(inject, monkeypatch):
     """Kmm's launch (1 / 2) or B's (11 / 12) called off / aborted: the factorisation is redone right there (no second pass
     over the data, no collective), the evaluation has the bits of an undisturbed one."""

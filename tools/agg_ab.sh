@@ -1,5 +1,7 @@
 #!/bin/bash
 # Run on the GPU box: A/B of the paired far updates (MI355GP_AGG2) on one box.
+# the switches driven here exist only in the diagnostics build of the library (make -C gpy_amd/csrc diag)
+export MI355GP_LIB=${MI355GP_LIB:-$PWD/gpy_amd/libmi355gp_diag.so}
 for N in 16384 8192 32768; do
   D=32; KIND="--kind matern52"; ST=20
   if [ $N != 16384 ]; then D=8; KIND="--kind rbf --iso"; fi

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Run on the GPU box: the loopback block-cyclic grid (bench.py --grid) over group sizes.  tools/grid_sweep.sh N PrxPc "G:GW ..."
+# the switches driven here exist only in the diagnostics build of the library (make -C gpy_amd/csrc diag)
+export MI355GP_LIB=${MI355GP_LIB:-$PWD/gpy_amd/libmi355gp_diag.so}
 N=${1:-32768}
 GRID=${2:-2x4}
 SETS=${3:-"1:1 2:0 4:0 8:0 4:8"}

@@ -84,12 +84,12 @@ __global__ void k_potf2(const double* A, double* Lout, double* Xout, int* info, 
         for (int c = 0; c < 16; ++c) a[c] = a0[c];
         asm volatile("" ::: "memory");
         if (V == 0) fail = potf2_v_cpp(a, xs, lane);
-        if (V == 1) fail = potf2_v_fused(a, xs, lane);
-        if (V == 2) fail = potf2_v_pad(a, xs, lane);
-        if (V == 3) fail = potf2_v_prsq(a, xs, lane);
-        if (V == 4) fail = potf2_v_pfmac(a, xs, lane);
-        if (V == 5) fail = potf2_v_plain(a, xs, lane);
-        if (V == 6) fail = potf2_v_plainpad(a, xs, lane);
+        if (V == 1) potf2_v_fused(a, xs, lane);   // (generated streams: no pivot test, a bad pivot turns into NaN)
+        if (V == 2) potf2_v_pad(a, xs, lane);   // (generated streams: no pivot test, a bad pivot turns into NaN)
+        if (V == 3) potf2_v_prsq(a, xs, lane);   // (generated streams: no pivot test, a bad pivot turns into NaN)
+        if (V == 4) potf2_v_pfmac(a, xs, lane);   // (generated streams: no pivot test, a bad pivot turns into NaN)
+        if (V == 5) potf2_v_plain(a, xs, lane);   // (generated streams: no pivot test, a bad pivot turns into NaN)
+        if (V == 6) potf2_v_plainpad(a, xs, lane);   // (generated streams: no pivot test, a bad pivot turns into NaN)
 #pragma unroll
         for (int c = 0; c < 16; ++c) a0[c] += 1e-300 * a[c];          // keep every iteration live
     }

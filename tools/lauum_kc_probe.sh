@@ -2,6 +2,8 @@
 # X^T X of a small matrix from the work list with cut k ranges (128 x 128 items from nt = 24): the stage time against the chunk
 # length, next to the length the host-side packing model picks (gemm.hip lauum_kc_rows_128), and against the single launch of
 # whole-K tiles (MI355GP_LAUUM_SPLIT=0).   tools/lauum_kc_probe.sh
+# the switches driven here exist only in the diagnostics build of the library (make -C gpy_amd/csrc diag)
+export MI355GP_LIB=${MI355GP_LIB:-$PWD/gpy_amd/libmi355gp_diag.so}
 export TMPDIR=/tmp
 one() {   # N KC(0 = the model's choice) SPLIT
     MI355GP_LAUUM_KC=$2 MI355GP_LAUUM_SPLIT=${3:-1} python - <<PY

@@ -2,6 +2,8 @@
 # A/B of the split hand-over of the sub-diagonal tiles in the persistent Cholesky (persist.hip: the owner of tile (i, i-2)
 # applies the last column to tile (i, i-1) itself; MI355GP_PERSIST_TUNE=4 switches it off): bit-identity tests, the chain's
 # per-step timeline, whole evaluations.  ONE box.
+# the switches driven here exist only in the diagnostics build of the library (make -C gpy_amd/csrc diag)
+export MI355GP_LIB=${MI355GP_LIB:-$PWD/gpy_amd/libmi355gp_diag.so}
 cd "$(dirname "$0")/.."
 OUT=${1:-gpurun_out/split_ab}
 mkdir -p "$OUT"

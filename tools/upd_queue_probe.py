@@ -14,6 +14,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the switches driven here exist only in the diagnostics build of the library (make -C gpy_amd/csrc diag)
+os.environ.setdefault("MI355GP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpy_amd", "libmi355gp_diag.so"))
 from gpy_amd import _lib as L  # noqa: E402
 
 

@@ -523,7 +523,7 @@ def compact_line(out):
         line["families"] = {k: [round(v["ms"], 3), v["launches"], round(v["tflops"], 2)] for k, v in out["families"].items()}
     for leg in legs:
         if isinstance(out.get(leg), dict):                    # LEG_DROP at the top level of a leg only (its cpu_baseline keeps `value`)
-            line[leg] = _slim({k: v for k, v in out[leg].items() if k not in LEG_DROP}, LINE_DROP + ("sample", "sample_N", "unit"))
+            line[leg] = _slim({k: v for k, v in out[leg].items() if k not in LEG_DROP}, LINE_DROP + ("sample", "sample_N", "unit", "reference_ratio_source"))
     line["legs_ms"] = {leg: (round(out[leg]["ms_per_step"], 4) if isinstance(out.get(leg), dict) and "ms_per_step" in out[leg]
                              else (out.get(leg) or {}).get("error", None) and "error") for leg in legs if leg in out}
     return json.dumps(line, separators=(",", ":"))

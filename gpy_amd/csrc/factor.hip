@@ -137,6 +137,8 @@ int factor_engine(int device, hipStream_t* main, hipStream_t* panel, hipStream_t
 }
 
 // ---- workspace --------------------------------------------------------------------------------------
+static bool lauum_plan_wanted(const FactorWs* ws, int nt);
+static bool lauum_plan_build(FactorWs* ws, int nt);
 int factor_ws_alloc(FactorWs* ws, long npad) {
     ws->nblk = npad / NB;
     HIP_CHECK(hipMalloc(&ws->dinv, sizeof(double) * ws->nblk * 8 * 256));
@@ -164,6 +166,7 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     const char* envp1 = DIAG_ENV("PART1_ON_PANEL");
     if (envp1 && *envp1) ws->part1_on_panel = atoi(envp1) ? 1 : 0;
     ws->sched_state = ws->sched_force_steps = ws->persist_auto_off = 0;
+    ws->sched_np = ws->sched_ns = 0;
     ws->evals_done = ws->early_pending = 0;
     const char* envpa = PRODUCT_ENV("PERSIST_AUTO");
     if (envpa && *envpa) ws->persist_auto = atoi(envpa) ? 1 : 0;
@@ -208,6 +211,8 @@ int factor_ws_alloc(FactorWs* ws, long npad) {
     const char* envx = DIAG_ENV("DIAG_EXCL_FIRST");
     if (envx && *envx) ws->diag_excl_first = atoi(envx) ? 1 : 0;
     HIP_CHECK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ws->ev_early_pre, hipEventDisableTiming));
+    if (lauum_plan_wanted(ws, (int)ws->nblk)) (void)lauum_plan_build(ws, (int)ws->nblk);   // never inside a capture later
     const size_t nouter = (size_t)(npad + NB - 1) / NB + 2;      // enough for the narrowest outer panel (nbo = 128)
     ws->ev_panel.resize(nouter);
     ws->ev_cols.resize(nouter);
@@ -230,6 +235,8 @@ void factor_ws_free(FactorWs* ws) {
     ws->ev_cols.clear();
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
     ws->ev_fork = nullptr;
+    if (ws->ev_early_pre) (void)hipEventDestroy(ws->ev_early_pre);
+    ws->ev_early_pre = nullptr;
     ws->st_panel = nullptr;                       // engine streams are shared and never destroyed by a workspace
     ws->st_tri = nullptr;
     ws->st_tri_half = ws->st_tri_cur = nullptr;
@@ -368,7 +375,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
         const int h = persist_early_h(npad, ws);
         const int gate_gives_up = (ws->persist_test == 3) ? 1 : 0;       // fault injection: the first gate times out at once
         hipEvent_t pre_saved = ws->ev_persist_pre;
-        if (h > 0 && !ws->ev_persist_pre) ws->ev_persist_pre = ws->ev_fork;
+        if (h > 0 && !ws->ev_persist_pre) ws->ev_persist_pre = ws->ev_early_pre;   // (its own event: ev_fork belongs to the look-ahead schedule)
         const bool ok = launch_potrf_persist(st, A, npad, ws);
         hipEvent_t pre = ws->ev_persist_pre;
         ws->ev_persist_pre = pre_saved;
@@ -388,7 +395,7 @@ void potrf_device(hipStream_t st, double* A, long npad, FactorWs* ws) {
     } else if (ws->persist_skip > 0 && ws->persist_skip != 0x7fffffff) {
         --ws->persist_skip;                                     // a called-off launch is retried after a number of evaluations
     }
-    ws->sched_force_steps = 0;                                  // (the calibration's one evaluation on launches is this one)
+    if (ws->sched_force_steps > 0) --ws->sched_force_steps;     // (one of the calibration's evaluations on launches is this one)
     if (ws->lookahead != 1) {
         potrf_serial(st, A, npad, ws);
         return;
@@ -549,35 +556,47 @@ void trtri_device(hipStream_t st, const double* L, double* X, double* T, long np
     ws->prof.end(st);
 }
 
+// The split X^T X of a small matrix runs from a work list that lives on the device; made once per size.  hipFree / hipMalloc /
+// synchronous copies: never inside a stream capture (factor_ws_alloc builds it ahead for the size it is given; a miss while a
+// capture is open falls back to the single launch for that call -- ADVICE r5).
+static bool lauum_plan_wanted(const FactorWs* ws, int nt) {
+    return ws->lauum_split && nt <= (ws->lauum_split > 1 ? ws->lauum_split : LAUUM_SPLIT_MAX_NT) && (long)nt * NB > 1024;
+}
+static bool lauum_plan_build(FactorWs* ws, int nt) {
+    std::vector<LauumItem> items;
+    std::vector<LauumSum> sums;
+    int nparts = 0;
+    lauum_split_plan(nt, items, sums, &nparts);
+    if (ws->lauum_plan_dev) (void)hipFree(ws->lauum_plan_dev);
+    if (ws->lauum_part) (void)hipFree(ws->lauum_part);
+    ws->lauum_plan_dev = nullptr;
+    ws->lauum_part = nullptr;
+    ws->lauum_plan_nt = 0;
+    const size_t bi = sizeof(LauumItem) * items.size(), bs = sizeof(LauumSum) * sums.size();
+    if (hipMalloc(&ws->lauum_plan_dev, bi + bs + 16) == hipSuccess &&
+        hipMalloc(&ws->lauum_part, sizeof(double) * (size_t)lauum_split_tile(nt) * lauum_split_tile(nt) * (size_t)(nparts + 1)) ==
+            hipSuccess) {
+        // (pageable copies: done before they return; the plan is made once per size)
+        (void)hipMemcpy(ws->lauum_plan_dev, items.data(), bi, hipMemcpyHostToDevice);
+        if (bs) (void)hipMemcpy((char*)ws->lauum_plan_dev + bi, sums.data(), bs, hipMemcpyHostToDevice);
+        ws->lauum_plan_nt = nt;
+        ws->lauum_nitems = (int)items.size();
+        ws->lauum_nsums = (int)sums.size();
+        return true;
+    }
+    (void)hipGetLastError();
+    return false;
+}
+
 void lauum_device(hipStream_t st, const double* X, double* W, long npad, FactorWs* ws) {
     const int nt = (int)(npad / NB);
     ws->prof.begin(st, PF_LAUUM, (double)npad * npad * npad / 3.0);
     // small matrix, long k ranges: the split work list (gemm.hip); the plan is made once per size and lives on the device
-    bool split = ws->lauum_split && nt <= (ws->lauum_split > 1 ? ws->lauum_split : LAUUM_SPLIT_MAX_NT) && (long)nt * NB > 1024;
+    bool split = lauum_plan_wanted(ws, nt);
     if (split && ws->lauum_plan_nt != nt) {
-        std::vector<LauumItem> items;
-        std::vector<LauumSum> sums;
-        int nparts = 0;
-        lauum_split_plan(nt, items, sums, &nparts);
-        if (ws->lauum_plan_dev) (void)hipFree(ws->lauum_plan_dev);
-        if (ws->lauum_part) (void)hipFree(ws->lauum_part);
-        ws->lauum_plan_dev = nullptr;
-        ws->lauum_part = nullptr;
-        ws->lauum_plan_nt = 0;
-        const size_t bi = sizeof(LauumItem) * items.size(), bs = sizeof(LauumSum) * sums.size();
-        if (hipMalloc(&ws->lauum_plan_dev, bi + bs + 16) == hipSuccess &&
-            hipMalloc(&ws->lauum_part, sizeof(double) * (size_t)lauum_split_tile(nt) * lauum_split_tile(nt) * (size_t)(nparts + 1)) ==
-                hipSuccess) {
-            // (pageable copies: done before they return; the plan is made once per size)
-            (void)hipMemcpy(ws->lauum_plan_dev, items.data(), bi, hipMemcpyHostToDevice);
-            if (bs) (void)hipMemcpy((char*)ws->lauum_plan_dev + bi, sums.data(), bs, hipMemcpyHostToDevice);
-            ws->lauum_plan_nt = nt;
-            ws->lauum_nitems = (int)items.size();
-            ws->lauum_nsums = (int)sums.size();
-        } else {
-            (void)hipGetLastError();
-            split = false;
-        }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+        split = (cap == hipStreamCaptureStatusNone) && lauum_plan_build(ws, nt);
     }
     if (split && ws->lauum_plan_nt == nt)
         launch_lauum_split(st, X, W, npad, nt, (const LauumItem*)ws->lauum_plan_dev, ws->lauum_nitems,

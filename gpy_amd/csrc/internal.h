@@ -84,6 +84,7 @@ struct FactorWs {
     std::vector<hipEvent_t> ev_panel;        // [p]: outer panel p is factored
     std::vector<hipEvent_t> ev_cols;         // [p]: every update of panel p's columns has been issued (-> its factorisation)
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_early_pre = nullptr;       // "the progress words of this persistent launch are zeroed" for the early inverse's gates
     int agg2 = 0;               // MI355GP_AGG2: part 2 of the look-ahead schedule in pairs of panels (K = 2 nbo far updates; N >= 6144); measured: no gain
     // Which schedule a small factorisation takes is decided BY MEASUREMENT per workspace (MI355GP_PERSIST_AUTO=0: always the
     // persistent launch): on most boxes the persistent launch + early inverse wins at N = 4096 (2.85 against 3.3 ms per evaluation),
@@ -91,6 +92,7 @@ struct FactorWs {
     // the launch-per-step schedule only 10 % slower than elsewhere).  The third evaluation of a workspace is timed on the
     // persistent schedule, the fourth on launches; the faster one stays (both give the same bits).
     int persist_auto = 1, sched_state = 0, sched_force_steps = 0, persist_auto_off = 0;
+    int sched_np = 0, sched_ns = 0;  // samples taken so far: persistent schedule (two, warm) / launches (one untimed, then two)
     int can_calibrate = 0;      // set by the owner of a workspace that times its evaluations (the exact-inference contexts)
     float sched_ms_persist = 0.f, sched_ms_steps = 0.f;
     int evals_done = 0;         // inverses taken through this workspace (the early inverse under the persistent launch starts with the second)

@@ -832,12 +832,32 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
 
 // ---- host side --------------------------------------------------------------------------------------------------------
 int persist_box_verdict(int set) {
-    static std::atomic<int> verdict{[] {                       // MI355GP_DBG_BOX_VERDICT: start from a verdict (tests)
+    // votes of the calibrated contexts of this process; MI355GP_DBG_BOX_VERDICT (diagnostics build): start from one vote (tests)
+    static std::atomic<int> votes[2] = {{0}, {0}};
+    static const bool seeded = [] {
         const char* e = DIAG_ENV("DBG_BOX_VERDICT");
-        return (e && *e) ? atoi(e) : -1;
-    }()};
-    if (set >= -1) verdict.store(set);
-    return verdict.load();
+        if (e && *e && (atoi(e) == 0 || atoi(e) == 1)) votes[atoi(e)].fetch_add(1);
+        return true;
+    }();
+    (void)seeded;
+    if (set == 0 || set == 1) votes[set].fetch_add(1);
+    else if (set == -1) { votes[0].store(0); votes[1].store(0); }
+    const int v0 = votes[0].load(), v1 = votes[1].load();
+    return (v0 + v1 == 0) ? -1 : (v1 > v0 ? 1 : 0);
+}
+
+// Host mirror of Ownership: do the tiles of the busiest near owner and of the busiest far worker fit the workers' per-tile
+// state (s_prog / s_wait[PS_MAXT])?  nw workers, tune as passed to the kernel (its bits 6..15 change D and the near share).
+static bool persist_tiles_fit(int nt, int nw, int tune) {
+    if (nw < 1) return false;
+    const int D = ps_neard(tune), hdiv = ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt);
+    const int nnear = near_tiles_in_rows(nt, D), nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
+    int H = nw / hdiv > 0 ? nw / hdiv : 1;
+    if (H > nnear) H = nnear;
+    if (nfar == 0) H = nw < nnear ? nw : nnear;
+    if ((nnear + H - 1) / H > PS_MAXT) return false;
+    if (nfar > 0 && (nw - H < 1 || (nfar + (nw - H) - 1) / (nw - H) > PS_MAXT)) return false;
+    return true;
 }
 
 bool potrf_persist_eligible(long npad, const FactorWs* ws) {
@@ -847,8 +867,13 @@ bool potrf_persist_eligible(long npad, const FactorWs* ws) {
     if (ws->persist_auto && ws->sched_state == 0 && nt >= 21 && ws->persist_test == 0 && persist_box_verdict() == 1 && !ws->can_calibrate)
         return false;                                          // a workspace that never calibrates itself follows the process's verdict
     if (nt < 2 || nt > PS_MAXNT || nt > ws->persist_max_nt) return false;
-    // tiles per worker: near 3 nt / (cus / 2) <= 2, far (nt-3)(nt-2)/2 / (cus / 2)
-    return ws->persist_cus >= 16 && (nt - 3) * (nt - 2) / 2 / (ws->persist_cus / 2 - 1) + 2 <= PS_MAXT;
+    // tiles per worker (near and far, with this workspace's share of near owners) must fit the workers' per-tile state; the
+    // launch itself checks again with the grid it really gets
+    if (ws->persist_cus < 16) return false;
+    const long ntl = nt * (nt + 1) / 2;
+    const long grid = (ws->persist_cus > 32 ? ws->persist_cus - 1 : ws->persist_cus) < ntl + 1
+                          ? (ws->persist_cus > 32 ? ws->persist_cus - 1 : ws->persist_cus) : ntl + 1;
+    return persist_tiles_fit((int)nt, (int)grid - 1, ws->persist_tune);
 }
 
 bool potrf_persist_aborted(int info, FactorWs* ws, bool* clean) {
@@ -898,7 +923,9 @@ static long persist_grid_for(long npad, FactorWs* ws) {
     // One CU stays out of the launch: a workgroup asks for ALL of a CU's registers (8 waves x 256), so a single wave of anything
     // else that reaches a CU first -- the one-thread gate kernels of the early inverse on the side stream, a neighbour's memset
     // kernel -- would keep one workgroup from ever becoming resident and the whole launch would be called off at its gate.
-    if (grid > 32) grid -= 1;
+    // (on a device / partition of <= 32 CUs the spare CU is kept as well whenever the early inverse's gate kernels will run next
+    //  to the launch: without it every evaluation there would be called off at the gate and redone -- ADVICE r5)
+    if (grid > 32 || (grid > 16 && persist_early_h(npad, ws) > 0)) grid -= 1;
     if (grid > ntl + 1) grid = ntl + 1;
     return grid;
 }
@@ -906,7 +933,7 @@ static long persist_grid_for(long npad, FactorWs* ws) {
 bool launch_potrf_persist(hipStream_t st, double* A, long npad, FactorWs* ws, long long* dbg) {
     const int nt = (int)(npad / NB);
     const long grid = persist_grid_for(npad, ws);
-    if (grid < 2) return false;
+    if (grid < 2 || !persist_tiles_fit(nt, (int)grid - 1, ws->persist_tune)) return false;
     // (the bracket of a profiled launch opens HERE, in front of the two memsets: a timing event between ev_persist_pre and the
     //  launch lets the side stream's one-thread gate kernel reach a CU before the launch's workgroups do, and the launch is then
     //  called off at its co-residency gate nearly every time -- tools/bracket_calloff_probe.py: 11 of 12 eligible launches)

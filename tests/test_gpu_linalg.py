@@ -120,8 +120,8 @@ def test_persistent_cholesky_option_reports_non_pd_and_can_be_switched_off_per_c
 
 
 def test_a_context_settles_on_one_schedule_by_its_own_timing_and_reports_it():
-    """`MI355GP_PERSIST_AUTO`: from nt = 16 on a context times its third evaluation (persistent launch + early
-    inverse) and its fourth (launches), keeps the faster one and says which through the read-only option "persist_sched"
+    """`MI355GP_PERSIST_AUTO`: from nt = 16 on a context times its fourth and fifth evaluation (persistent launch
+    + early inverse, warm), then runs three on launches (the first untimed), compares the minima, keeps the faster schedule and says which through the read-only option "persist_sched"
     (0 undecided, 1 persistent launch, 2 launches).  Every evaluation on the way has the same bits; an explicit "persist"
     option ends the calibration, -1 re-opens it."""
     X, Y = O.synthetic(2304, 4, seed=11)
@@ -132,7 +132,7 @@ def test_a_context_settles_on_one_schedule_by_its_own_timing_and_reports_it():
         c.set_data(X, Y)
         assert c.get_option("persist_sched") == 0
         outs = []
-        for _ in range(7):
+        for _ in range(9):                                     # 3 + two persistent samples + one untimed and two timed on launches (+1)
             info, r = c.exact_inference("rbf", False, th, noise)
             assert info == 0
             outs.append((r["lml"], r["dtheta"].tobytes(), r["alpha"].tobytes()))

@@ -28,9 +28,9 @@ import json, sys
 try:
     d = json.loads(sys.stdin.read())
     print({k: d.get(k) for k in ('value', 'n_gpus', 'ms_per_step', 'scaling')})
-    for leg in ('c2', 'grid', 'c5', 'c4_single'):
+    for leg in ('c2', 'grid', 'grid16k', 'grid4k', 'c5', 'c4_single'):
         r = d.get(leg) or {}
-        print(' ', leg, {k: r.get(k) for k in ('ms_per_step', 'n_gpus', 'transport', 'error', 'stderr_tail', 'parity_vs_golden') if r.get(k) is not None})
+        print(' ', leg, {k: r.get(k) for k in ('ms_per_step', 'n_gpus', 'N', 'transport', 'stage_ms_rank_min_max', 'error', 'stderr_tail', 'parity_vs_golden') if r.get(k) is not None})
 except Exception as e:
     print('no JSON line:', e)
 "

@@ -641,12 +641,13 @@ def dbg_persist(N, reps=3, kcap=0, device=0):
     step the six wall-clock stamps in microseconds relative to the first)."""
     require_device(device)
     nt = (int(N) + 127) // 128
-    out = np.zeros(8 + 20 * nt)
+    out = np.zeros(8 + 32 * nt)
     check(lib().mi355gp_dbg_persist(device, int(N), int(reps), int(kcap), out), "mi355gp_dbg_persist")
     st = out[8:8 + 8 * nt].reshape(nt, 8)
-    near = out[8 + 8 * nt:].reshape(nt, 3, 4)              # [..., 3] of entry (j+1, 0): the chain published row j+1
+    near = out[8 + 8 * nt:8 + 20 * nt].reshape(nt, 3, 4)   # [..., 3] of entry (j+1, 0): the chain published row j+1
+    far = out[8 + 20 * nt:].reshape(nt, 12)                # far tile (i, i-3): last pass picked / done, solve picked / staged / solved / published
     return dict(ms_steps=out[0], ms_persist=out[1], mismatches=int(out[2]), info=int(out[3]), abort=int(out[4]), nt=nt,
-                steps=(st - st[0, 0]) / 100.0, near=(near - st[0, 0]) / 100.0)
+                steps=(st - st[0, 0]) / 100.0, near=(near - st[0, 0]) / 100.0, far=(far - st[0, 0]) / 100.0)
 
 
 def dbg_mask_probe(pct=75, order=0, device=0):

@@ -1400,13 +1400,13 @@ int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out) 
     HIP_CHECK(dNoise.alloc(1));
     HIP_CHECK(A.alloc(np * np));
     HIP_CHECK(B.alloc(np * np));
-    HIP_CHECK(dStamp.alloc(20 * nt));
+    HIP_CHECK(dStamp.alloc(32 * nt));
     HIP_CHECK(dCount.alloc(1));
     const double il[4] = {0.7, 0.7, 0.7, 0.7}, noise = 0.1;
     HIP_CHECK(hipMemcpy(dX, X.data(), sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dIl, il, sizeof(il), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dNoise, &noise, sizeof(double), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemset(dStamp, 0, sizeof(double) * 20 * nt));
+    HIP_CHECK(hipMemset(dStamp, 0, sizeof(double) * 32 * nt));
     HIP_CHECK(hipMemset(dCount, 0, sizeof(double)));
     hipStream_t st;
     if (factor_engine(device, &st, nullptr, nullptr) != 0) return -2;
@@ -1421,7 +1421,7 @@ int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out) 
     for (auto& ev : e) HIP_CHECK(hipEventCreate(&ev));
     const KernParams kp{MI355GP_RBF, 0, D, 1.0};
     launch_scale_inputs(st, dX, N, D, dIl, 0, dXt, np);
-    for (int i = 0; i < 8 + 20 * nt; ++i) out[i] = 0.0;
+    for (int i = 0; i < 8 + 32 * nt; ++i) out[i] = 0.0;
     int info[4] = {0, 0, 0, 0};
     for (int mode = 0; mode < 2; ++mode) {                      // 0: launch per step into B, 1: persistent into A
         double* M = mode == 0 ? (double*)B : (double*)A;
@@ -1460,9 +1460,9 @@ int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out) 
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipMemcpy(&cnt, dCount, sizeof(cnt), hipMemcpyDeviceToHost));
     out[2] = (double)cnt;
-    std::vector<long long> stamps((size_t)20 * nt);
-    HIP_CHECK(hipMemcpy(stamps.data(), dStamp, sizeof(long long) * 20 * nt, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 20 * nt; ++i) out[8 + i] = (double)stamps[(size_t)i];
+    std::vector<long long> stamps((size_t)32 * nt);
+    HIP_CHECK(hipMemcpy(stamps.data(), dStamp, sizeof(long long) * 32 * nt, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 32 * nt; ++i) out[8 + i] = (double)stamps[(size_t)i];
     for (auto& ev : e) (void)hipEventDestroy(ev);
     factor_ws_free(&ws);
     HIP_CHECK(hipGetLastError());

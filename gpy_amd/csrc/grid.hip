@@ -497,6 +497,10 @@ struct mi355gp_grid {
     int check_seq = 0;               // MI355GP_GRID_CHECK_SEQ=1: compare the collective logs of all ranks after every evaluation
     int G = 1;                       // MI355GP_GRID_G: steps per group of the two-level blocked factorisation (K = G * nb updates)
     int GW = 4;                      // MI355GP_GRID_GW: steps per W = X^T X update; 0 = one deep-K pass after the last step
+    // diagnostics build, MI355GP_GRID_DBG_CRIT (WRONG RESULTS; tools/grid_crit_probe.py): 1 = every update (near / part1 / bulk /
+    // W) skipped: the critical path crit(k) of every step alone; 2 = ... and its broadcasts skipped; 3 = ... and only phase (a),
+    // the factorisation + inverse of the diagonal tile, left
+    int dbg_crit = 0;
     long n = 0, npad = 0, T = 0;
     int D = 0, Dy = 0;
     hipEvent_t ev[6] = {};
@@ -956,6 +960,7 @@ int mi355gp_grid_create(int device, int rank, int world, int Pr, int Pc, int nb,
         HIP_CHECK(hipStreamCreateWithPriority(&g->sw, hipStreamNonBlocking, least));
         HIP_CHECK(hipEventCreateWithFlags(&g->ev_w, hipEventDisableTiming));
         for (int o = 0; o < MI355GP_GRID_OPT_NUM; ++o) grid_default_option(g, o);
+        g->dbg_crit = diag_env_int(DIAG_ENV("GRID_DBG_CRIT"), 0);
     }
     for (auto& e : g->ev) HIP_CHECK(hipEventCreate(&e));
     if (g->loopback) {
@@ -1219,9 +1224,13 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
             HIP_CHECK(hipMemcpy2DAsync(At, sizeof(double) * r.LC, r.Dt, sizeof(double) * nb, sizeof(double) * nb, nb,
                                        hipMemcpyDeviceToDevice, s));
         }
+        if (g->dbg_crit >= 3) return 0;
+        const bool nobc = g->dbg_crit >= 2;
         // (b) D to the panel owners (process column opc) and to the owners of row k of X (process row opr)
-        if (int rc = grid_bcast(g, GROUP_COL, opc, opr, tile, [](GridRank& r, bool) { return r.Dv; })) return rc;
-        if (int rc = grid_bcast(g, GROUP_ROW, opr, opc, tile, [](GridRank& r, bool) { return r.Dv; })) return rc;
+        if (!nobc) {
+            if (int rc = grid_bcast(g, GROUP_COL, opc, opr, tile, [](GridRank& r, bool) { return r.Dv; })) return rc;
+            if (int rc = grid_bcast(g, GROUP_ROW, opr, opc, tile, [](GridRank& r, bool) { return r.Dv; })) return rc;
+        }
         // (c) panel solve L_ik = A_ik D^T on process column opc
         for (GridRank& r : g->ranks) {
             if (r.pc != opc) continue;
@@ -1236,7 +1245,7 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
                                        sizeof(double) * nb, rows, hipMemcpyDeviceToDevice, s));
         }
         // (d) row panel along every process row
-        for (int pr = 0; pr < Pr; ++pr) {
+        for (int pr = 0; pr < Pr && !nobc; ++pr) {
             const int lr0 = cnt_le(k, pr, Pr), TLr = cnt_le(T - 1, pr, Pr);
             const size_t cnt = (size_t)(TLr - lr0) * tile;
             if (int rc = grid_bcast(g, GROUP_ROW, pr, opc, cnt,
@@ -1245,7 +1254,7 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
         }
         // (e) column panel: L_jk for the local columns j > k comes from process row j % Pr
         if (int rc = grid_group_start(g)) return rc;
-        for (long j = k + 1; j < T; ++j) {
+        for (long j = k + 1; j < T && !nobc; ++j) {
             const int pc = (int)(j % Pc), root = (int)(j % Pr);
             const long lj = j / Pc, li = j / Pr;
             if (int rc = grid_bcast(g, GROUP_COL, pc, root, tile, [&](GridRank& r, bool is_root) {
@@ -1270,13 +1279,13 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
                                    (const double*)r.hXR[k], (int)nb);
         }
         // (h) X row panel down every process column
-        for (int pc = 0; pc < Pc; ++pc) {
+        for (int pc = 0; pc < Pc && !nobc; ++pc) {
             const size_t cnt = (size_t)cnt_le(k, pc, Pc) * tile;
             if (int rc = grid_bcast(g, GROUP_COL, pc, opr, cnt, [&](GridRank& r, bool) { return r.hXR[k]; })) return rc;
         }
         // (i) X_ki for the local rows i <= k comes from process column i % Pc
         if (int rc = grid_group_start(g)) return rc;
-        for (long i = 0; i <= k; ++i) {
+        for (long i = 0; i <= k && !nobc; ++i) {
             const int pr = (int)(i % Pr), root = (int)(i % Pc);
             const long li = i / Pr, lj = i / Pc;
             if (int rc = grid_bcast(g, GROUP_ROW, pr, root, tile, [&](GridRank& r, bool is_root) {
@@ -1290,6 +1299,7 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
     // updates of A and B by the panels [k0, k1) on local tile columns J in [ca, cb) (A, rows I >= ca) and tile rows I in
     // [ca, cb) (B, columns J < k1; panel k reaches the columns J <= k)
     auto update_AB = [&](hipStream_t (*pick)(GridRank&, bool), long k0, long k1, long ca, long cb) {
+        if (g->dbg_crit) return;
         for (GridRank& r : g->ranks) {
             hipStream_t s = pick(r, la);
             const GridPred lower{1, Pr, r.pr, Pc, r.pc, 0, 0}, all{0, Pr, r.pr, Pc, r.pc, 0, 0};
@@ -1318,7 +1328,7 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
         if (ge2 < T) update_AB(on_st, kb, ge, ge2, T);                             // bulk(g)
         if (la) HIP_CHECK(hipEventRecord(g->ev_p1[gi], g->st));
         // W_ij += sum_k X_ki^T X_kj over the finished steps, k >= i >= j
-        const bool flush = (ge == T) || (GW > 0 && ge - kw0 >= GW);
+        const bool flush = !g->dbg_crit && ((ge == T) || (GW > 0 && ge - kw0 >= GW));
         if (flush) {                                          // on the low-priority stream: fills whatever the other two leave idle
             if (la) HIP_CHECK(hipStreamWaitEvent(g->sw, g->ev_cr[gi], 0));
             for (GridRank& r : g->ranks) {

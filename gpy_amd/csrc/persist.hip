@@ -663,7 +663,7 @@ __device__ __forceinline__ void chain_workgroup(double* A, long ld, int nt, doub
 // accumulator carried through memory in fp64 between them as before: the same bits.
 __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
                                  int* __restrict__ sync, int kcap, double* __restrict__ hs, long long* __restrict__ dbg,
-                                 int split, int neard, int hdiv, double* sm) {
+                                 int split, int neard, int hdiv, int colorder, int trsmfirst, double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
     __shared__ int s_pre[PS_MAXNT];                            // PS_PRE snapshot
     __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished;
@@ -675,9 +675,28 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
     const Ownership own(nt, nw, neard, hdiv);
     const int nmine = own.count(me);
     if (nmine == 0) return;
+    // The owned tiles and the order they are looked at.  A near owner looks at its tiles by row (the order the chain needs them);
+    // a FAR worker by COLUMN, then row: tile (i, k) feeds column k's panel, which every tile to its right waits for, so among
+    // tiles that both have something to do the one with the smaller k is the more urgent whatever its row (modelled with
+    // tools/persist_sim.py: N = 4096 -4 %, N = 4608 -15 %; measured: see DESIGN.md 3b "round 6").
+    __shared__ short s_ti[PS_MAXT], s_tk[PS_MAXT], s_order[PS_MAXT];
     for (int s = t; s < PS_MAXT; s += 256) {
         s_prog[s] = (s == 0 && me == 0) ? -1 : 0;              // tile 0 = block (0,0): the chain's
         s_wait[s] = 0;
+        if (s < nmine) {
+            int i, k;
+            own.tile(me, s, i, k);
+            s_ti[s] = (short)i;
+            s_tk[s] = (short)k;
+        }
+    }
+    __syncthreads();
+    if (t < nmine) {
+        const bool bycol = colorder && me >= own.H;
+        const int key = bycol ? s_tk[t] * 256 + s_ti[t] : t;
+        int rank = 0;
+        for (int u = 0; u < nmine; ++u) rank += ((bycol ? s_tk[u] * 256 + s_ti[u] : u) < key) ? 1 : 0;
+        s_order[rank] = (short)t;
     }
     int left = nmine - ((me == 0) ? 1 : 0);
     long long idle0 = 0;
@@ -693,11 +712,23 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
         if (s_cnt[nt + 1] != 0) return;
         // ---- pick the first owned tile (ascending row: the chain needs low rows first) that has something to do
         int pick = -1, pi = 0, pk = 0, pj0 = 0, pj1 = 0, ptrsm = 0, pfin = 0;
-        for (int s = 0; s < nmine; ++s) {
+        // a finished tile whose L_kk has arrived goes first, wherever it stands in the order: its solve publishes a final tile of
+        // L, which other workers' passes and the near owners of its row wait for; a pass only moves this worker's own tile on
+        if (trsmfirst)
+            for (int o = 0; o < nmine; ++o) {
+                const int s = s_order[o];
+                if (s_prog[s] >= 0 && s_wait[s] && s_cnt[nt] >= s_tk[s] + 1) {
+                    pick = s; pi = s_ti[s]; pk = s_tk[s];
+                    pj0 = pj1 = (pi == pk) ? pi - 1 : ((split && pi == pk + 1 && pi >= 2) ? pk - 1 : pk);
+                    ptrsm = 1;
+                    break;
+                }
+            }
+        for (int o = 0; o < nmine && pick < 0; ++o) {
+            const int s = s_order[o];
             const int p = s_prog[s];
             if (p == -1) continue;
-            int i, k;
-            own.tile(me, s, i, k);
+            const int i = s_ti[s], k = s_tk[s];
             if (p == -2) {                                     // column i-2 of tile (i, i-1): L(i, i-2) is this worker's own
                 if (s_cnt[i - 1] >= i - 1 && s_pre[i]) { pick = s; pi = i; pk = i - 1; pj0 = i - 2; pj1 = i - 1; pfin = 1; break; }
                 continue;
@@ -734,6 +765,8 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
         // diagnostics: the LAST task of a near tile: [picked, compute done, published]
         long long* dn = (dbg && pi - pk <= 2 && (pj1 == limit)) ? dbg + 8 * nt + 4 * (3 * pi + (pi - pk)) : nullptr;
         if (dn && t == 0) dn[0] = wall_clock64();
+        long long* df = (dbg && pi - pk == 3 && pj1 == limit) ? dbg + 20 * nt + 12 * pi : nullptr;   // far tile (i, i-3): compare with far_worker_workgroup
+        if (df && t == 0 && pj1 > pj0) df[0] = wall_clock64();
         const bool pre = (pj1 == limit && split && subdiag && pi >= 2 && !pfin);   // all but the last column: leave it in place
         const bool handover = (pj1 == limit && !general && !pre);                  // the tile's last write before the chain takes it
         if (pj1 > pj0 || (handover && subdiag)) {              // ---- columns [pj0, pj1): C -= L(i, cols) L(k, cols)^T
@@ -756,6 +789,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
             }
         }
         if (dn && t == 0) dn[1] = wall_clock64();
+        if (df && t == 0 && pj1 > pj0) df[1] = wall_clock64();
         if (handover) {                                        // ---- hand the tile to the chain
             drain_stores();
             __syncthreads();
@@ -780,12 +814,15 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
         } else if (ptrsm) {                                    // ---- L(i,k) = C L_kk^-T, final
             drain_stores();
             __syncthreads();                                   // the tile's own stores are done, the GEMM's LDS stages are free
+            if (df && t == 0) df[2] = wall_clock64();
             trsm_stage_L(A, ld, (long)pk * NB, dinv_all + (long)pk * 8 * 256, sm);
             __syncthreads();
+            if (df && t == 0) df[3] = wall_clock64();
             {
                 d4 Y0[8], Y1[8];
                 trsm_strip2_regs(A, ld, (long)pk * NB, (long)pi * NB + 16 * w, sm, lane, Y0, Y1);
                 __syncthreads();                               // the L_kk image is dead
+                if (df && t == 0) df[4] = wall_clock64();
                 stage_put_strips(sm, w, Y0, Y1, lane);
             }
             __syncthreads();
@@ -796,6 +833,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
             if (t == 0) {
                 st_flag(sync + PS_CNT + pi, pk + 1);
                 if (dn) dn[2] = wall_clock64();
+                if (df) df[5] = wall_clock64();
                 s_prog[pick] = more ? -2 : -1;
             }
             if (!more) --left;
@@ -806,7 +844,6 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
         __syncthreads();
     }
 }
-
 
 __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A, long ld, int nt,
                                                           double* __restrict__ dinv_all, double* __restrict__ logsum,
@@ -826,7 +863,7 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
     } else {
         worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, ps_neard(tune),
-                         ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt), sm);
+                         ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt), (tune & 1) ? 0 : 1, (tune & 2) ? 0 : 1, sm);
     }
 }
 

@@ -518,6 +518,7 @@ void launch_grad_fused(hipStream_t st, KernParams kp, const double* Xt, long ldx
 // columns over ITS range of row tiles -- H = dL_dKnm * (dK/dr)/r never goes to memory (the separate pass wrote and
 // re-read the 3.3 GB chunk).  Block = (column tile, row split); partial sums per split are combined in fixed order by
 // launch_sum_splits, so the result stays bit-reproducible.  G: n x m weights, optionally formed on the fly (RankTerm).
+#ifdef MI355GP_DIAG   // the VALU-only form (18 % of the issue rate at configuration 5): kept for A/B in the diagnostics build
 template <bool ARD>
 __global__ __launch_bounds__(256) void k_grad_cols(KernParams kp, const double* __restrict__ Xt1, long ld1, long n,
                                                    const double* __restrict__ Xt2, long ld2, long m,
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(256) void k_grad_cols(KernParams kp, const double* 
         }
     }
 }
+#endif   // MI355GP_DIAG
 
 
 // The same pass with the column reductions on the MATRIX pipe.  k_grad_cols keeps hc[4][17] per thread (136 VGPRs of accumulators:
@@ -660,6 +662,7 @@ __global__ __launch_bounds__(256) void k_grad_cols(KernParams kp, const double* 
 // instead of 68, no cross-thread reduction (every (j, c) lives in one lane) and the same fp64 pipe time as the FMAs it replaces
 // (MFMA and VALU fp64 share the pipe) -- the gain is occupancy.  The column SUMS of H (the "ones" column) stay on the
 // VALU (4 partial sums per thread, reduced once per block).  Rows in fixed order per block: bit reproducible.
+#define GC_DY 4                                     // output columns the rank term keeps in registers (more: per-element loads)
 #define GC_HS 80                                    // row stride (doubles) of the LDS H tile: rows 128 B apart in bank space
 template <bool ARD>
 __global__ __launch_bounds__(256, 2) void k_grad_cols_mfma(KernParams kp, const double* __restrict__ Xt1, long ld1, long n,
@@ -684,6 +687,15 @@ __global__ __launch_bounds__(256, 2) void k_grad_cols_mfma(KernParams kp, const 
 #pragma unroll
     for (int q = 0; q < DM; ++q) a_q[q] = 0.0;
     for (int idx = t; idx < KT * 18; idx += 256) sit[idx] = 0.0;      // columns c >= D stay zero
+    // this thread's four columns: are all of them there (vector loads of the weights), and the rank term's column values
+    const bool vec4 = (j0 + tx * 4 + 3 < m) && (ldg % 4 == 0) && ((reinterpret_cast<unsigned long long>(G) & 31ull) == 0);
+    const bool rkfast = rk.Y != nullptr && rk.Dy <= GC_DY;
+    double vcol[4][GC_DY];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int d = 0; d < GC_DY; ++d)
+            vcol[b][d] = (rkfast && d < rk.Dy && j0 + tx * 4 + b < m) ? rk.V[(j0 + tx * 4 + b) * rk.Dy + d] : 0.0;
     const int ti_end = ((split + 1) * tiles_per_split < ntr) ? (split + 1) * tiles_per_split : ntr;
     for (int ti = split * tiles_per_split; ti < ti_end; ++ti) {
         const long i0 = (long)ti * KT;
@@ -706,17 +718,39 @@ __global__ __launch_bounds__(256, 2) void k_grad_cols_mfma(KernParams kp, const 
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const long i = i0 + ty * 4 + a;
+            // the weights of this row: one 32-byte load when the four columns exist (the scalar loads it replaces touched every
+            // cache line four times), the rank term's row values once per row (they used to be fetched per element)
+            d4 gv = {0.0, 0.0, 0.0, 0.0};
+            double yrow[GC_DY], rs = 1.0;
+            if (i < n) {
+                if (vec4) gv = *reinterpret_cast<const d4*>(G + i * ldg + j0 + tx * 4);
+                else
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (j0 + tx * 4 + b < m) gv[b] = G[i * ldg + j0 + tx * 4 + b];
+                if (rk.Y && rkfast) {
+#pragma unroll
+                    for (int d = 0; d < GC_DY; ++d) yrow[d] = (d < rk.Dy) ? rk.Y[i * rk.Dy + d] : 0.0;
+                    if (rk.rowscale) rs = rk.rowscale[i];
+                }
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const long j = j0 + tx * 4 + b;
                 double g = 0.0;
                 if (i < n && j < m) {
-                    g = G[i * ldg + j];
+                    g = gv[b];
                     if (rk.Y) {
                         double yv = 0.0;
-                        for (int d = 0; d < rk.Dy; ++d) yv = fma(rk.Y[i * rk.Dy + d], rk.V[j * rk.Dy + d], yv);
+                        if (rkfast) {
+#pragma unroll
+                            for (int d = 0; d < GC_DY; ++d)
+                                if (d < rk.Dy) yv = fma(yrow[d], vcol[b][d], yv);
+                        } else {
+                            for (int d = 0; d < rk.Dy; ++d) yv = fma(rk.Y[i * rk.Dy + d], rk.V[j * rk.Dy + d], yv);
+                        }
                         g = fma(rk.gscale, g, rk.beta * yv);
-                        if (rk.rowscale) g *= rk.rowscale[i];
+                        if (rk.rowscale) g *= rkfast ? rs : rk.rowscale[i];
                     }
                 }
                 const CovVal c = cov_all(kp.kind, kp.variance, r2[a][b], false);
@@ -826,12 +860,14 @@ int launch_grad_cols(hipStream_t st, KernParams kp, const double* Xt1, long ld1,
         *nblocks_out = nb;
         return nsplit;
     }
+#ifdef MI355GP_DIAG
     if (kp.ard)
         hipLaunchKernelGGL((k_grad_cols<true>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg, rk, ntc, ntr,
                            tps, partials, colpart, mcols, kp.D + 1);
     else
         hipLaunchKernelGGL((k_grad_cols<false>), dim3(nb), dim3(256), 0, st, kp, Xt1, ld1, n, Xt2, ld2, m, G, ldg, rk, ntc, ntr,
                            tps, partials, colpart, mcols, kp.D + 1);
+#endif
     *nblocks_out = nb;
     return nsplit;
 }

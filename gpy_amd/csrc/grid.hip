@@ -454,6 +454,7 @@ struct GridRank {
     const double **dRP = nullptr, **dCP = nullptr, **dXR = nullptr, **dXRr = nullptr;
     double* cpart = nullptr;         // column-reduction partials [row chunk][LC]
     double *Dt = nullptr, *Dv = nullptr, *Ds = nullptr;
+    double* bstage = nullptr;        // one-rank-per-process transports: packed tiles of a strided panel broadcast (grid_bcast_tile_runs)
     double *XtR = nullptr, *XtC = nullptr, *XsR = nullptr, *XsC = nullptr;   // scaled dimension-major / raw row-major
     long *gR = nullptr, *gC = nullptr;                                       // global index of every local row / col
     int *dl_r = nullptr, *dl_c = nullptr, *dg = nullptr;
@@ -549,7 +550,7 @@ static int cnt_le(long k, int p, int P) { return (k >= p) ? (int)((k - p) / P + 
 static int cnt_lt(long k, int p, int P) { return (k > 0) ? cnt_le(k - 1, p, P) : 0; }
 
 static void free_rank(GridRank& r) {
-    void* ptrs[] = {r.A, r.X, r.W, r.RPs, r.CPs, r.XRs, r.XRrs, (void*)r.dRP, (void*)r.dCP, (void*)r.dXR, (void*)r.dXRr, r.cpart, r.Dt, r.Dv, r.Ds, r.XtR, r.XtC, r.XsR, r.XsC, r.gR, r.gC,
+    void* ptrs[] = {r.A, r.X, r.W, r.RPs, r.CPs, r.XRs, r.XRrs, (void*)r.dRP, (void*)r.dCP, (void*)r.dXR, (void*)r.dXRr, r.cpart, r.Dt, r.Dv, r.Ds, r.bstage, r.XtR, r.XtC, r.XsR, r.XsC, r.gR, r.gC,
                     r.dl_r, r.dl_c, r.dg, r.vloc, r.gvec, r.gvec2, r.alpha, r.ybuf, r.Rg, r.scal, r.gradPart,
                     r.gradOut, r.invls, r.noise, r.info_g, r.seqbuf};
     for (void* p : ptrs)
@@ -688,6 +689,121 @@ static int grid_group_end(mi355gp_grid* g) {
     }
     g->batching = false;
     return grid_flush_bcasts(g);
+}
+// ---- panel tiles that change hands between process rows / columns: ONE broadcast per (communicator, root) ----------------------
+// Phases (e) and (i) of crit(k) move single tiles whose source and destination are both determined by the tile's GLOBAL index:
+// tile j of a column panel lives on process row j % Pr (local tile j / Pr of the row panel there) and is wanted by process
+// column j % Pc (local tile j / Pc of its column panel).  For one communicator and one root the tiles form an arithmetic
+// progression in j with step lcm(Pr, Pc): a run of `n` tiles at local index s0 + m * ss on the root and d0 + m * ds on every
+// member.  Rounds 2-5 sent every tile as its own broadcast inside a group (up to T - k - 1 of them per step: ~4,000 RCCL calls
+// per evaluation at N = 32768); now a run travels as ONE broadcast of n tiles: packed into the staging buffer by one small kernel
+// where the root's tiles are not contiguous (ss != 1), received in place where the members' are (ds == 1) and unpacked by one
+// kernel where they are not.  On a Pr x Pc grid with Pr | Pc (2 x 4) a column panel needs no unpack and an X panel no pack.
+// The loopback transport moves the same tiles with its batched copy kernel and LOGS the merged broadcast, so that the collective
+// sequences of the two transports stay comparable (tests/test_gpu_multiproc.py).
+struct TileRun { int group, index, root, n; long s0, ss, d0, ds; };
+__global__ __launch_bounds__(256) void k_tiles_restride(double* __restrict__ dst, long dstride, const double* __restrict__ src,
+                                                        long sstride, long tile) {
+    const d2* s2 = reinterpret_cast<const d2*>(src + (long)blockIdx.y * sstride);
+    d2* q2 = reinterpret_cast<d2*>(dst + (long)blockIdx.y * dstride);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (tile >> 1); i += (long)gridDim.x * blockDim.x) q2[i] = s2[i];
+}
+typedef std::function<double*(GridRank&)> BaseFn;
+static int grid_bcast_tile_runs(mi355gp_grid* g, const std::vector<TileRun>& runs, size_t tile, const BaseFn& srcbase,
+                                const BaseFn& dstbase) {
+    hipStream_t lst = g->lookahead ? g->sc : g->st;
+    if (g->loopback) {
+        if (int rc = grid_group_start(g)) return rc;
+        for (const TileRun& tr : runs) {
+            if (tr.n <= 0) continue;
+            for (GridRank& r : g->ranks) {
+                const bool in = (tr.group == GROUP_ROW) ? (r.pr == tr.index) : (r.pc == tr.index);
+                if (in) coll_log(r, tr.group == GROUP_ROW ? 1 : 2, 1, tr.root, (size_t)tr.n * tile);
+            }
+            for (int m = 0; m < tr.n; ++m) {
+                if (g->batch_count != tile || g->batch_stream != lst)
+                    if (int rc = grid_flush_bcasts(g)) return rc;
+                BcastItem item;
+                item.nd = 0;
+                item.src = nullptr;
+                for (GridRank& r : g->ranks) {
+                    const bool in = (tr.group == GROUP_ROW) ? (r.pr == tr.index) : (r.pc == tr.index);
+                    const int coord = (tr.group == GROUP_ROW) ? r.pc : r.pr;
+                    if (in && coord == tr.root) item.src = srcbase(r) + (tr.s0 + m * tr.ss) * (long)tile;
+                }
+                auto emit = [&]() {
+                    if (item.nd == 0) return;
+                    g->batch_count = tile;
+                    g->batch_stream = lst;
+                    g->batch.push_back(item);
+                    item.nd = 0;
+                };
+                for (GridRank& r : g->ranks) {
+                    const bool in = (tr.group == GROUP_ROW) ? (r.pr == tr.index) : (r.pc == tr.index);
+                    if (!in) continue;
+                    if (item.nd == BCAST_MAX_DST) emit();
+                    item.dst[item.nd++] = dstbase(r) + (tr.d0 + m * tr.ds) * (long)tile;
+                }
+                emit();
+            }
+        }
+        return grid_group_end(g);
+    }
+    GridRank& r = g->ranks[0];
+    struct Mine { const TileRun* tr; bool is_root; const double* send; double* recv; double* stage; };
+    std::vector<Mine> mine;
+    long used = 0;
+    for (const TileRun& tr : runs) {
+        if (tr.n <= 0) continue;
+        const bool in = (tr.group == GROUP_ROW) ? (r.pr == tr.index) : (r.pc == tr.index);
+        if (!in) continue;
+        Mine m;
+        m.tr = &tr;
+        m.is_root = ((tr.group == GROUP_ROW) ? r.pc : r.pr) == tr.root;
+        const bool need_stage = (m.is_root && tr.ss != 1 && tr.n > 1) || (tr.ds != 1 && tr.n > 1);
+        m.stage = need_stage ? r.bstage + used * (long)tile : nullptr;
+        if (need_stage) used += tr.n;
+        double* dst0 = dstbase(r) + tr.d0 * (long)tile;
+        m.recv = (tr.ds != 1 && tr.n > 1) ? m.stage : dst0;
+        m.send = m.recv;
+        if (m.is_root) {
+            const double* src0 = srcbase(r) + tr.s0 * (long)tile;
+            if (tr.ss != 1 && tr.n > 1) {                    // pack the root's tiles
+                hipLaunchKernelGGL(k_tiles_restride, dim3(64, (unsigned)tr.n), dim3(256), 0, lst, m.stage, (long)tile, src0,
+                                   tr.ss * (long)tile, (long)tile);
+                m.send = m.stage;
+            } else {
+                m.send = src0;
+            }
+        }
+        mine.push_back(m);
+    }
+    if (mine.empty()) return 0;
+    HIP_CHECK(hipGetLastError());
+    if (mine.size() > 1) NCCL_CHECK(g_rccl.GroupStart());
+    for (const Mine& m : mine) {
+        coll_log(r, m.tr->group == GROUP_ROW ? 1 : 2, 1, m.tr->root, (size_t)m.tr->n * tile);
+        NCCL_CHECK(g_rccl.Broadcast(m.send, m.recv, (size_t)m.tr->n * tile, ncclFloat64, m.tr->root,
+                                    m.tr->group == GROUP_ROW ? g->comm_row : g->comm_col, lst));
+    }
+    if (mine.size() > 1) NCCL_CHECK(g_rccl.GroupEnd());
+    for (const Mine& m : mine)
+        if (m.tr->ds != 1 && m.tr->n > 1)                    // unpack into the members' panel
+            hipLaunchKernelGGL(k_tiles_restride, dim3(64, (unsigned)m.tr->n), dim3(256), 0, lst,
+                               dstbase(r) + m.tr->d0 * (long)tile, m.tr->ds * (long)tile, (const double*)m.stage, (long)tile, (long)tile);
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// the tiles t in (lo, hi] ... [lo, hi) with t % Pa == a and t % Pb == b, as first / step / count (step = lcm(Pa, Pb))
+static void tile_progression(long lo, long hi, int a, int Pa, int b, int Pb, long* first, long* step, int* count) {
+    long L = Pa;
+    while (L % Pb != 0) L += Pa;
+    *step = L;
+    *first = -1;
+    *count = 0;
+    for (long t = lo; t < hi && t < lo + L; ++t)
+        if (t % Pa == a && t % Pb == b) { *first = t; break; }
+    if (*first >= 0) *count = (int)((hi - 1 - *first) / L + 1);
 }
 // ---- self-test of the bound transport (RCCL, or the hipIpc stand-in under MI355GP_TRANSPORT=ipc) --------------------------------
 // Exactly the communicator set-up and the call patterns of the per-rank grid code, without the numerics: world communicator,
@@ -1069,6 +1185,7 @@ int mi355gp_grid_set_data(mi355gp_grid* g, const double* X, int64_t N, int D, co
         HIP_CHECK(hipMalloc(&r.Dt, sizeof(double) * nb * nb));
         HIP_CHECK(hipMalloc(&r.Dv, sizeof(double) * nb * nb));
         HIP_CHECK(hipMalloc(&r.Ds, sizeof(double) * nb * nb));
+        if (!g->loopback) HIP_CHECK(hipMalloc(&r.bstage, sizeof(double) * nb * nb * (size_t)(TLrM > TLcM ? TLrM : TLcM)));
         // local point sets (host-side gather, uploaded once)
         std::vector<long> gR((size_t)r.LR), gC((size_t)r.LC);
         std::vector<double> XsR((size_t)r.LR * D, 0.0), XsC((size_t)r.LC * D, 0.0);
@@ -1252,17 +1369,20 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
                                     [&](GridRank& r, bool) { return r.hRP[k] + (long)lr0 * tile; }))
                 return rc;
         }
-        // (e) column panel: L_jk for the local columns j > k comes from process row j % Pr
-        if (int rc = grid_group_start(g)) return rc;
-        for (long j = k + 1; j < T && !nobc; ++j) {
-            const int pc = (int)(j % Pc), root = (int)(j % Pr);
-            const long lj = j / Pc, li = j / Pr;
-            if (int rc = grid_bcast(g, GROUP_COL, pc, root, tile, [&](GridRank& r, bool is_root) {
-                    return is_root ? r.hRP[k] + li * tile : r.hCP[k] + lj * tile;
-                }))
+        // (e) column panel: L_jk for the local columns j > k comes from process row j % Pr -- one broadcast per (process column,
+        //     root) pair: at most Pr per column (grid_bcast_tile_runs)
+        if (!nobc) {
+            std::vector<TileRun> runs;
+            for (int pc = 0; pc < Pc; ++pc)
+                for (int root = 0; root < Pr; ++root) {
+                    long first, step;
+                    int cnt;
+                    tile_progression(k + 1, T, pc, Pc, root, Pr, &first, &step, &cnt);
+                    if (cnt > 0) runs.push_back(TileRun{GROUP_COL, pc, root, cnt, first / Pr, step / Pr, first / Pc, step / Pc});
+                }
+            if (int rc = grid_bcast_tile_runs(g, runs, tile, [&](GridRank& r) { return r.hRP[k]; }, [&](GridRank& r) { return r.hCP[k]; }))
                 return rc;
         }
-        if (int rc = grid_group_end(g)) return rc;
         // (g) row k of X on process row opr: X_kj = D * B_kj (j < k), X_kk = D
         for (GridRank& r : g->ranks) {
             if (r.pr != opr) continue;
@@ -1283,17 +1403,19 @@ static int grid_run(mi355gp_grid* g, KernParams kp, const double* theta, const s
             const size_t cnt = (size_t)cnt_le(k, pc, Pc) * tile;
             if (int rc = grid_bcast(g, GROUP_COL, pc, opr, cnt, [&](GridRank& r, bool) { return r.hXR[k]; })) return rc;
         }
-        // (i) X_ki for the local rows i <= k comes from process column i % Pc
-        if (int rc = grid_group_start(g)) return rc;
-        for (long i = 0; i <= k && !nobc; ++i) {
-            const int pr = (int)(i % Pr), root = (int)(i % Pc);
-            const long li = i / Pr, lj = i / Pc;
-            if (int rc = grid_bcast(g, GROUP_ROW, pr, root, tile, [&](GridRank& r, bool is_root) {
-                    return is_root ? r.hXR[k] + lj * tile : r.hXRr[k] + li * tile;
-                }))
+        // (i) X_ki for the local rows i <= k comes from process column i % Pc -- at most Pc broadcasts per process row
+        if (!nobc) {
+            std::vector<TileRun> runs;
+            for (int pr = 0; pr < Pr; ++pr)
+                for (int root = 0; root < Pc; ++root) {
+                    long first, step;
+                    int cnt;
+                    tile_progression(0, k + 1, pr, Pr, root, Pc, &first, &step, &cnt);
+                    if (cnt > 0) runs.push_back(TileRun{GROUP_ROW, pr, root, cnt, first / Pc, step / Pc, first / Pr, step / Pr});
+                }
+            if (int rc = grid_bcast_tile_runs(g, runs, tile, [&](GridRank& r) { return r.hXR[k]; }, [&](GridRank& r) { return r.hXRr[k]; }))
                 return rc;
         }
-        if (int rc = grid_group_end(g)) return rc;
         return 0;
     };
     // updates of A and B by the panels [k0, k1) on local tile columns J in [ca, cb) (A, rows I >= ca) and tile rows I in

@@ -87,11 +87,26 @@ def step_traffic_bytes(N, nb, Pr, Pc):
                 total=row_panel + col_panel + xrow + xrowT + diag)
 
 
+def _has_tile(lo, hi, a, Pa, b, Pb):
+    """Is there a tile t in [lo, hi) with t % Pa == a and t % Pb == b?  (Chinese remainder: the residues must agree modulo
+    gcd(Pa, Pb); the solutions then repeat with period lcm(Pa, Pb).)"""
+    import math
+    g = math.gcd(Pa, Pb)
+    if (a - b) % g:
+        return False
+    L = Pa // g * Pb
+    t0 = next(t for t in range(L) if t % Pa == a and t % Pb == b)
+    first = t0 if t0 >= lo else t0 + -(-(lo - t0) // L) * L
+    return first < hi
+
+
 def expected_collectives(N, nb, Pr, Pc, rank, Dy=1, D=1):
     """Number of collectives ONE evaluation enqueues on the world / process-row / process-column communicator of grid rank
-    `rank` (csrc/grid.hip, crit(k): the diagonal inverse down its column and along its row, the row panel along every process
-    row, the column-panel tiles, the X row panel down every process column, the transposed X tiles; then five all-reduces).
-    Independent of the look-ahead / grouping options: only the ORDER of compute changes with them, never the collectives."""
+    `rank` (csrc/grid.hip, crit(k)): the diagonal inverse down its column and along its row, the row panel along every process
+    row, the column-panel tiles as ONE broadcast per (process column, root process row) that has tiles, the X row panel down
+    every process column, the transposed X tiles as one broadcast per (process row, root process column); then five
+    all-reduces.  At most 2 + 1 + Pr + 1 + Pc per step and rank (2 x 4: 7 or fewer).  Independent of the look-ahead / grouping
+    options: only the ORDER of compute changes with them, never the collectives."""
     T = -(-N // nb)
     pr, pc = rank // Pc, rank % Pc
     row = col = 0
@@ -100,9 +115,9 @@ def expected_collectives(N, nb, Pr, Pc, rank, Dy=1, D=1):
         col += 1 if pc == opc else 0                                   # (b) D down process column opc
         row += 1 if pr == opr else 0                                   # (b) D along process row opr
         row += 1 if count_le(T - 1, pr, Pr) - count_le(k, pr, Pr) > 0 else 0     # (d) row panel (skipped when empty)
-        col += sum(1 for j in range(k + 1, T) if j % Pc == pc)         # (e) column-panel tiles
+        col += sum(1 for root in range(Pr) if _has_tile(k + 1, T, pc, Pc, root, Pr))   # (e) column-panel runs, one per root
         col += 1 if count_le(k, pc, Pc) > 0 else 0                     # (h) X row panel down process column pc
-        row += sum(1 for i in range(k + 1) if i % Pr == pr)            # (i) transposed X tiles
+        row += sum(1 for root in range(Pc) if _has_tile(0, k + 1, pr, Pr, root, Pc))    # (i) transposed X runs, one per root
     return {"world": 5, "row": row, "col": col}
 
 

@@ -77,7 +77,7 @@ def _spawn(world, tmp_path, **kw):
     return res
 
 
-@pytest.mark.parametrize("Pr,Pc,nb,N", [(1, 2, 256, 1300), (2, 2, 256, 1536), (2, 4, 512, 4096)])
+@pytest.mark.parametrize("Pr,Pc,nb,N", [(1, 2, 256, 1300), (2, 2, 256, 1536), (2, 4, 512, 4096), (3, 2, 128, 1100)])
 def test_one_process_per_rank_matches_the_single_process_loopback_bit_for_bit(Pr, Pc, nb, N, tmp_path):
     from gpy_amd.datasets import default_theta, synthetic
     D, world = 5, Pr * Pc

@@ -149,7 +149,7 @@ def test_expected_collectives_equals_a_brute_force_enumeration_of_one_evaluation
     the membership rule of `grid_bcast` (a rank takes part iff it belongs to that process row / column; empty broadcasts are
     skipped by everybody)."""
     from gpy_amd import grid as G
-    for N, nb, Pr, Pc in ((4096, 512, 2, 4), (1536, 256, 2, 2), (1300, 256, 1, 2), (3000, 128, 3, 2), (700, 128, 1, 1)):
+    for N, nb, Pr, Pc in ((4096, 512, 2, 4), (1536, 256, 2, 2), (1300, 256, 1, 2), (3000, 128, 3, 2), (700, 128, 1, 1), (5000, 128, 4, 6)):
         T = -(-N // nb)
         tile = nb * nb
         calls = []                                   # (kind, index, doubles)
@@ -160,15 +160,33 @@ def test_expected_collectives_equals_a_brute_force_enumeration_of_one_evaluation
             for pr in range(Pr):                                                 # row panel along every process row
                 below = sum(1 for i in range(k + 1, T) if i % Pr == pr)
                 calls.append(("row", pr, below * tile))
-            for j in range(k + 1, T):                                            # column-panel tiles
-                calls.append(("col", j % Pc, tile))
+            for pc in range(Pc):                                                 # column-panel tiles: one run per root
+                for root in range(Pr):
+                    run = [j for j in range(k + 1, T) if j % Pc == pc and j % Pr == root]
+                    calls.append(("col", pc, len(run) * tile))
             for pc in range(Pc):                                                 # X row panel down every process column
                 upto = sum(1 for j in range(k + 1) if j % Pc == pc)
                 calls.append(("col", pc, upto * tile))
-            for i in range(k + 1):                                               # transposed X tiles
-                calls.append(("row", i % Pr, tile))
+            for pr in range(Pr):                                                 # transposed X tiles: one run per root
+                for root in range(Pc):
+                    run = [i for i in range(k + 1) if i % Pr == pr and i % Pc == root]
+                    calls.append(("row", pr, len(run) * tile))
         for rank in range(Pr * Pc):
             pr, pc = rank // Pc, rank % Pc
             row = sum(1 for kind, idx, cnt in calls if kind == "row" and idx == pr and cnt > 0)
             col = sum(1 for kind, idx, cnt in calls if kind == "col" and idx == pc and cnt > 0)
             assert G.expected_collectives(N, nb, Pr, Pc, rank) == {"world": 5, "row": row, "col": col}, (N, nb, Pr, Pc, rank)
+
+
+def test_collectives_per_step_and_rank_stay_within_the_budget_of_the_merged_panel_broadcasts():
+    """at most 8 collectives per step and rank on the 2 x 4 grid of BASELINE configs[3] (the per-tile column
+    broadcasts of rounds 2-5 were up to T - 1 = 63 per step); in general at most 4 + Pr + Pc."""
+    from gpy_amd import grid as G
+    for N, nb, Pr, Pc in ((32768, 512, 2, 4), (16384, 512, 2, 4), (4096, 512, 2, 4), (8192, 512, 2, 2), (3000, 128, 3, 2)):
+        T = -(-N // nb)
+        for rank in range(Pr * Pc):
+            e = G.expected_collectives(N, nb, Pr, Pc, rank)
+            per_step = (e["row"] + e["col"]) / T
+            assert per_step <= 4 + Pr + Pc, (N, Pr, Pc, rank, per_step)
+            if (Pr, Pc) == (2, 4):
+                assert per_step <= 8, (N, rank, per_step)

@@ -22,10 +22,11 @@ def hdiv_default(nt):
 
 class Sim(object):
     def __init__(self, nt, cus=255, hdiv=None, kcap=2, pass_fix=7.0, pass_col=13.5, trsm=17.0, near_scale=1.0, far_scale=1.0,
-                 order="row", chain=(F, S, U), lazy=0):
+                 order="row", chain=(F, S, U), lazy=0, reserve=None):
         self.nt, self.kcap = nt, kcap
         self.pass_fix, self.pass_col, self.trsm = pass_fix, pass_col, trsm
         self.near_scale, self.far_scale, self.order, self.lazy = near_scale, far_scale, order, lazy
+        self.reserve = reserve
         self.F, self.S, self.U = chain
         D = 2
         ntl = nt * (nt + 1) // 2
@@ -132,7 +133,16 @@ class Sim(object):
                 if self.order == "col" and w >= self.H:
                     tiles = sorted(tiles, key=lambda x: (x[1], x[0]))
                 pick = None
+                hot = False
+                if self.reserve is not None and w >= self.H:
+                    # visible dcnt
+                    dc = 0
+                    while dc < nt and dcnt_t[dc + 1] <= t:
+                        dc += 1
+                    hot = any(state[x] != 2 and x[1] <= dc + self.reserve for x in tiles)
                 for tl in tiles:
+                    if hot and tl[1] > dc + self.reserve:
+                        continue
                     st = state[tl]
                     if st == 2:
                         continue
@@ -211,6 +221,11 @@ def main():
         ("far tiles picked by column (deadline) instead of by row", dict(order="col")),
         ("far tiles: lazy deep passes (>= 4 columns unless urgent), kcap 8", dict(lazy=4, kcap=8)),
         ("kcap 4", dict(kcap=4)),
+        ("by column + a worker with a tile of column <= dcnt + 0 works on nothing else", dict(order="col", reserve=0)),
+        ("by column + ... column <= dcnt + 1", dict(order="col", reserve=1)),
+        ("by column + ... column <= dcnt + 2", dict(order="col", reserve=2)),
+        ("by column, kcap 1", dict(order="col", kcap=1)),
+        ("by column + reserve 1, kcap 1", dict(order="col", reserve=1, kcap=1)),
         ("half of the workers near", dict(hdiv=2)),
         ("chain 30 us per step (solve pipelined under the factor) + near halves", dict(chain=(F, 2.0, U), near_scale=0.55)),
         ("chain 30 us + near halves + two pipelines", dict(chain=(F, 2.0, U), near_scale=0.55, far_scale=0.7)),

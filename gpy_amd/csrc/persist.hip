@@ -663,7 +663,7 @@ __device__ __forceinline__ void chain_workgroup(double* A, long ld, int nt, doub
 // accumulator carried through memory in fp64 between them as before: the same bits.
 __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
                                  int* __restrict__ sync, int kcap, double* __restrict__ hs, long long* __restrict__ dbg,
-                                 int split, int neard, int hdiv, int colorder, int trsmfirst, double* sm) {
+                                 int split, int neard, int hdiv, int colorder, int trsmfirst, int reserve, int nreserve, double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
     __shared__ int s_pre[PS_MAXNT];                            // PS_PRE snapshot
     __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished;
@@ -712,11 +712,28 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
         if (s_cnt[nt + 1] != 0) return;
         // ---- pick the first owned tile (ascending row: the chain needs low rows first) that has something to do
         int pick = -1, pi = 0, pk = 0, pj0 = 0, pj1 = 0, ptrsm = 0, pfin = 0;
+        // RESERVE.  Tasks are not pre-empted: a 20-34 us pass on a tile that is not needed for another ten steps, started a moment
+        // before the operand of an urgent tile arrives, delays that tile -- and with it the chain -- by the rest of the pass.
+        //  * FAR workers: a worker that still owns a tile of a column the chain has reached (k <= dcnt + reserve) works on nothing
+        //    else (the sporadic 10-35 us waits of the chain's first twenty steps at N = 4096, profiles/r6_far_row_latency.txt).
+        //    Its dependences lie in columns < k, whose tiles are urgent for THEIR owners: no cycle.
+        //  * NEAR owners (two or three tiles each, rows 14-20 steps apart): every tile receives one new column per step whatever
+        //    its row, and an owner that starts a pass on its row-(i+14) tile a moment before row i's solve becomes possible delays
+        //    the chain by the rest of that pass (tools/persist_near.py: the solve of tile (i, i-2) was picked 12-20 us late in every
+        //    row whose owner has a later tile, on time in the others).  An owner with a tile of a row the chain is about to reach
+        //    (i <= dcnt + nreserve) works on nothing else; the later tiles' columns pile up and go in deeper passes afterwards.
+        // Same passes on the same data in the same order per tile: the same bits (N = 4096: 1.57 -> 1.46 ms).
+        const bool nearw = me < own.H;
+        const int hotk = nearw ? 0x7fff : s_cnt[nt] + reserve, hoti = nearw ? s_cnt[nt] + nreserve : 0x7fff;
+        bool hot = false;
+        if (nearw ? (nreserve >= 0) : (reserve >= 0))
+            for (int o = 0; o < nmine; ++o) hot = hot || (s_prog[o] != -1 && s_tk[o] <= hotk && s_ti[o] <= hoti);
         // a finished tile whose L_kk has arrived goes first, wherever it stands in the order: its solve publishes a final tile of
         // L, which other workers' passes and the near owners of its row wait for; a pass only moves this worker's own tile on
         if (trsmfirst)
             for (int o = 0; o < nmine; ++o) {
                 const int s = s_order[o];
+                if (hot && (s_tk[s] > hotk || s_ti[s] > hoti)) continue;
                 if (s_prog[s] >= 0 && s_wait[s] && s_cnt[nt] >= s_tk[s] + 1) {
                     pick = s; pi = s_ti[s]; pk = s_tk[s];
                     pj0 = pj1 = (pi == pk) ? pi - 1 : ((split && pi == pk + 1 && pi >= 2) ? pk - 1 : pk);
@@ -728,6 +745,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
             const int s = s_order[o];
             const int p = s_prog[s];
             if (p == -1) continue;
+            if (hot && (s_tk[s] > hotk || s_ti[s] > hoti)) continue;
             const int i = s_ti[s], k = s_tk[s];
             if (p == -2) {                                     // column i-2 of tile (i, i-1): L(i, i-2) is this worker's own
                 if (s_cnt[i - 1] >= i - 1 && s_pre[i]) { pick = s; pi = i; pk = i - 1; pj0 = i - 2; pj1 = i - 1; pfin = 1; break; }
@@ -863,7 +881,8 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
     } else {
         worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, ps_neard(tune),
-                         ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt), (tune & 1) ? 0 : 1, (tune & 2) ? 0 : 1, sm);
+                         ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt), (tune & 1) ? 0 : 1, (tune & 2) ? 0 : 1,
+                         (tune & 8) ? -1 : ((tune & 16) ? 1 : 0), (tune & 32) ? -1 : (((tune >> 16) & 7) ? ((tune >> 16) & 7) : 3), sm);
     }
 }
 

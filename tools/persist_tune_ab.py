@@ -4,6 +4,8 @@
 
     python tools/persist_tune_ab.py 2048,3072,4096,4608 0,1,1024,1025 [rounds=3]
 tune bits: 1 = far workers look at their tiles by ROW (the order up to round 5; default now: by column), 4 = no split hand-over,
+8 = far workers do not reserve themselves for the tiles of the column the chain has reached, 16 = ... reserve one column earlier,
+32 = near owners do not reserve themselves for the row the chain is about to reach, bits 16..18 = rows ahead they do (default 3),
 64 / 128 = near ownership of 3 / 4 block diagonals, bits 8..15 = share of near owners (workers / that number)."""
 import os
 import sys

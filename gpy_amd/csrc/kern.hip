@@ -1022,7 +1022,20 @@ __global__ __launch_bounds__(256) void k_trmv_rows(const double* __restrict__ X,
 #pragma unroll
     for (int d = 0; d < DC; ++d) acc[d] = 0.0;
     const double* xr = X + i * ld;
-    for (long j = lane; j <= i; j += 64) {
+    // eight 512-byte row segments in flight per wave (one load per lane and segment was one load in flight: 0.4-0.8 TB/s, and the
+    // pass sits on the CUs X^T X wants); the sums run in the same order as before: the same bits
+    long j = lane;
+    for (; j + 7 * 64 <= i; j += 8 * 64) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = xr[j + u * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int d = 0; d < DC; ++d)
+                if (d0 + d < Dy) acc[d] = fma(x[u], R[(j + u * 64) * Dy + d0 + d], acc[d]);
+    }
+    for (; j <= i; j += 64) {
         const double x = xr[j];
 #pragma unroll
         for (int d = 0; d < DC; ++d)
@@ -1052,7 +1065,22 @@ __global__ __launch_bounds__(256) void k_trmv_cols(const double* __restrict__ X,
 #pragma unroll
     for (int d = 0; d < DC; ++d) acc[d] = 0.0;
     if (j < n) {
-        for (long i = (ibeg > j ? ibeg : j); i < iend; ++i) {
+        // the rows of the chunk eight at a time (eight independent loads in flight per thread instead of one); rows above the
+        // diagonal are skipped by predicate, the sums run in the same order as before: the same bits
+        long i = ibeg;
+        for (; i + 8 <= iend; i += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = (i + u >= j) ? X[(i + u) * ld + j] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + u >= j) {
+#pragma unroll
+                    for (int d = 0; d < DC; ++d)
+                        if (d0 + d < Dy) acc[d] = fma(x[u], y[(i + u) * Dy + d0 + d], acc[d]);
+                }
+        }
+        for (i = (i > j ? i : j); i < iend; ++i) {
             const double x = X[i * ld + j];
 #pragma unroll
             for (int d = 0; d < DC; ++d)
@@ -1070,7 +1098,15 @@ __global__ void k_trmv_finish(const double* __restrict__ part, long n, int Dy, l
     if (idx >= n * Dy) return;
     const long j = idx / Dy;
     double s = 0.0;
-    for (long c = j / crows; c < nchunks; ++c) s += part[c * n * Dy + idx];
+    long c = j / crows;
+    for (; c + 8 <= nchunks; c += 8) {                       // eight partials in flight (was: one dependent load per chunk)
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(c + u) * n * Dy + idx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < nchunks; ++c) s += part[c * n * Dy + idx];
     alpha[idx] = s;
 }
 

@@ -81,6 +81,12 @@ __device__ __forceinline__ long uni(long v) {
 // override the divisor (diagnostics).
 __host__ __device__ __forceinline__ int ps_hdiv(int nt) { return nt <= 20 ? 2 : (nt <= 27 ? 4 : 6); }
 
+// Far tiles are dealt out round-robin in ROW-major order up to nt = 32 and in COLUMN-major order above (Ownership::tile): same
+// box, whole evaluations, N = 3584 / 4096: 2.369 / 2.620 ms (rows) against 2.386 / 2.632 (columns); N = 4224 / 4352 / 4480 / 4608:
+// 2.961 / 3.136 / 3.295 / 3.465 against 2.913 / 2.989 / 3.125 / 3.251 (profiles/r6_far_order_ab.txt).  Tune bits 20 / 21 force
+// rows / columns (diagnostics).
+__host__ __device__ __forceinline__ int ps_far_rowmajor(int nt) { return nt <= 32 ? 1 : 0; }
+
 // tune bits 6 / 7 (diagnostics): near ownership of D = 3 / 4 block diagonals instead of PS_NEARD
 __host__ __device__ __forceinline__ int ps_neard(int tune) { return (tune & 64) ? 3 : ((tune & 128) ? 4 : PS_NEARD); }
 
@@ -161,8 +167,8 @@ __host__ __device__ __forceinline__ int near_tiles_in_rows(int rows, int D) {   
     return rows <= D ? rows * (rows + 1) / 2 : D * (D + 1) / 2 + (rows - D) * (D + 1);
 }
 struct Ownership {
-    int H, nnear, nfar, nw, D;
-    __device__ Ownership(int nt, int nworkers, int neard, int hdiv = 2) : nw(nworkers), D(neard) {
+    int H, nnear, nfar, nw, D, nt, rowmajor;
+    __device__ Ownership(int nt_, int nworkers, int neard, int hdiv = 2, int rowmajor_ = 0) : nw(nworkers), D(neard), nt(nt_), rowmajor(rowmajor_) {
         nnear = near_tiles_in_rows(nt, D);
         nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
         H = nw / hdiv > 0 ? nw / hdiv : 1;
@@ -187,10 +193,19 @@ struct Ownership {
             const int q = e - T0;
             i = D + q / (D + 1);
             k = i - D + q % (D + 1);
-        } else {
+        } else if (rowmajor) {
             int r;
             tri((me - H) + s * (nw - H), r, k);
             i = r + D + 1;
+        } else {
+            // COLUMN-major (round 6, nt >= 33): column k holds M - k far tiles (M = nt - D - 1, rows k + D + 1 .. nt - 1).  Round-robin
+            // over this order a worker's LAST tile lies in a middle column instead of in one of the last rows: the far workers retire
+            // one after the other from a third of the factorisation on instead of all staying to its last steps.
+            const int M = nt - D - 1;
+            int f = (me - H) + s * (nw - H);
+            k = 0;
+            while (k < M - 1 && f >= M - k) { f -= M - k; ++k; }
+            i = k + D + 1 + f;
         }
     }
 };
@@ -663,7 +678,7 @@ __device__ __forceinline__ void chain_workgroup(double* A, long ld, int nt, doub
 // accumulator carried through memory in fp64 between them as before: the same bits.
 __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
                                  int* __restrict__ sync, int kcap, double* __restrict__ hs, long long* __restrict__ dbg,
-                                 int split, int neard, int hdiv, int colorder, int trsmfirst, int reserve, int nreserve, double* sm) {
+                                 int split, int neard, int hdiv, int colorder, int trsmfirst, int reserve, int nreserve, int rowmajor, double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
     __shared__ int s_pre[PS_MAXNT];                            // PS_PRE snapshot
     __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished;
@@ -672,7 +687,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (w >= 4) return;              // the launch has eight waves per workgroup for the chain's sake; a worker uses four
     const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
-    const Ownership own(nt, nw, neard, hdiv);
+    const Ownership own(nt, nw, neard, hdiv, rowmajor);
     const int nmine = own.count(me);
     if (nmine == 0) return;
     // The owned tiles and the order they are looked at.  A near owner looks at its tiles by row (the order the chain needs them);
@@ -882,7 +897,8 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
     } else {
         worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, ps_neard(tune),
                          ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt), (tune & 1) ? 0 : 1, (tune & 2) ? 0 : 1,
-                         (tune & 8) ? -1 : ((tune & 16) ? 1 : 0), (tune & 32) ? -1 : (((tune >> 16) & 7) ? ((tune >> 16) & 7) : 3), sm);
+                         (tune & 8) ? -1 : ((tune & 16) ? 1 : 0), (tune & 32) ? -1 : (((tune >> 16) & 7) ? ((tune >> 16) & 7) : 3),
+                         ((tune >> 20) & 1) ? 1 : (((tune >> 21) & 1) ? 0 : ps_far_rowmajor(nt)), sm);
     }
 }
 

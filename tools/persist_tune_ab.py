@@ -6,7 +6,7 @@
 tune bits: 1 = far workers look at their tiles by ROW (the order up to round 5; default now: by column), 4 = no split hand-over,
 8 = far workers do not reserve themselves for the tiles of the column the chain has reached, 16 = ... reserve one column earlier,
 32 = near owners do not reserve themselves for the row the chain is about to reach, bits 16..18 = rows ahead they do (default 3),
-64 / 128 = near ownership of 3 / 4 block diagonals, bits 8..15 = share of near owners (workers / that number)."""
+64 / 128 = near ownership of 3 / 4 block diagonals, 1048576 / 2097152 = far tiles dealt out row- / column-major (default: rows up to nt = 32), bits 8..15 = share of near owners (workers / that number)."""
 import os
 import sys
 

@@ -12,9 +12,12 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define FACTOR_NBO_SMALL 256
 #define FACTOR_DEFAULT_TRI_OVERLAP 1    // 1: inverse of the leading block overlapped with the second half of potrf
 #define FACTOR_DEFAULT_PERSIST 1        // 1: small factorisations run as ONE persistent dataflow launch (persist.hip)
-#define FACTOR_PERSIST_MAX_NT 36        // ... up to this many 128-tiles per dimension (N <= 4608): measured A/B on one box, whole
-                                        // evaluation N=2048 -3.2 %, N=4096 -4.4 % (potrf stage -16 %), N=5120 +4 % (the far-tile
-                                        // owners saturate and starve the near tiles); MI355GP_PERSIST_MAX_NT overrides
+#define FACTOR_PERSIST_MAX_NT 64        // ... up to this many 128-tiles per dimension (N <= 8192 = the sync block's PS_MAXNT).  Round 5
+                                        // stopped at 36 (N=5120: +4 %, the far-tile owners saturated and starved the near tiles);
+                                        // with round 6's reserve policy and column-major far ownership (persist.hip) the launch wins
+                                        // up to the layout's limit: whole evaluations, one box, N=5120 4.86 -> 3.83 ms, N=6144 6.92 ->
+                                        // 5.61, N=7168 9.13 -> 8.08, N=8192 12.16 -> 11.17 (profiles/r6_persist_range.txt);
+                                        // MI355GP_PERSIST_MAX_NT (diagnostics build) overrides
 // info[0] codes of a persistent launch that did not complete (far above any column index):
 //   PS_ABORT_INFO : a wait inside the dataflow timed out -- the matrix is partly overwritten, the caller rebuilds it
 //   PS_ABORT_CLEAN: the launch was called off at its co-residency gate before anything was written -- the matrix is intact

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): the persistent single-launch Cholesky (persist.hip) is the default below N = 4608 and spin-waits between
+"""GPU (-m gpu): the persistent single-launch Cholesky (persist.hip) is the default up to N = 8192 and spin-waits between
 workgroups, so it needs all its workgroups resident at once.  What happens when they are not: the launch is called off at
 its co-residency gate with the matrix untouched (or, never seen in a sane run, aborts on a wait timeout) and the SAME C-ABI
 call redoes the factorisation on the launch-per-step schedule -- same bits, no error, nothing for the jitter ladder to see

@@ -55,8 +55,10 @@
 #define PS_CNT 16                          // [nt] cnt[i]: L(i, 0 .. cnt[i]-1) final
 #define PS_SUB (16 + PS_MAXNT)             // [nt] tile (i, i-1) holds columns 0 .. i-2, published for the chain
 #define PS_DIA (16 + 2 * PS_MAXNT)         // [nt] tile (i, i)   holds columns 0 .. i-2, published for the chain
+#define PS_HA (16 + 3 * PS_MAXNT)          // [nt] halves of L(i, i-2) written through (the second one publishes cnt[i] = i - 1)
 #define PS_PRE (16 + 4 * PS_MAXNT)          // [nt] tile (i, i-1) holds columns 0 .. i-3 in place (its owner is done with it)
-#define PS_SYNC_INTS (16 + 5 * PS_MAXNT)
+#define PS_HB (16 + 5 * PS_MAXNT)          // [nt] halves of tile (i, i-1) in the hand-off buffer (the second one sets PS_SUB)
+#define PS_SYNC_INTS (16 + 6 * PS_MAXNT)
 
 // a pointer / int that is the same in every lane, moved to scalar registers (arguments of a non-inlined device function
 // arrive in vector registers: without this every buffer access built from them becomes a waterfall loop)
@@ -86,6 +88,14 @@ __host__ __device__ __forceinline__ int ps_hdiv(int nt) { return nt <= 20 ? 2 : 
 // 2.961 / 3.136 / 3.295 / 3.465 against 2.913 / 2.989 / 3.125 / 3.251 (profiles/r6_far_order_ab.txt).  Tune bits 20 / 21 force
 // rows / columns (diagnostics).
 __host__ __device__ __forceinline__ int ps_far_rowmajor(int nt) { return nt <= 32 ? 1 : 0; }
+
+// The tiles of the second sub-diagonal in 64-row halves on two CUs (half_workgroup): default with the split hand-over and two near
+// diagonals; tune bit 22 switches it off (diagnostics: the single-owner path of rounds 4-5 stays in worker_workgroup).
+__host__ __device__ __forceinline__ int ps_halves(int nt, int tune) {
+    if (!(nt >= 3 && !(tune & 4) && !(tune & (64 | 128)) && !((tune >> 22) & 1))) return 0;
+    if ((tune >> 23) & 0x7f) return (tune >> 23) & 0x7f;           // bits 23..29 (diagnostics): number of half owners, any nt
+    return nt <= 40 ? 1 : 0;                                       // (PS_HALVES_MAX_NT: beyond it the far tiles' throughput bounds the launch)
+}
 
 // tune bits 6 / 7 (diagnostics): near ownership of D = 3 / 4 block diagonals instead of PS_NEARD
 __host__ __device__ __forceinline__ int ps_neard(int tune) { return (tune & 64) ? 3 : ((tune & 128) ? 4 : PS_NEARD); }
@@ -166,19 +176,52 @@ __device__ __forceinline__ bool ps_arrive(int* sync, int* info, int extra) {
 __host__ __device__ __forceinline__ int near_tiles_in_rows(int rows, int D) {       // near tiles in rows 0 .. rows-1
     return rows <= D ? rows * (rows + 1) / 2 : D * (D + 1) / 2 + (rows - D) * (D + 1);
 }
-struct Ownership {
-    int H, nnear, nfar, nw, D, nt, rowmajor;
-    __device__ Ownership(int nt_, int nworkers, int neard, int hdiv = 2, int rowmajor_ = 0) : nw(nworkers), D(neard), nt(nt_), rowmajor(rowmajor_) {
-        nnear = near_tiles_in_rows(nt, D);
-        nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
-        H = nw / hdiv > 0 ? nw / hdiv : 1;
-        if (H > nnear) H = nnear;
-        if (nfar == 0) H = nw < nnear ? nw : nnear;
+// HALVES (round 6, default for 3 <= nt <= PS_HALVES_MAX_NT with the split hand-over): the tiles of the second sub-diagonal (i, i-2),
+// i >= 2, leave the near enumeration and are owned in 64-row halves by Hh dedicated workgroups (half_workgroup).  With them the
+// near owners hold T0 + D (nt - D) tiles (D = 2: the sub-diagonal and the diagonal tile of every row >= 2): two thirds of the
+// tiles they had, so they get two thirds of the near share nw / hdiv; the half owners are PS_HALF_OWNERS more workgroups (ten
+// pairs: each pair's tile turns critical every tenth step; fewer and the late rows' column backlog starves them, more and the far
+// tiles lose workers -- sweep in profiles/r6_halves_sweep.txt).
+#define PS_HALF_OWNERS 20
+#define PS_HALVES_MAX_NT 40
+__host__ __device__ __forceinline__ void ps_near_split(int nt, int nw, int D, int hdiv, int halves, int* H_out, int* Hh_out, int* nnear_out) {
+    const int nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
+    int G = nw / hdiv > 0 ? nw / hdiv : 1;
+    if (nfar == 0) G = nw;
+    if (!halves || D != 2 || nt < 3) {
+        const int nnear = near_tiles_in_rows(nt, D);
+        *H_out = G < nnear ? G : nnear;
+        *Hh_out = 0;
+        *nnear_out = nnear;
+        return;
     }
+    const int nnear = D * (D + 1) / 2 + (nt - D) * D, nhalf = 2 * (nt - D);
+    int Hh = halves > 1 ? 2 * (halves / 2) : PS_HALF_OWNERS;
+    if (Hh < 2) Hh = 2;
+    if (Hh > nhalf) Hh = nhalf;
+    int H = halves > 1 ? G - Hh : (2 * G + 2) / 3;            // (an explicit number of half owners comes out of the near share: sweeps)
+    if (nfar == 0) H = nw - Hh;
+    if (H > nnear) H = nnear;
+    if (H > nw - Hh - (nfar > 0 ? 1 : 0)) H = nw - Hh - (nfar > 0 ? 1 : 0);
+    if (H < 1) H = 1;
+    *H_out = H;
+    *Hh_out = Hh;
+    *nnear_out = nnear;
+}
+struct Ownership {
+    int H, Hh, nnear, nfar, nw, D, nt, rowmajor, halves;
+    __device__ Ownership(int nt_, int nworkers, int neard, int hdiv = 2, int rowmajor_ = 0, int halves_ = 0)
+        : nw(nworkers), D(neard), nt(nt_), rowmajor(rowmajor_), halves(halves_) {
+        nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
+        ps_near_split(nt, nw, D, hdiv, halves_, &H, &Hh, &nnear);
+        halves = Hh > 0 ? halves_ : 0;
+    }
+    // workers [0, H): near owners, [H, H + Hh): half owners (no tiles through this interface), [H + Hh, nw): far workers
     __device__ int count(int me) const {
         if (me < H) return (nnear - me + H - 1) / H;
-        const int m = me - H, W = nw - H;
-        return m < nfar ? (nfar - m + W - 1) / W : 0;
+        if (me < H + Hh) return 0;
+        const int m = me - H - Hh, W = nw - H - Hh;
+        return (W > 0 && m < nfar) ? (nfar - m + W - 1) / W : 0;
     }
     __device__ static void tri(int f, int& r, int& k) {
         r = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
@@ -191,23 +234,37 @@ struct Ownership {
             const int e = me + s * H, T0 = D * (D + 1) / 2;
             if (e < T0) { tri(e, i, k); return; }
             const int q = e - T0;
-            i = D + q / (D + 1);
-            k = i - D + q % (D + 1);
-        } else if (rowmajor) {
+            if (halves) {                                      // rows >= D: tiles (i, i-1), (i, i)
+                i = D + q / D;
+                k = i - D + 1 + q % D;
+            } else {
+                i = D + q / (D + 1);
+                k = i - D + q % (D + 1);
+            }
+            return;
+        }
+        const int m = me - H - Hh, W = nw - H - Hh;
+        if (rowmajor) {
             int r;
-            tri((me - H) + s * (nw - H), r, k);
+            tri(m + s * W, r, k);
             i = r + D + 1;
         } else {
             // COLUMN-major (round 6, nt >= 33): column k holds M - k far tiles (M = nt - D - 1, rows k + D + 1 .. nt - 1).  Round-robin
             // over this order a worker's LAST tile lies in a middle column instead of in one of the last rows: the far workers retire
             // one after the other from a third of the factorisation on instead of all staying to its last steps.
             const int M = nt - D - 1;
-            int f = (me - H) + s * (nw - H);
+            int f = m + s * W;
             k = 0;
             while (k < M - 1 && f >= M - k) { f -= M - k; ++k; }
             i = k + D + 1 + f;
         }
     }
+    // half owner q (0 .. Hh-1): half q & 1 (0: rows 0..63, 1: rows 64..127 of the tile) of the tiles (i, i-2), i = D + (q >> 1) + m (Hh / 2)
+    __device__ int half_rows(int q) const {
+        const int P = Hh / 2, c = q >> 1, n = nt - D;
+        return c < n ? (n - c + P - 1) / P : 0;
+    }
+    __device__ int half_row(int q, int m) const { return D + (q >> 1) + m * (Hh / 2); }
 };
 
 // C tile = acc, write-through (the tile's LAST write before another workgroup reads it)
@@ -678,7 +735,7 @@ __device__ __forceinline__ void chain_workgroup(double* A, long ld, int nt, doub
 // accumulator carried through memory in fp64 between them as before: the same bits.
 __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all,
                                  int* __restrict__ sync, int kcap, double* __restrict__ hs, long long* __restrict__ dbg,
-                                 int split, int neard, int hdiv, int colorder, int trsmfirst, int reserve, int nreserve, int rowmajor, double* sm) {
+                                 int split, int neard, int hdiv, int colorder, int trsmfirst, int reserve, int nreserve, int rowmajor, int halves, double* sm) {
     __shared__ int s_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
     __shared__ int s_pre[PS_MAXNT];                            // PS_PRE snapshot
     __shared__ int s_prog[PS_MAXT];                            // columns applied per owned tile; -1: tile finished;
@@ -687,7 +744,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (w >= 4) return;              // the launch has eight waves per workgroup for the chain's sake; a worker uses four
     const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
-    const Ownership own(nt, nw, neard, hdiv, rowmajor);
+    const Ownership own(nt, nw, neard, hdiv, rowmajor, halves);
     const int nmine = own.count(me);
     if (nmine == 0) return;
     // The owned tiles and the order they are looked at.  A near owner looks at its tiles by row (the order the chain needs them);
@@ -707,7 +764,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
     }
     __syncthreads();
     if (t < nmine) {
-        const bool bycol = colorder && me >= own.H;
+        const bool bycol = colorder && me >= own.H + own.Hh;
         const int key = bycol ? s_tk[t] * 256 + s_ti[t] : t;
         int rank = 0;
         for (int u = 0; u < nmine; ++u) rank += ((bycol ? s_tk[u] * 256 + s_ti[u] : u) < key) ? 1 : 0;
@@ -785,7 +842,7 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
             if (t == 0) {
                 if (idle0 == 0) idle0 = wall_clock64();
                 else if (wall_clock64() - idle0 > PS_TIMEOUT_TICKS) st_flag(sync + PS_ABORT, 1);
-                if (me >= own.H) __builtin_amdgcn_s_sleep(8);    // owners of near tiles are on the chain's critical path
+                if (me >= own.H + own.Hh) __builtin_amdgcn_s_sleep(8);    // owners of near tiles are on the chain's critical path
             }
             __syncthreads();
             continue;
@@ -878,6 +935,199 @@ __device__ void worker_workgroup(double* __restrict__ A, long ld, int nt, const 
     }
 }
 
+// ---- a half owner (round 6) -----------------------------------------------------------------------------------------------
+// The owners' path of a step -- solve of tile (i, i-2) against L_kk, then its column applied to tile (i, i-1), which the chain
+// waits for -- is two tasks at ONE CU's matrix rate (17 + 21 us of W = 46.5, section 3b of DESIGN.md), and the step equation
+// S = max(chain, (W + solve + update + factor) / 2) had W, not the chain's 42 us, in front.  Both tasks are independent per
+// row of the tile: a half owner holds rows 64 h .. 64 h + 63 of its tiles (i, i-2) for their whole life -- the K = 128 column
+// passes as two 64 x 64 tile products (gemm_tile_64_v3: the bits of the 128 x 128 pipeline), the solve as four 16-row strips,
+// one per wave, and the last column of ITS rows of tile (i, i-1) -- so the two tasks run on two CUs at once.  Whoever of the two
+// halves finishes second publishes the row's progress word (PS_HA) / hands the tile to the chain (PS_HB).
+#define PH_IMG (NTILE * TSZ)               // doubles: the half image (32 tiles [16][18]) sits behind the L_kk image of the solve
+__device__ __forceinline__ void half_put_acc(double* img, const d4 (&acc)[2][2], int qc) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            double* T = img + ((wr * 2 + mi) * 8 + qc * 4 + wc * 2 + ni) * TSZ + (lane >> 4) * TS + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[4 * r * TS] = acc[mi][ni][r];
+        }
+}
+__device__ __forceinline__ void half_put_strip(double* img, int a, const d4 (&Y)[8], int lane) {
+    const int fi = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        double* Ta = img + (a * 8 + jb) * TSZ + fi * TS + fk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ta[4 * r] = Y[jb][r];
+    }
+}
+// image (64 rows x 128 columns) -> global, write-through, 256 threads; Ct: first row of the half
+__device__ __forceinline__ void half_store_coherent(const double* img, double* __restrict__ Ct, long ld, int t) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
+#pragma unroll 4
+    for (int it = 0; it < 4096 / 256; ++it) {
+        const int idx = it * 256 + t, row = idx >> 6, cp = idx & 63;
+        const d2 v = *reinterpret_cast<const d2*>(img + ((row >> 4) * 8 + (cp >> 3)) * TSZ + (row & 15) * TS + 2 * (cp & 7));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, (int)((row * ld + 2 * cp) * 8), 0, 16);
+    }
+}
+// image -> strips 4 h .. 4 h + 3 of the tile's hand-off buffer, in the chain's load order (stage_store_chain_order)
+__device__ __forceinline__ void half_store_chain_order(const double* img, double* __restrict__ hs_tile, int h, int t) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hs_tile + h * 4 * 2048, 0, 0x7fffffff, 0x00020000);
+#pragma unroll 4
+    for (int it = 0; it < 4096 / 256; ++it) {
+        const int idx = it * 256 + t, l = idx & 63, c = (idx >> 6) & 15, a = idx >> 10;
+        const int fi = l & 15, fk = l >> 4, jb = c >> 1, r = 2 * (c & 1);
+        const double* T = img + (a * 8 + jb) * TSZ + fi * TS + fk + 4 * r;
+        const d2 v = {T[0], T[4]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, idx * 16, 0, 16);
+    }
+}
+
+__device__ void half_workgroup(double* __restrict__ A, long ld, int nt, const double* __restrict__ dinv_all, int* __restrict__ sync,
+                               int kcap, double* __restrict__ hs, long long* __restrict__ dbg, int neard, int hdiv, int nreserve,
+                               int halves, double* sm) {
+    __shared__ int h_cnt[PS_MAXNT + 2];                        // [nt] row progress, [nt] dcnt, [nt+1] abort
+    __shared__ int h_pre[PS_MAXNT];
+    __shared__ int h_prog[PS_MAXT];                            // columns applied to this half of tile (i, i-2)
+    __shared__ int h_stage[PS_MAXT];                           // 0 columns, 1 waiting for L_kk, 2 solved: last column of (i, i-1) pending, 3 done
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (w >= 4) return;
+    const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
+    const Ownership own(nt, nw, neard, hdiv, 0, halves);
+    const int q = me - own.H, h = q & 1;
+    const int nmine = own.half_rows(q);
+    if (nmine == 0) return;
+    for (int s = t; s < PS_MAXT; s += 256) { h_prog[s] = 0; h_stage[s] = 0; }
+    int left = nmine;
+    long long idle0 = 0;
+    double* img = sm + PH_IMG;
+    __syncthreads();
+    while (left > 0) {
+        if (t < nt) h_cnt[t] = ld_flag(sync + PS_CNT + t);
+        if (t == 64) h_cnt[nt] = ld_flag(sync + PS_DCNT);
+        if (t == 65) h_cnt[nt + 1] = ld_flag(sync + PS_ABORT);
+        if (t >= 128 && t < 128 + nt) h_pre[t - 128] = ld_flag(sync + PS_PRE + t - 128);
+        if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        if (h_cnt[nt + 1] != 0) return;
+        // pick: rows ascend (the order the chain needs them); a row within nreserve steps of the chain keeps the owner to itself
+        const int dc = h_cnt[nt];
+        bool hot = false;
+        if (nreserve >= 0)
+            for (int s = 0; s < nmine; ++s) hot = hot || (h_stage[s] != 3 && own.half_row(q, s) <= dc + nreserve);
+        int pick = -1, pi = 0, pj0 = 0, pj1 = 0, act = 0;     // act: 1 pass, 2 solve, 3 last column of tile (i, i-1)
+        for (int s = 0; s < nmine && pick < 0; ++s) {
+            const int st = h_stage[s];
+            if (st == 3) continue;
+            const int i = own.half_row(q, s), k = i - 2;
+            if (hot && i > dc + nreserve) continue;
+            if (st == 2) {
+                if (h_cnt[i - 1] >= i - 1 && h_pre[i] != 0) { pick = s; pi = i; act = 3; }
+                continue;
+            }
+            if (st == 1) {
+                if (dc >= k + 1) { pick = s; pi = i; act = 2; }
+                continue;
+            }
+            const int p = h_prog[s];
+            if (p >= k) {                                      // (k = 0: nothing to apply)
+                pick = s; pi = i; act = (dc >= k + 1) ? 2 : 0;
+                if (act == 0) { pick = -1; if (t == 0) h_stage[s] = 1; }
+                continue;
+            }
+            int jmax = h_cnt[i] < h_cnt[k] ? h_cnt[i] : h_cnt[k];
+            if (jmax > k) jmax = k;
+            if (jmax > p) { pick = s; pi = i; act = 1; pj0 = p; pj1 = (jmax > p + kcap) ? p + kcap : jmax; }
+        }
+        if (pick < 0) {
+            if (t == 0) {
+                if (idle0 == 0) idle0 = wall_clock64();
+                else if (wall_clock64() - idle0 > PS_TIMEOUT_TICKS) st_flag(sync + PS_ABORT, 1);
+            }
+            __syncthreads();
+            continue;
+        }
+        idle0 = 0;
+        const int pk = pi - 2;
+        const long r0 = (long)pi * NB + 64 * h;               // first row of this half
+        long long* dn2 = (dbg && h == 0) ? dbg + 8 * nt + 4 * (3 * pi + 2) : nullptr;   // near slot (i, 2): the solve
+        long long* dn1 = (dbg && h == 0) ? dbg + 8 * nt + 4 * (3 * pi + 1) : nullptr;   // near slot (i, 1): the last column + hand-over
+        if (act == 1) {                                        // ---- columns [pj0, pj1) of this half of tile (i, i-2)
+#pragma unroll 1
+            for (int qc = 0; qc < 2; ++qc) {
+                double* Cq = A + r0 * ld + (long)pk * NB + 64 * qc;
+                d4 acc[2][2];
+                gt64_load(Cq, ld, acc);
+                gemm_tile_64_v3<true, true, true>(A + r0 * ld + (long)pj0 * NB, ld, A + ((long)pk * NB + 64 * qc) * ld + (long)pj0 * NB, ld,
+                                                  (pj1 - pj0) * NB, acc, sm);
+                gt64_store<0>(Cq, ld, acc);
+            }
+            __syncthreads();
+            if (t == 0) {
+                h_prog[pick] = pj1;
+                if (pj1 >= pk) h_stage[pick] = 1;
+            }
+        } else if (act == 2) {                                 // ---- L(i, i-2)[rows of this half] = C L_kk^-T, final
+            if (dn2 && t == 0) dn2[0] = wall_clock64();
+            drain_stores();
+            __syncthreads();
+            trsm_stage_L(A, ld, (long)pk * NB, dinv_all + (long)pk * 8 * 256, sm);
+            __syncthreads();
+            {
+                const int fi = lane & 15, fk = lane >> 4;
+                const double* Pa = A + (r0 + 16 * w + fi) * ld + (long)pk * NB;
+                d4 P[8], Y[8];
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) P[jb][r] = Pa[jb * 16 + fk + 4 * r];
+                trsm_strip_core(P, Y, [sm](int jb, int k) { return sm + tix_sl(jb, k) * TSZ; }, [sm](int jb) { return sm + (28 + jb) * TSZ; },
+                                lane);
+                if (dn2 && t == 0) dn2[1] = wall_clock64();
+                half_put_strip(img, w, Y, lane);
+            }
+            __syncthreads();
+            half_store_coherent(img, A + r0 * ld + (long)pk * NB, ld, t);
+            drain_stores();
+            __syncthreads();
+            if (t == 0) {
+                if (__hip_atomic_fetch_add(sync + PS_HA + pi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)
+                    st_flag(sync + PS_CNT + pi, pk + 1);
+                if (dn2) dn2[2] = wall_clock64();
+                h_stage[pick] = 2;
+            }
+        } else {                                               // ---- last column of this half of tile (i, i-1), into the hand-off buffer
+            if (dn1 && t == 0) dn1[0] = wall_clock64();
+#pragma unroll 1
+            for (int qc = 0; qc < 2; ++qc) {
+                const double* Cq = A + r0 * ld + (long)(pi - 1) * NB + 64 * qc;
+                d4 acc[2][2];
+                gt64_load(Cq, ld, acc);
+                gemm_tile_64_v3<true, true, true>(A + r0 * ld + (long)pk * NB, ld, A + ((long)(pi - 1) * NB + 64 * qc) * ld + (long)pk * NB, ld,
+                                                  NB, acc, sm);
+                half_put_acc(img, acc, qc);
+            }
+            __syncthreads();
+            if (dn1 && t == 0) dn1[1] = wall_clock64();
+            half_store_chain_order(img, hs + (long)pi * (NB * NB), h, t);
+            drain_stores();
+            __syncthreads();
+            if (t == 0) {
+                if (__hip_atomic_fetch_add(sync + PS_HB + pi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)
+                    st_flag(sync + PS_SUB + pi, 1);
+                if (dn1) dn1[2] = wall_clock64();
+                h_stage[pick] = 3;
+            }
+            --left;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A, long ld, int nt,
                                                           double* __restrict__ dinv_all, double* __restrict__ logsum,
                                                           int* __restrict__ info, int* __restrict__ sync, int kcap,
@@ -895,10 +1145,18 @@ __global__ __launch_bounds__(512, 1) void k_potrf_persist(double* __restrict__ A
         chain_workgroup(A, ld, nt, dinv_all, logsum, info, sync, hs, dbg);
         if (threadIdx.x == 0 && ld_flag(sync + PS_ABORT) != 0) atomicMax(info, PS_ABORT_INFO);
     } else {
-        worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, (tune & 4) ? 0 : 1, ps_neard(tune),
-                         ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt), (tune & 1) ? 0 : 1, (tune & 2) ? 0 : 1,
-                         (tune & 8) ? -1 : ((tune & 16) ? 1 : 0), (tune & 32) ? -1 : (((tune >> 16) & 7) ? ((tune >> 16) & 7) : 3),
-                         ((tune >> 20) & 1) ? 1 : (((tune >> 21) & 1) ? 0 : ps_far_rowmajor(nt)), sm);
+        const int split = (tune & 4) ? 0 : 1, neard = ps_neard(tune), hdiv = ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt);
+        const int nreserve = (tune & 32) ? -1 : (((tune >> 16) & 7) ? ((tune >> 16) & 7) : 3);
+        const int halves = ps_halves(nt, tune);
+        int H, Hh, nnear;
+        ps_near_split(nt, (int)gridDim.x - 1, neard, hdiv, halves, &H, &Hh, &nnear);
+        const int me = (int)blockIdx.x - 1;
+        if (me >= H && me < H + Hh)
+            half_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, neard, hdiv, nreserve, halves, sm);
+        else
+            worker_workgroup(A, ld, nt, dinv_all, sync, kcap, hs, dbg, split, neard, hdiv, (tune & 1) ? 0 : 1, (tune & 2) ? 0 : 1,
+                             (tune & 8) ? -1 : ((tune & 16) ? 1 : 0), nreserve,
+                             ((tune >> 20) & 1) ? 1 : (((tune >> 21) & 1) ? 0 : ps_far_rowmajor(nt)), halves, sm);
     }
 }
 
@@ -923,12 +1181,13 @@ int persist_box_verdict(int set) {
 static bool persist_tiles_fit(int nt, int nw, int tune) {
     if (nw < 1) return false;
     const int D = ps_neard(tune), hdiv = ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt);
-    const int nnear = near_tiles_in_rows(nt, D), nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
-    int H = nw / hdiv > 0 ? nw / hdiv : 1;
-    if (H > nnear) H = nnear;
-    if (nfar == 0) H = nw < nnear ? nw : nnear;
-    if ((nnear + H - 1) / H > PS_MAXT) return false;
-    if (nfar > 0 && (nw - H < 1 || (nfar + (nw - H) - 1) / (nw - H) > PS_MAXT)) return false;
+    const int nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
+    int H, Hh, nnear;
+    ps_near_split(nt, nw, D, hdiv, ps_halves(nt, tune), &H, &Hh, &nnear);
+    if (H < 1 || (nnear + H - 1) / H > PS_MAXT) return false;
+    if (Hh > 0 && ((nt - D) + Hh / 2 - 1) / (Hh / 2) > PS_MAXT) return false;
+    const int W = nw - H - Hh;
+    if (nfar > 0 && (W < 1 || (nfar + W - 1) / W > PS_MAXT)) return false;
     return true;
 }
 

@@ -165,6 +165,8 @@ def lib():
     L.mi355gp_dbg_mask_probe.argtypes = [ci, ci, ci, _dp]
     L.mi355gp_dbg_lauum_plan.argtypes = [ci, ctypes.POINTER(ci), ci, ctypes.POINTER(ci)]
     L.mi355gp_dbg_lauum_plan.restype = ci
+    L.mi355gp_dbg_persist_owners.argtypes = [ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    L.mi355gp_dbg_persist_owners.restype = ci
     L.mi355gp_dbg_persist.argtypes = [ci, i64, ci, ci, _dp]
     L.mi355gp_dbg_ipc_selftest.argtypes = [ctypes.c_char_p, ci, ci, ci, ci, i64, _dp]
     for name in ("device_count", "create", "destroy", "set_data", "set_targets", "kern_K", "kern_Kdiag",
@@ -198,7 +200,7 @@ EXPORTED = ("mi355gp_last_error", "mi355gp_version", "mi355gp_device_count", "mi
             "mi355gp_predictive_gradients_sum", "mi355gp_dbg_pipe_share", "mi355gp_pdinv_full", "mi355gp_dbg_graph_factor",
             "mi355gp_dbg_mfma", "mi355gp_dbg_gemm", "mi355gp_dbg_peaks", "mi355gp_dbg_mask_probe", "mi355gp_get_option",
             "mi355gp_sparse_get_profile", "mi355gp_dbg_persist", "mi355gp_dbg_grid_multi", "mi355gp_dbg_update_nt", "mi355gp_dbg_update_rect",
-            "mi355gp_dbg_ipc_selftest", "mi355gp_grid_coll_log", "mi355gp_dbg_lauum_plan")
+            "mi355gp_dbg_ipc_selftest", "mi355gp_grid_coll_log", "mi355gp_dbg_lauum_plan", "mi355gp_dbg_persist_owners")
 
 
 # mi355gp_set_option / mi355gp_get_option ids (include/mi355gp.h, MI355GP_OPT_*)
@@ -717,6 +719,15 @@ def dbg_update_rect(ntr, ntc, ks, reps=5, device=0):
     out = np.zeros(len(ks))
     check(lib().mi355gp_dbg_update_rect(device, int(ntr), int(ntc), ka, len(ks), int(reps), out), "mi355gp_dbg_update_rect")
     return out
+
+
+def persist_owners(nt, nw, tune=0):
+    """Host only: the ownership map of a persistent launch (persist.hip): (owner matrix nt x nt as described in
+    include/mi355gp_debug.h, near owners, half owners, far workers, most tiles one worker holds, tiles claimed twice)."""
+    owner = (ctypes.c_int * (nt * nt))()
+    out4 = (ctypes.c_int * 4)()
+    dup = lib().mi355gp_dbg_persist_owners(nt, nw, tune, owner, out4)
+    return np.frombuffer(owner, dtype=np.int32, count=nt * nt).reshape(nt, nt).copy(), out4[0], out4[1], out4[2], out4[3], dup
 
 
 def lauum_plan(nt):

@@ -210,26 +210,26 @@ __host__ __device__ __forceinline__ void ps_near_split(int nt, int nw, int D, in
 }
 struct Ownership {
     int H, Hh, nnear, nfar, nw, D, nt, rowmajor, halves;
-    __device__ Ownership(int nt_, int nworkers, int neard, int hdiv = 2, int rowmajor_ = 0, int halves_ = 0)
+    __host__ __device__ Ownership(int nt_, int nworkers, int neard, int hdiv = 2, int rowmajor_ = 0, int halves_ = 0)
         : nw(nworkers), D(neard), nt(nt_), rowmajor(rowmajor_), halves(halves_) {
         nfar = nt > D + 1 ? (nt - D - 1) * (nt - D) / 2 : 0;
         ps_near_split(nt, nw, D, hdiv, halves_, &H, &Hh, &nnear);
         halves = Hh > 0 ? halves_ : 0;
     }
     // workers [0, H): near owners, [H, H + Hh): half owners (no tiles through this interface), [H + Hh, nw): far workers
-    __device__ int count(int me) const {
+    __host__ __device__ int count(int me) const {
         if (me < H) return (nnear - me + H - 1) / H;
         if (me < H + Hh) return 0;
         const int m = me - H - Hh, W = nw - H - Hh;
         return (W > 0 && m < nfar) ? (nfar - m + W - 1) / W : 0;
     }
-    __device__ static void tri(int f, int& r, int& k) {
+    __host__ __device__ static void tri(int f, int& r, int& k) {
         r = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
         while (r * (r + 1) / 2 > f) --r;
         while ((r + 1) * (r + 2) / 2 <= f) ++r;
         k = f - r * (r + 1) / 2;
     }
-    __device__ void tile(int me, int s, int& i, int& k) const {
+    __host__ __device__ void tile(int me, int s, int& i, int& k) const {
         if (me < H) {
             const int e = me + s * H, T0 = D * (D + 1) / 2;
             if (e < T0) { tri(e, i, k); return; }
@@ -260,11 +260,11 @@ struct Ownership {
         }
     }
     // half owner q (0 .. Hh-1): half q & 1 (0: rows 0..63, 1: rows 64..127 of the tile) of the tiles (i, i-2), i = D + (q >> 1) + m (Hh / 2)
-    __device__ int half_rows(int q) const {
+    __host__ __device__ int half_rows(int q) const {
         const int P = Hh / 2, c = q >> 1, n = nt - D;
         return c < n ? (n - c + P - 1) / P : 0;
     }
-    __device__ int half_row(int q, int m) const { return D + (q >> 1) + m * (Hh / 2); }
+    __host__ __device__ int half_row(int q, int m) const { return D + (q >> 1) + m * (Hh / 2); }
 };
 
 // C tile = acc, write-through (the tile's LAST write before another workgroup reads it)
@@ -1326,4 +1326,43 @@ void launch_wait_persist_rows(hipStream_t st, const FactorWs* ws, int r0, int r1
 }
 void launch_wait_persist_resident(hipStream_t st, const FactorWs* ws, int timeout_ms) {
     hipLaunchKernelGGL(k_wait_persist_resident, dim3(1), dim3(1), 0, st, ws->persist_sync, ws->persist_grid_last, timeout_ms);
+}
+
+// Host only (tests/test_host_logic.py): who owns what in a persistent launch of nw workers for nt x nt tiles with the given tune
+// word, as the kernel computes it.  owner[i * nt + k] (k <= i) = worker of tile (i, k), -1 for block (0, 0) (the chain's); a tile
+// of the second sub-diagonal held in halves reports its TOP half's owner there and its bottom half's owner in owner[k * nt + i]
+// (the mirrored, otherwise unused entry).  out4 = near owners, half owners, far workers, most tiles (or rows) any worker holds.
+extern "C" int mi355gp_dbg_persist_owners(int nt, int nw, int tune, int* owner, int* out4) {
+    if (nt < 2 || nt > PS_MAXNT || nw < 1 || !owner || !out4) return -1;
+    for (int e = 0; e < nt * nt; ++e) owner[e] = -2;
+    owner[0] = -1;
+    const int D = ps_neard(tune), hdiv = ((tune >> 8) & 0xff) ? ((tune >> 8) & 0xff) : ps_hdiv(nt);
+    const int rowmajor = ((tune >> 20) & 1) ? 1 : (((tune >> 21) & 1) ? 0 : ps_far_rowmajor(nt));
+    const Ownership own(nt, nw, D, hdiv, rowmajor, ps_halves(nt, tune));
+    int most = 0, dup = 0;
+    for (int me = 0; me < nw; ++me) {
+        const int n = own.count(me);
+        most = n > most ? n : most;
+        for (int s = 0; s < n; ++s) {
+            int i, k;
+            own.tile(me, s, i, k);
+            if (i == 0 && k == 0) continue;                    // worker 0's first near tile is block (0, 0): the chain's
+            if (i < 0 || i >= nt || k < 0 || k > i || owner[i * nt + k] != -2) { ++dup; continue; }
+            owner[i * nt + k] = me;
+        }
+    }
+    for (int q = 0; q < own.Hh; ++q) {
+        const int n = own.half_rows(q);
+        most = n > most ? n : most;
+        for (int m = 0; m < n; ++m) {
+            const int i = own.half_row(q, m), k = i - 2, e = (q & 1) ? k * nt + i : i * nt + k;
+            if (i < 2 || i >= nt || owner[e] != -2) { ++dup; continue; }
+            owner[e] = own.H + q;
+        }
+    }
+    out4[0] = own.H;
+    out4[1] = own.Hh;
+    out4[2] = nw - own.H - own.Hh;
+    out4[3] = most;
+    return dup;
 }

@@ -65,6 +65,12 @@ int mi355gp_dbg_persist(int device, int64_t N, int reps, int kcap, double* out);
  * items: up to max_items rows of 6 ints (ti, tj, q, k0, klen, part); out4 = number of items, number of partial tiles, edge of an
  * item's output tile (64 or 128), longest chunk in rows.  Returns 0, or -1 if max_items is too small (out4[0] still set). */
 int mi355gp_dbg_lauum_plan(int nt, int* items, int max_items, int* out4);
+/* Host only (no GPU call): who owns which 128 x 128 tile in a persistent launch (persist.hip) of nw worker workgroups for an nt x nt
+ * tile matrix under the diagnostics tune word (0 = what ships).  owner: nt * nt ints; owner[i * nt + k] for k <= i = worker of tile
+ * (i, k), -1 for block (0, 0) (the chain's); a tile (i, i - 2) held in 64-row halves reports its top half's owner there and its bottom
+ * half's owner in the mirrored entry owner[k * nt + i].  out4 = near owners, half owners, far workers, most tiles / rows one worker
+ * holds.  Returns the number of tiles claimed twice or out of range (0), -1 on bad arguments. */
+int mi355gp_dbg_persist_owners(int nt, int nw, int tune, int* owner, int* out4);
 /* diagnostics: is a CU-masked stream really confined?  out3 = ms of a 4096^3 GEMM on [plain, masked, masked] streams */
 int mi355gp_dbg_mask_probe(int device, int pct, int order, double* out3);
 

@@ -385,3 +385,40 @@ def test_lauum_work_list_covers_every_k_range_exactly_once(nt):
             assert ps == list(range(ps[0], ps[0] + len(ps))) and ps[0] >= 0      # summed in chunk order
             parts_seen += ps
     assert sorted(parts_seen) == list(range(nparts))
+
+
+@pytest.mark.parametrize("tune", [0, 1 << 22, 1 << 20, 1 << 21, (5 << 8) | (24 << 23)])
+def test_every_tile_of_a_persistent_launch_has_exactly_one_owner(tune):
+    """persist.hip `Ownership` (host mirror, no GPU): for every size the launch takes (nt = 2 .. 64) and several worker counts, every
+    tile of the lower triangle but block (0, 0) has exactly one owner -- the tiles of the second sub-diagonal one owner per 64-row half
+    when they are held in halves (default up to nt = 40; tune bit 22 switches them off) -- near owners, half owners and far workers
+    are disjoint ranges, nobody holds more tiles than the workers' per-tile state has room for (48), and far tiles dealt out
+    column-major (nt >= 33, or forced) cover the same set as row-major."""
+    from gpy_amd import _lib as L
+    for nt in list(range(2, 41)) + [44, 48, 56, 64]:
+        for nw in (15, 31, 136, 254):
+            nfar = (nt - 3) * (nt - 2) // 2 if nt > 3 else 0
+            owner, H, Hh, W, most, dup = L.persist_owners(nt, nw, tune)
+            if nfar > 0 and W < 1:
+                continue                                      # the host refuses such a launch (persist_tiles_fit)
+            assert dup == 0, (nt, nw)
+            assert H >= 1 and Hh >= 0 and H + Hh + W == nw
+            halves = Hh > 0
+            for i in range(nt):
+                for k in range(i + 1):
+                    o = owner[i, k]
+                    if (i, k) == (0, 0):
+                        assert o == -1
+                        continue
+                    assert o >= 0, (nt, nw, i, k)
+                    if halves and i - k == 2:
+                        lo = owner[k, i]
+                        assert H <= o < H + Hh and H <= lo < H + Hh and lo == o + 1 and (o - H) % 2 == 0, (nt, nw, i, k, o, lo)
+                    elif i - k <= 2:
+                        assert 0 <= o < H, (nt, nw, i, k, o)
+                    else:
+                        assert H + Hh <= o < nw, (nt, nw, i, k, o)
+            upper = [owner[k, i] for i in range(nt) for k in range(i) if not (halves and i - k == 2)]
+            assert all(v == -2 for v in upper)
+            if nw >= 136:
+                assert most <= 48, (nt, nw, most)

@@ -197,6 +197,7 @@ __host__ __device__ __forceinline__ void ps_near_split(int nt, int nw, int D, in
     }
     const int nnear = D * (D + 1) / 2 + (nt - D) * D, nhalf = 2 * (nt - D);
     int Hh = halves > 1 ? 2 * (halves / 2) : PS_HALF_OWNERS;
+    if (halves == 1 && Hh > 2 * (nw / 12)) Hh = 2 * (nw / 12);   // a small device / partition (CPX: 32 CUs) keeps most of its workers for the far tiles
     if (Hh < 2) Hh = 2;
     if (Hh > nhalf) Hh = nhalf;
     int H = halves > 1 ? G - Hh : (2 * G + 2) / 3;            // (an explicit number of half owners comes out of the near share: sweeps)

@@ -51,11 +51,13 @@ def test_jitchol_ladder_and_errors_follow_the_reference():
     assert np.abs(gpy_amd.linalg.jitchol(A2) - O.jitchol(A2)).max() <= 1e-12
 
 
-@pytest.mark.parametrize("N", [256, 384, 1000, 2048, 3333, 4096, 4608, 5120, 6500, 8192])
+@pytest.mark.parametrize("N", [256, 384, 640, 1000, 1408, 2048, 2944, 3333, 4096, 4224, 4608, 5120, 5248, 6500, 8192])
 def test_persistent_dataflow_cholesky_is_bit_identical_to_the_launch_per_step_schedule(N):
     """persist.hip: one persistent launch (chain workgroup + static tile owners, write-through hand-offs between workgroups on
     different XCDs) against factor.hip's launch-per-step schedule on the same resident SPD matrix: every double of the lower
-    triangle of L must have the same BITS, no wait may have timed out, and the chain's timeline must be monotone."""
+    triangle of L must have the same BITS, no wait may have timed out, and the chain's timeline must be monotone.  The sizes cross
+    the policy boundaries of round 6: the second sub-diagonal in 64-row halves up to nt = 40 (5120 / 5248), far tiles dealt out
+    column-major from nt = 33 (4096 / 4224), odd tile counts; `tools/persist_all_sizes.py` runs every nt = 2 .. 64."""
     r = L.dbg_persist(N, reps=2)
     assert r["mismatches"] == 0 and r["info"] == 0 and r["abort"] == 0
     st = r["steps"]

@@ -341,7 +341,7 @@ static void early_inverse(hipStream_t sq, double* A, long npad, int h, FactorWs*
     ws->early_pending = 1;
 }
 
-// Leading tiles whose inverse (+ T21) goes on the side stream underneath the PERSISTENT launch: the largest power of two <= nt/2,
+// Leading tiles whose inverse (+ T21) goes on the side stream underneath the PERSISTENT launch: the largest power of two <= 2 nt / 3,
 // 0 = not this time.  (The hipGraph replay of the factorisation region is not used then -- api.hip asks here: measured at
 // N = 4096, replay + early inverse 3.73 ms per evaluation, replay alone 3.35, plain launches + early inverse 3.05.)
 int persist_early_h(long npad, const FactorWs* ws) {
@@ -352,7 +352,12 @@ int persist_early_h(long npad, const FactorWs* ws) {
         ntl < ws->persist_tri_min_nt || ws->evals_done < 1)
         return 0;
     int h = 1;
-    while (4 * h <= ntl) h *= 2;
+    // the largest power of two <= 2 nt / 3 (round 6; up to round 5: <= nt / 2, which a tile count between two powers of two turns into a
+    // third of the rows and 4 % of the inverse): whole evaluations N = 3072 1.83 -> 1.79 ms, N = 3584 2.30 -> 2.15, N = 7168 8.01 -> 7.77,
+    // powers of two unchanged (profiles/r6_early_h_ab.txt); MI355GP_PERSIST_TRI_H23=0 (diagnostics build) brings nt / 2 back
+    static const int two_thirds = diag_env_int(DIAG_ENV("PERSIST_TRI_H23"), 1);
+    if (two_thirds) while (6 * h <= 2 * ntl) h *= 2;
+    else while (4 * h <= ntl) h *= 2;
     return h;
 }
 

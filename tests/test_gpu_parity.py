@@ -587,3 +587,33 @@ def test_in_place_edits_of_caller_buffers_reach_the_device():
     Xb[100, 0] += 0.5
     K2 = k.K(Xb)
     assert K2 is not K1 and np.abs(K2 - O.kern_K("rbf", Xb, None, var, ls, False)).max() <= TOL_K * var
+
+
+@pytest.mark.parametrize("N", [3100, 3600])
+def test_inverse_underneath_the_persistent_launch_with_a_ragged_trailing_block(N):
+    """Round 6: the block inverted on the side stream underneath the persistent Cholesky is the largest power of two <= 2 nt / 3
+    tiles (nt = 25: 16 of 25, nt = 29: 16 of 29), so the trailing block is SHORTER than the leading one and the top-level pair is
+    ragged (`trtri_rows_last`).  The early inverse starts with a context's second evaluation: evaluations 2 .. 4 must agree with the
+    oracle to the parity contract and with each other bit for bit."""
+    D = 4
+    X, Y = O.synthetic(N, D, seed=N)
+    var, ls, noise = O.default_theta(D, True)
+    th = L.theta_vec(var, ls, True, D)
+    ref = O.parameters_changed("matern52", X, Y, var, ls, True, noise)
+    gref = np.concatenate([[ref["dvar"]], ref["dlen"]])
+    c = L.Context(0)
+    try:
+        c.set_data(X, Y)
+        outs = []
+        for _ in range(4):
+            info, r = c.exact_inference("matern52", True, th, noise)
+            assert info == 0
+            outs.append(r)
+        for r in outs[1:]:
+            assert abs(r["lml"] - ref["lml"]) <= TOL_LML * abs(ref["lml"])
+            assert np.linalg.norm(r["alpha"].ravel() - ref["alpha"].ravel()) <= TOL_ALPHA * np.linalg.norm(ref["alpha"])
+            assert np.abs(r["dtheta"] - gref).max() <= TOL_GRAD * np.abs(gref).max()
+            assert r["lml"] == outs[1]["lml"] and r["dtheta"].tobytes() == outs[1]["dtheta"].tobytes()
+        assert c.get_option("persist_aborts") == 0
+    finally:
+        c.close()

@@ -8,6 +8,12 @@ profiles/r5b_persist_probe.txt / r6a_persist_probe_baseline.txt (microseconds):
     worker: K = 128 c columns in one pass 7 + 13.5 c, solve of a finished tile against L_kk 17, hand-over / poll latency ~1.5
 
     python tools/persist_sim.py [nt ...]        prints the modelled time of the shipped policy and of the variants
+
+State of the model (end of round 6): it prices the far half of the reserve rule (it predicted -3 %, measured -1.5 %) and the far
+order; it does NOT model the near owners' reserve (measured -7 % at nt = 32: the model lets a near owner serve its most urgent
+tile first, which the kernel only does since that rule), the second sub-diagonal in 64-row halves on two CUs ("near tasks x0.55"
+is its stand-in: the model says -0.1 %, measured -4.4 %, because in the kernel the halves also take a third of the near owners'
+load away) or the slower factorisation of the first steps (18-21 us against 15.2 while the whole chip is busy).
 """
 import sys
 
